@@ -1,0 +1,176 @@
+/* vnet_hip.h -- C ABI of libvnet_hip.so: the MI355X (gfx950) kernels behind the V-Net hot path.
+ *
+ * The reference (jackyko1991/vnet-tensorflow) has no native ABI of its own: its hot path is a
+ * list of stock TensorFlow-1.15 ops reached from Python.  Each entry point below replaces the
+ * TF op named in its comment at the cited reference call site.  A maintainer binds them with
+ * ctypes; vnet_tensorflow_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - all tensors are float32, channels-last (NDHWC), contiguous; labels are int32.
+ *   - every pointer is a DEVICE pointer owned by the caller (incl. workspace `ws`); the library
+ *     allocates nothing and keeps no state; all work is enqueued on `stream` (hipStream_t);
+ *     no hidden synchronisation -> safe to overlap with RCCL on another stream and to capture
+ *     into a hipGraph.
+ *   - return value: 0 on success, a negative VNET_E_* code for argument errors, or a positive
+ *     hipError_t from the launch.  Nothing throws, nothing exits.
+ */
+#ifndef VNET_HIP_H
+#define VNET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VNET_OK            0
+#define VNET_E_BADARG     -1   /* null pointer / non-positive dimension                  */
+#define VNET_E_UNSUPPORTED -2  /* kernel size / stride / channel multiple not instantiated */
+#define VNET_E_WORKSPACE  -3   /* ws too small: query vnet_conv_ws_bytes / vnet_wgrad_ws_bytes */
+
+/* activation kinds for vnet_bn_act_* (networks.py:239-244) */
+#define VNET_ACT_NONE  0
+#define VNET_ACT_RELU  1       /* tf.nn.relu                                              */
+#define VNET_ACT_PRELU 2       /* layers2.py:97-99                                        */
+#define VNET_ACT_LRELU 3       /* tf.nn.leaky_relu (alpha 0.2)                            */
+
+/* weight packing modes for vnet_pack_weights */
+#define VNET_PACK_FWD  0       /* conv forward:        wp[t][ci/4][co][ci%4] = w[t][ci][co]                 */
+#define VNET_PACK_BWD  1       /* conv backward-data:  wp[t][co/4][ci][co%4] = w[T-1-t][ci][co]             */
+#define VNET_PACK_UP   2       /* 2x2x2 transposed:    wp[0][ci/4][a*O+o][ci%4] = w[a][o][ci], w=[8][O][I]  */
+
+/* loss kinds for vnet_softmax_dice_* (model.py:495-558) */
+#define VNET_LOSS_SORENSEN 0
+#define VNET_LOSS_JACCARD  1
+#define VNET_LOSS_XENT     2
+/* flags or-ed into loss kind */
+#define VNET_LOSS_WEIGHTED 16  /* weighted_* variants (model.py:70-75 / 87-92)            */
+#define VNET_LOSS_MIXED    32  /* mixed_* = dice + Alpha * xent (model.py:524-556)        */
+
+const char* vnet_version(void);
+
+/* ---- weight repacking ---------------------------------------------------------------------
+ * Re-lays a TF filter (layers2.py:60 `weights`, DHWIO [taps][I][O]) into the MFMA-fragment
+ * order the conv kernels stream.  `dims` = {taps, I, O} of the TF tensor.  Output size in
+ * floats = vnet_packed_weight_floats(mode, taps, I, O). */
+size_t vnet_packed_weight_floats(int mode, int taps, int I, int O);
+int vnet_pack_weights(int mode, const float* w, float* wp, int taps, int I, int O, void* stream);
+
+/* ---- N-D convolution, replaces tf.nn.convolution(x, w, 'SAME', strides) + b  (layers2.py:63)
+ * and, with up=1, tf.nn.conv3d_transpose(x, w, output_shape, [1,2,2,2,1], 'SAME') + b
+ * (layers2.py:73).  Also serves backward-data (conv with VNET_PACK_BWD weights; the 2^3
+ * down/up pair are each other's backward-data).
+ *   ks/stride : (5,1) (3,1) (1,1) (2,2);  up=1 requires ks=1 semantics internally: pass ks=2,stride=2,up=1.
+ *   x0,C0,x1,C1 : input as the channel-concat of two NDHWC tensors (tf.concat, networks.py:325,
+ *                 is never materialised); x1 may be NULL (C1=0).
+ *   wp         : packed weights (vnet_pack_weights) for Cin=C0+C1 -> Cout=Cy0+Cy1.
+ *   bias       : [Cout] or NULL.
+ *   y0,Cy0,y1,Cy1 : output split over two NDHWC tensors along channels (backward-data of a concat);
+ *                 y1 may be NULL.
+ *   B, Di,Hi,Wi : input spatial dims;  Do,Ho,Wo : output dims (SAME: ceil(in/stride); up: skip shape).
+ *   ws         : workspace for split-K partials, >= vnet_conv_ws_bytes(...) bytes (may be NULL if 0). */
+size_t vnet_conv_ws_bytes(int ks, int stride, int up, int Cin, int Cout, int B, int Do, int Ho, int Wo);
+int vnet_conv_fwd(int ks, int stride, int up,
+                  const float* x0, int C0, const float* x1, int C1,
+                  const float* wp, const float* bias,
+                  float* y0, int Cy0, float* y1, int Cy1,
+                  int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* ---- convolution filter gradient (the Conv3DBackpropFilterV2 autodiff builds at model.py:660)
+ *   dw[t][ci][co] = sum_v x[v*stride + t - pad][ci] * dy[v][co]     (TF layout, unpadded)
+ * x is the (possibly two-source) forward input, dy the gradient at the conv output [B,Do,Ho,Wo,Cout].
+ * For the transposed 2^3 conv call it with x := dy_fine, dy := x_coarse (ks=2,stride=2). */
+size_t vnet_wgrad_ws_bytes(int ks, int stride, int Cin, int Cout, int B, int Do, int Ho, int Wo);
+int vnet_conv_wgrad(int ks, int stride,
+                    const float* x0, int C0, const float* x1, int C1,
+                    const float* dy, int Cout, float* dw,
+                    int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* ---- 1x1x1 output head, networks.py:298-303 `convolution(x,[1,1,1,C,K])` (K <= 8) ---------- */
+int vnet_head_fwd(const float* x, const float* w, const float* bias, float* y, int64_t M, int C, int K, void* stream);
+int vnet_head_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                  int64_t M, int C, int K, void* ws, size_t ws_bytes, void* stream);
+size_t vnet_head_ws_bytes(int C, int K);
+
+/* ---- column sums: db = sum over voxels of dy (bias gradient of layers2.py:61) --------------- */
+size_t vnet_colsum_ws_bytes(int C);
+int vnet_colsum(const float* x, float* out, int64_t M, int C, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- train-mode batch-norm + residual + activation  ----------------------------------------
+ * Replaces tf.layers.batch_normalization(momentum=.99, epsilon=.001, training=True)
+ * (networks.py:259,265,279,293,303,319,334-337,347,358,361) fused with the residual add in
+ * front of it (networks.py:318,336,360), the tf.tile of the 1-channel input (networks.py:258,
+ * bcast=1: x has 1 channel, broadcast to C) and the activation behind it (layers2.py:97-99).
+ *   s = x (+ r);  mean/var over M = B*D*H*W rows (biased);  y = act(gamma*(s-mean)*invstd+beta)
+ * stats: writes mean[C], invstd[C]; updates moving_mean/moving_var (may be NULL) as
+ *   moving -= (moving - batch) * (1 - momentum).                                               */
+size_t vnet_bn_ws_bytes(int C);
+int vnet_bn_stats(const float* x, const float* r, int bcast, int64_t M, int C, float eps, float momentum,
+                  float* mean, float* invstd, float* moving_mean, float* moving_var,
+                  void* ws, size_t ws_bytes, void* stream);
+int vnet_bn_act_fwd(const float* x, const float* r, int bcast, int64_t M, int C,
+                    const float* mean, const float* invstd, const float* gamma, const float* beta,
+                    int act, const float* alpha, float* y, void* stream);
+/* backward: pass 1 reduces dgamma,dbeta,dalpha; pass 2 writes ds (gradient w.r.t. s = x + r;
+ * the same tensor is the gradient of both x and r).  bcast=1: ds has C channels (caller sums). */
+int vnet_bn_act_bwd(const float* dy, const float* x, const float* r, int bcast, int64_t M, int C,
+                    const float* mean, const float* invstd, const float* gamma, const float* beta,
+                    int act, const float* alpha,
+                    float* dgamma, float* dbeta, float* dalpha, float* ds,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* ---- stand-alone activation, layers2.py:97-99 prelu / tf.nn.relu / tf.nn.leaky_relu -------------
+ * (inside the networks the activation is fused into vnet_bn_act_*; this is the unfused API form) */
+int vnet_act_fwd(const float* x, int64_t M, int C, int act, const float* alpha, float* y, void* stream);
+int vnet_act_bwd(const float* dy, const float* x, int64_t M, int C, int act, const float* alpha,
+                 float* dalpha, float* dx, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- fused softmax + soft-Dice / cross-entropy loss head -----------------------------------
+ * Replaces tf.nn.softmax (model.py:447) + tf.one_hot (model.py:474-477) + dice_coe
+ * (model.py:26-85) + the loss switch (model.py:495-558).  logits [B,V,K], labels int32 [B,V].
+ *   loss_kind  : VNET_LOSS_* | flags;  weights [K] (may be NULL); alpha = Loss.Alpha.
+ *   softmax_out: optional [B,V,K];  pred_out: optional int64 argmax of logits (model.py:567-568)
+ *   loss_out   : device scalar;  dice_out: optional device scalar (the dice_coe value)
+ *   coef       : [B][K][2] + 1 floats kept for the backward pass.
+ * backward: dlogits = d loss / d logits * (*gscale)  (gscale device scalar, may be NULL = 1).   */
+size_t vnet_loss_ws_bytes(int B, int K);
+int vnet_softmax_dice_fwd(const float* logits, const int32_t* labels, int B, int64_t V, int K,
+                          int loss_kind, const float* weights, float alpha, float smooth,
+                          float* softmax_out, int64_t* pred_out, float* loss_out, float* dice_out,
+                          float* coef, void* ws, size_t ws_bytes, void* stream);
+int vnet_softmax_dice_bwd(const float* logits, const int32_t* labels, int B, int64_t V, int K,
+                          int loss_kind, const float* weights, float alpha,
+                          const float* coef, const float* gscale, float* dlogits, void* stream);
+
+/* ---- stand-alone dice_coe(output, target, loss_type, axis=(1,2,3), weights, smooth) (model.py:26-85)
+ * on probability / one-hot tensors [B,V,K]; ws >= vnet_loss_ws_bytes(B,K) + 4.  coef as above. */
+int vnet_dice_coe_fwd(const float* output, const float* target, int B, int64_t V, int K, int jaccard,
+                      const float* weights, float smooth, float* dice_out, float* coef,
+                      void* ws, size_t ws_bytes, void* stream);
+int vnet_dice_coe_bwd(const float* output, const float* target, int B, int64_t V, int K, int jaccard,
+                      const float* coef, const float* gscale, float* doutput, void* stream);
+
+/* ---- dropout, tf.nn.dropout(x, rate) (networks.py:321,339,349,363): counter-based RNG ------- */
+int vnet_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float rate, uint64_t seed, void* stream);
+int vnet_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float rate, void* stream);
+
+/* ---- optimiser apply ops (model.py:649-656): fused over one flat fp32 parameter buffer -------
+ * TF1 AdamOptimizer: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v update; p -= lr_t*m/(sqrt(v)+eps).
+ * lr_t is passed in (host computes the scalar schedule, model.py:641-644).  gscale multiplies
+ * the gradient first (1/world for data-parallel mean). */
+int vnet_adam_apply(float* p, const float* g, float* m, float* v, int64_t n,
+                    float lr_t, float beta1, float beta2, float eps, float gscale, void* stream);
+int vnet_sgd_apply(float* p, const float* g, int64_t n, float lr, float gscale, void* stream);
+int vnet_momentum_apply(float* p, const float* g, float* acc, int64_t n, float lr, float momentum,
+                        int nesterov, float gscale, void* stream);
+
+/* ---- sliding-window accumulation for evaluate (model.py:919-929) ----------------------------- */
+int vnet_accumulate_patch(const float* patch, float* vol, float* count, int K,
+                          int pz, int py, int px, int z0, int y0, int x0, int D, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VNET_HIP_H */

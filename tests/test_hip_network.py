@@ -1,0 +1,195 @@
+"""-m gpu: the whole V-Net hot path (networks.VNet / VNet.VNet -> softmax -> loss -> backward ->
+optimiser) on the HIP library against (a) the committed golden vectors and (b) the live numpy
+oracle.  Tolerances: logits atol/rtol 1e-3, loss/Dice abs 1e-5 (target 1e-6),
+per-tensor gradient rel-L2 1e-3, argmax agreement >= 99.99 %."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vnet_oracle as O
+from tests.golden.make_golden import SMALL, c1_weights
+from tests.util import g, check_close, rel_l2
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _build(dev, variant, K, C0, levels, ncv, nb, values, in_shape):
+    from vnet_tensorflow_amd import networks, VNet
+    if variant == "networks":
+        net = networks.VNet(K, 0.0, C0, levels, ncv, nb, True, "prelu", device=dev)
+    else:
+        net = VNet.VNet(K, 1.0, C0, levels, ncv, nb, True, "prelu", device=dev)
+    net.variables.values = values
+    net.build(in_shape)
+    return net
+
+
+def _fwd_bwd(net, variant, x, lab, loss, wts, dev):
+    from vnet_tensorflow_amd import ops
+    logits = net.GetNetwork(g(x, dev)) if variant == "networks" else net.network_fn(g(x, dev))
+    l, dice, sm, pred = ops.softmax_loss(logits, g(lab, dev, torch.int32), loss, list(wts), 0.7, want_softmax=True, want_pred=True)
+    l.backward()
+    return logits, l, sm, pred
+
+
+@pytest.mark.parametrize("name", [n for n in SMALL if n != "small_networks_l3"])
+def test_small_network_golden(dev, name):
+    variant, cin, K, P, B, C0, levels, ncv, nb, loss, wts = SMALL[name]
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    values = {k[6:]: z[k] for k in z.files if k.startswith("param:")}
+    net = _build(dev, variant, K, C0, levels, ncv, nb, values, z["images"].shape)
+    assert set(values) == set(n for n, _ in net.named_parameters()), "TF variable names differ from the oracle's"
+    logits, l, sm, pred = _fwd_bwd(net, variant, z["images"], z["labels"], loss, wts, dev)
+    check_close(name + " logits", logits, z["logits"], 1e-4, atol=1e-3)
+    assert abs(float(l) - float(z["loss"])) < 1e-5, (float(l), float(z["loss"]))
+    agree = (pred.cpu().numpy() == z["pred"]).mean()
+    assert agree >= 0.9999, agree
+    for n, p in net.named_parameters():
+        ref = z["grad:" + n]
+        if p.grad is None:
+            assert np.abs(ref).max() == 0.0, n     # dead batch-norms only
+            continue
+        if np.linalg.norm(ref) < 1e-7:     # conv biases in front of a BN: analytically zero gradient
+            assert np.abs(p.grad.cpu().numpy()).max() < 1e-4, n
+            continue
+        assert rel_l2(p.grad.cpu().numpy(), ref) < 1e-3, (n, rel_l2(p.grad.cpu().numpy(), ref))
+    # moving statistics of every batch-norm (incl. the dead ones) after one step
+    for k in z.files:
+        if k.startswith("state:"):
+            check_close(k, net.variables.buffers[k[6:]], z[k], 1e-4, atol=1e-6)
+
+
+def _recipe_case(dev, gold, K, C0, levels, ncv, nb, P, seed, store):
+    z = np.load(os.path.join(GOLD, gold))
+    x, lab = O.synthetic_batch(1, P, 1, K, seed=seed)
+    ref_net = O.VNetOracle(K, 0.0, C0, levels, ncv, nb, "prelu", "networks", store)
+    ref_net.GetNetwork(np.zeros((1, 2 ** levels,) * 1 + (2 ** levels, 2 ** levels, 1)))   # creates the variables in order
+    values = {k: v.v for k, v in store.vars.items()}
+    net = _build(dev, "networks", K, C0, levels, ncv, nb, values, x.shape)
+    logits, l, sm, pred = _fwd_bwd(net, "networks", x, lab, "sorensen", (), dev)
+    check_close(gold + " logits", logits, z["logits"], 1e-4, atol=1e-3)
+    assert abs(float(l) - float(z["loss"])) < 1e-5, (float(l), float(z["loss"]))
+    assert (pred.cpu().numpy() == z["pred"]).mean() >= 0.9999
+    params = dict(net.named_parameters())
+    for i, n in enumerate(z["names"]):
+        p = params[str(n)]
+        gn = float(z["grad_norm"][i])
+        if p.grad is None:
+            assert gn == 0.0
+            continue
+        got = p.grad.cpu().numpy().astype(np.float64)
+        if gn < 1e-7:
+            continue
+        assert abs(np.linalg.norm(got) - gn) / gn < 1e-3, (n, np.linalg.norm(got), gn)
+        head = np.resize(got.ravel()[:8], 8)
+        assert np.abs(head - z["grad_head"][i]).max() <= 1e-3 * max(gn, np.abs(z["grad_head"][i]).max()), n
+    return net, logits, l
+
+
+def test_three_level_network_golden(dev):
+    _recipe_case(dev, "small_networks_l3.npz", 2, 4, 3, (1, 2, 3), 3, 16, 2000,
+                 O.ParamStore(rng=np.random.default_rng(11), perturb=0.15))
+
+
+def test_config_c1_full_width_golden(dev):
+    """BASELINE.json configs[0]: one 32^3 1-modality 2-class patch through the full-width network."""
+    _recipe_case(dev, "c1_32cube_fullwidth.npz", 2, 16, 4, (1, 2, 3, 3), 3, 32, 1000, c1_weights())
+
+
+def test_config_c2_live_oracle(dev):
+    """BASELINE.json configs[1] geometry at reduced width (oracle time): 64^3, batch 2, all stages fwd+bwd."""
+    ps = O.ParamStore(rng=np.random.default_rng(5), perturb=0.1)
+    ref_net = O.VNetOracle(2, 0.0, 4, 4, (1, 2, 3, 3), 3, "prelu", "networks", ps)
+    x, lab = O.synthetic_batch(2, 64, 1, 2, seed=3000)
+    ref = O.run_step(x.astype(np.float64), lab, ref_net, "sorensen")
+    net = _build(dev, "networks", 2, 4, 4, (1, 2, 3, 3), 3, {k: v.v for k, v in ps.vars.items()}, x.shape)
+    logits, l, sm, pred = _fwd_bwd(net, "networks", x, lab, "sorensen", (), dev)
+    check_close("c2 logits", logits, ref["logits"], 1e-4, atol=1e-3)
+    assert abs(float(l) - ref["loss"]) < 1e-5
+    for n, p in net.named_parameters():
+        r = ref["grads"][n]
+        if p.grad is not None and np.linalg.norm(r) > 1e-7:
+            assert rel_l2(p.grad.cpu().numpy(), r) < 1e-3, n
+
+
+def test_training_steps_match_oracle_adam(dev):
+    """Three optimiser steps (TF-form Adam + exponential LR decay, model.py:641-666) track the oracle."""
+    from vnet_tensorflow_amd import ops, optim
+    ps = O.ParamStore(rng=np.random.default_rng(9), perturb=0.1)
+    ref_net = O.VNetOracle(2, 0.0, 4, 2, (1, 2), 2, "prelu", "networks", ps)
+    x, lab = O.synthetic_batch(2, 16, 1, 2, seed=4000)
+    ref_net.GetNetwork(x.astype(np.float64))
+    net = _build(dev, "networks", 2, 4, 2, (1, 2), 2, {k: v.v for k, v in ps.vars.items()}, x.shape)
+    flat = optim.FlatParams(net.named_parameters())
+    opt = optim.AdamOptimizer(flat)
+    adam = O.TFAdam()
+    tx, tl = g(x, dev), g(lab, dev, torch.int32)
+    for step in range(3):
+        lr = optim.exponential_decay(1e-3, step, 100, 0.99)
+        ref = O.run_step(x.astype(np.float64), lab, ref_net, "sorensen")
+        params = adam.step({k: v.v for k, v in ps.vars.items()}, ref["grads"], lr)
+        for k, v in params.items():
+            ps.vars[k].v = v
+        flat.zero_grad()
+        loss, _, _, _ = ops.softmax_loss(net.GetNetwork(tx), tl, "sorensen")
+        loss.backward()
+        opt.apply(lr)
+        assert abs(float(loss) - ref["loss"]) < 2e-5, (step, float(loss), ref["loss"])
+    for n, p in net.named_parameters():
+        check_close("after 3 steps " + n, p, ps.vars[n].v, 2e-3, atol=2e-4)
+
+
+def test_sliding_window_evaluate(dev):
+    """model.py:866-937: patch enumeration with stride, last patch clamped, duplicated last batch,
+    argmax of the summed softmax -- against a numpy re-enactment using the same forward."""
+    from vnet_tensorflow_amd import model as M
+    cfg = {"TrainingSetting": {"Data": {"TrainingDataDirectory": "", "TestingDataDirectory": "", "ImageFilenames": ["i.npy"],
+                                        "LabelFilename": "l.npy"},
+                               "SegmentationClasses": [0, 1], "BatchSize": 1, "PatchShape": [16, 16, 16],
+                               "Networks": {"Name": "VNet", "Dropout": 0.0, "NumChannel": 4, "NumLevels": 2,
+                                            "NumCovolutions": [1, 2], "BottomConvolutions": 1},
+                               "Optimizer": {"Name": "Adam", "InitialLearningRate": 1e-3, "Decay": {"Factor": 0.99, "Steps": 100}},
+                               "Loss": {"Name": "sorensen"}},
+           "EvaluationSetting": {"Stride": [8, 12, 16], "BatchSize": 2, "ProbabilityOutput": True}}
+    m = M.image2label(None, cfg, device=dev, verbose=False)
+    m.read_config()
+    m.build_model_graph()
+    vol, _ = O.synthetic_batch(1, 24, 1, 2, seed=77)
+    vol = vol[0][:, :22, :20]
+    label, softmax = m.evaluate_single_3D(vol)
+    # numpy re-enactment
+    ps, st = [16, 16, 16], [8, 12, 16]
+    dims = vol.shape[:3]
+    acc = np.zeros(dims + (2,), np.float64)
+    cnt = np.zeros(dims, np.float64)
+    import math
+    nums = [int(math.ceil((dims[a] - ps[a]) / float(st[a]))) + 1 for a in range(3)]
+    idxs = []
+    for i in range(nums[0]):
+        for j in range(nums[1]):
+            for k in range(nums[2]):
+                s = [min(n * st[a], dims[a] - ps[a]) for a, n in enumerate((i, j, k))]
+                idxs.append(s)
+    groups = [idxs[i:i + 2] for i in range(0, len(idxs), 2)]
+    groups.append(groups[-1])
+    for grp in groups:
+        batch = np.stack([vol[s[0]:s[0] + 16, s[1]:s[1] + 16, s[2]:s[2] + 16] for s in grp])
+        sm = m.run(['softmax:0'], {'images_placeholder:0': batch})[0]
+        for s, p in zip(grp, sm):
+            acc[s[0]:s[0] + 16, s[1]:s[1] + 16, s[2]:s[2] + 16] += p
+            cnt[s[0]:s[0] + 16, s[1]:s[1] + 16, s[2]:s[2] + 16] += 1
+    assert (label == acc.argmax(-1)).mean() > 0.9999
+    check_close("probability", np.moveaxis(softmax, 0, -1), acc / cnt[..., None], 1e-5)
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly off-GPU (no CPU / eager-PyTorch fallback)."""
+    from vnet_tensorflow_amd import ops, VnetHipError
+    x = torch.zeros(1, 4, 4, 4, 16)
+    with pytest.raises(VnetHipError):
+        ops.conv(x, torch.zeros(5, 5, 5, 16, 16), torch.zeros(16), 5, 1)
+    with pytest.raises(VnetHipError):
+        ops.bn_act(x, torch.ones(16), torch.zeros(16))

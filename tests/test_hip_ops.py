@@ -1,0 +1,254 @@
+"""-m gpu: every HIP kernel family, through the C ABI (ctypes via vnet_tensorflow_amd.ops), against
+the numpy-fp64 oracle on the same seeded inputs.  Tolerances are fp32-roundoff class (stated per test)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vnet_oracle as O
+from tests.util import g, check_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv_case(dev, B, D, H, W, C0, C1, Co, ks, stride, seed):
+    from vnet_tensorflow_amd import ops
+    rng = np.random.default_rng(seed)
+    x0 = rng.standard_normal((B, D, H, W, C0))
+    x1 = rng.standard_normal((B, D, H, W, C1)) if C1 else None
+    w = rng.standard_normal((ks, ks, ks, C0 + C1, Co)) * 0.1
+    b = rng.standard_normal(Co)
+    xcat = x0 if x1 is None else np.concatenate((x0, x1), -1)
+    y_ref = O.conv_nd_fwd(xcat, w, stride) + b
+    dy = rng.standard_normal(y_ref.shape)
+    dx_ref, dw_ref = O.conv_nd_bwd(xcat, w, dy, stride)
+    tx0 = g(x0, dev).requires_grad_(True)
+    tx1 = g(x1, dev).requires_grad_(True) if C1 else None
+    tw, tb = g(w, dev).requires_grad_(True), g(b, dev).requires_grad_(True)
+    y = ops.conv(tx0, tw, tb, ks, stride, x1=tx1)
+    tag = "conv k%d s%d [%d,%d,%d,%d] %d+%d->%d" % (ks, stride, B, D, H, W, C0, C1, Co)
+    check_close(tag + " fwd", y, y_ref, 2e-6)
+    y.backward(g(dy, dev))
+    check_close(tag + " dx0", tx0.grad, dx_ref[..., :C0], 2e-6)
+    if C1:
+        check_close(tag + " dx1", tx1.grad, dx_ref[..., C0:], 2e-6)
+    check_close(tag + " dw", tw.grad, dw_ref, 2e-6)
+    check_close(tag + " db", tb.grad, dy.reshape(-1, Co).sum(0), 2e-6)
+
+
+@pytest.mark.parametrize("shape", [
+    (1, 8, 16, 32, 16, 0, 16),     # wide brick, NS=1
+    (2, 5, 9, 17, 16, 16, 16),     # ragged dims, two-source (concat), batch 2
+    (1, 8, 8, 16, 32, 0, 32),      # NS=2, two chunks
+    (1, 4, 8, 16, 64, 0, 64),      # NS=4, four chunks
+    (1, 8, 8, 8, 32, 32, 32),      # cube brick (W<16), split-K
+    (1, 4, 4, 4, 128, 0, 128),     # tiny volume, many chunks -> split-K, 2 cout blocks
+    (1, 2, 2, 2, 64, 0, 64),       # 2^3 volume (bottom of config C1)
+    (1, 6, 7, 9, 4, 4, 8),         # narrow channels: zero-padded chunk, Cout<16
+    (1, 6, 6, 18, 3, 0, 16),       # Cin not a multiple of 4: scalar gather path
+    (1, 4, 6, 16, 16, 0, 5),       # Cout not a multiple of 4: scalar scatter path
+])
+def test_conv5(dev, shape):
+    _conv_case(dev, *shape, ks=5, stride=1, seed=sum(shape))
+
+
+@pytest.mark.parametrize("shape", [
+    (1, 8, 16, 32, 16, 0, 32),
+    (2, 4, 8, 16, 32, 0, 64),
+    (1, 8, 8, 8, 64, 0, 128),
+    (1, 6, 10, 14, 8, 0, 16),
+    (1, 5, 7, 9, 4, 0, 8),         # odd dims: SAME pads one voxel on the high side
+    (1, 2, 2, 2, 128, 0, 256),
+])
+def test_down_conv(dev, shape):
+    _conv_case(dev, *shape, ks=2, stride=2, seed=sum(shape))
+
+
+@pytest.mark.parametrize("shape", [
+    # B, d, h, w (coarse), Cin, Cout, (out dims)
+    (1, 4, 8, 16, 32, 16, None),
+    (2, 4, 4, 8, 64, 32, None),
+    (1, 8, 8, 8, 128, 64, None),
+    (1, 1, 1, 1, 256, 128, None),
+    (1, 3, 4, 5, 8, 4, (5, 7, 9)),   # odd output shape (skip tensor of an odd level)
+])
+def test_up_conv(dev, shape):
+    from vnet_tensorflow_amd import ops
+    B, d, h, w_, Ci, Co, outsp = shape
+    rng = np.random.default_rng(sum(shape[:6]))
+    outsp = outsp or (2 * d, 2 * h, 2 * w_)
+    x = rng.standard_normal((B, d, h, w_, Ci))
+    w = rng.standard_normal((2, 2, 2, Co, Ci)) * 0.2
+    b = rng.standard_normal(Co)
+    X, Wv, Bv = O.Var(x), O.Var(w), O.Var(b)
+    y = O.deconvolution(X, Wv, Bv, outsp, 2)
+    dy = rng.standard_normal(y.v.shape)
+    O.backward(y, dy)
+    tx, tw, tb = (g(a, dev).requires_grad_(True) for a in (x, w, b))
+    ty = ops.conv_transpose2(tx, tw, tb, outsp)
+    tag = "upconv %s" % (shape,)
+    check_close(tag + " fwd", ty, y.v, 2e-6)
+    ty.backward(g(dy, dev))
+    check_close(tag + " dx", tx.grad, X.g, 2e-6)
+    check_close(tag + " dw", tw.grad, Wv.g, 2e-6)
+    check_close(tag + " db", tb.grad, Bv.g, 2e-6)
+
+
+@pytest.mark.parametrize("C,act,res,tile", [
+    (16, "prelu", False, False), (16, "prelu", True, False), (32, "relu", True, False), (64, None, False, False),
+    (256, "prelu", True, False), (16, None, False, True), (2, None, False, False), (5, "lrelu", True, False),
+    (12, "prelu", False, False), (8, "prelu", False, True),
+])
+def test_bn_act(dev, C, act, res, tile):
+    from vnet_tensorflow_amd import ops
+    rng = np.random.default_rng(C + 7 * bool(res))
+    shp = (2, 5, 6, 7)
+    x = rng.standard_normal(shp + ((1,) if tile else (C,))) * 3.0 + 1.5
+    r = rng.standard_normal(shp + (C,)) if res else None
+    gamma, beta = rng.uniform(0.5, 1.5, C), rng.standard_normal(C)
+    alpha = rng.uniform(0.05, 0.3, C)
+    X, G_, B_, A_ = O.Var(x), O.Var(gamma), O.Var(beta), O.Var(alpha)
+    s = O.tile_channels(X, C) if tile else X
+    R = O.Var(r) if res else None
+    if res:
+        s = O.add(s, R)
+    st = []
+    y = O.batch_norm_train(s, G_, B_, stats_out=st)
+    y = O.prelu(y, A_) if act == "prelu" else O.relu(y) if act == "relu" else O.leaky_relu(y) if act == "lrelu" else y
+    dy = rng.standard_normal(y.v.shape)
+    O.backward(y, dy)
+    tx = g(x, dev).requires_grad_(True)
+    tr = g(r, dev).requires_grad_(True) if res else None
+    tg, tb, ta = (g(a, dev).requires_grad_(True) for a in (gamma, beta, alpha))
+    mm, mv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    ty = ops.bn_act(tx, tg, tb, act, ta if act == "prelu" else None, tr, tile, mm, mv)
+    tag = "bn_act C%d %s res%d tile%d" % (C, act, res, tile)
+    check_close(tag + " fwd", ty, y.v, 5e-6)
+    ty.backward(g(dy, dev))
+    check_close(tag + " dx", tx.grad, X.g, 5e-5, atol=1e-5)
+    if res:
+        check_close(tag + " dr", tr.grad, R.g, 5e-5, atol=1e-5)
+    check_close(tag + " dgamma", tg.grad, G_.g, 2e-5)
+    check_close(tag + " dbeta", tb.grad, B_.g, 2e-5)
+    if act == "prelu":
+        check_close(tag + " dalpha", ta.grad, A_.g, 2e-5)
+    mu, var = st[0]
+    check_close(tag + " moving_mean", mm, 0.01 * mu, 1e-5, atol=1e-7)
+    check_close(tag + " moving_var", mv, 0.99 + 0.01 * var, 1e-5)
+
+
+@pytest.mark.parametrize("C,K", [(16, 2), (16, 5), (4, 3), (8, 8)])
+def test_head(dev, C, K):
+    from vnet_tensorflow_amd import ops
+    rng = np.random.default_rng(C * K)
+    x = rng.standard_normal((2, 4, 5, 6, C))
+    w = rng.standard_normal((1, 1, 1, C, K))
+    b = rng.standard_normal(K)
+    y_ref = x @ w[0, 0, 0] + b
+    dy = rng.standard_normal(y_ref.shape)
+    tx, tw, tb = (g(a, dev).requires_grad_(True) for a in (x, w, b))
+    y = ops.head_conv(tx, tw, tb)
+    check_close("head fwd", y, y_ref, 2e-6)
+    y.backward(g(dy, dev))
+    check_close("head dx", tx.grad, dy @ w[0, 0, 0].T, 2e-6)
+    check_close("head dw", tw.grad, (x.reshape(-1, C).T @ dy.reshape(-1, K)).reshape(w.shape), 2e-6)
+    check_close("head db", tb.grad, dy.reshape(-1, K).sum(0), 2e-6)
+
+
+LOSSES = ["sorensen", "jaccard", "weighted_sorensen", "weighted_jaccard", "xent", "weighted_xent",
+          "mixed_sorensen", "mixed_weighted_sorensen", "mixed_jaccard", "mixed_weighted_jaccard"]
+
+
+@pytest.mark.parametrize("loss_name", LOSSES)
+@pytest.mark.parametrize("B,K", [(2, 3), (1, 2), (3, 5)])
+def test_softmax_loss(dev, loss_name, B, K):
+    from vnet_tensorflow_amd import ops
+    rng = np.random.default_rng(B * 10 + K)
+    z = rng.standard_normal((B, 6, 7, 9, K)) * 2.0
+    lab = rng.integers(0, K, size=(B, 6, 7, 9, 1)).astype(np.int32)
+    wts = list(rng.uniform(0.1, 1.0, K))
+    Z = O.Var(z)
+    loss, sm = O.loss_head(Z, lab, loss_name, wts, 0.7)
+    O.backward(loss, 1.7)
+    tz = g(z, dev).requires_grad_(True)
+    tl, _, tsm, tpred = ops.softmax_loss(tz, g(lab, dev, torch.int32), loss_name, wts, 0.7, want_softmax=True, want_pred=True)
+    check_close(loss_name + " loss", tl, loss.v, 2e-6)
+    check_close(loss_name + " softmax", tsm, sm.v, 2e-6)
+    assert (tpred.cpu().numpy() == O.argmax_pred(z)).all()
+    (tl * 1.7).backward()
+    check_close(loss_name + " dlogits", tz.grad, Z.g, 1e-5)
+
+
+def test_dice_coe_known_answers(dev):
+    """SURVEY 8(c) known answers: dice(t,t)=1 exactly for one-hot t; dice(p,0)=s/(sum p+s)."""
+    from vnet_tensorflow_amd import model
+    rng = np.random.default_rng(0)
+    lab = rng.integers(0, 3, size=(2, 4, 5, 6))
+    t = g(O.one_hot(lab, 3), dev)
+    assert float(model.dice_coe(t, t, 'sorensen')) == 1.0
+    p = torch.softmax(g(rng.standard_normal((2, 4, 5, 6, 3)), dev), -1)
+    d0 = float(model.dice_coe(p, torch.zeros_like(p), 'sorensen'))
+    ref = np.mean(1e-5 / (p.cpu().numpy().astype(np.float64).sum((1, 2, 3)) + 1e-5))
+    assert abs(d0 - ref) < 1e-9
+    for kind in ("sorensen", "jaccard"):
+        for w in ([], [0.2, 0.5, 1.0]):
+            P = O.Var(p.cpu().numpy().astype(np.float64))
+            d = O.dice_coe(P, t.cpu().numpy(), kind, weights=w)
+            O.backward(d)
+            tp = p.clone().requires_grad_(True)
+            td = model.dice_coe(tp, t, kind, weights=w)
+            check_close("dice_coe %s %s" % (kind, w), td, d.v, 2e-6)
+            td.backward()
+            check_close("dice_coe grad %s %s" % (kind, w), tp.grad, P.g, 1e-5)
+
+
+def test_activation_standalone(dev):
+    from vnet_tensorflow_amd import ops
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 3, 4, 5, 16))
+    x[0, 0, 0, 0, :4] = 0.0      # exact zeros: TF tie rule gives gradient 0
+    a = rng.uniform(0.05, 0.3, 16)
+    X, A_ = O.Var(x), O.Var(a)
+    y = O.prelu(X, A_)
+    dy = rng.standard_normal(x.shape)
+    O.backward(y, dy)
+    tx, ta = g(x, dev).requires_grad_(True), g(a, dev).requires_grad_(True)
+    ty = ops.activation(tx, "prelu", ta)
+    check_close("prelu fwd", ty, y.v, 1e-6)
+    ty.backward(g(dy, dev))
+    check_close("prelu dx", tx.grad, X.g, 1e-6)
+    check_close("prelu dalpha", ta.grad, A_.g, 2e-6)
+
+
+def test_dropout(dev):
+    from vnet_tensorflow_amd import ops
+    x = torch.ones(4, 8, 8, 8, 16, device=dev, requires_grad=True)
+    y = ops.dropout(x, 0.25)
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.75) < 0.01
+    assert torch.allclose(y[y != 0], torch.full_like(y[y != 0], 1.0 / 0.75))
+    y.sum().backward()
+    assert torch.equal(x.grad != 0, y != 0)
+    assert ops.dropout(x, 0.0) is x
+
+
+def test_optimisers(dev):
+    from vnet_tensorflow_amd import optim
+    rng = np.random.default_rng(5)
+    shapes = [(5, 5, 5, 4, 8), (8,), (3,), (2, 2, 2, 8, 16)]
+    vals = {("v%d" % i): rng.standard_normal(s) for i, s in enumerate(shapes)}
+    for name in ("Adam", "SGD", "Momentum", "NesterovMomentum"):
+        params = [(k, torch.nn.Parameter(g(v, dev))) for k, v in vals.items()]
+        flat = optim.FlatParams(params)
+        opt = optim.make_optimizer(name, flat, 0.9)
+        ref = {k: v.copy() for k, v in vals.items()}
+        ro = O.TFAdam() if name == "Adam" else O.TFMomentum(0.9, name == "NesterovMomentum") if "Momentum" in name else None
+        for step in range(3):
+            grads = {k: rng.standard_normal(v.shape) for k, v in vals.items()}
+            lr = optim.exponential_decay(1e-2, step, 100, 0.99)
+            flat.zero_grad()
+            for k, p in params:
+                p.grad.copy_(g(grads[k], dev))
+            opt.apply(lr)
+            ref = ro.step(ref, grads, lr) if ro else O.sgd_step(ref, grads, lr)
+        for k, p in params:
+            check_close("%s %s" % (name, k), p, ref[k], 2e-6)

@@ -1,0 +1,90 @@
+"""ctypes binding of libvnet_hip.so (include/vnet_hip.h).
+
+The library is the product: there is NO fallback.  If the shared object is missing, or a
+kernel reports an error, this module raises -- nothing silently routes to PyTorch or the CPU.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvnet_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_vp, _i, _i64, _f, _sz, _u64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
+                                ctypes.c_size_t, ctypes.c_uint64)
+
+# name -> (restype, argtypes) : must list every symbol include/vnet_hip.h declares
+SIGNATURES = {
+    "vnet_version": (ctypes.c_char_p, []),
+    "vnet_packed_weight_floats": (_sz, [_i, _i, _i, _i]),
+    "vnet_pack_weights": (_i, [_i, _vp, _vp, _i, _i, _i, _vp]),
+    "vnet_conv_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "vnet_conv_fwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i,
+                           _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "vnet_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "vnet_conv_wgrad": (_i, [_i, _i, _vp, _i, _vp, _i, _vp, _i, _vp,
+                             _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "vnet_head_fwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "vnet_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _sz, _vp]),
+    "vnet_head_ws_bytes": (_sz, [_i, _i]),
+    "vnet_colsum_ws_bytes": (_sz, [_i]),
+    "vnet_colsum": (_i, [_vp, _vp, _i64, _i, _vp, _sz, _vp]),
+    "vnet_bn_ws_bytes": (_sz, [_i]),
+    "vnet_bn_stats": (_i, [_vp, _vp, _i, _i64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vnet_bn_act_fwd": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "vnet_bn_act_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp,
+                             _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vnet_act_fwd": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp]),
+    "vnet_act_bwd": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vnet_loss_ws_bytes": (_sz, [_i, _i]),
+    "vnet_softmax_dice_fwd": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vnet_softmax_dice_bwd": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _f, _vp, _vp, _vp, _vp]),
+    "vnet_dice_coe_fwd": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _f, _vp, _vp, _vp, _sz, _vp]),
+    "vnet_dice_coe_bwd": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp]),
+    "vnet_dropout_fwd": (_i, [_vp, _vp, _vp, _i64, _f, _u64, _vp]),
+    "vnet_dropout_bwd": (_i, [_vp, _vp, _vp, _i64, _f, _vp]),
+    "vnet_adam_apply": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp]),
+    "vnet_sgd_apply": (_i, [_vp, _vp, _i64, _f, _f, _vp]),
+    "vnet_momentum_apply": (_i, [_vp, _vp, _vp, _i64, _f, _f, _i, _f, _vp]),
+    "vnet_accumulate_patch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+}
+
+ERRORS = {-1: "VNET_E_BADARG", -2: "VNET_E_UNSUPPORTED", -3: "VNET_E_WORKSPACE"}
+
+
+class VnetHipError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libvnet_hip.so in-tree with hipcc for gfx950 (works without a GPU)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    res = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
+    if res.returncode != 0 or not os.path.exists(LIB_PATH):
+        raise VnetHipError("building libvnet_hip.so failed:\n" + res.stdout + res.stderr)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library (raises if it has not been built: there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VnetHipError("libvnet_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc, gfx950).  The HIP library is the only compute path." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise VnetHipError("%s failed: %s" % (what, ERRORS.get(code, "hipError_t %d" % code)))

@@ -1,0 +1,600 @@
+// conv_mfma.hip -- NDHWC fp32 3-D convolution family on CDNA4 matrix cores (gfx950).
+//
+// Replaces tf.nn.convolution / tf.nn.conv3d_transpose (reference layers2.py:63,73) and the
+// Conv3DBackpropInput/Filter ops TF autodiff builds at model.py:660.  One implicit-GEMM kernel
+// serves forward, backward-data (flipped/transposed packed weights) and the 2x2x2 stride-2
+// down / transposed-up pair; a second kernel computes filter gradients.
+//
+// Mapping (exact fp32: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD = the fp32 peak of the chip):
+//   D[row = cout][col = voxel] += A[cout][k] * B[k][voxel],   k = (tap, cin)
+//   * a workgroup owns a TZxTYxTX brick of output voxels and NS*16 output channels;
+//   * the input brick + halo for one 16-channel chunk is staged in LDS once and re-used by all
+//     KS^3 taps (zero-filled outside the volume = TF 'SAME');
+//   * B fragments are 16-byte LDS reads (4 consecutive cin of one voxel), A fragments are 16-byte
+//     global/L2 reads of weights pre-packed as [tap][cin/4][cout][cin%4]; MFMA step j of a
+//     k-group uses element j of both, i.e. hardware k-index kk <-> cin 4*kk+j (a K permutation
+//     shared by A and B);
+//   * each lane ends up with 4 consecutive cout of one voxel -> 16-byte NDHWC stores.
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+    const float* x0; const float* x1; int C0, C1, Cin;
+    const float4* wp; const float* bias;
+    float* y0; float* y1; int Cy0, Cy1, Cout;
+    int B, Di, Hi, Wi, Do, Ho, Wo;
+    int CQ;            // padded Cin / 4
+    int CoutP;         // padded Cout (multiple of 16)
+    int nchunks, cps;  // 16-channel chunks, chunks per K-split
+    int nbz, nby, nbx; // bricks per axis
+    int pad;           // low-side SAME padding
+    int vec_in, vec_out;
+    float* part; size_t part_stride;  // split-K partials [split][vox][CoutP]
+    int upO;           // UP: real output channels O (N' = 8*O)
+};
+
+template <int KS, int STRIDE, int TZ, int TY, int TX>
+struct TileGeom {
+    static constexpr int IZ = (TZ - 1) * STRIDE + KS;
+    static constexpr int IY = (TY - 1) * STRIDE + KS;
+    static constexpr int IX = (TX - 1) * STRIDE + KS;
+    static constexpr int NVOX_IN = IZ * IY * IX;
+    static constexpr int LDS_FLOATS = NVOX_IN * 16;
+};
+
+// Stage one 16-channel chunk of the input brick (+halo) into LDS as [iz][iy][ix][16].
+template <int IZ, int IY, int IX, int NT>
+__device__ __forceinline__ void load_tile(float* lds, const float* __restrict__ x0, const float* __restrict__ x1,
+                                          int C0, int C1, int vec_in, int chunk, int b, int gz0, int gy0, int gx0,
+                                          int Di, int Hi, int Wi, int tid) {
+    constexpr int NQ = IZ * IY * IX * 4;
+    const int Cin = C0 + C1;
+    for (int q = tid; q < NQ; q += NT) {
+        const int vox = q >> 2, cq = q & 3;
+        const int ix = vox % IX, iy = (vox / IX) % IY, iz = vox / (IX * IY);
+        const int gz = gz0 + iz, gy = gy0 + iy, gx = gx0 + ix;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = chunk * 16 + cq * 4;
+        if ((unsigned)gz < (unsigned)Di && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi && c < Cin) {
+            const size_t gv = ((size_t)(b * Di + gz) * Hi + gy) * Wi + gx;
+            if (vec_in && c + 3 < Cin) {
+                const float* p = (c < C0) ? x0 + gv * C0 + c : x1 + gv * C1 + (c - C0);
+                v = *reinterpret_cast<const float4*>(p);
+            } else {
+                float e[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ck = c + k;
+                    e[k] = 0.f;
+                    if (ck < Cin) e[k] = (ck < C0) ? x0[gv * C0 + ck] : x1[gv * C1 + (ck - C0)];
+                }
+                v = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+        *reinterpret_cast<float4*>(lds + (size_t)vox * 16 + cq * 4) = v;
+    }
+}
+
+template <int KS, int STRIDE, int TZ, int TY, int TX, int WAVES, int MS, int NS, bool UP>
+__global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
+    using G = TileGeom<KS, STRIDE, TZ, TY, TX>;
+    static_assert(TZ * TY * TX == WAVES * MS * 16, "brick must be WAVES*MS 16-voxel subtiles");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, kk = lane >> 4;
+
+    const int nbrick = a.B * a.nbz * a.nby * a.nbx;
+    int brick = xcd_remap(blockIdx.x, nbrick);
+    const int bx = brick % a.nbx; brick /= a.nbx;
+    const int by = brick % a.nby; brick /= a.nby;
+    const int bz = brick % a.nbz; const int b = brick / a.nbz;
+    const int co0 = blockIdx.y * (NS * 16);
+    const int split = blockIdx.z;
+    const int c_begin = split * a.cps;
+    const int c_end = min(a.nchunks, c_begin + a.cps);
+
+    // per-lane LDS offsets of this wave's MS voxel subtiles (B operand: voxel = lane&15, k-group = lane>>4)
+    int boff[MS];
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+        const int v = (wave * MS + m) * 16 + i;
+        const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+        boff[m] = ((vz * STRIDE * G::IY + vy * STRIDE) * G::IX + vx * STRIDE) * 16 + kk * 4;
+    }
+
+    f32x4 acc[MS][NS];
+#pragma unroll
+    for (int m = 0; m < MS; ++m)
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int gz0 = bz * TZ * STRIDE - a.pad, gy0 = by * TY * STRIDE - a.pad, gx0 = bx * TX * STRIDE - a.pad;
+    const size_t tap_stride = (size_t)a.CQ * a.CoutP;   // float4 units
+
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        __syncthreads();
+        load_tile<G::IZ, G::IY, G::IX, WAVES * 64>(lds, a.x0, a.x1, a.C0, a.C1, a.vec_in, chunk, b, gz0, gy0, gx0,
+                                                   a.Di, a.Hi, a.Wi, tid);
+        __syncthreads();
+        const float4* wq = a.wp + ((size_t)(chunk * 4 + kk) * a.CoutP + co0 + i);
+        for (int dz = 0; dz < KS; ++dz) {
+            for (int dy = 0; dy < KS; ++dy) {
+                const float* lrow = lds + (dz * G::IY + dy) * G::IX * 16;
+                const float4* wrow = wq + (size_t)((dz * KS + dy) * KS) * tap_stride;
+#pragma unroll
+                for (int dx = 0; dx < KS; ++dx) {
+                    float4 wf[NS];
+#pragma unroll
+                    for (int n = 0; n < NS; ++n) wf[n] = wrow[dx * tap_stride + n * 16];
+                    float4 xf[MS];
+#pragma unroll
+                    for (int m = 0; m < MS; ++m) xf[m] = *reinterpret_cast<const float4*>(lrow + boff[m] + dx * 16);
+#pragma unroll
+                    for (int m = 0; m < MS; ++m)
+#pragma unroll
+                        for (int n = 0; n < NS; ++n) {
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].x, xf[m].x, acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].y, xf[m].y, acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].z, xf[m].z, acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].w, xf[m].w, acc[m][n], 0, 0, 0);
+                        }
+                }
+            }
+        }
+    }
+
+    // epilogue: lane holds cout = co0 + n*16 + 4*kk + {0..3} of voxel (m, i)
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+        const int v = (wave * MS + m) * 16 + i;
+        const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+        const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
+        if (UP) {
+            if (oz >= a.Di || oy >= a.Hi || ox >= a.Wi) continue;
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {
+                const int cop = co0 + n * 16 + kk * 4;          // index into N' = 8*O
+                if (cop >= 8 * a.upO) continue;
+                const int tap = cop / a.upO, o = cop - tap * a.upO;
+                const int zz = 2 * oz + (tap >> 2), yy = 2 * oy + ((tap >> 1) & 1), xx = 2 * ox + (tap & 1);
+                if (zz >= a.Do || yy >= a.Ho || xx >= a.Wo) continue;
+                const size_t ov = ((size_t)(b * a.Do + zz) * a.Ho + yy) * a.Wo + xx;
+                f32x4 r = acc[m][n];
+                if (a.bias) { r.x += a.bias[o]; r.y += a.bias[o + 1]; r.z += a.bias[o + 2]; r.w += a.bias[o + 3]; }
+                *reinterpret_cast<float4*>(a.y0 + ov * a.upO + o) = make_float4(r.x, r.y, r.z, r.w);
+            }
+        } else {
+            if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
+            const size_t ov = ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {
+                const int co = co0 + n * 16 + kk * 4;
+                f32x4 r = acc[m][n];
+                if (a.part) {
+                    *reinterpret_cast<float4*>(a.part + split * a.part_stride + ov * a.CoutP + co) =
+                        make_float4(r.x, r.y, r.z, r.w);
+                    continue;
+                }
+                if (co >= a.Cout) continue;
+                float e[4] = {r.x, r.y, r.z, r.w};
+                if (a.vec_out && co + 3 < a.Cout) {
+                    if (a.bias) { e[0] += a.bias[co]; e[1] += a.bias[co + 1]; e[2] += a.bias[co + 2]; e[3] += a.bias[co + 3]; }
+                    float* p = (co < a.Cy0) ? a.y0 + ov * a.Cy0 + co : a.y1 + ov * a.Cy1 + (co - a.Cy0);
+                    *reinterpret_cast<float4*>(p) = make_float4(e[0], e[1], e[2], e[3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int ck = co + k;
+                        if (ck >= a.Cout) break;
+                        const float val = e[k] + (a.bias ? a.bias[ck] : 0.f);
+                        if (ck < a.Cy0) a.y0[ov * a.Cy0 + ck] = val; else a.y1[ov * a.Cy1 + (ck - a.Cy0)] = val;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// y = sum_s part[s] + bias, scattered to the (possibly dual) NDHWC destination
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, size_t part_stride, int nsplit,
+                                     const float* __restrict__ bias, float* y0, float* y1, int Cy0, int Cy1,
+                                     int CoutP, size_t nvox) {
+    const int Cout = Cy0 + Cy1;
+    const size_t total = nvox * (size_t)Cout;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t v = idx / Cout; const int c = (int)(idx - v * Cout);
+        float s = bias ? bias[c] : 0.f;
+        for (int k = 0; k < nsplit; ++k) s += part[k * part_stride + v * CoutP + c];
+        if (c < Cy0) y0[v * Cy0 + c] = s; else y1[v * Cy1 + (c - Cy0)] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// filter gradient:  D[row = cout][col = cin] += A[cout][k = voxel] * B[voxel][cin(tap-shifted)]
+// A workgroup = 4 waves; wave w owns TW taps (all of the workgroup's NS*16 cout x 16 cin), so the
+// x tile in LDS is re-used by 4*TW taps and the dy tile by all of them.
+// ------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* x0; const float* x1; int C0, C1, Cin;
+    const float* dy; int Cout;
+    int B, Di, Hi, Wi, Do, Ho, Wo;
+    int CinP, CoutP, ncob;
+    int nbz, nby, nbx, nbrick, nsplit;
+    int pad, vec_in, vec_dy;
+    float* part;   // [split][tap][CinP][CoutP]
+};
+
+template <int KS, int STRIDE, int TZ, int TY, int TX, int NS, int TW>
+__global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
+    using G = TileGeom<KS, STRIDE, TZ, TY, TX>;
+    constexpr int NV = TZ * TY * TX;
+    constexpr int T3 = KS * KS * KS;
+    static_assert(TX % 4 == 0, "voxel groups are 4 consecutive x");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xt = lds;
+    float* dyt = lds + G::LDS_FLOATS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, kk = lane >> 4;
+    const int split = blockIdx.x;
+    const int chunk = blockIdx.y / a.ncob, cob = blockIdx.y - chunk * a.ncob;
+    const int co0 = cob * NS * 16;
+    const int tap0 = (blockIdx.z * 4 + wave) * TW;
+
+    int toff[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        int tap = tap0 + t;
+        tap = tap < T3 ? tap : 0;
+        const int dx = tap % KS, dy = (tap / KS) % KS, dz = tap / (KS * KS);
+        toff[t] = ((dz * G::IY + dy) * G::IX + dx) * 16;
+    }
+
+    f32x4 acc[TW][NS];
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int brick = split; brick < a.nbrick; brick += a.nsplit) {
+        int br = brick;
+        const int bx = br % a.nbx; br /= a.nbx;
+        const int by = br % a.nby; br /= a.nby;
+        const int bz = br % a.nbz; const int b = br / a.nbz;
+        __syncthreads();
+        load_tile<G::IZ, G::IY, G::IX, 256>(xt, a.x0, a.x1, a.C0, a.C1, a.vec_in, chunk, b,
+                                            bz * TZ * STRIDE - a.pad, by * TY * STRIDE - a.pad, bx * TX * STRIDE - a.pad,
+                                            a.Di, a.Hi, a.Wi, tid);
+        // dy tile [NV][NS*16]
+        for (int q = tid; q < NV * NS * 4; q += 256) {
+            const int v = q / (NS * 4), cq = q - v * (NS * 4);
+            const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+            const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
+            const int c = co0 + cq * 4;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout) {
+                const size_t ov = ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+                const float* p = a.dy + ov * a.Cout + c;
+                if (a.vec_dy && c + 3 < a.Cout) val = *reinterpret_cast<const float4*>(p);
+                else {
+                    float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (c + k < a.Cout) e[k] = p[k];
+                    val = make_float4(e[0], e[1], e[2], e[3]);
+                }
+            }
+            *reinterpret_cast<float4*>(dyt + (size_t)v * (NS * 16) + cq * 4) = val;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int g = 0; g < NV / 4; ++g) {
+            const int v = g * 4 + kk;
+            const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+            const float* xb = xt + ((vz * STRIDE * G::IY + vy * STRIDE) * G::IX + vx * STRIDE) * 16 + i;
+            float av[NS];
+#pragma unroll
+            for (int n = 0; n < NS; ++n) av[n] = dyt[v * (NS * 16) + n * 16 + i];
+#pragma unroll
+            for (int t = 0; t < TW; ++t) {
+                const float bv = xb[toff[t]];
+#pragma unroll
+                for (int n = 0; n < NS; ++n)
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[n], bv, acc[t][n], 0, 0, 0);
+            }
+        }
+    }
+    // lane holds dW[tap][ci = chunk*16 + i][co = co0 + n*16 + 4*kk + {0..3}]
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        const int tap = tap0 + t;
+        if (tap >= T3) continue;
+        float* dst = a.part + ((size_t)(split * T3 + tap) * a.CinP + chunk * 16 + i) * a.CoutP + co0 + kk * 4;
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            const f32x4 r = acc[t][n];
+            *reinterpret_cast<float4*>(dst + n * 16) = make_float4(r.x, r.y, r.z, r.w);
+        }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int T3, int CinP, int CoutP,
+                                    int Cin, int Cout, float* __restrict__ dw) {
+    const size_t total = (size_t)T3 * Cin * Cout;
+    const size_t sstride = (size_t)T3 * CinP * CoutP;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(idx % Cout);
+        const size_t r = idx / Cout;
+        const int ci = (int)(r % Cin), t = (int)(r / Cin);
+        const float* p = part + ((size_t)t * CinP + ci) * CoutP + co;
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += p[k * sstride];
+        dw[idx] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------
+__global__ void pack_kernel(int mode, const float* __restrict__ w, float* __restrict__ wp, int T, int I, int O,
+                            int CQ, int NP, size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(idx & 3);
+        size_t q = idx >> 2;
+        const int n = (int)(q % NP); q /= NP;
+        const int cq = (int)(q % CQ);
+        const int t = (int)(q / CQ);
+        const int k = cq * 4 + r;
+        float v = 0.f;
+        if (mode == VNET_PACK_FWD) {            // k = ci, n = co
+            if (k < I && n < O) v = w[((size_t)t * I + k) * O + n];
+        } else if (mode == VNET_PACK_BWD) {     // k = co_f, n = ci_f, flipped tap
+            if (k < O && n < I) v = w[((size_t)(T - 1 - t) * I + n) * O + k];
+        } else {                                // UP: w [8][O][I]; k = ci (I), n = a*O + o
+            if (k < I && n < 8 * O) v = w[(size_t)n * I + k];
+        }
+        wp[idx] = v;
+    }
+}
+
+void packed_dims(int mode, int T, int I, int O, int* Tp, int* CQ, int* NP) {
+    if (mode == VNET_PACK_FWD) { *Tp = T; *CQ = round_up(I, 16) / 4; *NP = round_up(O, 16); }
+    else if (mode == VNET_PACK_BWD) { *Tp = T; *CQ = round_up(O, 16) / 4; *NP = round_up(I, 16); }
+    else { *Tp = 1; *CQ = round_up(I, 16) / 4; *NP = round_up(8 * O, 16); }
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+int pick_ns(int CoutP) { return (CoutP % 64 == 0) ? 4 : (CoutP % 32 == 0) ? 2 : 1; }
+
+struct ConvPlan { int ns, ncob, nbz, nby, nbx, nsplit, cps, small; };
+
+template <int TZ, int TY, int TX>
+void brick_counts(int Do, int Ho, int Wo, ConvPlan& p) { p.nbz = ceil_div(Do, TZ); p.nby = ceil_div(Ho, TY); p.nbx = ceil_div(Wo, TX); }
+
+// brick shapes: "wide" for W >= 16, "cube" otherwise
+ConvPlan plan_conv(int ks, int stride, int up, int Cin, int Cout, int B, int Do, int Ho, int Wo, int gridW) {
+    ConvPlan p{};
+    const int CoutP = up ? round_up(8 * Cout, 16) : round_up(Cout, 16);
+    p.ns = pick_ns(CoutP);
+    p.ncob = CoutP / (16 * p.ns);
+    p.small = gridW < 16;
+    if (stride == 2 && !up) { if (p.small) brick_counts<2, 8, 8>(Do, Ho, Wo, p); else brick_counts<2, 4, 16>(Do, Ho, Wo, p); }
+    else { if (p.small) brick_counts<8, 8, 8>(Do, Ho, Wo, p); else brick_counts<4, 8, 16>(Do, Ho, Wo, p); }
+    const int nchunks = round_up(Cin, 16) / 16;
+    const int nwg = B * p.nbz * p.nby * p.nbx * p.ncob;
+    p.nsplit = 1;
+    if (!up && nwg < 256 && nchunks > 1) p.nsplit = min(nchunks, ceil_div(512, nwg));
+    p.cps = ceil_div(nchunks, p.nsplit);
+    p.nsplit = ceil_div(nchunks, p.cps);
+    return p;
+}
+
+template <int KS, int STRIDE, int TZ, int TY, int TX, int WAVES, int MS, bool UP>
+int launch_conv_ns(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
+    using G = TileGeom<KS, STRIDE, TZ, TY, TX>;
+    const size_t lds = (size_t)G::LDS_FLOATS * 4;
+    dim3 grid(a.B * p.nbz * p.nby * p.nbx, p.ncob, p.nsplit), block(WAVES * 64);
+    int e = 0;
+#define VNET_GO(NSV)                                                                              \
+    {                                                                                             \
+        auto k = conv_kernel<KS, STRIDE, TZ, TY, TX, WAVES, MS, NSV, UP>;                         \
+        static int attr_done = -1;                                                                \
+        if (attr_done != 0) attr_done = set_lds(k, lds);                                          \
+        if (attr_done != 0) return attr_done;                                                     \
+        hipLaunchKernelGGL(k, grid, block, lds, st, a);                                           \
+    }
+    if (p.ns == 4) VNET_GO(4) else if (p.ns == 2) VNET_GO(2) else VNET_GO(1)
+#undef VNET_GO
+    e = (int)hipGetLastError();
+    return e;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vnet_version(void) { return "vnet_hip 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
+
+size_t vnet_packed_weight_floats(int mode, int taps, int I, int O) {
+    int Tp, CQ, NP; packed_dims(mode, taps, I, O, &Tp, &CQ, &NP);
+    return (size_t)Tp * CQ * NP * 4;
+}
+
+int vnet_pack_weights(int mode, const float* w, float* wp, int taps, int I, int O, void* stream) {
+    if (!w || !wp || taps <= 0 || I <= 0 || O <= 0) return VNET_E_BADARG;
+    if (mode < 0 || mode > 2) return VNET_E_UNSUPPORTED;
+    if (mode == VNET_PACK_UP && (taps != 8 || (O & 3))) return VNET_E_UNSUPPORTED;
+    int Tp, CQ, NP; packed_dims(mode, taps, I, O, &Tp, &CQ, &NP);
+    const size_t total = (size_t)Tp * CQ * NP * 4;
+    const int blocks = (int)min((size_t)4096, (total + 255) / 256);
+    hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mode, w, wp, taps, I, O, CQ, NP, total);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+size_t vnet_conv_ws_bytes(int ks, int stride, int up, int Cin, int Cout, int B, int Do, int Ho, int Wo) {
+    const int gridW = up ? (Wo + 1) / 2 : Wo;
+    ConvPlan p = plan_conv(ks, stride, up, Cin, Cout, B, up ? (Do + 1) / 2 : Do, up ? (Ho + 1) / 2 : Ho, gridW, gridW);
+    if (p.nsplit <= 1) return 0;
+    return (size_t)p.nsplit * B * Do * Ho * Wo * round_up(Cout, 16) * sizeof(float);
+}
+
+int vnet_conv_fwd(int ks, int stride, int up, const float* x0, int C0, const float* x1, int C1,
+                  const float* wp, const float* bias, float* y0, int Cy0, float* y1, int Cy1,
+                  int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                  void* ws, size_t ws_bytes, void* stream) {
+    if (!x0 || !wp || !y0 || C0 <= 0 || Cy0 <= 0 || B <= 0) return VNET_E_BADARG;
+    if ((C1 > 0 && !x1) || (Cy1 > 0 && !y1) || C1 < 0 || Cy1 < 0) return VNET_E_BADARG;
+    if (Di <= 0 || Hi <= 0 || Wi <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return VNET_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    ConvArgs a{};
+    a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1;
+    a.wp = reinterpret_cast<const float4*>(wp); a.bias = bias;
+    a.y0 = y0; a.y1 = y1; a.Cy0 = Cy0; a.Cy1 = Cy1; a.Cout = Cy0 + Cy1;
+    a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
+    a.CQ = round_up(a.Cin, 16) / 4;
+    a.nchunks = a.CQ / 4;
+    a.vec_in = (C0 % 4 == 0) && (C1 % 4 == 0);
+    a.vec_out = (Cy0 % 4 == 0) && (Cy1 % 4 == 0);
+    a.part = nullptr; a.part_stride = 0; a.upO = 0;
+    const bool is5 = (ks == 5 && stride == 1 && !up), isdown = (ks == 2 && stride == 2 && !up), isup = (ks == 2 && stride == 2 && up);
+    if (!is5 && !isdown && !isup) return VNET_E_UNSUPPORTED;
+    if (isup) {
+        if (Cy1 != 0 || (Cy0 & 3)) return VNET_E_UNSUPPORTED;
+        a.CoutP = round_up(8 * Cy0, 16); a.upO = Cy0; a.pad = 0;
+    } else {
+        a.CoutP = round_up(a.Cout, 16); a.pad = is5 ? 2 : 0;
+    }
+    const int gD = isup ? Di : Do, gH = isup ? Hi : Ho, gW = isup ? Wi : Wo;
+    ConvPlan p = plan_conv(ks, stride, up, a.Cin, isup ? Cy0 : a.Cout, B, gD, gH, gW, gW);
+    a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.cps = p.cps;
+    const size_t nvox = (size_t)B * Do * Ho * Wo;
+    if (p.nsplit > 1) {
+        const size_t need = (size_t)p.nsplit * nvox * a.CoutP * sizeof(float);
+        if (!ws || ws_bytes < need) return VNET_E_WORKSPACE;
+        a.part = reinterpret_cast<float*>(ws); a.part_stride = nvox * a.CoutP;
+    }
+    int e;
+    if (is5) {
+        e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 16, 8, 4, false>(a, p, st);
+    } else if (isdown) {
+        e = p.small ? launch_conv_ns<2, 2, 2, 8, 8, 4, 2, false>(a, p, st) : launch_conv_ns<2, 2, 2, 4, 16, 4, 2, false>(a, p, st);
+    } else {
+        e = p.small ? launch_conv_ns<1, 1, 8, 8, 8, 8, 4, true>(a, p, st) : launch_conv_ns<1, 1, 4, 8, 16, 8, 4, true>(a, p, st);
+    }
+    if (e) return e;
+    if (p.nsplit > 1) {
+        const size_t total = nvox * a.Cout;
+        const int blocks = (int)min((size_t)2048, (total + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, a.part_stride, p.nsplit, bias,
+                           y0, y1, Cy0, Cy1, a.CoutP, nvox);
+        VNET_LAUNCH_CHECK();
+    }
+    return VNET_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// filter-gradient dispatch
+// ------------------------------------------------------------------------------------------
+namespace {
+struct WgradPlan { int ns, tw, ncob, ntg, nbz, nby, nbx, nbrick, nsplit, small; };
+
+WgradPlan plan_wgrad(int ks, int stride, int Cin, int Cout, int B, int Do, int Ho, int Wo) {
+    WgradPlan p{};
+    const int CoutP = round_up(Cout, 16);
+    p.ns = pick_ns(CoutP);
+    p.ncob = CoutP / (16 * p.ns);
+    p.small = Wo < 16;
+    const int T3 = ks * ks * ks;
+    if (ks == 5) {
+        p.tw = 32 / p.ns;
+        if (p.small) { p.nbz = ceil_div(Do, 4); p.nby = ceil_div(Ho, 8); p.nbx = ceil_div(Wo, 8); }
+        else if (p.ns == 1) { p.nbz = ceil_div(Do, 4); p.nby = ceil_div(Ho, 8); p.nbx = ceil_div(Wo, 16); }
+        else { p.nbz = ceil_div(Do, 4); p.nby = ceil_div(Ho, 4); p.nbx = ceil_div(Wo, 16); }
+    } else {  // ks == 2, stride 2: out brick 2x4x16 / 2x8x8
+        p.tw = 2;
+        if (p.small) { p.nbz = ceil_div(Do, 2); p.nby = ceil_div(Ho, 8); p.nbx = ceil_div(Wo, 8); }
+        else { p.nbz = ceil_div(Do, 2); p.nby = ceil_div(Ho, 4); p.nbx = ceil_div(Wo, 16); }
+    }
+    p.ntg = ceil_div(T3, 4 * p.tw);
+    p.nbrick = B * p.nbz * p.nby * p.nbx;
+    const int base = (round_up(Cin, 16) / 16) * p.ncob * p.ntg;
+    p.nsplit = max(1, min(p.nbrick, ceil_div(768, base)));
+    return p;
+}
+
+template <int KS, int STRIDE, int TZ, int TY, int TX, int NS, int TW>
+int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
+    using G = TileGeom<KS, STRIDE, TZ, TY, TX>;
+    const size_t lds = ((size_t)G::LDS_FLOATS + (size_t)TZ * TY * TX * NS * 16) * 4;
+    auto k = wgrad_kernel<KS, STRIDE, TZ, TY, TX, NS, TW>;
+    static int attr_done = -1;
+    if (attr_done != 0) attr_done = set_lds(k, lds);
+    if (attr_done != 0) return attr_done;
+    dim3 grid(p.nsplit, (a.CinP / 16) * p.ncob, p.ntg);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" {
+
+size_t vnet_wgrad_ws_bytes(int ks, int stride, int Cin, int Cout, int B, int Do, int Ho, int Wo) {
+    WgradPlan p = plan_wgrad(ks, stride, Cin, Cout, B, Do, Ho, Wo);
+    return (size_t)p.nsplit * ks * ks * ks * round_up(Cin, 16) * round_up(Cout, 16) * sizeof(float);
+}
+
+int vnet_conv_wgrad(int ks, int stride, const float* x0, int C0, const float* x1, int C1,
+                    const float* dy, int Cout, float* dw,
+                    int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                    void* ws, size_t ws_bytes, void* stream) {
+    if (!x0 || !dy || !dw || C0 <= 0 || Cout <= 0 || B <= 0 || C1 < 0 || (C1 > 0 && !x1)) return VNET_E_BADARG;
+    if (Di <= 0 || Hi <= 0 || Wi <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return VNET_E_BADARG;
+    if (!((ks == 5 && stride == 1) || (ks == 2 && stride == 2))) return VNET_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    WgradArgs a{};
+    a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.dy = dy; a.Cout = Cout;
+    a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
+    a.CinP = round_up(a.Cin, 16); a.CoutP = round_up(Cout, 16);
+    a.pad = ks == 5 ? 2 : 0;
+    a.vec_in = (C0 % 4 == 0) && (C1 % 4 == 0); a.vec_dy = (Cout % 4 == 0);
+    WgradPlan p = plan_wgrad(ks, stride, a.Cin, Cout, B, Do, Ho, Wo);
+    a.ncob = p.ncob; a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.nbrick = p.nbrick; a.nsplit = p.nsplit;
+    const int T3 = ks * ks * ks;
+    const size_t need = (size_t)p.nsplit * T3 * a.CinP * a.CoutP * sizeof(float);
+    if (!ws || ws_bytes < need) return VNET_E_WORKSPACE;
+    a.part = reinterpret_cast<float*>(ws);
+    int e;
+    if (ks == 5) {
+        if (p.small) {
+            e = p.ns == 4 ? launch_wgrad<5, 1, 4, 8, 8, 4, 8>(a, p, st) : p.ns == 2 ? launch_wgrad<5, 1, 4, 8, 8, 2, 16>(a, p, st)
+                                                                                     : launch_wgrad<5, 1, 4, 8, 8, 1, 32>(a, p, st);
+        } else {
+            e = p.ns == 4 ? launch_wgrad<5, 1, 4, 4, 16, 4, 8>(a, p, st) : p.ns == 2 ? launch_wgrad<5, 1, 4, 4, 16, 2, 16>(a, p, st)
+                                                                                      : launch_wgrad<5, 1, 4, 8, 16, 1, 32>(a, p, st);
+        }
+    } else {
+        if (p.small) {
+            e = p.ns == 4 ? launch_wgrad<2, 2, 2, 8, 8, 4, 2>(a, p, st) : p.ns == 2 ? launch_wgrad<2, 2, 2, 8, 8, 2, 2>(a, p, st)
+                                                                                     : launch_wgrad<2, 2, 2, 8, 8, 1, 2>(a, p, st);
+        } else {
+            e = p.ns == 4 ? launch_wgrad<2, 2, 2, 4, 16, 4, 2>(a, p, st) : p.ns == 2 ? launch_wgrad<2, 2, 2, 4, 16, 2, 2>(a, p, st)
+                                                                                      : launch_wgrad<2, 2, 2, 4, 16, 1, 2>(a, p, st);
+        }
+    }
+    if (e) return e;
+    const size_t total = (size_t)T3 * a.Cin * Cout;
+    const int blocks = (int)min((size_t)2048, (total + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, p.nsplit, T3, a.CinP, a.CoutP, a.Cin, Cout, dw);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1001 @@
+// elementwise.hip -- the HBM-bound part of the V-Net step on gfx950: train-mode batch-norm
+// (+ residual + tile + activation), fused softmax/Dice/cross-entropy head, 1x1x1 output conv,
+// bias-gradient column sums, dropout, optimiser apply ops and sliding-window accumulation.
+// Every kernel streams NDHWC rows with 16-byte accesses where the channel count allows, keeps
+// its reductions in registers -> wave shuffles -> LDS -> one partial row per workgroup, and a
+// tiny finalize kernel sums the partials in float64 (deterministic, no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+constexpr int EW_MAXBLK = 1024;   // partial rows per reduction
+constexpr int MAXC = 1024;
+
+inline int ew_blocks(size_t work_items) {
+    size_t b = (work_items + EW_BLOCK - 1) / EW_BLOCK;
+    if (b < 1) b = 1;
+    if (b > EW_MAXBLK) b = EW_MAXBLK;
+    return (int)b;
+}
+inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+__device__ __forceinline__ float act_fwd(float z, int act, float al) {
+    if (act == VNET_ACT_RELU) return fmaxf(z, 0.f);
+    if (act == VNET_ACT_PRELU) return fmaxf(z, 0.f) + al * fminf(z, 0.f);
+    if (act == VNET_ACT_LRELU) return z > 0.f ? z : 0.2f * z;
+    return z;
+}
+// TF tie rule: gradient of max(0,x)/min(0,x) at x==0 goes to the constant -> 0
+__device__ __forceinline__ float act_grad(float z, int act, float al) {
+    if (act == VNET_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+    if (act == VNET_ACT_PRELU) return z > 0.f ? 1.f : (z < 0.f ? al : 0.f);
+    if (act == VNET_ACT_LRELU) return z > 0.f ? 1.f : 0.2f;
+    return 1.f;
+}
+
+// ---------------------------------------------------------------------------------------
+// column reductions over rows of an [M][C] tensor.  NACC accumulators per channel.
+// The functor F(row-major element index, channel, values...) is inlined per kernel below.
+// ---------------------------------------------------------------------------------------
+
+// block-level reduction of per-thread float4 accumulators for threads sharing (tid % CQ)
+template <int NACC>
+__device__ __forceinline__ void block_reduce_vec(float4 (&acc)[NACC], int CQ, int C, float* __restrict__ prow) {
+    __shared__ float4 sh[EW_BLOCK];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+        __syncthreads();
+        sh[tid] = acc[a];
+        __syncthreads();
+        for (int off = EW_BLOCK / 2; off >= CQ; off >>= 1) {
+            if (tid < off) {
+                float4 o = sh[tid + off];
+                sh[tid].x += o.x; sh[tid].y += o.y; sh[tid].z += o.z; sh[tid].w += o.w;
+            }
+            __syncthreads();
+        }
+        if (tid < CQ) *reinterpret_cast<float4*>(prow + a * C + tid * 4) = sh[tid];
+    }
+}
+
+// block-level reduction for the row path (every thread holds all C<=8 channels)
+template <int NACC, int CMAX>
+__device__ __forceinline__ void block_reduce_row(float (&acc)[NACC][CMAX], int C, float* __restrict__ prow) {
+    __shared__ float sh[4][NACC * CMAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            const float s = wave_sum(acc[a][c]);
+            if (lane == 0) sh[wave][a * CMAX + c] = s;
+        }
+    __syncthreads();
+    if (threadIdx.x < NACC * CMAX) {
+        const int a = threadIdx.x / CMAX, c = threadIdx.x % CMAX;
+        if (c < C) prow[a * C + c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    }
+}
+
+// ---- BN statistics -----------------------------------------------------------------------
+__global__ void __launch_bounds__(EW_BLOCK) bn_stats_vec_kernel(const float4* __restrict__ x, const float4* __restrict__ r,
+                                                                size_t nq, int CQ, float* __restrict__ partial) {
+    float4 acc[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    const size_t stride = (size_t)gridDim.x * EW_BLOCK;
+    for (size_t idx = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x; idx < nq; idx += stride) {
+        float4 v = x[idx];
+        if (r) { const float4 t = r[idx]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+        acc[1].x += v.x * v.x; acc[1].y += v.y * v.y; acc[1].z += v.z * v.z; acc[1].w += v.w * v.w;
+    }
+    block_reduce_vec<2>(acc, CQ, CQ * 4, partial + (size_t)blockIdx.x * 2 * CQ * 4);
+}
+
+__global__ void __launch_bounds__(EW_BLOCK) bn_stats_row_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                                size_t M, int C, float* __restrict__ partial) {
+    float acc[2][8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[0][c] = acc[1][c] = 0.f;
+    const size_t stride = (size_t)gridDim.x * EW_BLOCK;
+    for (size_t row = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x; row < M; row += stride) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < C) {
+                float v = x[row * C + c];
+                if (r) v += r[row * C + c];
+                acc[0][c] += v; acc[1][c] += v * v;
+            }
+    }
+    block_reduce_row<2, 8>(acc, C, partial + (size_t)blockIdx.x * 2 * C);
+}
+
+__global__ void __launch_bounds__(EW_BLOCK) bn_stats_generic_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                                    size_t n, int C, float* __restrict__ partial) {
+    __shared__ float sh[2 * MAXC];
+    for (int c = threadIdx.x; c < 2 * C; c += EW_BLOCK) sh[c] = 0.f;
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * EW_BLOCK;
+    for (size_t idx = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x; idx < n; idx += stride) {
+        float v = x[idx];
+        if (r) v += r[idx];
+        const int c = (int)(idx % C);
+        atomicAdd(&sh[c], v); atomicAdd(&sh[C + c], v * v);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += EW_BLOCK) partial[(size_t)blockIdx.x * 2 * C + c] = sh[c];
+}
+
+// sums NACC partial rows in float64; mode 0: BN stats finalize, 1: plain sums to out[a][C]
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int Cs, int C, double M, float eps,
+                                   float momentum, float* mean, float* invstd, float* mm, float* mv) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        const int cs = (Cs == 1) ? 0 : c;
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < nblk; ++b) {
+            s += (double)partial[(size_t)b * 2 * Cs + cs];
+            q += (double)partial[(size_t)b * 2 * Cs + Cs + cs];
+        }
+        const double mu = s / M;
+        double var = q / M - mu * mu;
+        var = var > 0.0 ? var : 0.0;
+        mean[c] = (float)mu;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (mm) mm[c] = mm[c] - (mm[c] - (float)mu) * (1.f - momentum);
+        if (mv) mv[c] = mv[c] - (mv[c] - (float)var) * (1.f - momentum);
+    }
+}
+
+__global__ void sum_finalize_kernel(const float* __restrict__ partial, int nblk, int nacc, int C,
+                                    float* o0, float* o1, float* o2) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        for (int a = 0; a < nacc; ++a) {
+            float* o = a == 0 ? o0 : (a == 1 ? o1 : o2);
+            if (!o) continue;
+            double s = 0.0;
+            for (int b = 0; b < nblk; ++b) s += (double)partial[((size_t)b * nacc + a) * C + c];
+            o[c] = (float)s;
+        }
+    }
+}
+
+// ---- BN apply (+residual, +tile broadcast, +activation) -------------------------------------
+struct BnP {
+    const float* x; const float* r; const float* dy;
+    const float* mean; const float* invstd; const float* gamma; const float* beta; const float* alpha;
+    const float* dgamma; const float* dbeta;
+    float* out; float* partial;
+    size_t M; int C; int bcast; int act; float invM; int identity;
+};
+
+__device__ __forceinline__ void bn_load_coef(const BnP& p, float* sc, float* sf, float* al) {
+    for (int c = threadIdx.x; c < p.C; c += EW_BLOCK) {
+        const float s = p.identity ? 1.f : p.gamma[c] * p.invstd[c];
+        sc[c] = s; sf[c] = p.identity ? 0.f : p.beta[c] - p.mean[c] * s;
+        al[c] = (p.act == VNET_ACT_PRELU) ? p.alpha[c] : 0.f;
+    }
+    __syncthreads();
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(EW_BLOCK) bn_act_fwd_kernel(BnP p) {
+    __shared__ float sc[MAXC], sf[MAXC], al[MAXC];
+    bn_load_coef(p, sc, sf, al);
+    const size_t stride = (size_t)gridDim.x * EW_BLOCK;
+    const size_t start = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (VEC) {
+        const int CQ = p.C >> 2;
+        const size_t nq = p.M * CQ;
+        for (size_t idx = start; idx < nq; idx += stride) {
+            const int c = (int)(idx % CQ) * 4;
+            float4 v;
+            if (p.bcast) { const float t = p.x[idx / CQ]; v = make_float4(t, t, t, t); }
+            else v = reinterpret_cast<const float4*>(p.x)[idx];
+            if (p.r) { const float4 t = reinterpret_cast<const float4*>(p.r)[idx]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            float4 o;
+            o.x = act_fwd(v.x * sc[c] + sf[c], p.act, al[c]);
+            o.y = act_fwd(v.y * sc[c + 1] + sf[c + 1], p.act, al[c + 1]);
+            o.z = act_fwd(v.z * sc[c + 2] + sf[c + 2], p.act, al[c + 2]);
+            o.w = act_fwd(v.w * sc[c + 3] + sf[c + 3], p.act, al[c + 3]);
+            reinterpret_cast<float4*>(p.out)[idx] = o;
+        }
+    } else {
+        const size_t n = p.M * p.C;
+        for (size_t idx = start; idx < n; idx += stride) {
+            const int c = (int)(idx % p.C);
+            float v = p.bcast ? p.x[idx / p.C] : p.x[idx];
+            if (p.r) v += p.r[idx];
+            p.out[idx] = act_fwd(v * sc[c] + sf[c], p.act, al[c]);
+        }
+    }
+}
+
+// backward pass 1: per-channel sums of dz, dz*xhat, dy*min(0,z)
+template <int MODE>   // 0 = vec (C%4==0, C/4 pow2 <= 256), 1 = row (C<=8), 2 = generic
+__global__ void __launch_bounds__(EW_BLOCK) bn_act_bwd_reduce_kernel(BnP p) {
+    __shared__ float sc[MAXC], sf[MAXC], al[MAXC];
+    bn_load_coef(p, sc, sf, al);
+    const size_t stride = (size_t)gridDim.x * EW_BLOCK;
+    const size_t start = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x;
+    const int C = p.C;
+    if (MODE == 0) {
+        const int CQ = C >> 2;
+        const size_t nq = p.M * CQ;
+        float4 acc[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+        const int c = (int)(start % CQ) * 4;      // fixed per thread (grid*256 % CQ == 0)
+        for (size_t idx = start; idx < nq; idx += stride) {
+            float4 v;
+            if (p.bcast) { const float t = p.x[idx / CQ]; v = make_float4(t, t, t, t); }
+            else v = reinterpret_cast<const float4*>(p.x)[idx];
+            if (p.r) { const float4 t = reinterpret_cast<const float4*>(p.r)[idx]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            const float4 g = reinterpret_cast<const float4*>(p.dy)[idx];
+            const float vv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
+            float a0[4], a1[4], a2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float z = vv[k] * sc[c + k] + sf[c + k];
+                const float dz = gg[k] * act_grad(z, p.act, al[c + k]);
+                const float xh = p.identity ? 0.f : (vv[k] - p.mean[c + k]) * p.invstd[c + k];
+                a0[k] = dz; a1[k] = dz * xh; a2[k] = gg[k] * fminf(z, 0.f);
+            }
+            acc[0].x += a0[0]; acc[0].y += a0[1]; acc[0].z += a0[2]; acc[0].w += a0[3];
+            acc[1].x += a1[0]; acc[1].y += a1[1]; acc[1].z += a1[2]; acc[1].w += a1[3];
+            acc[2].x += a2[0]; acc[2].y += a2[1]; acc[2].z += a2[2]; acc[2].w += a2[3];
+        }
+        block_reduce_vec<3>(acc, CQ, C, p.partial + (size_t)blockIdx.x * 3 * C);
+    } else if (MODE == 1) {
+        float acc[3][8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[0][c] = acc[1][c] = acc[2][c] = 0.f;
+        for (size_t row = start; row < p.M; row += stride) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < C) {
+                    float v = p.bcast ? p.x[row] : p.x[row * C + c];
+                    if (p.r) v += p.r[row * C + c];
+                    const float g = p.dy[row * C + c];
+                    const float z = v * sc[c] + sf[c];
+                    const float dz = g * act_grad(z, p.act, al[c]);
+                    acc[0][c] += dz; acc[1][c] += p.identity ? 0.f : dz * (v - p.mean[c]) * p.invstd[c]; acc[2][c] += g * fminf(z, 0.f);
+                }
+        }
+        block_reduce_row<3, 8>(acc, C, p.partial + (size_t)blockIdx.x * 3 * C);
+    } else {
+        __shared__ float sh[3 * MAXC];
+        for (int c = threadIdx.x; c < 3 * C; c += EW_BLOCK) sh[c] = 0.f;
+        __syncthreads();
+        const size_t n = p.M * C;
+        for (size_t idx = start; idx < n; idx += stride) {
+            const int c = (int)(idx % C);
+            float v = p.bcast ? p.x[idx / C] : p.x[idx];
+            if (p.r) v += p.r[idx];
+            const float g = p.dy[idx];
+            const float z = v * sc[c] + sf[c];
+            const float dz = g * act_grad(z, p.act, al[c]);
+            atomicAdd(&sh[c], dz); atomicAdd(&sh[C + c], p.identity ? 0.f : dz * (v - p.mean[c]) * p.invstd[c]);
+            atomicAdd(&sh[2 * C + c], g * fminf(z, 0.f));
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < 3 * C; c += EW_BLOCK) p.partial[(size_t)blockIdx.x * 3 * C + c] = sh[c];
+    }
+}
+
+// backward pass 2: ds = gamma*invstd*(dz - dbeta/M - xhat*dgamma/M)
+template <bool VEC>
+__global__ void __launch_bounds__(EW_BLOCK) bn_act_bwd_apply_kernel(BnP p) {
+    __shared__ float sc[MAXC], sf[MAXC], al[MAXC], k1[MAXC], k2[MAXC], mu[MAXC], is[MAXC];
+    bn_load_coef(p, sc, sf, al);
+    for (int c = threadIdx.x; c < p.C; c += EW_BLOCK) {
+        if (p.identity) { k1[c] = 0.f; k2[c] = 0.f; mu[c] = 0.f; is[c] = 1.f; }
+        else { k1[c] = p.dbeta[c] * p.invM; k2[c] = p.dgamma[c] * p.invM; mu[c] = p.mean[c]; is[c] = p.invstd[c]; }
+    }
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * EW_BLOCK;
+    const size_t start = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x;
+    if (VEC) {
+        const int CQ = p.C >> 2;
+        const size_t nq = p.M * CQ;
+        for (size_t idx = start; idx < nq; idx += stride) {
+            const int c = (int)(idx % CQ) * 4;
+            float4 v;
+            if (p.bcast) { const float t = p.x[idx / CQ]; v = make_float4(t, t, t, t); }
+            else v = reinterpret_cast<const float4*>(p.x)[idx];
+            if (p.r) { const float4 t = reinterpret_cast<const float4*>(p.r)[idx]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            const float4 g = reinterpret_cast<const float4*>(p.dy)[idx];
+            const float vv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float z = vv[k] * sc[c + k] + sf[c + k];
+                const float dz = gg[k] * act_grad(z, p.act, al[c + k]);
+                const float xh = (vv[k] - mu[c + k]) * is[c + k];
+                o[k] = sc[c + k] * (dz - k1[c + k] - xh * k2[c + k]);
+            }
+            reinterpret_cast<float4*>(p.out)[idx] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    } else {
+        const size_t n = p.M * p.C;
+        for (size_t idx = start; idx < n; idx += stride) {
+            const int c = (int)(idx % p.C);
+            float v = p.bcast ? p.x[idx / p.C] : p.x[idx];
+            if (p.r) v += p.r[idx];
+            const float z = v * sc[c] + sf[c];
+            const float dz = p.dy[idx] * act_grad(z, p.act, al[c]);
+            p.out[idx] = sc[c] * (dz - k1[c] - (v - mu[c]) * is[c] * k2[c]);
+        }
+    }
+}
+
+// pick grid so that (grid*256) % CQ == 0 holds trivially (CQ pow2 <= 256)
+inline int red_mode(int C) {
+    if (C % 4 == 0 && is_pow2(C / 4) && C / 4 <= EW_BLOCK) return 0;
+    if (C <= 8) return 1;
+    return 2;
+}
+
+// ---- column sums (bias gradient) ----------------------------------------------------------
+__global__ void __launch_bounds__(EW_BLOCK) colsum_vec_kernel(const float4* __restrict__ x, size_t nq, int CQ, float* __restrict__ partial) {
+    float4 acc[1] = {make_float4(0, 0, 0, 0)};
+    const size_t stride = (size_t)gridDim.x * EW_BLOCK;
+    for (size_t idx = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x; idx < nq; idx += stride) {
+        const float4 v = x[idx];
+        acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+    }
+    block_reduce_vec<1>(acc, CQ, CQ * 4, partial + (size_t)blockIdx.x * CQ * 4);
+}
+__global__ void __launch_bounds__(EW_BLOCK) colsum_generic_kernel(const float* __restrict__ x, size_t n, int C, float* __restrict__ partial) {
+    __shared__ float sh[MAXC];
+    for (int c = threadIdx.x; c < C; c += EW_BLOCK) sh[c] = 0.f;
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * EW_BLOCK;
+    for (size_t idx = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x; idx < n; idx += stride) atomicAdd(&sh[idx % C], x[idx]);
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += EW_BLOCK) partial[(size_t)blockIdx.x * C + c] = sh[c];
+}
+
+// ---- 1x1x1 output head (C -> K<=8) ----------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(EW_BLOCK) head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ y, size_t M, int C) {
+    __shared__ float ws[MAXC * 8 / 8];   // C*K <= 1024
+    for (int t = threadIdx.x; t < C * K; t += EW_BLOCK) ws[t] = w[t];
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * EW_BLOCK;
+    for (size_t row = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x; row < M; row += stride) {
+        float o[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) o[k] = bias ? bias[k] : 0.f;
+        const float* xr = x + row * C;
+        if ((C & 3) == 0) {
+            for (int c = 0; c < C; c += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(xr + c);
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    o[k] += v.x * ws[c * K + k] + v.y * ws[(c + 1) * K + k] + v.z * ws[(c + 2) * K + k] + v.w * ws[(c + 3) * K + k];
+            }
+        } else {
+            for (int c = 0; c < C; ++c) {
+                const float v = xr[c];
+#pragma unroll
+                for (int k = 0; k < K; ++k) o[k] += v * ws[c * K + k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) y[row * K + k] = o[k];
+    }
+}
+
+// backward: dx[row][c] = sum_k dy[row][k] w[c][k];  dw[c][k] = sum_rows x*dy;  db[k] = sum dy
+// one thread per (row, channel quad); partial[block][C*K + K]
+template <int K>
+__global__ void __launch_bounds__(EW_BLOCK) head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ dy, float* __restrict__ dx,
+                                                            size_t M, int C, float* __restrict__ partial) {
+    __shared__ float ws[1024];
+    __shared__ float red[EW_BLOCK];
+    for (int t = threadIdx.x; t < C * K; t += EW_BLOCK) ws[t] = w[t];
+    __syncthreads();
+    const int CQ = C >> 2;
+    const size_t nq = M * CQ;
+    const size_t stride = (size_t)gridDim.x * EW_BLOCK;
+    const size_t start = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x;
+    const int cq = (int)(start % CQ), c0 = cq * 4;     // fixed per thread (CQ pow2 <= 256)
+    float aw[4][K], ab[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { ab[k] = 0.f; aw[0][k] = aw[1][k] = aw[2][k] = aw[3][k] = 0.f; }
+    for (size_t idx = start; idx < nq; idx += stride) {
+        const size_t row = idx / CQ;
+        const float4 v = reinterpret_cast<const float4*>(x)[idx];
+        float g[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) g[k] = dy[row * K + k];
+        float4 o = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            o.x += g[k] * ws[c0 * K + k]; o.y += g[k] * ws[(c0 + 1) * K + k];
+            o.z += g[k] * ws[(c0 + 2) * K + k]; o.w += g[k] * ws[(c0 + 3) * K + k];
+            aw[0][k] += v.x * g[k]; aw[1][k] += v.y * g[k]; aw[2][k] += v.z * g[k]; aw[3][k] += v.w * g[k];
+            if (cq == 0) ab[k] += g[k];
+        }
+        if (dx) reinterpret_cast<float4*>(dx)[idx] = o;
+    }
+    float* prow = partial + (size_t)blockIdx.x * (C * K + K);
+    // reduce across threads with equal cq, one scalar at a time (4K+K values; tiny)
+    for (int s = 0; s < 5 * K; ++s) {
+        const int j = s / K, k = s % K;
+        __syncthreads();
+        red[threadIdx.x] = (j < 4) ? aw[j][k] : ab[k];
+        __syncthreads();
+        for (int off = EW_BLOCK / 2; off >= CQ; off >>= 1) {
+            if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (j < 4) { if (threadIdx.x < CQ) prow[(threadIdx.x * 4 + j) * K + k] = red[threadIdx.x]; }
+        else if (threadIdx.x == 0) prow[C * K + k] = red[0];
+    }
+}
+
+// ---- fused softmax + Dice / cross-entropy ------------------------------------------------------
+struct LossP {
+    const float* logits; const int32_t* labels; const float* weights;
+    float* softmax_out; long long* pred_out; float* partial;
+    size_t V; int B; int K; int kind; int nblk;
+};
+
+template <int K>
+__global__ void __launch_bounds__(EW_BLOCK) softmax_dice_fwd_kernel(LossP p) {
+    const int b = blockIdx.y;
+    const bool jac = (p.kind & 15) == VNET_LOSS_JACCARD;
+    const bool wx = (p.kind & VNET_LOSS_WEIGHTED) && p.weights;
+    float aI[K], aL[K], aR[K], aX = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) aI[k] = aL[k] = aR[k] = 0.f;
+    const float* lg = p.logits + (size_t)b * p.V * K;
+    const int32_t* lb = p.labels + (size_t)b * p.V;
+    const size_t stride = (size_t)gridDim.x * EW_BLOCK;
+    for (size_t v = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x; v < p.V; v += stride) {
+        float z[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) z[k] = lg[v * K + k];
+        float mx = z[0]; int am = 0;
+#pragma unroll
+        for (int k = 1; k < K; ++k) if (z[k] > mx) { mx = z[k]; am = k; }
+        float e[K], se = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { e[k] = expf(z[k] - mx); se += e[k]; }
+        const float inv = 1.f / se;
+        const int lab = lb[v];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float pk = e[k] * inv;
+            const float t = (lab == k) ? 1.f : 0.f;
+            aI[k] += pk * t; aL[k] += jac ? pk * pk : pk; aR[k] += t;
+            if (p.softmax_out) p.softmax_out[((size_t)b * p.V + v) * K + k] = pk;
+            if (lab == k) aX += (wx ? p.weights[k] : 1.f) * (logf(se) - (z[k] - mx));
+        }
+        if (p.pred_out) p.pred_out[(size_t)b * p.V + v] = am;
+    }
+    // block reduce 3K+1 values
+    __shared__ float sh[4][3 * K + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float s0 = wave_sum(aI[k]), s1 = wave_sum(aL[k]), s2 = wave_sum(aR[k]);
+        if (lane == 0) { sh[wave][k] = s0; sh[wave][K + k] = s1; sh[wave][2 * K + k] = s2; }
+    }
+    { const float s = wave_sum(aX); if (lane == 0) sh[wave][3 * K] = s; }
+    __syncthreads();
+    if (threadIdx.x < 3 * K + 1)
+        p.partial[((size_t)b * gridDim.x + blockIdx.x) * (3 * K + 1) + threadIdx.x] =
+            sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+// one block: sums partials in float64, evaluates the loss switch (model.py:495-558), stores
+// coef[b][k][0] = dloss/dI, coef[b][k][1] = dloss/dL, coef[2BK] = xent coefficient (per voxel)
+__global__ void loss_finalize_kernel(const float* __restrict__ partial, int nblk, int B, int K, double V, int kind,
+                                     const float* __restrict__ weights, float alpha, float smooth,
+                                     float* loss_out, float* dice_out, float* coef) {
+    __shared__ double sI[64], sL[64], sR[64], sX[8];
+    const int tid = threadIdx.x;
+    const int NS = 3 * K + 1;
+    for (int t = tid; t < B * K; t += blockDim.x) {
+        const int b = t / K, k = t % K;
+        double I = 0, L = 0, R = 0;
+        for (int j = 0; j < nblk; ++j) {
+            const float* pr = partial + ((size_t)b * nblk + j) * NS;
+            I += pr[k]; L += pr[K + k]; R += pr[2 * K + k];
+        }
+        sI[t] = I; sL[t] = L; sR[t] = R;
+    }
+    if (tid < B) {
+        double X = 0;
+        for (int j = 0; j < nblk; ++j) X += partial[((size_t)tid * nblk + j) * NS + 3 * K];
+        sX[tid] = X;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    const int base = kind & 15;
+    const bool weighted = (kind & VNET_LOSS_WEIGHTED) != 0, mixed = (kind & VNET_LOSS_MIXED) != 0;
+    double xsum = 0; for (int b = 0; b < B; ++b) xsum += sX[b];
+    const double xent = xsum / (V * B);
+    double loss = 0, dice = 0;
+    double xc = 0;
+    if (base == VNET_LOSS_XENT) {
+        loss = xent; xc = 1.0 / (V * B);
+        for (int t = 0; t < 2 * B * K; ++t) coef[t] = 0.f;
+    } else {
+        if (weighted && weights) {
+            for (int b = 0; b < B; ++b) {
+                double num = 0, den = 0;
+                for (int k = 0; k < K; ++k) {
+                    num += 2.0 * weights[k] * sI[b * K + k] + smooth;
+                    den += weights[k] * (sL[b * K + k] + sR[b * K + k]) + smooth;
+                }
+                dice += num / den / B;
+                for (int k = 0; k < K; ++k) {
+                    coef[(b * K + k) * 2 + 0] = (float)(-2.0 * weights[k] / den / B);
+                    coef[(b * K + k) * 2 + 1] = (float)(num / (den * den) * weights[k] / B);
+                }
+            }
+        } else {
+            for (int t = 0; t < B * K; ++t) {
+                const double den = sL[t] + sR[t] + smooth, num = 2.0 * sI[t] + smooth;
+                dice += num / den / (B * K);
+                coef[t * 2 + 0] = (float)(-2.0 / den / (B * K));
+                coef[t * 2 + 1] = (float)(num / (den * den) / (B * K));
+            }
+        }
+        loss = 1.0 - dice;
+        if (mixed) { loss += alpha * xent; xc = alpha / (V * B); }
+    }
+    coef[2 * B * K] = (float)xc;
+    *loss_out = (float)loss;
+    if (dice_out) *dice_out = (float)dice;
+}
+
+template <int K>
+__global__ void __launch_bounds__(EW_BLOCK) softmax_dice_bwd_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                                    size_t V, int kind, const float* __restrict__ weights,
+                                                                    const float* __restrict__ coef, int B,
+                                                                    const float* __restrict__ gscale, float* __restrict__ dlogits) {
+    const int b = blockIdx.y;
+    const bool jac = (kind & 15) == VNET_LOSS_JACCARD;
+    const bool wx = (kind & VNET_LOSS_WEIGHTED) && weights;
+    const float gs = gscale ? *gscale : 1.f;
+    float gI[K], gL[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { gI[k] = coef[(b * K + k) * 2] * gs; gL[k] = coef[(b * K + k) * 2 + 1] * gs; }
+    const float xc = coef[2 * B * K] * gs;
+    const float* lg = logits + (size_t)b * V * K;
+    float* dl = dlogits + (size_t)b * V * K;
+    const int32_t* lb = labels + (size_t)b * V;
+    const size_t stride = (size_t)gridDim.x * EW_BLOCK;
+    for (size_t v = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x; v < V; v += stride) {
+        float z[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) z[k] = lg[v * K + k];
+        float mx = z[0];
+#pragma unroll
+        for (int k = 1; k < K; ++k) mx = fmaxf(mx, z[k]);
+        float pk[K], se = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { pk[k] = expf(z[k] - mx); se += pk[k]; }
+        const float inv = 1.f / se;
+        const int lab = lb[v];
+        float g[K], dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            pk[k] *= inv;
+            const float t = (lab == k) ? 1.f : 0.f;
+            g[k] = gI[k] * t + gL[k] * (jac ? 2.f * pk[k] : 1.f);
+            dot += g[k] * pk[k];
+        }
+        const bool has = lab >= 0 && lab < K;
+        const float wv = has ? (wx ? weights[lab] : 1.f) : 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float t = (lab == k) ? 1.f : 0.f;
+            dl[v * K + k] = pk[k] * (g[k] - dot) + xc * wv * (pk[k] - t);
+        }
+    }
+}
+
+// ---- stand-alone dice_coe(output, target) on probability / one-hot tensors (model.py:26-85) -------
+template <int K>
+__global__ void __launch_bounds__(EW_BLOCK) dice_sums_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                             size_t V, int jac, float* __restrict__ partial) {
+    const int b = blockIdx.y;
+    float aI[K], aL[K], aR[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) aI[k] = aL[k] = aR[k] = 0.f;
+    const float* po = out + (size_t)b * V * K;
+    const float* pt = tgt + (size_t)b * V * K;
+    const size_t stride = (size_t)gridDim.x * EW_BLOCK;
+    for (size_t v = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x; v < V; v += stride) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float p = po[v * K + k], t = pt[v * K + k];
+            aI[k] += p * t; aL[k] += jac ? p * p : p; aR[k] += jac ? t * t : t;
+        }
+    }
+    __shared__ float sh[4][3 * K + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float s0 = wave_sum(aI[k]), s1 = wave_sum(aL[k]), s2 = wave_sum(aR[k]);
+        if (lane == 0) { sh[wave][k] = s0; sh[wave][K + k] = s1; sh[wave][2 * K + k] = s2; }
+    }
+    if (lane == 0) sh[wave][3 * K] = 0.f;
+    __syncthreads();
+    if (threadIdx.x < 3 * K + 1)
+        partial[((size_t)b * gridDim.x + blockIdx.x) * (3 * K + 1) + threadIdx.x] =
+            sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+// d dice / d output = -(dloss/dI * t + dloss/dL * (1 | 2p)) * gscale   (coef holds d(1-dice))
+__global__ void dice_grad_kernel(const float* __restrict__ out, const float* __restrict__ tgt, size_t V, int K, int jac,
+                                 const float* __restrict__ coef, const float* __restrict__ gscale, float* __restrict__ dout) {
+    const int b = blockIdx.y;
+    const float gs = gscale ? *gscale : 1.f;
+    const size_t n = V * K, base = (size_t)b * n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const float gI = coef[(b * K + k) * 2], gL = coef[(b * K + k) * 2 + 1];
+        const float p = out[base + i], t = tgt[base + i];
+        dout[base + i] = -gs * (gI * t + gL * (jac ? 2.f * p : 1.f));
+    }
+}
+
+// ---- dropout -----------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return (uint32_t)x;
+}
+__global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ mask,
+                                   size_t n, float rate, uint64_t seed) {
+    const float sc = 1.f / (1.f - rate);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float u = (mix32(seed * 0x9E3779B97F4A7C15ULL + i) >> 8) * (1.f / 16777216.f);
+        const uint8_t keep = u >= rate;
+        mask[i] = keep; y[i] = keep ? x[i] * sc : 0.f;
+    }
+}
+__global__ void dropout_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask, float* __restrict__ dx, size_t n, float rate) {
+    const float sc = 1.f / (1.f - rate);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dx[i] = mask[i] ? dy[i] * sc : 0.f;
+}
+
+// ---- optimisers ----------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            size_t n, float lr_t, float b1, float b2, float eps, float gs) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gs;
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+        const float vi = v[i] + (gi * gi - v[i]) * (1.f - b2);
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, size_t n, float lr, float gs) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] -= lr * gs * g[i];
+}
+__global__ void momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ acc, size_t n,
+                                float lr, float mom, int nesterov, float gs) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gs;
+        const float a = acc[i] * mom + gi;
+        acc[i] = a;
+        p[i] -= nesterov ? lr * (gi + mom * a) : lr * a;
+    }
+}
+
+// ---- sliding-window accumulation ------------------------------------------------------------------
+__global__ void accumulate_patch_kernel(const float* __restrict__ patch, float* __restrict__ vol, float* __restrict__ cnt, int K,
+                                        int pz, int py, int px, int z0, int y0, int x0, int D, int H, int W) {
+    const size_t n = (size_t)pz * py * px;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % px), y = (int)((i / px) % py), z = (int)(i / ((size_t)px * py));
+        const int gz = z0 + z, gy = y0 + y, gx = x0 + x;
+        if (gz >= D || gy >= H || gx >= W) continue;
+        const size_t gv = ((size_t)gz * H + gy) * W + gx;
+        for (int k = 0; k < K; ++k) vol[gv * K + k] += patch[i * K + k];
+        if (cnt) cnt[gv] += 1.f;
+    }
+}
+
+__global__ void head_finalize_kernel(const float* __restrict__ partial, int nblk, int CK, int K, float* dw, float* db) {
+    const int n = CK + K;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * n + c];
+        if (c < CK) dw[c] = (float)s; else db[c - CK] = (float)s;
+    }
+}
+
+}  // namespace
+
+#define K_SWITCH(K, STMT)                                                   \
+    switch (K) {                                                            \
+        case 1: { constexpr int KK = 1; STMT; } break;                      \
+        case 2: { constexpr int KK = 2; STMT; } break;                      \
+        case 3: { constexpr int KK = 3; STMT; } break;                      \
+        case 4: { constexpr int KK = 4; STMT; } break;                      \
+        case 5: { constexpr int KK = 5; STMT; } break;                      \
+        case 6: { constexpr int KK = 6; STMT; } break;                      \
+        case 7: { constexpr int KK = 7; STMT; } break;                      \
+        case 8: { constexpr int KK = 8; STMT; } break;                      \
+        default: return VNET_E_UNSUPPORTED;                                 \
+    }
+
+extern "C" {
+
+size_t vnet_bn_ws_bytes(int C) { return (size_t)EW_MAXBLK * 3 * (C > 8 ? C : 8) * sizeof(float); }
+size_t vnet_colsum_ws_bytes(int C) { return (size_t)EW_MAXBLK * (C > 8 ? C : 8) * sizeof(float); }
+size_t vnet_head_ws_bytes(int C, int K) { return (size_t)EW_MAXBLK * (C * K + K) * sizeof(float); }
+size_t vnet_loss_ws_bytes(int B, int K) { return (size_t)B * EW_MAXBLK * (3 * K + 1) * sizeof(float); }
+
+int vnet_bn_stats(const float* x, const float* r, int bcast, int64_t M, int C, float eps, float momentum,
+                  float* mean, float* invstd, float* moving_mean, float* moving_var,
+                  void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !mean || !invstd || M <= 0 || C <= 0 || C > MAXC) return VNET_E_BADARG;
+    if (bcast && r) return VNET_E_UNSUPPORTED;
+    if (!ws || ws_bytes < vnet_bn_ws_bytes(C)) return VNET_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)ws;
+    const int Cs = bcast ? 1 : C;
+    const int mode = red_mode(Cs);
+    int nblk;
+    if (mode == 0) {
+        const size_t nq = (size_t)M * (Cs / 4);
+        nblk = ew_blocks(nq);
+        hipLaunchKernelGGL(bn_stats_vec_kernel, dim3(nblk), dim3(EW_BLOCK), 0, st, (const float4*)x, (const float4*)r, nq, Cs / 4, partial);
+    } else if (mode == 1) {
+        nblk = ew_blocks((size_t)M);
+        hipLaunchKernelGGL(bn_stats_row_kernel, dim3(nblk), dim3(EW_BLOCK), 0, st, x, r, (size_t)M, Cs, partial);
+    } else {
+        nblk = ew_blocks((size_t)M * Cs);
+        hipLaunchKernelGGL(bn_stats_generic_kernel, dim3(nblk), dim3(EW_BLOCK), 0, st, x, r, (size_t)M * Cs, Cs, partial);
+    }
+    VNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, partial, nblk, Cs, C, (double)M, eps, momentum,
+                       mean, invstd, moving_mean, moving_var);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_bn_act_fwd(const float* x, const float* r, int bcast, int64_t M, int C,
+                    const float* mean, const float* invstd, const float* gamma, const float* beta,
+                    int act, const float* alpha, float* y, void* stream) {
+    if (!x || !mean || !invstd || !gamma || !beta || !y || M <= 0 || C <= 0 || C > MAXC) return VNET_E_BADARG;
+    if (act == VNET_ACT_PRELU && !alpha) return VNET_E_BADARG;
+    if (act < 0 || act > 3) return VNET_E_UNSUPPORTED;
+    BnP p{}; p.x = x; p.r = r; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.alpha = alpha;
+    p.out = y; p.M = (size_t)M; p.C = C; p.bcast = bcast; p.act = act;
+    hipStream_t st = (hipStream_t)stream;
+    if (C % 4 == 0) hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(ew_blocks((size_t)M * C / 4 / 4 + 1) ), dim3(EW_BLOCK), 0, st, p);
+    else hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(ew_blocks((size_t)M * C / 4 + 1)), dim3(EW_BLOCK), 0, st, p);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_bn_act_bwd(const float* dy, const float* x, const float* r, int bcast, int64_t M, int C,
+                    const float* mean, const float* invstd, const float* gamma, const float* beta,
+                    int act, const float* alpha, float* dgamma, float* dbeta, float* dalpha, float* ds,
+                    void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !mean || !invstd || !gamma || !beta || !dgamma || !dbeta || M <= 0 || C <= 0 || C > MAXC) return VNET_E_BADARG;
+    if (act == VNET_ACT_PRELU && (!alpha || !dalpha)) return VNET_E_BADARG;
+    if (!ws || ws_bytes < vnet_bn_ws_bytes(C)) return VNET_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    BnP p{}; p.x = x; p.r = r; p.dy = dy; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.alpha = alpha;
+    p.partial = (float*)ws; p.M = (size_t)M; p.C = C; p.bcast = bcast; p.act = act; p.invM = (float)(1.0 / (double)M);
+    const int mode = red_mode(C);
+    int nblk;
+    if (mode == 0) { nblk = ew_blocks((size_t)M * C / 4 / 4 + 1); hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<0>, dim3(nblk), dim3(EW_BLOCK), 0, st, p); }
+    else if (mode == 1) { nblk = ew_blocks((size_t)M); hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<1>, dim3(nblk), dim3(EW_BLOCK), 0, st, p); }
+    else { nblk = ew_blocks((size_t)M * C / 4 + 1); hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<2>, dim3(nblk), dim3(EW_BLOCK), 0, st, p); }
+    VNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, p.partial, nblk, 3, C, dbeta, dgamma,
+                       act == VNET_ACT_PRELU ? dalpha : (float*)nullptr);
+    VNET_LAUNCH_CHECK();
+    if (ds) {
+        p.out = ds; p.dgamma = dgamma; p.dbeta = dbeta;
+        if (C % 4 == 0) hipLaunchKernelGGL(bn_act_bwd_apply_kernel<true>, dim3(ew_blocks((size_t)M * C / 4 / 4 + 1)), dim3(EW_BLOCK), 0, st, p);
+        else hipLaunchKernelGGL(bn_act_bwd_apply_kernel<false>, dim3(ew_blocks((size_t)M * C / 4 + 1)), dim3(EW_BLOCK), 0, st, p);
+        VNET_LAUNCH_CHECK();
+    }
+    return VNET_OK;
+}
+
+int vnet_act_fwd(const float* x, int64_t M, int C, int act, const float* alpha, float* y, void* stream) {
+    if (!x || !y || M <= 0 || C <= 0 || C > MAXC) return VNET_E_BADARG;
+    if (act == VNET_ACT_PRELU && !alpha) return VNET_E_BADARG;
+    if (act < 0 || act > 3) return VNET_E_UNSUPPORTED;
+    BnP p{}; p.x = x; p.alpha = alpha; p.out = y; p.M = (size_t)M; p.C = C; p.act = act; p.identity = 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (C % 4 == 0) hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(ew_blocks((size_t)M * C / 4 / 4 + 1)), dim3(EW_BLOCK), 0, st, p);
+    else hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(ew_blocks((size_t)M * C / 4 + 1)), dim3(EW_BLOCK), 0, st, p);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_act_bwd(const float* dy, const float* x, int64_t M, int C, int act, const float* alpha,
+                 float* dalpha, float* dx, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !dx || M <= 0 || C <= 0 || C > MAXC) return VNET_E_BADARG;
+    if (act == VNET_ACT_PRELU && (!alpha || !dalpha)) return VNET_E_BADARG;
+    if (!ws || ws_bytes < vnet_bn_ws_bytes(C)) return VNET_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    BnP p{}; p.x = x; p.dy = dy; p.alpha = alpha; p.partial = (float*)ws; p.M = (size_t)M; p.C = C; p.act = act; p.identity = 1;
+    if (act == VNET_ACT_PRELU) {
+        const int mode = red_mode(C);
+        int nblk;
+        if (mode == 0) { nblk = ew_blocks((size_t)M * C / 4 / 4 + 1); hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<0>, dim3(nblk), dim3(EW_BLOCK), 0, st, p); }
+        else if (mode == 1) { nblk = ew_blocks((size_t)M); hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<1>, dim3(nblk), dim3(EW_BLOCK), 0, st, p); }
+        else { nblk = ew_blocks((size_t)M * C / 4 + 1); hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<2>, dim3(nblk), dim3(EW_BLOCK), 0, st, p); }
+        VNET_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sum_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, p.partial, nblk, 3, C, (float*)nullptr, (float*)nullptr, dalpha);
+        VNET_LAUNCH_CHECK();
+    }
+    p.out = dx;
+    if (C % 4 == 0) hipLaunchKernelGGL(bn_act_bwd_apply_kernel<true>, dim3(ew_blocks((size_t)M * C / 4 / 4 + 1)), dim3(EW_BLOCK), 0, st, p);
+    else hipLaunchKernelGGL(bn_act_bwd_apply_kernel<false>, dim3(ew_blocks((size_t)M * C / 4 + 1)), dim3(EW_BLOCK), 0, st, p);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_colsum(const float* x, float* out, int64_t M, int C, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !out || M <= 0 || C <= 0 || C > MAXC) return VNET_E_BADARG;
+    if (!ws || ws_bytes < vnet_colsum_ws_bytes(C)) return VNET_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)ws;
+    int nblk;
+    if (red_mode(C) == 0) {
+        const size_t nq = (size_t)M * (C / 4);
+        nblk = ew_blocks(nq / 4 + 1);
+        hipLaunchKernelGGL(colsum_vec_kernel, dim3(nblk), dim3(EW_BLOCK), 0, st, (const float4*)x, nq, C / 4, partial);
+    } else {
+        nblk = ew_blocks((size_t)M * C / 4 + 1);
+        hipLaunchKernelGGL(colsum_generic_kernel, dim3(nblk), dim3(EW_BLOCK), 0, st, x, (size_t)M * C, C, partial);
+    }
+    VNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, partial, nblk, 1, C, out, (float*)nullptr, (float*)nullptr);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_head_fwd(const float* x, const float* w, const float* bias, float* y, int64_t M, int C, int K, void* stream) {
+    if (!x || !w || !y || M <= 0 || C <= 0 || K <= 0) return VNET_E_BADARG;
+    if (C * K > 1024) return VNET_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = ew_blocks((size_t)M / 2 + 1);
+    K_SWITCH(K, hipLaunchKernelGGL(head_fwd_kernel<KK>, dim3(nblk), dim3(EW_BLOCK), 0, st, x, w, bias, y, (size_t)M, C));
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_head_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                  int64_t M, int C, int K, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !w || !dy || !dw || !db || M <= 0 || C <= 0 || K <= 0) return VNET_E_BADARG;
+    if (C * K > 1024 || (C & 3) || !is_pow2(C / 4) || C / 4 > EW_BLOCK) return VNET_E_UNSUPPORTED;
+    if (!ws || ws_bytes < vnet_head_ws_bytes(C, K)) return VNET_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)ws;
+    const int nblk = ew_blocks((size_t)M * (C / 4) / 4 + 1);
+    K_SWITCH(K, hipLaunchKernelGGL(head_bwd_kernel<KK>, dim3(nblk), dim3(EW_BLOCK), 0, st, x, w, dy, dx, (size_t)M, C, partial));
+    VNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(ceil_div(C * K + K, 256)), dim3(256), 0, st, partial, nblk, C * K, K, dw, db);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_softmax_dice_fwd(const float* logits, const int32_t* labels, int B, int64_t V, int K,
+                          int loss_kind, const float* weights, float alpha, float smooth,
+                          float* softmax_out, int64_t* pred_out, float* loss_out, float* dice_out,
+                          float* coef, void* ws, size_t ws_bytes, void* stream) {
+    if (!logits || !labels || !loss_out || !coef || B <= 0 || V <= 0 || K <= 0) return VNET_E_BADARG;
+    if (B * K > 64 || B > 8) return VNET_E_UNSUPPORTED;
+    if ((loss_kind & 15) > VNET_LOSS_XENT) return VNET_E_UNSUPPORTED;
+    if ((loss_kind & VNET_LOSS_WEIGHTED) && !weights) return VNET_E_BADARG;
+    if (!ws || ws_bytes < vnet_loss_ws_bytes(B, K)) return VNET_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    LossP p{}; p.logits = logits; p.labels = labels; p.weights = weights; p.softmax_out = softmax_out;
+    p.pred_out = (long long*)pred_out; p.partial = (float*)ws; p.V = (size_t)V; p.B = B; p.K = K; p.kind = loss_kind;
+    const int nblk = ew_blocks((size_t)V / 4 + 1);
+    p.nblk = nblk;
+    K_SWITCH(K, hipLaunchKernelGGL(softmax_dice_fwd_kernel<KK>, dim3(nblk, B), dim3(EW_BLOCK), 0, st, p));
+    VNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, p.partial, nblk, B, K, (double)V, loss_kind, weights, alpha,
+                       smooth, loss_out, dice_out, coef);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_softmax_dice_bwd(const float* logits, const int32_t* labels, int B, int64_t V, int K,
+                          int loss_kind, const float* weights, float alpha,
+                          const float* coef, const float* gscale, float* dlogits, void* stream) {
+    (void)alpha;
+    if (!logits || !labels || !coef || !dlogits || B <= 0 || V <= 0 || K <= 0) return VNET_E_BADARG;
+    if (B * K > 64 || B > 8) return VNET_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = ew_blocks((size_t)V / 4 + 1);
+    K_SWITCH(K, hipLaunchKernelGGL(softmax_dice_bwd_kernel<KK>, dim3(nblk, B), dim3(EW_BLOCK), 0, st, logits, labels, (size_t)V,
+                                   loss_kind, weights, coef, B, gscale, dlogits));
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_dice_coe_fwd(const float* output, const float* target, int B, int64_t V, int K, int jaccard,
+                      const float* weights, float smooth, float* dice_out, float* coef,
+                      void* ws, size_t ws_bytes, void* stream) {
+    if (!output || !target || !dice_out || !coef || B <= 0 || V <= 0 || K <= 0) return VNET_E_BADARG;
+    if (B * K > 64 || B > 8) return VNET_E_UNSUPPORTED;
+    if (!ws || ws_bytes < vnet_loss_ws_bytes(B, K) + sizeof(float)) return VNET_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)ws;
+    float* loss_tmp = partial + (size_t)B * EW_MAXBLK * (3 * K + 1);
+    const int nblk = ew_blocks((size_t)V / 4 + 1);
+    K_SWITCH(K, hipLaunchKernelGGL(dice_sums_kernel<KK>, dim3(nblk, B), dim3(EW_BLOCK), 0, st, output, target, (size_t)V, jaccard, partial));
+    VNET_LAUNCH_CHECK();
+    const int kind = (jaccard ? VNET_LOSS_JACCARD : VNET_LOSS_SORENSEN) | (weights ? VNET_LOSS_WEIGHTED : 0);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, partial, nblk, B, K, (double)V, kind, weights, 0.f,
+                       smooth, loss_tmp, dice_out, coef);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_dice_coe_bwd(const float* output, const float* target, int B, int64_t V, int K, int jaccard,
+                      const float* coef, const float* gscale, float* doutput, void* stream) {
+    if (!output || !target || !coef || !doutput || B <= 0 || V <= 0 || K <= 0) return VNET_E_BADARG;
+    hipLaunchKernelGGL(dice_grad_kernel, dim3(ew_blocks((size_t)V * K / 4 + 1), B), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       output, target, (size_t)V, K, jaccard, coef, gscale, doutput);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float rate, uint64_t seed, void* stream) {
+    if (!x || !y || !mask || n <= 0 || rate < 0.f || rate >= 1.f) return VNET_E_BADARG;
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(ew_blocks((size_t)n / 4 + 1)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, y, mask, (size_t)n, rate, seed);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+int vnet_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float rate, void* stream) {
+    if (!dy || !dx || !mask || n <= 0 || rate < 0.f || rate >= 1.f) return VNET_E_BADARG;
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(ew_blocks((size_t)n / 4 + 1)), dim3(EW_BLOCK), 0, (hipStream_t)stream, dy, mask, dx, (size_t)n, rate);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_adam_apply(float* p, const float* g, float* m, float* v, int64_t n,
+                    float lr_t, float beta1, float beta2, float eps, float gscale, void* stream) {
+    if (!p || !g || !m || !v || n <= 0) return VNET_E_BADARG;
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks((size_t)n / 4 + 1) * 2), dim3(EW_BLOCK), 0, (hipStream_t)stream, p, g, m, v, (size_t)n,
+                       lr_t, beta1, beta2, eps, gscale);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+int vnet_sgd_apply(float* p, const float* g, int64_t n, float lr, float gscale, void* stream) {
+    if (!p || !g || n <= 0) return VNET_E_BADARG;
+    hipLaunchKernelGGL(sgd_kernel, dim3(ew_blocks((size_t)n / 4 + 1) * 2), dim3(EW_BLOCK), 0, (hipStream_t)stream, p, g, (size_t)n, lr, gscale);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+int vnet_momentum_apply(float* p, const float* g, float* acc, int64_t n, float lr, float momentum,
+                        int nesterov, float gscale, void* stream) {
+    if (!p || !g || !acc || n <= 0) return VNET_E_BADARG;
+    hipLaunchKernelGGL(momentum_kernel, dim3(ew_blocks((size_t)n / 4 + 1) * 2), dim3(EW_BLOCK), 0, (hipStream_t)stream, p, g, acc, (size_t)n,
+                       lr, momentum, nesterov, gscale);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_accumulate_patch(const float* patch, float* vol, float* count, int K,
+                          int pz, int py, int px, int z0, int y0, int x0, int D, int H, int W, void* stream) {
+    if (!patch || !vol || K <= 0 || pz <= 0 || py <= 0 || px <= 0 || z0 < 0 || y0 < 0 || x0 < 0) return VNET_E_BADARG;
+    hipLaunchKernelGGL(accumulate_patch_kernel, dim3(ew_blocks((size_t)pz * py * px)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       patch, vol, count, K, pz, py, px, z0, y0, x0, D, H, W);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,145 @@
+"""Input side of the hot path: the data contract of the reference's NiftiDataset3D
+(pipeline/NiftiDataset3D.py:125-165) without SimpleITK (absent here): image float32
+[X,Y,Z,Cin] (axis order after the (2,1,0) transpose, NiftiDataset3D.py:154), label int32
+[X,Y,Z] remapped to class *indices* of SegmentationClasses (NiftiDataset3D.py:125-137).
+
+Sources: a case directory tree holding `.npy` or uncompressed NIfTI-1 `.nii` files, or the
+synthetic generator of SURVEY.md 8(d) (the shipped sample volumes are Git-LFS stubs).  The
+SimpleITK resampling transforms of the YAML pipeline are out of scope;
+only the pure index-math RandomCrop to PatchShape is provided."""
+import os
+import struct
+
+import numpy as np
+
+
+# ---- minimal NIfTI-1 (single-file, uncompressed) ------------------------------------------------
+_NIFTI_DTYPES = {2: np.uint8, 4: np.int16, 8: np.int32, 16: np.float32, 64: np.float64, 256: np.int8,
+                 512: np.uint16, 768: np.uint32}
+
+
+def read_nifti(path):
+    """Returns (array [X,Y,Z], header dict).  NIfTI stores x fastest, i.e. Fortran order [X,Y,Z]."""
+    with open(path, "rb") as f:
+        hdr = f.read(348)
+        if len(hdr) < 348 or struct.unpack("<i", hdr[:4])[0] != 348:
+            raise ValueError("%s: not a little-endian NIfTI-1 file (Git-LFS pointer?)" % path)
+        dim = struct.unpack("<8h", hdr[40:56])
+        datatype, bitpix = struct.unpack("<hh", hdr[70:74])
+        pixdim = struct.unpack("<8f", hdr[76:108])
+        vox_offset = struct.unpack("<f", hdr[108:112])[0]
+        slope, inter = struct.unpack("<ff", hdr[112:120])
+        shape = tuple(int(d) for d in dim[1:1 + dim[0]])
+        f.seek(int(vox_offset))
+        dt = _NIFTI_DTYPES[datatype]
+        data = np.frombuffer(f.read(int(np.prod(shape)) * np.dtype(dt).itemsize), dtype=dt).reshape(shape, order="F")
+    if slope not in (0.0, 1.0) or inter != 0.0:
+        data = data.astype(np.float32) * (slope if slope != 0 else 1.0) + inter
+    return data, {"pixdim": pixdim[1:4], "dim": shape, "datatype": datatype}
+
+
+def write_nifti(path, arr, pixdim=(1.0, 1.0, 1.0)):
+    arr = np.asarray(arr)
+    code = {v: k for k, v in _NIFTI_DTYPES.items()}[arr.dtype.type]
+    hdr = bytearray(348)
+    struct.pack_into("<i", hdr, 0, 348)
+    dim = [arr.ndim] + list(arr.shape) + [1] * (7 - arr.ndim)
+    struct.pack_into("<8h", hdr, 40, *dim)
+    struct.pack_into("<hh", hdr, 70, code, arr.dtype.itemsize * 8)
+    struct.pack_into("<8f", hdr, 76, 1.0, *pixdim, 1.0, 1.0, 1.0, 1.0)
+    struct.pack_into("<f", hdr, 108, 352.0)
+    struct.pack_into("<ff", hdr, 112, 1.0, 0.0)
+    hdr[344:348] = b"n+1\0"
+    with open(path, "wb") as f:
+        f.write(bytes(hdr) + b"\0\0\0\0")
+        f.write(np.asfortranarray(arr).tobytes(order="F"))
+
+
+def load_volume(path):
+    if path.endswith(".npy"):
+        return np.load(path)
+    if path.endswith(".nii"):
+        return read_nifti(path)[0]
+    raise ValueError("unsupported volume format: %s (.npy or uncompressed .nii; SimpleITK is not available)" % path)
+
+
+def remap_labels(label, classes):
+    """NiftiDataset3D.py:125-137: label values -> index into SegmentationClasses (others -> 0)."""
+    out = np.zeros(label.shape, dtype=np.int32)
+    for idx, c in enumerate(classes):
+        out[label == c] = idx
+    return out
+
+
+def synthetic_case(shape, cin, K, seed):
+    """One synthetic volume per SURVEY.md 8(d): clamp(127.5 + 40 N(0,1), 0, 255) + 60 inside the
+    label spheres; background 0 plus one sphere of radius P/6 per foreground class."""
+    rng = np.random.default_rng(seed)
+    shape = tuple(shape)
+    img = 127.5 + 40.0 * rng.standard_normal(shape + (cin,), dtype=np.float32)
+    lab = np.zeros(shape, dtype=np.int32)
+    P = min(shape)
+    grids = np.ogrid[tuple(slice(0, s) for s in shape)]
+    for c in range(1, K):
+        ctr = [rng.uniform(s / 4.0, 3.0 * s / 4.0) for s in shape]
+        d2 = sum((g - c0) ** 2 for g, c0 in zip(grids, ctr))
+        lab[d2 <= (P / 6.0) ** 2] = c
+    img += 60.0 * (lab > 0)[..., None]
+    return np.clip(img, 0.0, 255.0).astype(np.float32), lab
+
+
+def random_crop(image, label, patch, rng):
+    """Index-math RandomCrop (NiftiDataset3D.py:458-548 without the SimpleITK resampling): pad with
+    zeros up to the patch size, then take a uniformly random window."""
+    pads = [(0, max(p - s, 0)) for s, p in zip(label.shape, patch)]
+    if any(hi for _, hi in pads):
+        image = np.pad(image, pads + [(0, 0)])
+        label = np.pad(label, pads)
+    start = [int(rng.integers(0, s - p + 1)) for s, p in zip(label.shape, patch)]
+    sl = tuple(slice(a, a + p) for a, p in zip(start, patch))
+    return image[sl], label[sl]
+
+
+class VolumeDataset(object):
+    """Iterates batches (image float32 [B,*P,Cin], label int32 [B,*P,1]) like the reference's
+    tf.data pipeline: shuffle, batch(drop_remainder=True) (model.py:289-295)."""
+
+    def __init__(self, data_dir, image_filenames, label_filename, classes, patch_shape, batch_size,
+                 train=True, seed=0, synthetic=None, rank=0, world=1):
+        self.image_filenames, self.label_filename = list(image_filenames), label_filename
+        self.classes, self.patch, self.batch = list(classes), tuple(patch_shape), int(batch_size)
+        self.train, self.rng = train, np.random.default_rng(seed + 7919 * rank)
+        self.rank, self.world = rank, world
+        self.synthetic = synthetic
+        if synthetic is not None:
+            self.cases = list(range(int(synthetic.get("Cases", 8))))
+        else:
+            if not os.path.isdir(data_dir):
+                raise FileNotFoundError("data directory %s does not exist" % data_dir)
+            self.cases = sorted(os.path.join(data_dir, d) for d in os.listdir(data_dir)
+                                if os.path.isdir(os.path.join(data_dir, d)))
+
+    def _load(self, case):
+        if self.synthetic is not None:
+            shape = self.synthetic.get("Shape", self.patch)
+            return synthetic_case(shape, len(self.image_filenames), len(self.classes),
+                                  int(self.synthetic.get("Seed", 1000)) + case)
+        chans = [np.asarray(load_volume(os.path.join(case, f)), dtype=np.float32) for f in self.image_filenames]
+        image = np.stack(chans, axis=-1)
+        label = remap_labels(load_volume(os.path.join(case, self.label_filename)), self.classes)
+        return image, label
+
+    def __iter__(self):
+        order = list(self.cases)
+        if self.train:
+            self.rng.shuffle(order)
+        order = order[self.rank::self.world] if self.world > 1 else order
+        imgs, labs = [], []
+        for case in order:
+            image, label = self._load(case)
+            image, label = random_crop(image, label, self.patch, self.rng)
+            imgs.append(image)
+            labs.append(label[..., None])
+            if len(imgs) == self.batch:
+                yield np.stack(imgs).astype(np.float32), np.stack(labs).astype(np.int32)
+                imgs, labs = [], []

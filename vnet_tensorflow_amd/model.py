@@ -1,0 +1,403 @@
+"""Mirror of the reference's model.py for the V-Net hot path: `dice_coe` (model.py:26-85) and
+`class image2label` (model.py:169-1242) with `.train()` / `.evaluate()`, driven by the same
+config.json contract (model.py:185-245) -- on the HIP library instead of a tf.Session.
+
+What is carried over: the graph of model.py:428-568 (network, softmax, one-hot, the Loss.Name
+switch, argmax), the optimiser/LR schedule of model.py:641-666, the step loop of model.py:716-810
+(feed images/labels, dropout from config, batch-statistics BN, one optimiser step, print loss,
+checkpoint cadence, periodic test batch) and the sliding-window inference of model.py:866-937.
+What is not: SimpleITK I/O + resampling transforms, TensorBoard summaries,
+the 2-D path, UNet.  `sess` is accepted and ignored.
+"""
+import datetime
+import math
+import os
+import shutil
+import sys
+
+import numpy as np
+import torch
+
+from . import data as vdata
+from . import networks, ops, optim, parallel
+from ._lib import VnetHipError, check, lib
+
+
+# ------------------------------------------------------------------------------------------------
+# dice_coe -- reference model.py:26-85 (same signature and defaults)
+# ------------------------------------------------------------------------------------------------
+class _DiceCoeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, output, target, jaccard, weights, smooth):
+        L = lib()
+        output, target = output.contiguous(), target.contiguous()
+        B, K = output.shape[0], output.shape[-1]
+        V = output.numel() // (B * K)
+        dev = output.device
+        dice = torch.empty((), dtype=torch.float32, device=dev)
+        coef = torch.empty(2 * B * K + 1, dtype=torch.float32, device=dev)
+        nb = L.vnet_loss_ws_bytes(B, K) + 4
+        ws = ops.workspace(nb, dev)
+        check(L.vnet_dice_coe_fwd(ops._ptr(output), ops._ptr(target), B, V, K, int(jaccard), ops._ptr(weights), smooth,
+                                  ops._ptr(dice), ops._ptr(coef), ops._ptr(ws), nb, ops._stream()), "vnet_dice_coe_fwd")
+        ctx.save_for_backward(output, target, coef)
+        ctx.cfg = (B, V, K, int(jaccard))
+        return dice
+
+    @staticmethod
+    def backward(ctx, g):
+        output, target, coef = ctx.saved_tensors
+        B, V, K, jac = ctx.cfg
+        d = torch.empty_like(output)
+        check(lib().vnet_dice_coe_bwd(ops._ptr(output), ops._ptr(target), B, V, K, jac, ops._ptr(coef),
+                                      ops._ptr(g.contiguous()), ops._ptr(d), ops._stream()), "vnet_dice_coe_bwd")
+        return d, None, None, None, None
+
+
+def dice_coe(output, target, loss_type='jaccard', axis=(1, 2, 3), weights=[], smooth=1e-5):
+    """Soft dice (Sorensen or Jaccard) coefficient, reference model.py:26-85.  `output` / `target`:
+    float32 [B, D, H, W, K] on the HIP device; reduction over `axis` = all spatial axes."""
+    if loss_type not in ('jaccard', 'sorensen'):
+        raise Exception("Unknown loss_type")
+    if tuple(axis) != tuple(range(1, output.dim() - 1)):
+        raise NotImplementedError("dice_coe reduces over all spatial axes (the only use in the reference)")
+    ops._need_gpu(output, "dice_coe")
+    wt = None
+    if len(weights) != 0:
+        assert len(weights) == target.shape[-1], "Length of DICE weight is {}, should be {}".format(len(weights), target.shape[-1])
+        wt = torch.as_tensor(list(weights), dtype=torch.float32).to(output.device)
+    return _DiceCoeFn.apply(output, target.to(torch.float32), loss_type == 'jaccard', wt, float(smooth))
+
+
+def prepare_batch(image_ijk_patch_indices_dict):
+    """reference model.py:94-115"""
+    images, ijk = image_ijk_patch_indices_dict['images'], image_ijk_patch_indices_dict['indexes']
+    return np.asarray([images[p[0]:p[1], p[2]:p[3], p[4]:p[5], :] for p in ijk])
+
+
+def _now():
+    return datetime.datetime.now()
+
+
+# ------------------------------------------------------------------------------------------------
+# image2label -- reference model.py:169-1242
+# ------------------------------------------------------------------------------------------------
+class image2label(object):
+    def __init__(self, sess, config, device=None, verbose=True):
+        """Args: sess: ignored (kept for signature parity, model.py:170); config: parsed config.json"""
+        self.sess = sess
+        self.config = config
+        self.model = None
+        self.epoches = 999999999999999999
+        self.verbose = verbose
+        self.rank, self.local_rank, self.world = 0, 0, 1
+        self.device = torch.device(device) if device is not None else None
+        self.network = None
+        self.global_step = 0
+        self.start_epoch = 0
+        self.momentum = 0.9
+        self.last_loss = None
+
+    def _print(self, *a):
+        if self.verbose and self.rank == 0:
+            print(*a)
+
+    # -- reference model.py:185-245, with the corrected key set of SURVEY.md B.3 --------------------
+    def read_config(self):
+        self._print("{}: Reading configuration file...".format(_now()))
+        T = self.config['TrainingSetting']
+        self.input_channel_num = len(T['Data']['ImageFilenames'])
+        self.output_channel_num = len(T['SegmentationClasses'])
+        self.label_classes = T['SegmentationClasses']
+        self.train_data_dir = T['Data']['TrainingDataDirectory']
+        self.test_data_dir = T['Data']['TestingDataDirectory']
+        self.image_filenames = T['Data']['ImageFilenames']
+        self.label_filename = T['Data']['LabelFilename']
+        self.synthetic = T['Data'].get('Synthetic')            # extension: synthetic generator (no NIfTI shipped)
+        self.batch_size = T['BatchSize']
+        self.patch_shape = T['PatchShape']
+        self.dimension = len(T['PatchShape'])
+        self.image_log = T.get('ImageLog', False)
+        self.testing = T.get('Testing', False)
+        self.test_step = T.get('TestStep', 100)                 # missing from the shipped config.json
+        self.restore_training = T.get('Restore', False)
+        self.log_dir = T.get('LogDir', './tmp/log')
+        self.ckpt_dir = T.get('CheckpointDir', './tmp/ckpt')
+        self.epoches = T.get('Epoches', 1)
+        self.max_itr = T.get('MaxIterations', 10 ** 12)        # missing from the shipped config.json
+        self.log_interval = T.get('LogInterval', 100)
+        N = T['Networks']
+        self.network_name = N['Name']
+        self.dropout_rate = N['Dropout']
+        self.num_channel = N['NumChannel']
+        self.num_levels = N['NumLevels']
+        # the shipped JSONs spell it "NumCovolutions" (configs/config.json:29); accept both
+        self.num_convolutions = N['NumConvolutions'] if 'NumConvolutions' in N else N['NumCovolutions']
+        self.bottom_convolutions = N['BottomConvolutions']
+        O = T['Optimizer']
+        self.optimizer_name = O['Name']
+        self.initial_learning_rate = O['InitialLearningRate']
+        self.decay_factor = O['Decay']['Factor']
+        self.decay_steps = O['Decay']['Steps']
+        self.momentum = O.get('Momentum', 0.9)                  # the reference never sets self.momentum (model.py:654)
+        self.spacing = T.get('Spacing')
+        self.drop_ratio = T.get('DropRatio')
+        self.min_pixel = T.get('MinPixel')
+        self.loss_name = T['Loss']['Name']
+        self.loss_weights = T['Loss'].get('Weights', [])
+        self.loss_alpha = T['Loss'].get('Alpha', 1)
+        self.training_pipeline = T.get('Pipeline')
+        E = self.config.get('EvaluationSetting', {})
+        self.checkpoint_path = E.get('CheckpointPath')
+        ED = E.get('Data', {})
+        self.evaluate_data_dir = ED.get('EvaluateDataDirectory')
+        self.evaluate_image_filenames = ED.get('ImageFilenames', self.image_filenames)
+        self.evaluate_label_filename = ED.get('LabelFilename', 'label_tf.nii')
+        self.evaluate_probability_filename = ED.get('ProbabilityFilename', 'probability_tf.nii')
+        self.evaluate_stride = E.get('Stride', self.patch_shape)
+        self.evaluate_batch = E.get('BatchSize', 1)
+        self.evaluate_probability_output = E.get('ProbabilityOutput', False)
+        self.evaluate_lcc = E.get('LargestConnectedComponent', False)
+        self.evaluate_volume_threshold = E.get('VolumeThreshold', False)
+        self.evaluate_pipeline = E.get('Pipeline')
+        self._print("{}: Reading configuration file complete".format(_now()))
+
+    # -- reference model.py:297-630 (network + loss head; summaries/metrics not carried) ---------------
+    def build_model_graph(self):
+        self._print("{}: Start to build model graph...".format(_now()))
+        if self.dimension != 3:
+            sys.exit("Only 3D PatchShape is built (2D is out of scope)")
+        if self.device is None:
+            if not torch.cuda.is_available():
+                raise VnetHipError("no HIP device: the MI355X kernels are the only compute path")
+            self.device = torch.device("cuda", self.local_rank)
+        self.input_batch_shape = (self.batch_size,) + tuple(self.patch_shape) + (self.input_channel_num,)
+        self.output_batch_shape = (self.batch_size,) + tuple(self.patch_shape) + (1,)
+        self.dropout_placeholder = self.dropout_rate     # stand-in for "dropout_placeholder" (model.py:312)
+        if self.network_name == "VNet":
+            self.network = networks.VNet(
+                num_classes=self.output_channel_num,
+                dropout_rate=lambda: self.dropout_placeholder,
+                num_channels=self.num_channel,
+                num_levels=self.num_levels,
+                num_convolutions=self.num_convolutions,
+                bottom_convolutions=self.bottom_convolutions,
+                is_training=True,
+                activation_fn="prelu",
+                device=self.device)
+        else:
+            sys.exit("Invalid Network")
+        self.network.build(self.input_batch_shape)
+        ops.parse_loss(self.loss_name)                   # validates Loss.Name like model.py:559-560
+        self._print("{}: Core network complete".format(_now()))
+
+    def forward(self, images, labels=None, dropout=0.0, want_softmax=False, want_pred=False):
+        """One pass of the graph of model.py:444-568.  images float32 [B,*P,Cin]; labels int32 [B,*P,1]."""
+        self.dropout_placeholder = dropout
+        logits = self.network.GetNetwork(images)
+        if labels is None:
+            sm, pred = ops.softmax_argmax(logits)
+            return logits, None, sm, pred
+        loss, dice, sm, pred = ops.softmax_loss(logits, labels, self.loss_name, self.loss_weights, self.loss_alpha,
+                                                want_softmax=want_softmax, want_pred=want_pred)
+        return logits, loss, sm, pred
+
+    def run(self, fetches, feed_dict):
+        """sess.run shim keyed by the reference's graph tensor names (model.py:914-917)."""
+        img = feed_dict['images_placeholder:0']
+        img = torch.as_tensor(np.ascontiguousarray(img), dtype=torch.float32).to(self.device)
+        lab = feed_dict.get('labels_placeholder:0')
+        if lab is not None:
+            lab = torch.as_tensor(np.ascontiguousarray(lab), dtype=torch.int32).to(self.device)
+        with torch.no_grad():
+            logits, loss, sm, pred = self.forward(img, lab, float(feed_dict.get('dropout_placeholder:0', 0.0)), True, True)
+        table = {'softmax:0': sm, 'predicted_label/prediction:0': pred, 'logits:0': logits, 'loss:0': loss}
+        return [table[f].cpu().numpy() for f in fetches]
+
+    # -- distributed / optimiser set-up -------------------------------------------------------------
+    def _setup_training(self):
+        self.flat = optim.FlatParams(self.network.named_parameters())
+        self.optimizer = optim.make_optimizer(self.optimizer_name, self.flat, self.momentum)
+        self.sync = None
+        if self.world > 1:
+            parallel.broadcast_parameters(self.flat.data)
+            self.optimizer.gscale = 1.0 / self.world
+            self.sync = parallel.BucketedGradAllReduce(self.flat)
+
+    def train_step(self, images, labels, dropout=None):
+        """reference model.py:743-748: one fwd + loss + bwd + optimiser step; returns the loss tensor."""
+        lr = optim.exponential_decay(self.initial_learning_rate, self.global_step, self.decay_steps, self.decay_factor)
+        self.flat.zero_grad()
+        if self.sync is not None:
+            self.sync.begin_step()
+        _, loss, _, _ = self.forward(images, labels, self.dropout_rate if dropout is None else dropout)
+        loss.backward()
+        if self.sync is not None:
+            self.sync.finish()
+        self.optimizer.apply(lr)
+        self.global_step += 1
+        return loss
+
+    # -- checkpoints (reference model.py:689-702, 758-764, 806-808) ----------------------------------------
+    def _ckpt_prefix(self):
+        return os.path.join(self.ckpt_dir, "checkpoint")
+
+    def save_checkpoint(self):
+        if self.rank != 0:
+            return
+        os.makedirs(self.ckpt_dir, exist_ok=True)
+        path = "%s-%d" % (self._ckpt_prefix(), self.global_step)
+        sd = {k: v.cpu() for k, v in self.network.state_dict().items()}
+        opt = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in self.optimizer.state_dict().items()}
+        torch.save({"variables": sd, "global_step": self.global_step, "start_epoch": self.start_epoch,
+                    "optimizer": opt, "opt_names": self.flat.names}, path)
+        with open(self._ckpt_prefix() + "-latest", "w") as f:
+            f.write('model_checkpoint_path: "%s"\n' % os.path.basename(path))
+
+    def load_checkpoint(self, path=None, with_optimizer=True):
+        if path is None:
+            with open(self._ckpt_prefix() + "-latest") as f:
+                path = os.path.join(self.ckpt_dir, f.readline().split('"')[1])
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        self.network.load_state_dict(ck["variables"])
+        ops.invalidate_packed()
+        self.global_step, self.start_epoch = int(ck["global_step"]), int(ck["start_epoch"])
+        if with_optimizer and getattr(self, "optimizer", None) is not None and ck.get("optimizer"):
+            self.optimizer.load_state_dict(ck["optimizer"])
+        return path
+
+    def _dataset(self, data_dir, train):
+        return vdata.VolumeDataset(data_dir, self.image_filenames, self.label_filename, self.label_classes,
+                                   self.patch_shape, self.batch_size, train=train, synthetic=self.synthetic,
+                                   rank=self.rank, world=self.world)
+
+    # -- reference model.py:632-815 ---------------------------------------------------------------------------
+    def train(self):
+        self._print("{}: VNet training start...".format(_now()))
+        self.rank, self.local_rank, self.world = parallel.init_from_env()
+        self.read_config()
+        self.build_model_graph()
+        self._setup_training()
+        if not self.restore_training:
+            if self.rank == 0:
+                for d in (self.log_dir, self.ckpt_dir):
+                    if os.path.exists(d):
+                        shutil.rmtree(d)
+                    os.makedirs(d)
+        elif os.path.exists(self._ckpt_prefix() + "-latest"):
+            self._print("{}: Last checkpoint found at {}, loading...".format(_now(), self.ckpt_dir))
+            self.load_checkpoint()
+            self._print("{}: Last checkpoint epoch: {}".format(_now(), self.start_epoch))
+            self._print("{}: Last checkpoint global step: {}".format(_now(), self.global_step))
+        train_set = self._dataset(self.train_data_dir, True)
+        test_iter = None
+        if self.testing:
+            test_set = self._dataset(self.test_data_dir, False)
+            test_iter = iter(test_set)
+
+        for epoch in range(self.start_epoch, self.epoches):
+            self._print("{}: Epoch {} starts...".format(_now(), epoch + 1))
+            loss_sum, count = 0.0, 0
+            for image, label in train_set:
+                if self.global_step > self.max_itr:
+                    self._print("{}: Reach maximum iteration steps, training abort.".format(_now()))
+                    return
+                image = torch.from_numpy(image).to(self.device)
+                label = torch.from_numpy(label).to(self.device)
+                loss = float(self.train_step(image, label))
+                self.last_loss = loss
+                self._print('{}: Segmentation training loss: {}'.format(_now(), str(loss)))
+                loss_sum += loss
+                count += 1
+                if self.global_step % self.log_interval == 0:
+                    self._print("{}: Saving checkpoint of step {} at {}...".format(_now(), self.global_step, self.ckpt_dir))
+                    self.save_checkpoint()
+                if self.testing and (self.global_step % self.test_step == 0):
+                    try:
+                        timage, tlabel = next(test_iter)
+                    except StopIteration:
+                        test_iter = iter(test_set)
+                        timage, tlabel = next(test_iter)
+                    with torch.no_grad():
+                        _, tloss, _, _ = self.forward(torch.from_numpy(timage).to(self.device),
+                                                      torch.from_numpy(tlabel).to(self.device), 0.0)
+                    self._print('{}: Segmentation testing loss: {}'.format(_now(), str(float(tloss))))
+            self._print("{}: Training of epoch {} complete, epoch loss: {}".format(_now(), epoch + 1, loss_sum / max(count, 1)))
+            self.start_epoch += 1
+            self._print("{}: Saving checkpoint of epoch {} at {}...".format(_now(), epoch + 1, self.ckpt_dir))
+            self.save_checkpoint()
+
+    # -- reference model.py:817-977 (array in / arrays out; SimpleITK resampling not carried) -----------------
+    def evaluate_single_3D(self, images_np):
+        """images_np float32 [X,Y,Z,Cin] -> (label int64 [X,Y,Z], softmax float32 [K,X,Y,Z]).
+        Patch enumeration, the duplicated last batch and argmax-of-summed-softmax follow
+        model.py:866-937 exactly; accumulation runs on the GPU."""
+        ps, st = list(self.patch_shape), list(self.evaluate_stride)
+        pads = [(0, max(p - s, 0)) for s, p in zip(images_np.shape[:3], ps)]
+        orig = images_np.shape[:3]
+        if any(hi for _, hi in pads):
+            images_np = np.pad(images_np, pads + [(0, 0)])
+        dims = images_np.shape[:3]
+        nums = [int(math.ceil((dims[a] - ps[a]) / float(st[a]))) + 1 for a in range(3)]
+        batches, tmp, patch_total = [], [], 0
+        for i in range(nums[0]):
+            for j in range(nums[1]):
+                for k in range(nums[2]):
+                    if patch_total % self.evaluate_batch == 0:
+                        tmp = []
+                    idx = []
+                    for a, n in zip(range(3), (i, j, k)):
+                        s0 = n * st[a]
+                        if s0 + ps[a] > dims[a]:
+                            s0 = dims[a] - ps[a]
+                        idx += [s0, s0 + ps[a]]
+                    tmp.append(idx)
+                    if patch_total % self.evaluate_batch == 0:
+                        batches.append({'images': images_np, 'indexes': tmp})
+                    patch_total += 1
+        batches.append({'images': images_np, 'indexes': tmp})        # "for last batch" (model.py:903)
+        K = self.output_channel_num
+        vol = torch.zeros(dims + (K,), dtype=torch.float32, device=self.device)
+        cnt = torch.zeros(dims, dtype=torch.float32, device=self.device)
+        for bd in batches:
+            batch = torch.from_numpy(prepare_batch(bd)).to(self.device)
+            with torch.no_grad():
+                _, _, sm, _ = self.forward(batch, None, 0.0)
+            for j, idx in enumerate(bd['indexes']):
+                ops.accumulate_patch(sm[j], vol, cnt, (idx[0], idx[2], idx[4]))
+        vol_np, cnt_np = vol.cpu().numpy(), cnt.cpu().numpy()
+        label_np = np.argmax(vol_np, axis=-1)
+        softmax_np = np.moveaxis(vol_np, -1, 0)
+        if self.evaluate_probability_output:
+            softmax_np = softmax_np / np.float32(cnt_np)
+        sl = tuple(slice(0, s) for s in orig)
+        return label_np[sl], softmax_np[(slice(None),) + sl]
+
+    # -- reference model.py:1131-1242 ------------------------------------------------------------------------------
+    def evaluate(self):
+        self.read_config()
+        self.rank, self.local_rank, self.world = 0, 0, 1
+        self.build_model_graph()
+        self._print("{}: Restoring checkpoint {}".format(_now(), self.checkpoint_path))
+        self.load_checkpoint(self.checkpoint_path, with_optimizer=False)
+        for case in sorted(os.listdir(self.evaluate_data_dir)):
+            cdir = os.path.join(self.evaluate_data_dir, case)
+            if not os.path.isdir(cdir):
+                continue
+            chans = [np.asarray(vdata.load_volume(os.path.join(cdir, f)), dtype=np.float32) for f in self.evaluate_image_filenames]
+            label, softmax = self.evaluate_single_3D(np.stack(chans, axis=-1))
+            out = os.path.join(cdir, self.evaluate_label_filename)
+            if out.endswith(".npy"):
+                np.save(out, label.astype(np.int16))
+            else:
+                vdata.write_nifti(out[:-3] if out.endswith(".gz") else out, label.astype(np.int16))
+            if self.evaluate_probability_output:
+                for c in range(softmax.shape[0]):
+                    name = self.evaluate_probability_filename
+                    stem, ext = (name[:-7], ".nii") if name.endswith(".nii.gz") else os.path.splitext(name)
+                    pout = os.path.join(cdir, "%s_%s%s" % (stem, str(self.label_classes[c]), ext))
+                    if ext == ".npy":
+                        np.save(pout, softmax[c])
+                    else:
+                        vdata.write_nifti(pout, softmax[c].astype(np.float32))
+            self._print("{}: Evaluation of {} complete".format(_now(), case))

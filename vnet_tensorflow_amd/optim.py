@@ -1,0 +1,137 @@
+"""Flat parameter/gradient buffers + the TF1 optimisers the reference selects (model.py:641-666).
+
+All trainable variables live in ONE contiguous fp32 buffer (and their gradients in another), laid
+out in reverse creation order = the order autograd produces gradients (output layer, decoder
+level 1 .. 4, bottom, encoder level 4 .. 1).  That makes (a) the optimiser one fused HIP kernel
+over 44 M parameters and (b) data-parallel gradient buckets contiguous slices that RCCL can
+all-reduce in place while backward is still running (parallel.py)."""
+import math
+
+import torch
+
+from . import ops
+
+
+class FlatParams(object):
+    def __init__(self, named_params):
+        """named_params: list of (tf_name, Parameter) in creation (= forward) order."""
+        self.names = [n for n, _ in reversed(named_params)]
+        params = [p for _, p in reversed(named_params)]
+        self.params = params
+        dev = params[0].device
+        # 4-float (16 B) alignment for every variable so vector loads on slices stay aligned
+        self.offsets, off = [], 0
+        for p in params:
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        self.numel = off
+        self.data = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(params, self.offsets):
+                n = p.numel()
+                self.data[o:o + n].copy_(p.detach().reshape(-1))
+                p.data = self.data[o:o + n].view(p.shape)
+                p.grad = self.grad[o:o + n].view(p.shape)
+        ops.invalidate_packed()
+
+    def zero_grad(self):
+        self.grad.zero_()
+        # autograd may have replaced .grad objects; re-point them at the flat buffer
+        for p, o in zip(self.params, self.offsets):
+            g = p.grad
+            if g is None or g.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def buckets(self, bucket_bytes=32 << 20):
+        """Contiguous [start, end) slices of the flat buffer, cut at variable boundaries, plus the
+        index range of the variables each one holds."""
+        out, start, first = [], 0, 0
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            end = o + (p.numel() + 3) // 4 * 4
+            if (end - start) * 4 >= bucket_bytes or i == len(self.params) - 1:
+                out.append((start, end, first, i + 1))
+                start, first = end, i + 1
+        return out
+
+
+def exponential_decay(lr0, global_step, decay_steps, decay_rate):
+    """tf.train.exponential_decay(..., staircase=False) (reference model.py:642-643)."""
+    return lr0 * decay_rate ** (global_step / float(decay_steps))
+
+
+class _Base(object):
+    def __init__(self, flat):
+        self.flat = flat
+        self.gscale = 1.0       # 1/world_size under data parallelism (mean of per-rank gradients)
+
+    def state_dict(self):
+        return {}
+
+    def load_state_dict(self, sd):
+        pass
+
+
+class GradientDescentOptimizer(_Base):
+    """tf.train.GradientDescentOptimizer"""
+
+    def apply(self, lr):
+        ops.sgd_apply(self.flat.data, self.flat.grad, lr, self.gscale)
+        ops.invalidate_packed()
+
+
+class AdamOptimizer(_Base):
+    """tf.train.AdamOptimizer (epsilon-hat form): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
+    p -= lr_t * m / (sqrt(v) + eps)."""
+
+    def __init__(self, flat, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        super().__init__(flat)
+        self.b1, self.b2, self.eps, self.t = beta1, beta2, epsilon, 0
+        self.m = torch.zeros_like(flat.data)
+        self.v = torch.zeros_like(flat.data)
+
+    def apply(self, lr):
+        self.t += 1
+        lr_t = lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        ops.adam_apply(self.flat.data, self.flat.grad, self.m, self.v, lr_t, self.b1, self.b2, self.eps, self.gscale)
+        ops.invalidate_packed()
+
+    def state_dict(self):
+        return {"t": self.t, "m": self.m, "v": self.v}
+
+    def load_state_dict(self, sd):
+        self.t = int(sd["t"])
+        self.m.copy_(sd["m"].to(self.m.device))
+        self.v.copy_(sd["v"].to(self.v.device))
+
+
+class MomentumOptimizer(_Base):
+    """tf.train.MomentumOptimizer(use_nesterov=...)"""
+
+    def __init__(self, flat, momentum=0.9, use_nesterov=False):
+        super().__init__(flat)
+        self.momentum, self.nesterov = momentum, use_nesterov
+        self.acc = torch.zeros_like(flat.data)
+
+    def apply(self, lr):
+        ops.momentum_apply(self.flat.data, self.flat.grad, self.acc, lr, self.momentum, self.nesterov, self.gscale)
+        ops.invalidate_packed()
+
+    def state_dict(self):
+        return {"acc": self.acc}
+
+    def load_state_dict(self, sd):
+        self.acc.copy_(sd["acc"].to(self.acc.device))
+
+
+def make_optimizer(name, flat, momentum=0.9):
+    """Optimizer.Name switch of the reference (model.py:649-658)."""
+    if name == "SGD":
+        return GradientDescentOptimizer(flat)
+    if name == "Adam":
+        return AdamOptimizer(flat)
+    if name == "Momentum":
+        return MomentumOptimizer(flat, momentum)
+    if name == "NesterovMomentum":
+        return MomentumOptimizer(flat, momentum, use_nesterov=True)
+    raise SystemExit("Invalid optimizer")

@@ -1,0 +1,112 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, patches sharded across
+ranks, ONE exchange step per iteration -- a sum all-reduce (RCCL over xGMI; backend "nccl" is RCCL
+on ROCm) of the flat fp32 gradient buffer, cut into contiguous buckets in backward-production
+order and launched from autograd hooks on a side stream so it overlaps the remaining backward
+convolutions.  The reference has no multi-GPU code; semantics are those of
+SURVEY.md 8(e): per-replica batch-norm statistics, gradient = mean of per-rank gradients.
+
+The class is device-agnostic (gloo on CPU tensors exercises exactly the same bucket/hook logic)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Join the process group torchrun / torch.distributed.run prepared (RANK, WORLD_SIZE, MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.device_count() > 0 else "gloo"   # device_count() does not initialise the GPU
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def broadcast_parameters(flat_data, src=0, group=None):
+    """All replicas start from rank 0's weights (the reference initialises from an unseeded NumPy RNG)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat_data, src=src, group=group)
+
+
+class BucketedGradAllReduce(object):
+    """All-reduces `flat.grad` bucket by bucket as soon as every variable of a bucket has its gradient."""
+
+    def __init__(self, flat, bucket_bytes=32 << 20, group=None, overlap=True):
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets = flat.buckets(bucket_bytes)
+        self.is_cuda = flat.grad.is_cuda
+        self.overlap = overlap and self.is_cuda and self.world > 1
+        self.comm_stream = torch.cuda.Stream(device=flat.grad.device) if self.overlap else None
+        self._bucket_of = {}
+        for bi, (_, _, first, last) in enumerate(self.buckets):
+            for pi in range(first, last):
+                self._bucket_of[pi] = bi
+        self._pending = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+        self._hooks = []
+        if self.world > 1:
+            for pi, p in enumerate(flat.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(pi)))
+        self.begin_step()
+
+    def begin_step(self):
+        for bi, (_, _, first, last) in enumerate(self.buckets):
+            self._pending[bi] = last - first
+            self._launched[bi] = False
+        self._handles = []
+
+    def _make_hook(self, pi):
+        def hook(param):
+            # autograd may have swapped .grad for a fresh tensor: fold it back into the flat buffer
+            o = self.flat.offsets[pi]
+            g = param.grad
+            if g is not None and g.data_ptr() != self.flat.grad.data_ptr() + 4 * o:
+                view = self.flat.grad[o:o + param.numel()].view(param.shape)
+                view.add_(g)
+                param.grad = view
+            bi = self._bucket_of[pi]
+            self._pending[bi] -= 1
+            if self._pending[bi] == 0:
+                self._launch(bi)
+        return hook
+
+    def _launch(self, bi):
+        if self._launched[bi] or self.world == 1:
+            return
+        self._launched[bi] = True
+        s, e, _, _ = self.buckets[bi]
+        view = self.flat.grad[s:e]
+        if self.overlap:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Flush buckets whose variables never received a gradient (dead batch-norms), then make the
+        compute stream wait for every all-reduce.  The optimiser divides by world (gscale)."""
+        if self.world == 1:
+            return
+        for bi in range(len(self.buckets)):
+            self._launch(bi)
+        for h in self._handles:
+            h.wait()
+        if self.overlap:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._handles = []
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
