@@ -77,6 +77,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise VnetHipError("libvnet_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(hipcc, gfx950).  The HIP library is the only compute path." % LIB_PATH)
+        # torch ships its own libamdhip64: import it FIRST so the kernels, torch's streams and its
+        # allocator live in ONE HIP runtime (loading ours first would bind /opt/rocm's copy instead).
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if a declared symbol is not exported

@@ -83,6 +83,41 @@ def _same_out(n, s):
     return -(-n // s)
 
 
+# ---- optional per-launch timing (bench.py): HIP events on the launch stream ---------------------
+_PROFILE = {"on": False, "records": []}
+
+
+def profile_start():
+    _PROFILE["records"] = []
+    _PROFILE["on"] = True
+
+
+def profile_stop():
+    """Returns [(tag, flops, algorithmic_bytes, milliseconds)] after synchronising."""
+    _PROFILE["on"] = False
+    torch.cuda.synchronize()
+    out = [(t, f, b, e0.elapsed_time(e1)) for (t, f, b, e0, e1) in _PROFILE["records"]]
+    _PROFILE["records"] = []
+    return out
+
+
+class _Timed(object):
+    def __init__(self, tag, flops, nbytes):
+        self.rec = (tag, flops, nbytes)
+
+    def __enter__(self):
+        if _PROFILE["on"]:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()          # torch's current stream == the stream the kernel is launched on
+        return self
+
+    def __exit__(self, *a):
+        if _PROFILE["on"]:
+            self.e1.record()
+            _PROFILE["records"].append(self.rec + (self.e0, self.e1))
+
+
 # ---- convolution family ----------------------------------------------------------------------------
 def _conv_call(ks, stride, up, x0, x1, wp, bias, y0, y1, dims_in, dims_out):
     L = _lib.lib()
@@ -91,9 +126,16 @@ def _conv_call(ks, stride, up, x0, x1, wp, bias, y0, y1, dims_in, dims_out):
     Cy0, Cy1 = y0.shape[-1], (y1.shape[-1] if y1 is not None else 0)
     nb = L.vnet_conv_ws_bytes(ks, stride, up, C0 + C1, Cy0 + Cy1, B, *dims_out)
     ws = workspace(nb, x0.device) if nb else None
-    check(L.vnet_conv_fwd(ks, stride, up, _ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias),
-                          _ptr(y0), Cy0, _ptr(y1), Cy1, B, *dims_in, *dims_out,
-                          _ptr(ws), nb, _stream()), "vnet_conv_fwd")
+    nin, nout = B * dims_in[0] * dims_in[1] * dims_in[2], B * dims_out[0] * dims_out[1] * dims_out[2]
+    taps = 8 if up else ks ** 3
+    mac_vox = nin if up else nout          # the transposed conv does its 8 taps per INPUT voxel
+    flops = 2.0 * mac_vox * taps * (C0 + C1) * (Cy0 + Cy1)
+    nbytes = 4.0 * (nin * (C0 + C1) + nout * (Cy0 + Cy1) + taps * (C0 + C1) * (Cy0 + Cy1) + (Cy0 + Cy1))
+    tag = "conv k%d s%d%s %d^3x%d %d->%d" % (ks, stride, " up" if up else "", dims_out[2], B, C0 + C1, Cy0 + Cy1)
+    with _Timed(tag, flops, nbytes):
+        check(L.vnet_conv_fwd(ks, stride, up, _ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias),
+                              _ptr(y0), Cy0, _ptr(y1), Cy1, B, *dims_in, *dims_out,
+                              _ptr(ws), nb, _stream()), "vnet_conv_fwd")
 
 
 def _wgrad_call(ks, stride, x0, x1, dy, dw, dims_in, dims_out):
@@ -103,8 +145,13 @@ def _wgrad_call(ks, stride, x0, x1, dy, dw, dims_in, dims_out):
     Co = dy.shape[-1]
     nb = L.vnet_wgrad_ws_bytes(ks, stride, C0 + C1, Co, B, *dims_out)
     ws = workspace(nb, x0.device)
-    check(L.vnet_conv_wgrad(ks, stride, _ptr(x0), C0, _ptr(x1), C1, _ptr(dy), Co, _ptr(dw),
-                            B, *dims_in, *dims_out, _ptr(ws), nb, _stream()), "vnet_conv_wgrad")
+    nin, nout = B * dims_in[0] * dims_in[1] * dims_in[2], B * dims_out[0] * dims_out[1] * dims_out[2]
+    flops = 2.0 * nout * ks ** 3 * (C0 + C1) * Co
+    nbytes = 4.0 * (nin * (C0 + C1) + nout * Co + ks ** 3 * (C0 + C1) * Co)
+    tag = "wgrad k%d s%d %d^3x%d %d->%d" % (ks, stride, dims_out[2], B, C0 + C1, Co)
+    with _Timed(tag, flops, nbytes):
+        check(L.vnet_conv_wgrad(ks, stride, _ptr(x0), C0, _ptr(x1), C1, _ptr(dy), Co, _ptr(dw),
+                                B, *dims_in, *dims_out, _ptr(ws), nb, _stream()), "vnet_conv_wgrad")
 
 
 def colsum(x2d_like, C):
