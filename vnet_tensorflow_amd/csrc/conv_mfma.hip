@@ -119,27 +119,80 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
                                                    a.Di, a.Hi, a.Wi, tid);
         __syncthreads();
         const float4* wq = a.wp + ((size_t)(chunk * 4 + kk) * a.CoutP + co0 + i);
-        for (int dz = 0; dz < KS; ++dz) {
-            for (int dy = 0; dy < KS; ++dy) {
-                const float* lrow = lds + (dz * G::IY + dy) * G::IX * 16;
-                const float4* wrow = wq + (size_t)((dz * KS + dy) * KS) * tap_stride;
+        if constexpr (KS == 5) {
+            // Weight fragments come straight from L2 (the whole filter is shared by every workgroup), so
+            // they are software-pipelined PF taps ahead through a 5-slot register ring (5 | 25 taps per
+            // dz slab keeps every ring index a compile-time constant) -- the L2 round trip hides under
+            // the MFMAs of the taps in between instead of stalling each tap.
+            constexpr int T2 = KS * KS, T3 = T2 * KS, R = 5, PF = (NS == 1) ? 2 : 1;
+            float4 wf[R][NS];
+            float4 xf[R][MS];     // B fragments ride the same ring one tap ahead (LDS latency off the MFMA path)
 #pragma unroll
-                for (int dx = 0; dx < KS; ++dx) {
-                    float4 wf[NS];
+            for (int j = 0; j < PF; ++j)
 #pragma unroll
-                    for (int n = 0; n < NS; ++n) wf[n] = wrow[dx * tap_stride + n * 16];
-                    float4 xf[MS];
+                for (int n = 0; n < NS; ++n) wf[j][n] = wq[(size_t)j * tap_stride + n * 16];
 #pragma unroll
-                    for (int m = 0; m < MS; ++m) xf[m] = *reinterpret_cast<const float4*>(lrow + boff[m] + dx * 16);
+            for (int m = 0; m < MS; ++m) xf[0][m] = *reinterpret_cast<const float4*>(lds + boff[m]);
+            for (int dz = 0; dz < KS; ++dz) {
+#pragma unroll
+                for (int t2 = 0; t2 < T2; ++t2) {
+                    {
+                        const int tn = min(dz * T2 + t2 + PF, T3 - 1);
+                        const float4* wn = wq + (size_t)tn * tap_stride;
+#pragma unroll
+                        for (int n = 0; n < NS; ++n) wf[(t2 + PF) % R][n] = wn[n * 16];
+                        const int t2n = (t2 + 1) % T2;
+                        const int dzn = min(dz + (t2 == T2 - 1 ? 1 : 0), KS - 1);
+                        const float* ln = lds + ((dzn * G::IY + t2n / KS) * G::IX + t2n % KS) * 16;
+#pragma unroll
+                        for (int m = 0; m < MS; ++m) xf[(t2 + 1) % R][m] = *reinterpret_cast<const float4*>(ln + boff[m]);
+                        // pin the issue point: hipcc otherwise sinks the loads to just before their first use
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const float4* wc = wf[t2 % R];
+                    const float4* xc = xf[t2 % R];
+                    // element j of both fragments feeds MFMA step j; consecutive MFMAs hit different accumulators
 #pragma unroll
                     for (int m = 0; m < MS; ++m)
 #pragma unroll
-                        for (int n = 0; n < NS; ++n) {
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].x, xf[m].x, acc[m][n], 0, 0, 0);
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].y, xf[m].y, acc[m][n], 0, 0, 0);
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].z, xf[m].z, acc[m][n], 0, 0, 0);
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].w, xf[m].w, acc[m][n], 0, 0, 0);
-                        }
+                        for (int n = 0; n < NS; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[n].x, xc[m].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < MS; ++m)
+#pragma unroll
+                        for (int n = 0; n < NS; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[n].y, xc[m].y, acc[m][n], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < MS; ++m)
+#pragma unroll
+                        for (int n = 0; n < NS; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[n].z, xc[m].z, acc[m][n], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < MS; ++m)
+#pragma unroll
+                        for (int n = 0; n < NS; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[n].w, xc[m].w, acc[m][n], 0, 0, 0);
+                }
+            }
+        } else {
+            for (int dz = 0; dz < KS; ++dz) {
+                for (int dy = 0; dy < KS; ++dy) {
+                    const float* lrow = lds + (dz * G::IY + dy) * G::IX * 16;
+                    const float4* wrow = wq + (size_t)((dz * KS + dy) * KS) * tap_stride;
+#pragma unroll
+                    for (int dx = 0; dx < KS; ++dx) {
+                        float4 wf[NS];
+#pragma unroll
+                        for (int n = 0; n < NS; ++n) wf[n] = wrow[dx * tap_stride + n * 16];
+                        float4 xf[MS];
+#pragma unroll
+                        for (int m = 0; m < MS; ++m) xf[m] = *reinterpret_cast<const float4*>(lrow + boff[m] + dx * 16);
+#pragma unroll
+                        for (int m = 0; m < MS; ++m)
+#pragma unroll
+                            for (int n = 0; n < NS; ++n) {
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].x, xf[m].x, acc[m][n], 0, 0, 0);
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].y, xf[m].y, acc[m][n], 0, 0, 0);
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].z, xf[m].z, acc[m][n], 0, 0, 0);
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].w, xf[m].w, acc[m][n], 0, 0, 0);
+                            }
+                    }
                 }
             }
         }
@@ -227,7 +280,7 @@ struct WgradArgs {
 };
 
 template <int KS, int STRIDE, int TZ, int TY, int TX, int NS, int TW>
-__global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
+__global__ void __launch_bounds__(512) wgrad_kernel(WgradArgs a) {
     using G = TileGeom<KS, STRIDE, TZ, TY, TX>;
     constexpr int NV = TZ * TY * TX;
     constexpr int T3 = KS * KS * KS;
@@ -236,7 +289,11 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
     float* xt = lds;
     float* dyt = lds + G::LDS_FLOATS;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // 8 waves = 2 per SIMD: waves w and w+4 own the same TW taps and split the brick's voxel groups
+    // between them (even / odd groups), each writing its own partial slab -> the co-resident wave
+    // hides the LDS latency of the other.
+    const int lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3, half = wave8 >> 2;
     const int i = lane & 15, kk = lane >> 4;
     const int split = blockIdx.x;
     const int chunk = blockIdx.y / a.ncob, cob = blockIdx.y - chunk * a.ncob;
@@ -264,11 +321,11 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
         const int by = br % a.nby; br /= a.nby;
         const int bz = br % a.nbz; const int b = br / a.nbz;
         __syncthreads();
-        load_tile<G::IZ, G::IY, G::IX, 256>(xt, a.x0, a.x1, a.C0, a.C1, a.vec_in, chunk, b,
+        load_tile<G::IZ, G::IY, G::IX, 512>(xt, a.x0, a.x1, a.C0, a.C1, a.vec_in, chunk, b,
                                             bz * TZ * STRIDE - a.pad, by * TY * STRIDE - a.pad, bx * TX * STRIDE - a.pad,
                                             a.Di, a.Hi, a.Wi, tid);
         // dy tile [NV][NS*16]
-        for (int q = tid; q < NV * NS * 4; q += 256) {
+        for (int q = tid; q < NV * NS * 4; q += 512) {
             const int v = q / (NS * 4), cq = q - v * (NS * 4);
             const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
             const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
@@ -289,7 +346,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
         }
         __syncthreads();
 #pragma unroll 2
-        for (int g = 0; g < NV / 4; ++g) {
+        for (int g = half; g < NV / 4; g += 2) {
             const int v = g * 4 + kk;
             const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
             const float* xb = xt + ((vz * STRIDE * G::IY + vy * STRIDE) * G::IX + vx * STRIDE) * 16 + i;
@@ -310,7 +367,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
     for (int t = 0; t < TW; ++t) {
         const int tap = tap0 + t;
         if (tap >= T3) continue;
-        float* dst = a.part + ((size_t)(split * T3 + tap) * a.CinP + chunk * 16 + i) * a.CoutP + co0 + kk * 4;
+        float* dst = a.part + ((size_t)((split * 2 + half) * T3 + tap) * a.CinP + chunk * 16 + i) * a.CoutP + co0 + kk * 4;
 #pragma unroll
         for (int n = 0; n < NS; ++n) {
             const f32x4 r = acc[t][n];
@@ -319,18 +376,27 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int T3, int CinP, int CoutP,
-                                    int Cin, int Cout, float* __restrict__ dw) {
+// dw = sum over splits of the partial filter gradients; 64 outputs x 4 split-lanes per workgroup
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int T3, int CinP, int CoutP,
+                                                           int Cin, int Cout, float* __restrict__ dw) {
+    __shared__ float sh[4][64];
     const size_t total = (size_t)T3 * Cin * Cout;
     const size_t sstride = (size_t)T3 * CinP * CoutP;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int co = (int)(idx % Cout);
-        const size_t r = idx / Cout;
-        const int ci = (int)(r % Cin), t = (int)(r / Cin);
-        const float* p = part + ((size_t)t * CinP + ci) * CoutP + co;
+    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
+        const size_t idx = base + o;
         float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += p[k * sstride];
-        dw[idx] = s;
+        if (idx < total) {
+            const int co = (int)(idx % Cout);
+            const size_t r = idx / Cout;
+            const int ci = (int)(r % Cin), t = (int)(r / Cin);
+            const float* p = part + ((size_t)t * CinP + ci) * CoutP + co;
+            for (int k = sg; k < nsplit; k += 4) s += p[k * sstride];
+        }
+        __syncthreads();
+        sh[sg][o] = s;
+        __syncthreads();
+        if (sg == 0 && idx < total) dw[idx] = sh[0][o] + sh[1][o] + sh[2][o] + sh[3][o];
     }
 }
 
@@ -526,7 +592,7 @@ WgradPlan plan_wgrad(int ks, int stride, int Cin, int Cout, int B, int Do, int H
     p.ntg = ceil_div(T3, 4 * p.tw);
     p.nbrick = B * p.nbz * p.nby * p.nbx;
     const int base = (round_up(Cin, 16) / 16) * p.ncob * p.ntg;
-    p.nsplit = max(1, min(p.nbrick, ceil_div(768, base)));
+    p.nsplit = max(1, min(p.nbrick, ceil_div(512, base)));
     return p;
 }
 
@@ -539,7 +605,7 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
     if (attr_done != 0) attr_done = set_lds(k, lds);
     if (attr_done != 0) return attr_done;
     dim3 grid(p.nsplit, (a.CinP / 16) * p.ncob, p.ntg);
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL(k, grid, dim3(512), lds, st, a);
     return (int)hipGetLastError();
 }
 }  // namespace
@@ -548,7 +614,7 @@ extern "C" {
 
 size_t vnet_wgrad_ws_bytes(int ks, int stride, int Cin, int Cout, int B, int Do, int Ho, int Wo) {
     WgradPlan p = plan_wgrad(ks, stride, Cin, Cout, B, Do, Ho, Wo);
-    return (size_t)p.nsplit * ks * ks * ks * round_up(Cin, 16) * round_up(Cout, 16) * sizeof(float);
+    return (size_t)2 * p.nsplit * ks * ks * ks * round_up(Cin, 16) * round_up(Cout, 16) * sizeof(float);
 }
 
 int vnet_conv_wgrad(int ks, int stride, const float* x0, int C0, const float* x1, int C1,
@@ -568,7 +634,7 @@ int vnet_conv_wgrad(int ks, int stride, const float* x0, int C0, const float* x1
     WgradPlan p = plan_wgrad(ks, stride, a.Cin, Cout, B, Do, Ho, Wo);
     a.ncob = p.ncob; a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.nbrick = p.nbrick; a.nsplit = p.nsplit;
     const int T3 = ks * ks * ks;
-    const size_t need = (size_t)p.nsplit * T3 * a.CinP * a.CoutP * sizeof(float);
+    const size_t need = (size_t)2 * p.nsplit * T3 * a.CinP * a.CoutP * sizeof(float);
     if (!ws || ws_bytes < need) return VNET_E_WORKSPACE;
     a.part = reinterpret_cast<float*>(ws);
     int e;
@@ -591,8 +657,8 @@ int vnet_conv_wgrad(int ks, int stride, const float* x0, int C0, const float* x1
     }
     if (e) return e;
     const size_t total = (size_t)T3 * a.Cin * Cout;
-    const int blocks = (int)min((size_t)2048, (total + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, p.nsplit, T3, a.CinP, a.CoutP, a.Cin, Cout, dw);
+    const int blocks = (int)min((size_t)4096, (total + 63) / 64);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, 2 * p.nsplit, T3, a.CinP, a.CoutP, a.Cin, Cout, dw);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
 }

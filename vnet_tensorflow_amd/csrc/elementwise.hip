@@ -127,16 +127,25 @@ __global__ void __launch_bounds__(EW_BLOCK) bn_stats_generic_kernel(const float*
     for (int c = threadIdx.x; c < 2 * C; c += EW_BLOCK) partial[(size_t)blockIdx.x * 2 * C + c] = sh[c];
 }
 
-// sums NACC partial rows in float64; mode 0: BN stats finalize, 1: plain sums to out[a][C]
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int Cs, int C, double M, float eps,
-                                   float momentum, float* mean, float* invstd, float* mm, float* mv) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-        const int cs = (Cs == 1) ? 0 : c;
-        double s = 0.0, q = 0.0;
-        for (int b = 0; b < nblk; ++b) {
-            s += (double)partial[(size_t)b * 2 * Cs + cs];
-            q += (double)partial[(size_t)b * 2 * Cs + Cs + cs];
-        }
+// ---- finalize kernels: one workgroup per output column sums <= EW_MAXBLK partial rows in float64 ----
+__device__ __forceinline__ double block_colsum_d(const float* __restrict__ partial, int nblk, size_t row_stride, size_t col) {
+    __shared__ double shd[4];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) s += (double)partial[(size_t)b * row_stride + col];
+    s = wave_sum_d(s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = s;
+    __syncthreads();
+    return shd[0] + shd[1] + shd[2] + shd[3];
+}
+
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ partial, int nblk, int Cs, int C, double M, float eps,
+                                                          float momentum, float* mean, float* invstd, float* mm, float* mv) {
+    const int c = blockIdx.x;
+    const int cs = (Cs == 1) ? 0 : c;
+    const double s = block_colsum_d(partial, nblk, 2 * Cs, cs);
+    const double q = block_colsum_d(partial, nblk, 2 * Cs, Cs + cs);
+    if (threadIdx.x == 0) {
         const double mu = s / M;
         double var = q / M - mu * mu;
         var = var > 0.0 ? var : 0.0;
@@ -147,16 +156,14 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, 
     }
 }
 
-__global__ void sum_finalize_kernel(const float* __restrict__ partial, int nblk, int nacc, int C,
-                                    float* o0, float* o1, float* o2) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-        for (int a = 0; a < nacc; ++a) {
-            float* o = a == 0 ? o0 : (a == 1 ? o1 : o2);
-            if (!o) continue;
-            double s = 0.0;
-            for (int b = 0; b < nblk; ++b) s += (double)partial[((size_t)b * nacc + a) * C + c];
-            o[c] = (float)s;
-        }
+__global__ void __launch_bounds__(256) sum_finalize_kernel(const float* __restrict__ partial, int nblk, int nacc, int C,
+                                                           float* o0, float* o1, float* o2) {
+    const int c = blockIdx.x;
+    for (int a = 0; a < nacc; ++a) {
+        float* o = a == 0 ? o0 : (a == 1 ? o1 : o2);
+        if (!o) continue;
+        const double s = block_colsum_d(partial, nblk, (size_t)nacc * C, (size_t)a * C + c);
+        if (threadIdx.x == 0) o[c] = (float)s;
     }
 }
 
@@ -491,33 +498,16 @@ __global__ void __launch_bounds__(EW_BLOCK) softmax_dice_fwd_kernel(LossP p) {
             sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
-// one block: sums partials in float64, evaluates the loss switch (model.py:495-558), stores
+// one thread: evaluates the loss switch (model.py:495-558) from the float64 sums, stores
 // coef[b][k][0] = dloss/dI, coef[b][k][1] = dloss/dL, coef[2BK] = xent coefficient (per voxel)
-__global__ void loss_finalize_kernel(const float* __restrict__ partial, int nblk, int B, int K, double V, int kind,
+__global__ void loss_finalize_kernel(const double* __restrict__ sums, int B, int K, double V, int kind,
                                      const float* __restrict__ weights, float alpha, float smooth,
                                      float* loss_out, float* dice_out, float* coef) {
-    __shared__ double sI[64], sL[64], sR[64], sX[8];
-    const int tid = threadIdx.x;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int NS = 3 * K + 1;
-    for (int t = tid; t < B * K; t += blockDim.x) {
-        const int b = t / K, k = t % K;
-        double I = 0, L = 0, R = 0;
-        for (int j = 0; j < nblk; ++j) {
-            const float* pr = partial + ((size_t)b * nblk + j) * NS;
-            I += pr[k]; L += pr[K + k]; R += pr[2 * K + k];
-        }
-        sI[t] = I; sL[t] = L; sR[t] = R;
-    }
-    if (tid < B) {
-        double X = 0;
-        for (int j = 0; j < nblk; ++j) X += partial[((size_t)tid * nblk + j) * NS + 3 * K];
-        sX[tid] = X;
-    }
-    __syncthreads();
-    if (tid != 0) return;
     const int base = kind & 15;
     const bool weighted = (kind & VNET_LOSS_WEIGHTED) != 0, mixed = (kind & VNET_LOSS_MIXED) != 0;
-    double xsum = 0; for (int b = 0; b < B; ++b) xsum += sX[b];
+    double xsum = 0; for (int b = 0; b < B; ++b) xsum += sums[b * NS + 3 * K];
     const double xent = xsum / (V * B);
     double loss = 0, dice = 0;
     double xc = 0;
@@ -529,8 +519,8 @@ __global__ void loss_finalize_kernel(const float* __restrict__ partial, int nblk
             for (int b = 0; b < B; ++b) {
                 double num = 0, den = 0;
                 for (int k = 0; k < K; ++k) {
-                    num += 2.0 * weights[k] * sI[b * K + k] + smooth;
-                    den += weights[k] * (sL[b * K + k] + sR[b * K + k]) + smooth;
+                    num += 2.0 * weights[k] * sums[b * NS + k] + smooth;
+                    den += weights[k] * (sums[b * NS + K + k] + sums[b * NS + 2 * K + k]) + smooth;
                 }
                 dice += num / den / B;
                 for (int k = 0; k < K; ++k) {
@@ -539,12 +529,14 @@ __global__ void loss_finalize_kernel(const float* __restrict__ partial, int nblk
                 }
             }
         } else {
-            for (int t = 0; t < B * K; ++t) {
-                const double den = sL[t] + sR[t] + smooth, num = 2.0 * sI[t] + smooth;
-                dice += num / den / (B * K);
-                coef[t * 2 + 0] = (float)(-2.0 / den / (B * K));
-                coef[t * 2 + 1] = (float)(num / (den * den) / (B * K));
-            }
+            for (int b = 0; b < B; ++b)
+                for (int k = 0; k < K; ++k) {
+                    const double I = sums[b * NS + k], L = sums[b * NS + K + k], R = sums[b * NS + 2 * K + k];
+                    const double den = L + R + smooth, num = 2.0 * I + smooth;
+                    dice += num / den / (B * K);
+                    coef[(b * K + k) * 2 + 0] = (float)(-2.0 / den / (B * K));
+                    coef[(b * K + k) * 2 + 1] = (float)(num / (den * den) / (B * K));
+                }
         }
         loss = 1.0 - dice;
         if (mixed) { loss += alpha * xent; xc = alpha / (V * B); }
@@ -705,13 +697,17 @@ __global__ void accumulate_patch_kernel(const float* __restrict__ patch, float* 
     }
 }
 
-__global__ void head_finalize_kernel(const float* __restrict__ partial, int nblk, int CK, int K, float* dw, float* db) {
-    const int n = CK + K;
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
-        double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * n + c];
-        if (c < CK) dw[c] = (float)s; else db[c - CK] = (float)s;
-    }
+__global__ void __launch_bounds__(256) head_finalize_kernel(const float* __restrict__ partial, int nblk, int CK, int K, float* dw, float* db) {
+    const int c = blockIdx.x;
+    const double s = block_colsum_d(partial, nblk, (size_t)(CK + K), c);
+    if (threadIdx.x == 0) { if (c < CK) dw[c] = (float)s; else db[c - CK] = (float)s; }
+}
+
+// loss partial rows [b][blk][3K+1] -> float64 sums [b][3K+1]
+__global__ void __launch_bounds__(256) loss_colsum_kernel(const float* __restrict__ partial, int nblk, int NS, double* __restrict__ sums) {
+    const int b = blockIdx.y, col = blockIdx.x;
+    const double s = block_colsum_d(partial + (size_t)b * nblk * NS, nblk, NS, col);
+    if (threadIdx.x == 0) sums[b * NS + col] = s;
 }
 
 }  // namespace
@@ -734,7 +730,7 @@ extern "C" {
 size_t vnet_bn_ws_bytes(int C) { return (size_t)EW_MAXBLK * 3 * (C > 8 ? C : 8) * sizeof(float); }
 size_t vnet_colsum_ws_bytes(int C) { return (size_t)EW_MAXBLK * (C > 8 ? C : 8) * sizeof(float); }
 size_t vnet_head_ws_bytes(int C, int K) { return (size_t)EW_MAXBLK * (C * K + K) * sizeof(float); }
-size_t vnet_loss_ws_bytes(int B, int K) { return (size_t)B * EW_MAXBLK * (3 * K + 1) * sizeof(float); }
+size_t vnet_loss_ws_bytes(int B, int K) { return (size_t)B * EW_MAXBLK * (3 * K + 1) * sizeof(float) + (size_t)B * (3 * K + 1) * sizeof(double) + 16; }
 
 int vnet_bn_stats(const float* x, const float* r, int bcast, int64_t M, int C, float eps, float momentum,
                   float* mean, float* invstd, float* moving_mean, float* moving_var,
@@ -759,7 +755,7 @@ int vnet_bn_stats(const float* x, const float* r, int bcast, int64_t M, int C, f
         hipLaunchKernelGGL(bn_stats_generic_kernel, dim3(nblk), dim3(EW_BLOCK), 0, st, x, r, (size_t)M * Cs, Cs, partial);
     }
     VNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, partial, nblk, Cs, C, (double)M, eps, momentum,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, Cs, C, (double)M, eps, momentum,
                        mean, invstd, moving_mean, moving_var);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
@@ -796,7 +792,7 @@ int vnet_bn_act_bwd(const float* dy, const float* x, const float* r, int bcast, 
     else if (mode == 1) { nblk = ew_blocks((size_t)M); hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<1>, dim3(nblk), dim3(EW_BLOCK), 0, st, p); }
     else { nblk = ew_blocks((size_t)M * C / 4 + 1); hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<2>, dim3(nblk), dim3(EW_BLOCK), 0, st, p); }
     VNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, p.partial, nblk, 3, C, dbeta, dgamma,
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(C), dim3(256), 0, st, p.partial, nblk, 3, C, dbeta, dgamma,
                        act == VNET_ACT_PRELU ? dalpha : (float*)nullptr);
     VNET_LAUNCH_CHECK();
     if (ds) {
@@ -834,7 +830,7 @@ int vnet_act_bwd(const float* dy, const float* x, int64_t M, int C, int act, con
         else if (mode == 1) { nblk = ew_blocks((size_t)M); hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<1>, dim3(nblk), dim3(EW_BLOCK), 0, st, p); }
         else { nblk = ew_blocks((size_t)M * C / 4 + 1); hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<2>, dim3(nblk), dim3(EW_BLOCK), 0, st, p); }
         VNET_LAUNCH_CHECK();
-        hipLaunchKernelGGL(sum_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, p.partial, nblk, 3, C, (float*)nullptr, (float*)nullptr, dalpha);
+        hipLaunchKernelGGL(sum_finalize_kernel, dim3(C), dim3(256), 0, st, p.partial, nblk, 3, C, (float*)nullptr, (float*)nullptr, dalpha);
         VNET_LAUNCH_CHECK();
     }
     p.out = dx;
@@ -859,7 +855,7 @@ int vnet_colsum(const float* x, float* out, int64_t M, int C, void* ws, size_t w
         hipLaunchKernelGGL(colsum_generic_kernel, dim3(nblk), dim3(EW_BLOCK), 0, st, x, (size_t)M * C, C, partial);
     }
     VNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, partial, nblk, 1, C, out, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(sum_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, 1, C, out, (float*)nullptr, (float*)nullptr);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
 }
@@ -884,7 +880,7 @@ int vnet_head_bwd(const float* x, const float* w, const float* dy, float* dx, fl
     const int nblk = ew_blocks((size_t)M * (C / 4) / 4 + 1);
     K_SWITCH(K, hipLaunchKernelGGL(head_bwd_kernel<KK>, dim3(nblk), dim3(EW_BLOCK), 0, st, x, w, dy, dx, (size_t)M, C, partial));
     VNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(ceil_div(C * K + K, 256)), dim3(256), 0, st, partial, nblk, C * K, K, dw, db);
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(C * K + K), dim3(256), 0, st, partial, nblk, C * K, K, dw, db);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
 }
@@ -905,7 +901,10 @@ int vnet_softmax_dice_fwd(const float* logits, const int32_t* labels, int B, int
     p.nblk = nblk;
     K_SWITCH(K, hipLaunchKernelGGL(softmax_dice_fwd_kernel<KK>, dim3(nblk, B), dim3(EW_BLOCK), 0, st, p));
     VNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, p.partial, nblk, B, K, (double)V, loss_kind, weights, alpha,
+    double* sums = reinterpret_cast<double*>((char*)ws + align_up((size_t)B * EW_MAXBLK * (3 * K + 1) * sizeof(float), 16));
+    hipLaunchKernelGGL(loss_colsum_kernel, dim3(3 * K + 1, B), dim3(256), 0, st, p.partial, nblk, 3 * K + 1, sums);
+    VNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, sums, B, K, (double)V, loss_kind, weights, alpha,
                        smooth, loss_out, dice_out, coef);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
@@ -933,12 +932,15 @@ int vnet_dice_coe_fwd(const float* output, const float* target, int B, int64_t V
     if (!ws || ws_bytes < vnet_loss_ws_bytes(B, K) + sizeof(float)) return VNET_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)ws;
-    float* loss_tmp = partial + (size_t)B * EW_MAXBLK * (3 * K + 1);
+    double* sums = reinterpret_cast<double*>((char*)ws + align_up((size_t)B * EW_MAXBLK * (3 * K + 1) * sizeof(float), 16));
+    float* loss_tmp = reinterpret_cast<float*>(sums + (size_t)B * (3 * K + 1));
     const int nblk = ew_blocks((size_t)V / 4 + 1);
     K_SWITCH(K, hipLaunchKernelGGL(dice_sums_kernel<KK>, dim3(nblk, B), dim3(EW_BLOCK), 0, st, output, target, (size_t)V, jaccard, partial));
     VNET_LAUNCH_CHECK();
     const int kind = (jaccard ? VNET_LOSS_JACCARD : VNET_LOSS_SORENSEN) | (weights ? VNET_LOSS_WEIGHTED : 0);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, partial, nblk, B, K, (double)V, kind, weights, 0.f,
+    hipLaunchKernelGGL(loss_colsum_kernel, dim3(3 * K + 1, B), dim3(256), 0, st, partial, nblk, 3 * K + 1, sums);
+    VNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, sums, B, K, (double)V, kind, weights, 0.f,
                        smooth, loss_tmp, dice_out, coef);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
