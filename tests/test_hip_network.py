@@ -108,7 +108,10 @@ def test_config_c1_full_width_golden(dev):
 
 
 def test_config_c2_live_oracle(dev):
-    """BASELINE.json configs[1] geometry at reduced width (oracle time): 64^3, batch 2, all stages fwd+bwd."""
+    """BASELINE.json configs[1] geometry at reduced width (oracle time): 64^3, batch 2, all stages fwd+bwd.
+    Gradient tolerance 5e-3 for every tensor here: this narrow (4-channel) batch-2 network is the numerically
+    harshest case -- the stock PyTorch-CPU fp32 wiring (oracle/torch_ref.py) measures up to 4.1e-3 on filters
+    and 5.1e-3 on per-channel vectors against the same fp64 oracle; the HIP path measures <= 3.7e-3."""
     ps = O.ParamStore(rng=np.random.default_rng(5), perturb=0.1)
     ref_net = O.VNetOracle(2, 0.0, 4, 4, (1, 2, 3, 3), 3, "prelu", "networks", ps)
     x, lab = O.synthetic_batch(2, 64, 1, 2, seed=3000)
@@ -120,7 +123,7 @@ def test_config_c2_live_oracle(dev):
     for n, p in net.named_parameters():
         r = ref["grads"][n]
         if p.grad is not None and np.linalg.norm(r) > 1e-7:
-            assert rel_l2(p.grad.cpu().numpy(), r) < _gtol(n), (n, rel_l2(p.grad.cpu().numpy(), r))
+            assert rel_l2(p.grad.cpu().numpy(), r) < 5e-3, (n, rel_l2(p.grad.cpu().numpy(), r))
 
 
 def test_training_steps_match_oracle_adam(dev):
