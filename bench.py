@@ -135,10 +135,12 @@ def main():
     final_loss = float(loss.detach())
 
     if rank == 0:
-        # dominant kernel family: the 16-channel 5^3 conv at full resolution (enc1/conv_1 fwd, its backward-data
-        # and its filter gradient: 134.2 GF and 268.6 MB algorithmic each at 128^3)
+        # dominant kernel family: every launch of the two kernels that carry the 16-output-channel 5^3 convs at
+        # full resolution -- conv_kernel<5,1,4,8,16,8,4,1> (enc1 fwd 16->16, dec1/conv_1 fwd 32->16, enc1 bwd-data)
+        # and wgrad_kernel<5,1,4,8,16,1,32> (their filter gradients): 134.2 GF / 268.6 MB algorithmic per 16->16
+        # launch, 268.4 GF / 402.9 MB per 32->16 launch at 128^3
         P = args.patch
-        fam = {"conv k5 s1 %d^3x%d 16->16" % (P, args.batch): "fwd+bwd-data", "wgrad k5 s1 %d^3x%d 16->16" % (P, args.batch): "bwd-filter"}
+        fam = set("%s k5 s1 %d^3x%d %d->16" % (k, P, args.batch, c) for k in ("conv", "wgrad") for c in (16, 32))
         fl = by = ms = 0.0
         nl = 0
         per = {}
@@ -151,12 +153,17 @@ def main():
         if nl:
             ach = fl / (ms * 1e-3) / 1e12
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv16.json")
-            if os.path.exists(pmc):
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+            if os.path.exists(pmc) and P == 128 and args.batch == 1:
+                ks = json.load(open(pmc))["kernels"]
+                sel = [v for k, v in ks.items() if k.startswith("conv_kernel<5, 1, 4, 8, 16, 8, 4, 1, false> grid=2097152")
+                       or k.startswith("wgrad_kernel<5, 1, 4, 8, 16, 1, 32>")]
+                if sel:
+                    traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in sel) / sum(v["launches"] for v in sel))
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-                    "kernel": "conv_kernel<5,1,4,8,16,...>/wgrad_kernel<5,1,4,8,16,...> (16-ch 5^3 conv @%d^3: fwd, bwd-data, bwd-filter)" % P,
+                    "kernel": "conv_kernel<5,1,4,8,16,8,4,1> + wgrad_kernel<5,1,4,8,16,1,32>: the 5^3 convs with 16 output "
+                              "channels @%d^3 (fwd, bwd-data, bwd-filter)" % P,
                     "launches": nl, "avg_ms": round(ms / nl, 4), "flops_per_launch": fl / nl, "algorithmic_bytes_per_launch": by / nl,
                     "hbm_GBps_algorithmic": round(by / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
         conv_ms = sum(v[3] for v in per.values()) / args.steps
