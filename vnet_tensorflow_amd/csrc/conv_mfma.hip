@@ -32,6 +32,7 @@ struct ConvArgs {
     int vec_in, vec_out;
     float* part; size_t part_stride;  // split-K partials [split][vox][CoutP]
     int upO;           // UP: real output channels O (N' = 8*O)
+    int nz;            // tap (dz) splits per K-split: deep levels have too few bricks to fill 256 CUs
 };
 
 template <int KS, int STRIDE, int TZ, int TY, int TX>
@@ -44,35 +45,59 @@ struct TileGeom {
 };
 
 // Stage one 16-channel chunk of the input brick (+halo) into LDS as [iz][iy][ix][16].
-template <int IZ, int IY, int IX, int NT>
+template <int IZ, int IY, int IX, int NT, int MAXB = 16>
 __device__ __forceinline__ void load_tile(float* lds, const float* __restrict__ x0, const float* __restrict__ x1,
                                           int C0, int C1, int vec_in, int chunk, int b, int gz0, int gy0, int gx0,
                                           int Di, int Hi, int Wi, int tid) {
     constexpr int NQ = IZ * IY * IX * 4;
+    constexpr int PER = (NQ + NT - 1) / NT;
+    constexpr int NB = (PER + MAXB - 1) / MAXB, BATCH = (PER + NB - 1) / NB;
     const int Cin = C0 + C1;
-    for (int q = tid; q < NQ; q += NT) {
+    if (vec_in) {
+        // Every thread issues a whole batch of 16-byte loads before the first LDS store: the stage is
+        // latency-bound (one L2/HBM round trip per load), so the loads must be in flight together.
+#pragma unroll
+        for (int k0 = 0; k0 < PER; k0 += BATCH) {
+            float4 v[BATCH];
+#pragma unroll
+            for (int kb = 0; kb < BATCH; ++kb) {
+                const int q = tid + (k0 + kb) * NT;
+                const int vox = q >> 2, cq = q & 3;
+                const int ix = vox % IX, iy = (vox / IX) % IY, iz = vox / (IX * IY);
+                const int gz = gz0 + iz, gy = gy0 + iy, gx = gx0 + ix;
+                const int c = chunk * 16 + cq * 4;
+                // unconditional load from a clamped (always valid) address + select: a branch around each
+                // load would make hipcc wait vmcnt(0) per element and serialise the whole batch
+                const bool ok = q < NQ && (unsigned)gz < (unsigned)Di && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi && c < Cin;
+                const size_t gv = ok ? ((size_t)(b * Di + gz) * Hi + gy) * Wi + gx : 0;
+                const int cc = ok ? c : 0;
+                const float* p = (cc < C0) ? x0 + gv * C0 + cc : x1 + gv * C1 + (cc - C0);
+                const float4 t = *reinterpret_cast<const float4*>(p);
+                v[kb] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int kb = 0; kb < BATCH; ++kb) {
+                const int q = tid + (k0 + kb) * NT;
+                if (q < NQ) *reinterpret_cast<float4*>(lds + (size_t)q * 4) = v[kb];
+            }
+        }
+        return;
+    }
+    for (int q = tid; q < NQ; q += NT) {      // channel counts that are not multiples of 4: scalar gather
         const int vox = q >> 2, cq = q & 3;
         const int ix = vox % IX, iy = (vox / IX) % IY, iz = vox / (IX * IY);
         const int gz = gz0 + iz, gy = gy0 + iy, gx = gx0 + ix;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const int c = chunk * 16 + cq * 4;
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
         if ((unsigned)gz < (unsigned)Di && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi && c < Cin) {
             const size_t gv = ((size_t)(b * Di + gz) * Hi + gy) * Wi + gx;
-            if (vec_in && c + 3 < Cin) {
-                const float* p = (c < C0) ? x0 + gv * C0 + c : x1 + gv * C1 + (c - C0);
-                v = *reinterpret_cast<const float4*>(p);
-            } else {
-                float e[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int ck = c + k;
-                    e[k] = 0.f;
-                    if (ck < Cin) e[k] = (ck < C0) ? x0[gv * C0 + ck] : x1[gv * C1 + (ck - C0)];
-                }
-                v = make_float4(e[0], e[1], e[2], e[3]);
+            for (int k = 0; k < 4; ++k) {
+                const int ck = c + k;
+                if (ck < Cin) e[k] = (ck < C0) ? x0[gv * C0 + ck] : x1[gv * C1 + (ck - C0)];
             }
         }
-        *reinterpret_cast<float4*>(lds + (size_t)vox * 16 + cq * 4) = v;
+        *reinterpret_cast<float4*>(lds + (size_t)q * 4) = make_float4(e[0], e[1], e[2], e[3]);
     }
 }
 
@@ -91,7 +116,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
     const int by = brick % a.nby; brick /= a.nby;
     const int bz = brick % a.nbz; const int b = brick / a.nbz;
     const int co0 = blockIdx.y * (NS * 16);
-    const int split = blockIdx.z;
+    const int split = blockIdx.z / a.nz, zsplit = blockIdx.z - split * a.nz;
+    const int dz0 = zsplit * KS / a.nz, dz1 = (zsplit + 1) * KS / a.nz;
     const int c_begin = split * a.cps;
     const int c_end = min(a.nchunks, c_begin + a.cps);
 
@@ -130,10 +156,10 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < PF; ++j)
 #pragma unroll
-                for (int n = 0; n < NS; ++n) wf[j][n] = wq[(size_t)j * tap_stride + n * 16];
+                for (int n = 0; n < NS; ++n) wf[j][n] = wq[(size_t)(dz0 * T2 + j) * tap_stride + n * 16];
 #pragma unroll
-            for (int m = 0; m < MS; ++m) xf[0][m] = *reinterpret_cast<const float4*>(lds + boff[m]);
-            for (int dz = 0; dz < KS; ++dz) {
+            for (int m = 0; m < MS; ++m) xf[0][m] = *reinterpret_cast<const float4*>(lds + dz0 * G::IY * G::IX * 16 + boff[m]);
+            for (int dz = dz0; dz < dz1; ++dz) {
 #pragma unroll
                 for (int t2 = 0; t2 < T2; ++t2) {
                     {
@@ -226,7 +252,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
                 const int co = co0 + n * 16 + kk * 4;
                 f32x4 r = acc[m][n];
                 if (a.part) {
-                    *reinterpret_cast<float4*>(a.part + split * a.part_stride + ov * a.CoutP + co) =
+                    *reinterpret_cast<float4*>(a.part + blockIdx.z * a.part_stride + ov * a.CoutP + co) =
                         make_float4(r.x, r.y, r.z, r.w);
                     continue;
                 }
@@ -324,41 +350,86 @@ __global__ void __launch_bounds__(512) wgrad_kernel(WgradArgs a) {
         load_tile<G::IZ, G::IY, G::IX, 512>(xt, a.x0, a.x1, a.C0, a.C1, a.vec_in, chunk, b,
                                             bz * TZ * STRIDE - a.pad, by * TY * STRIDE - a.pad, bx * TX * STRIDE - a.pad,
                                             a.Di, a.Hi, a.Wi, tid);
-        // dy tile [NV][NS*16]
-        for (int q = tid; q < NV * NS * 4; q += 512) {
-            const int v = q / (NS * 4), cq = q - v * (NS * 4);
-            const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
-            const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
-            const int c = co0 + cq * 4;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout) {
-                const size_t ov = ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
-                const float* p = a.dy + ov * a.Cout + c;
-                if (a.vec_dy && c + 3 < a.Cout) val = *reinterpret_cast<const float4*>(p);
-                else {
-                    float e[4] = {0.f, 0.f, 0.f, 0.f};
+        // dy tile [NV][NS*16]: same all-loads-first staging (the vec/scalar choice is hoisted out of the
+        // unrolled batch: a branch inside it would serialise the loads)
+        {
+            constexpr int NQD = NV * NS * 4, PERD = (NQD + 511) / 512;
+            if (a.vec_dy) {
+                float4 val[PERD];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) if (c + k < a.Cout) e[k] = p[k];
-                    val = make_float4(e[0], e[1], e[2], e[3]);
+                for (int k = 0; k < PERD; ++k) {
+                    const int q = tid + k * 512;
+                    const int v = q / (NS * 4), cq = q - v * (NS * 4);
+                    const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+                    const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
+                    const int c = co0 + cq * 4;
+                    const bool ok = q < NQD && oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout;
+                    const size_t ov = ok ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
+                    const float4 t = *reinterpret_cast<const float4*>(a.dy + ov * a.Cout + (ok ? c : 0));
+                    val[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < PERD; ++k) {
+                    const int q = tid + k * 512;
+                    if (q < NQD) *reinterpret_cast<float4*>(dyt + (size_t)q * 4) = val[k];
+                }
+            } else {
+                for (int q = tid; q < NQD; q += 512) {
+                    const int v = q / (NS * 4), cq = q - v * (NS * 4);
+                    const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+                    const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
+                    const int c = co0 + cq * 4;
+                    float e[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout) {
+                        const float* p = a.dy + (((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.Cout + c;
+#pragma unroll
+                        for (int kk2 = 0; kk2 < 4; ++kk2) if (c + kk2 < a.Cout) e[kk2] = p[kk2];
+                    }
+                    *reinterpret_cast<float4*>(dyt + (size_t)q * 4) = make_float4(e[0], e[1], e[2], e[3]);
                 }
             }
-            *reinterpret_cast<float4*>(dyt + (size_t)v * (NS * 16) + cq * 4) = val;
         }
         __syncthreads();
-#pragma unroll 2
-        for (int g = half; g < NV / 4; g += 2) {
+        // The TW taps of a voxel group are processed in sub-blocks of CH taps with two register sets in
+        // ping-pong: the LDS reads of the next sub-block are issued (pinned by sched_barrier) before the
+        // MFMAs of the current one.  Left alone, hipcc serialises read -> wait -> MFMA through one register.
+        constexpr int NG = NV / 4;
+        constexpr int CH = TW < 8 ? TW : 8, SB = TW / CH, GPI = (SB % 2 == 0) ? 1 : 2;
+        static_assert(TW % CH == 0 && (NG / 2) % GPI == 0, "sub-block tiling");
+        auto fetch = [&](int g, int sb, float (&av)[NS], float (&bv)[CH]) {
+            g = min(g, NG - 2 + half);
             const int v = g * 4 + kk;
             const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
             const float* xb = xt + ((vz * STRIDE * G::IY + vy * STRIDE) * G::IX + vx * STRIDE) * 16 + i;
-            float av[NS];
 #pragma unroll
             for (int n = 0; n < NS; ++n) av[n] = dyt[v * (NS * 16) + n * 16 + i];
 #pragma unroll
-            for (int t = 0; t < TW; ++t) {
-                const float bv = xb[toff[t]];
+            for (int t = 0; t < CH; ++t) bv[t] = xb[toff[sb * CH + t]];
+        };
+        float avA[NS], bvA[CH], avB[NS], bvB[CH];
+        fetch(half, 0, avA, bvA);
+        for (int g = half; g < NG; g += 2 * GPI) {
 #pragma unroll
-                for (int n = 0; n < NS; ++n)
-                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[n], bv, acc[t][n], 0, 0, 0);
+            for (int u = 0; u < GPI * SB; ++u) {
+                const int sb = u % SB;
+                const int gn = g + 2 * ((u + 1) / SB), sbn = (u + 1) % SB;
+                if (u % 2 == 0) {
+                    fetch(gn, sbn, avB, bvB);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < CH; ++t)
+#pragma unroll
+                        for (int n = 0; n < NS; ++n)
+                            acc[sb * CH + t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(avA[n], bvA[t], acc[sb * CH + t][n], 0, 0, 0);
+                } else {
+                    fetch(gn, sbn, avA, bvA);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < CH; ++t)
+#pragma unroll
+                        for (int n = 0; n < NS; ++n)
+                            acc[sb * CH + t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(avB[n], bvB[t], acc[sb * CH + t][n], 0, 0, 0);
+                }
             }
         }
     }
@@ -437,7 +508,7 @@ int set_lds(K kernel, size_t bytes) {
 
 int pick_ns(int CoutP) { return (CoutP % 64 == 0) ? 4 : (CoutP % 32 == 0) ? 2 : 1; }
 
-struct ConvPlan { int ns, ncob, nbz, nby, nbx, nsplit, cps, small; };
+struct ConvPlan { int ns, ncob, nbz, nby, nbx, nsplit, cps, small, nz; };
 
 template <int TZ, int TY, int TX>
 void brick_counts(int Do, int Ho, int Wo, ConvPlan& p) { p.nbz = ceil_div(Do, TZ); p.nby = ceil_div(Ho, TY); p.nbx = ceil_div(Wo, TX); }
@@ -457,6 +528,7 @@ ConvPlan plan_conv(int ks, int stride, int up, int Cin, int Cout, int B, int Do,
     if (!up && nwg < 256 && nchunks > 1) p.nsplit = min(nchunks, ceil_div(512, nwg));
     p.cps = ceil_div(nchunks, p.nsplit);
     p.nsplit = ceil_div(nchunks, p.cps);
+    p.nz = (ks == 5 && !up && nwg * p.nsplit < 256) ? 5 : 1;
     return p;
 }
 
@@ -464,7 +536,7 @@ template <int KS, int STRIDE, int TZ, int TY, int TX, int WAVES, int MS, bool UP
 int launch_conv_ns(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
     using G = TileGeom<KS, STRIDE, TZ, TY, TX>;
     const size_t lds = (size_t)G::LDS_FLOATS * 4;
-    dim3 grid(a.B * p.nbz * p.nby * p.nbx, p.ncob, p.nsplit), block(WAVES * 64);
+    dim3 grid(a.B * p.nbz * p.nby * p.nbx, p.ncob, p.nsplit * p.nz), block(WAVES * 64);
     int e = 0;
 #define VNET_GO(NSV)                                                                              \
     {                                                                                             \
@@ -506,8 +578,8 @@ int vnet_pack_weights(int mode, const float* w, float* wp, int taps, int I, int 
 size_t vnet_conv_ws_bytes(int ks, int stride, int up, int Cin, int Cout, int B, int Do, int Ho, int Wo) {
     const int gridW = up ? (Wo + 1) / 2 : Wo;
     ConvPlan p = plan_conv(ks, stride, up, Cin, Cout, B, up ? (Do + 1) / 2 : Do, up ? (Ho + 1) / 2 : Ho, gridW, gridW);
-    if (p.nsplit <= 1) return 0;
-    return (size_t)p.nsplit * B * Do * Ho * Wo * round_up(Cout, 16) * sizeof(float);
+    if (p.nsplit * p.nz <= 1) return 0;
+    return (size_t)p.nsplit * p.nz * B * Do * Ho * Wo * round_up(Cout, 16) * sizeof(float);
 }
 
 int vnet_conv_fwd(int ks, int stride, int up, const float* x0, int C0, const float* x1, int C1,
@@ -538,10 +610,11 @@ int vnet_conv_fwd(int ks, int stride, int up, const float* x0, int C0, const flo
     }
     const int gD = isup ? Di : Do, gH = isup ? Hi : Ho, gW = isup ? Wi : Wo;
     ConvPlan p = plan_conv(ks, stride, up, a.Cin, isup ? Cy0 : a.Cout, B, gD, gH, gW, gW);
-    a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.cps = p.cps;
+    a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.cps = p.cps; a.nz = p.nz;
+    const int nslab = p.nsplit * p.nz;
     const size_t nvox = (size_t)B * Do * Ho * Wo;
-    if (p.nsplit > 1) {
-        const size_t need = (size_t)p.nsplit * nvox * a.CoutP * sizeof(float);
+    if (nslab > 1) {
+        const size_t need = (size_t)nslab * nvox * a.CoutP * sizeof(float);
         if (!ws || ws_bytes < need) return VNET_E_WORKSPACE;
         a.part = reinterpret_cast<float*>(ws); a.part_stride = nvox * a.CoutP;
     }
@@ -554,10 +627,10 @@ int vnet_conv_fwd(int ks, int stride, int up, const float* x0, int C0, const flo
         e = p.small ? launch_conv_ns<1, 1, 8, 8, 8, 8, 4, true>(a, p, st) : launch_conv_ns<1, 1, 4, 8, 16, 8, 4, true>(a, p, st);
     }
     if (e) return e;
-    if (p.nsplit > 1) {
+    if (nslab > 1) {
         const size_t total = nvox * a.Cout;
         const int blocks = (int)min((size_t)2048, (total + 255) / 256);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, a.part_stride, p.nsplit, bias,
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, a.part_stride, nslab, bias,
                            y0, y1, Cy0, Cy1, a.CoutP, nvox);
         VNET_LAUNCH_CHECK();
     }
@@ -582,7 +655,6 @@ WgradPlan plan_wgrad(int ks, int stride, int Cin, int Cout, int B, int Do, int H
     if (ks == 5) {
         p.tw = 32 / p.ns;
         if (p.small) { p.nbz = ceil_div(Do, 4); p.nby = ceil_div(Ho, 8); p.nbx = ceil_div(Wo, 8); }
-        else if (p.ns == 1) { p.nbz = ceil_div(Do, 4); p.nby = ceil_div(Ho, 8); p.nbx = ceil_div(Wo, 16); }
         else { p.nbz = ceil_div(Do, 4); p.nby = ceil_div(Ho, 4); p.nbx = ceil_div(Wo, 16); }
     } else {  // ks == 2, stride 2: out brick 2x4x16 / 2x8x8
         p.tw = 2;
@@ -644,7 +716,7 @@ int vnet_conv_wgrad(int ks, int stride, const float* x0, int C0, const float* x1
                                                                                      : launch_wgrad<5, 1, 4, 8, 8, 1, 32>(a, p, st);
         } else {
             e = p.ns == 4 ? launch_wgrad<5, 1, 4, 4, 16, 4, 8>(a, p, st) : p.ns == 2 ? launch_wgrad<5, 1, 4, 4, 16, 2, 16>(a, p, st)
-                                                                                      : launch_wgrad<5, 1, 4, 8, 16, 1, 32>(a, p, st);
+                                                                                      : launch_wgrad<5, 1, 4, 4, 16, 1, 32>(a, p, st);
         }
     } else {
         if (p.small) {
