@@ -305,26 +305,59 @@ struct WgradArgs {
     float* part;   // [split][tap][CinP][CoutP]
 };
 
+// Split staging: tile_issue puts a whole tile's 16-byte global loads in flight into registers,
+// tile_commit writes them to LDS later -- so the NEXT brick's loads overlap the CURRENT brick's MFMAs.
+template <int IZ, int IY, int IX, int NT>
+struct XTile {
+    static constexpr int NQ = IZ * IY * IX * 4;
+    static constexpr int PER = (NQ + NT - 1) / NT;
+    __device__ static __forceinline__ void issue(float4 (&v)[PER], const float* __restrict__ x0, const float* __restrict__ x1,
+                                                 int C0, int C1, int chunk, int b, int gz0, int gy0, int gx0,
+                                                 int Di, int Hi, int Wi, int tid) {
+        const int Cin = C0 + C1;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int q = tid + k * NT;
+            const int vox = q >> 2, cq = q & 3;
+            const int ix = vox % IX, iy = (vox / IX) % IY, iz = vox / (IX * IY);
+            const int gz = gz0 + iz, gy = gy0 + iy, gx = gx0 + ix;
+            const int c = chunk * 16 + cq * 4;
+            const bool ok = q < NQ && (unsigned)gz < (unsigned)Di && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi && c < Cin;
+            const size_t gv = ok ? ((size_t)(b * Di + gz) * Hi + gy) * Wi + gx : 0;
+            const int cc = ok ? c : 0;
+            const float* p = (cc < C0) ? x0 + gv * C0 + cc : x1 + gv * C1 + (cc - C0);
+            const float4 t = *reinterpret_cast<const float4*>(p);
+            v[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ static __forceinline__ void commit(float* lds, const float4 (&v)[PER], int tid) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int q = tid + k * NT;
+            if (q < NQ) *reinterpret_cast<float4*>(lds + (size_t)q * 4) = v[k];
+        }
+    }
+};
+
 template <int KS, int STRIDE, int TZ, int TY, int TX, int NS, int TW>
 __global__ void __launch_bounds__(512) wgrad_kernel(WgradArgs a) {
     using G = TileGeom<KS, STRIDE, TZ, TY, TX>;
+    using XT = XTile<G::IZ, G::IY, G::IX, 512>;
     constexpr int NV = TZ * TY * TX;
     constexpr int T3 = KS * KS * KS;
+    constexpr int NQD = NV * NS * 4, PERD = (NQD + 511) / 512;
     static_assert(TX % 4 == 0, "voxel groups are 4 consecutive x");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xt = lds;
     float* dyt = lds + G::LDS_FLOATS;
     const int tid = threadIdx.x;
-    // 8 waves = 2 per SIMD: waves w and w+4 own the same TW taps and split the brick's voxel groups
-    // between them (even / odd groups), each writing its own partial slab -> the co-resident wave
-    // hides the LDS latency of the other.
-    const int lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = wave8 & 3, half = wave8 >> 2;
+    // 8 waves = 2 per SIMD; wave w owns TW taps for the workgroup's NS*16 cout x 16 cin
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, kk = lane >> 4;
     const int split = blockIdx.x;
     const int chunk = blockIdx.y / a.ncob, cob = blockIdx.y - chunk * a.ncob;
     const int co0 = cob * NS * 16;
-    const int tap0 = (blockIdx.z * 4 + wave) * TW;
+    const int tap0 = (blockIdx.z * 8 + wave) * TW;
 
     int toff[TW];
 #pragma unroll
@@ -341,63 +374,77 @@ __global__ void __launch_bounds__(512) wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int n = 0; n < NS; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const bool pre = a.vec_in && a.vec_dy;       // uniform: register-prefetch path needs 16-byte accesses
+    float4 px[XT::PER];
+    float4 pd[PERD];
+
+    auto brick_coords = [&](int brick, int& b, int& bz, int& by, int& bx) {
+        bx = brick % a.nbx; brick /= a.nbx;
+        by = brick % a.nby; brick /= a.nby;
+        bz = brick % a.nbz; b = brick / a.nbz;
+    };
+    auto issue = [&](int brick) {
+        int b, bz, by, bx;
+        brick_coords(brick, b, bz, by, bx);
+        XT::issue(px, a.x0, a.x1, a.C0, a.C1, chunk, b, bz * TZ * STRIDE - a.pad, by * TY * STRIDE - a.pad,
+                  bx * TX * STRIDE - a.pad, a.Di, a.Hi, a.Wi, tid);
+#pragma unroll
+        for (int k = 0; k < PERD; ++k) {
+            const int q = tid + k * 512;
+            const int v = q / (NS * 4), cq = q - v * (NS * 4);
+            const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+            const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
+            const int c = co0 + cq * 4;
+            const bool ok = q < NQD && oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout;
+            const size_t ov = ok ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
+            const float4 t = *reinterpret_cast<const float4*>(a.dy + ov * a.Cout + (ok ? c : 0));
+            pd[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    if (pre && split < a.nbrick) issue(split);
     for (int brick = split; brick < a.nbrick; brick += a.nsplit) {
-        int br = brick;
-        const int bx = br % a.nbx; br /= a.nbx;
-        const int by = br % a.nby; br /= a.nby;
-        const int bz = br % a.nbz; const int b = br / a.nbz;
-        __syncthreads();
-        load_tile<G::IZ, G::IY, G::IX, 512>(xt, a.x0, a.x1, a.C0, a.C1, a.vec_in, chunk, b,
-                                            bz * TZ * STRIDE - a.pad, by * TY * STRIDE - a.pad, bx * TX * STRIDE - a.pad,
-                                            a.Di, a.Hi, a.Wi, tid);
-        // dy tile [NV][NS*16]: same all-loads-first staging (the vec/scalar choice is hoisted out of the
-        // unrolled batch: a branch inside it would serialise the loads)
-        {
-            constexpr int NQD = NV * NS * 4, PERD = (NQD + 511) / 512;
-            if (a.vec_dy) {
-                float4 val[PERD];
+        __syncthreads();                         // every wave is done reading the previous tiles
+        if (pre) {
+            XT::commit(xt, px, tid);
 #pragma unroll
-                for (int k = 0; k < PERD; ++k) {
-                    const int q = tid + k * 512;
-                    const int v = q / (NS * 4), cq = q - v * (NS * 4);
-                    const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
-                    const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
-                    const int c = co0 + cq * 4;
-                    const bool ok = q < NQD && oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout;
-                    const size_t ov = ok ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
-                    const float4 t = *reinterpret_cast<const float4*>(a.dy + ov * a.Cout + (ok ? c : 0));
-                    val[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+            for (int k = 0; k < PERD; ++k) {
+                const int q = tid + k * 512;
+                if (q < NQD) *reinterpret_cast<float4*>(dyt + (size_t)q * 4) = pd[k];
+            }
+        } else {
+            int b, bz, by, bx;
+            brick_coords(brick, b, bz, by, bx);
+            load_tile<G::IZ, G::IY, G::IX, 512>(xt, a.x0, a.x1, a.C0, a.C1, a.vec_in, chunk, b,
+                                                bz * TZ * STRIDE - a.pad, by * TY * STRIDE - a.pad, bx * TX * STRIDE - a.pad,
+                                                a.Di, a.Hi, a.Wi, tid);
+            for (int q = tid; q < NQD; q += 512) {
+                const int v = q / (NS * 4), cq = q - v * (NS * 4);
+                const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+                const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
+                const int c = co0 + cq * 4;
+                float e[4] = {0.f, 0.f, 0.f, 0.f};
+                if (oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout) {
+                    const float* p = a.dy + (((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.Cout + c;
 #pragma unroll
-                for (int k = 0; k < PERD; ++k) {
-                    const int q = tid + k * 512;
-                    if (q < NQD) *reinterpret_cast<float4*>(dyt + (size_t)q * 4) = val[k];
+                    for (int kk2 = 0; kk2 < 4; ++kk2) if (c + kk2 < a.Cout) e[kk2] = p[kk2];
                 }
-            } else {
-                for (int q = tid; q < NQD; q += 512) {
-                    const int v = q / (NS * 4), cq = q - v * (NS * 4);
-                    const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
-                    const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
-                    const int c = co0 + cq * 4;
-                    float e[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout) {
-                        const float* p = a.dy + (((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.Cout + c;
-#pragma unroll
-                        for (int kk2 = 0; kk2 < 4; ++kk2) if (c + kk2 < a.Cout) e[kk2] = p[kk2];
-                    }
-                    *reinterpret_cast<float4*>(dyt + (size_t)q * 4) = make_float4(e[0], e[1], e[2], e[3]);
-                }
+                *reinterpret_cast<float4*>(dyt + (size_t)q * 4) = make_float4(e[0], e[1], e[2], e[3]);
             }
         }
         __syncthreads();
+        if (pre && brick + a.nsplit < a.nbrick) {
+            issue(brick + a.nsplit);             // next brick's loads fly while this brick's MFMAs run
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // The TW taps of a voxel group are processed in sub-blocks of CH taps with two register sets in
         // ping-pong: the LDS reads of the next sub-block are issued (pinned by sched_barrier) before the
         // MFMAs of the current one.  Left alone, hipcc serialises read -> wait -> MFMA through one register.
         constexpr int NG = NV / 4;
         constexpr int CH = TW < 8 ? TW : 8, SB = TW / CH, GPI = (SB % 2 == 0) ? 1 : 2;
-        static_assert(TW % CH == 0 && (NG / 2) % GPI == 0, "sub-block tiling");
+        static_assert(TW % CH == 0 && NG % GPI == 0, "sub-block tiling");
         auto fetch = [&](int g, int sb, float (&av)[NS], float (&bv)[CH]) {
-            g = min(g, NG - 2 + half);
+            g = min(g, NG - 1);
             const int v = g * 4 + kk;
             const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
             const float* xb = xt + ((vz * STRIDE * G::IY + vy * STRIDE) * G::IX + vx * STRIDE) * 16 + i;
@@ -407,12 +454,12 @@ __global__ void __launch_bounds__(512) wgrad_kernel(WgradArgs a) {
             for (int t = 0; t < CH; ++t) bv[t] = xb[toff[sb * CH + t]];
         };
         float avA[NS], bvA[CH], avB[NS], bvB[CH];
-        fetch(half, 0, avA, bvA);
-        for (int g = half; g < NG; g += 2 * GPI) {
+        fetch(0, 0, avA, bvA);
+        for (int g = 0; g < NG; g += GPI) {
 #pragma unroll
             for (int u = 0; u < GPI * SB; ++u) {
                 const int sb = u % SB;
-                const int gn = g + 2 * ((u + 1) / SB), sbn = (u + 1) % SB;
+                const int gn = g + (u + 1) / SB, sbn = (u + 1) % SB;
                 if (u % 2 == 0) {
                     fetch(gn, sbn, avB, bvB);
                     __builtin_amdgcn_sched_barrier(0);
@@ -438,7 +485,7 @@ __global__ void __launch_bounds__(512) wgrad_kernel(WgradArgs a) {
     for (int t = 0; t < TW; ++t) {
         const int tap = tap0 + t;
         if (tap >= T3) continue;
-        float* dst = a.part + ((size_t)((split * 2 + half) * T3 + tap) * a.CinP + chunk * 16 + i) * a.CoutP + co0 + kk * 4;
+        float* dst = a.part + ((size_t)(split * T3 + tap) * a.CinP + chunk * 16 + i) * a.CoutP + co0 + kk * 4;
 #pragma unroll
         for (int n = 0; n < NS; ++n) {
             const f32x4 r = acc[t][n];
@@ -653,15 +700,15 @@ WgradPlan plan_wgrad(int ks, int stride, int Cin, int Cout, int B, int Do, int H
     p.small = Wo < 16;
     const int T3 = ks * ks * ks;
     if (ks == 5) {
-        p.tw = 32 / p.ns;
+        p.tw = 16 / p.ns;
         if (p.small) { p.nbz = ceil_div(Do, 4); p.nby = ceil_div(Ho, 8); p.nbx = ceil_div(Wo, 8); }
         else { p.nbz = ceil_div(Do, 4); p.nby = ceil_div(Ho, 4); p.nbx = ceil_div(Wo, 16); }
     } else {  // ks == 2, stride 2: out brick 2x4x16 / 2x8x8
-        p.tw = 2;
+        p.tw = 1;
         if (p.small) { p.nbz = ceil_div(Do, 2); p.nby = ceil_div(Ho, 8); p.nbx = ceil_div(Wo, 8); }
         else { p.nbz = ceil_div(Do, 2); p.nby = ceil_div(Ho, 4); p.nbx = ceil_div(Wo, 16); }
     }
-    p.ntg = ceil_div(T3, 4 * p.tw);
+    p.ntg = ceil_div(T3, 8 * p.tw);
     p.nbrick = B * p.nbz * p.nby * p.nbx;
     const int base = (round_up(Cin, 16) / 16) * p.ncob * p.ntg;
     p.nsplit = max(1, min(p.nbrick, ceil_div(512, base)));
@@ -686,7 +733,7 @@ extern "C" {
 
 size_t vnet_wgrad_ws_bytes(int ks, int stride, int Cin, int Cout, int B, int Do, int Ho, int Wo) {
     WgradPlan p = plan_wgrad(ks, stride, Cin, Cout, B, Do, Ho, Wo);
-    return (size_t)2 * p.nsplit * ks * ks * ks * round_up(Cin, 16) * round_up(Cout, 16) * sizeof(float);
+    return (size_t)p.nsplit * ks * ks * ks * round_up(Cin, 16) * round_up(Cout, 16) * sizeof(float);
 }
 
 int vnet_conv_wgrad(int ks, int stride, const float* x0, int C0, const float* x1, int C1,
@@ -706,31 +753,31 @@ int vnet_conv_wgrad(int ks, int stride, const float* x0, int C0, const float* x1
     WgradPlan p = plan_wgrad(ks, stride, a.Cin, Cout, B, Do, Ho, Wo);
     a.ncob = p.ncob; a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.nbrick = p.nbrick; a.nsplit = p.nsplit;
     const int T3 = ks * ks * ks;
-    const size_t need = (size_t)2 * p.nsplit * T3 * a.CinP * a.CoutP * sizeof(float);
+    const size_t need = (size_t)p.nsplit * T3 * a.CinP * a.CoutP * sizeof(float);
     if (!ws || ws_bytes < need) return VNET_E_WORKSPACE;
     a.part = reinterpret_cast<float*>(ws);
     int e;
     if (ks == 5) {
         if (p.small) {
-            e = p.ns == 4 ? launch_wgrad<5, 1, 4, 8, 8, 4, 8>(a, p, st) : p.ns == 2 ? launch_wgrad<5, 1, 4, 8, 8, 2, 16>(a, p, st)
-                                                                                     : launch_wgrad<5, 1, 4, 8, 8, 1, 32>(a, p, st);
+            e = p.ns == 4 ? launch_wgrad<5, 1, 4, 8, 8, 4, 4>(a, p, st) : p.ns == 2 ? launch_wgrad<5, 1, 4, 8, 8, 2, 8>(a, p, st)
+                                                                                     : launch_wgrad<5, 1, 4, 8, 8, 1, 16>(a, p, st);
         } else {
-            e = p.ns == 4 ? launch_wgrad<5, 1, 4, 4, 16, 4, 8>(a, p, st) : p.ns == 2 ? launch_wgrad<5, 1, 4, 4, 16, 2, 16>(a, p, st)
-                                                                                      : launch_wgrad<5, 1, 4, 4, 16, 1, 32>(a, p, st);
+            e = p.ns == 4 ? launch_wgrad<5, 1, 4, 4, 16, 4, 4>(a, p, st) : p.ns == 2 ? launch_wgrad<5, 1, 4, 4, 16, 2, 8>(a, p, st)
+                                                                                      : launch_wgrad<5, 1, 4, 4, 16, 1, 16>(a, p, st);
         }
     } else {
         if (p.small) {
-            e = p.ns == 4 ? launch_wgrad<2, 2, 2, 8, 8, 4, 2>(a, p, st) : p.ns == 2 ? launch_wgrad<2, 2, 2, 8, 8, 2, 2>(a, p, st)
-                                                                                     : launch_wgrad<2, 2, 2, 8, 8, 1, 2>(a, p, st);
+            e = p.ns == 4 ? launch_wgrad<2, 2, 2, 8, 8, 4, 1>(a, p, st) : p.ns == 2 ? launch_wgrad<2, 2, 2, 8, 8, 2, 1>(a, p, st)
+                                                                                     : launch_wgrad<2, 2, 2, 8, 8, 1, 1>(a, p, st);
         } else {
-            e = p.ns == 4 ? launch_wgrad<2, 2, 2, 4, 16, 4, 2>(a, p, st) : p.ns == 2 ? launch_wgrad<2, 2, 2, 4, 16, 2, 2>(a, p, st)
-                                                                                      : launch_wgrad<2, 2, 2, 4, 16, 1, 2>(a, p, st);
+            e = p.ns == 4 ? launch_wgrad<2, 2, 2, 4, 16, 4, 1>(a, p, st) : p.ns == 2 ? launch_wgrad<2, 2, 2, 4, 16, 2, 1>(a, p, st)
+                                                                                      : launch_wgrad<2, 2, 2, 4, 16, 1, 1>(a, p, st);
         }
     }
     if (e) return e;
     const size_t total = (size_t)T3 * a.Cin * Cout;
     const int blocks = (int)min((size_t)4096, (total + 63) / 64);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, 2 * p.nsplit, T3, a.CinP, a.CoutP, a.Cin, Cout, dw);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, p.nsplit, T3, a.CinP, a.CoutP, a.Cin, Cout, dw);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
 }
