@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(512) wgrad_kernel(WgradArgs a) {
         // ping-pong: the LDS reads of the next sub-block are issued (pinned by sched_barrier) before the
         // MFMAs of the current one.  Left alone, hipcc serialises read -> wait -> MFMA through one register.
         constexpr int NG = NV / 4;
-        constexpr int CH = TW < 8 ? TW : 8, SB = TW / CH, GPI = (SB % 2 == 0) ? 1 : 2;
+        constexpr int CH = TW < 16 ? TW : 16, SB = TW / CH, GPI = (SB % 2 == 0) ? 1 : 2;
         static_assert(TW % CH == 0 && NG % GPI == 0, "sub-block tiling");
         auto fetch = [&](int g, int sb, float (&av)[NS], float (&bv)[CH]) {
             g = min(g, NG - 1);
@@ -754,8 +754,10 @@ int vnet_conv_wgrad(int ks, int stride, const float* x0, int C0, const float* x1
     a.ncob = p.ncob; a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.nbrick = p.nbrick; a.nsplit = p.nsplit;
     const int T3 = ks * ks * ks;
     const size_t need = (size_t)p.nsplit * T3 * a.CinP * a.CoutP * sizeof(float);
-    if (!ws || ws_bytes < need) return VNET_E_WORKSPACE;
-    a.part = reinterpret_cast<float*>(ws);
+    // one slab and no channel padding: the slab IS dw (TF layout [tap][Cin][Cout]) -> no reduce pass
+    const bool direct = p.nsplit == 1 && a.CinP == a.Cin && a.CoutP == Cout;
+    if (!direct && (!ws || ws_bytes < need)) return VNET_E_WORKSPACE;
+    a.part = direct ? dw : reinterpret_cast<float*>(ws);
     int e;
     if (ks == 5) {
         if (p.small) {
@@ -775,6 +777,7 @@ int vnet_conv_wgrad(int ks, int stride, const float* x0, int C0, const float* x1
         }
     }
     if (e) return e;
+    if (direct) return VNET_OK;
     const size_t total = (size_t)T3 * a.Cin * Cout;
     const int blocks = (int)min((size_t)4096, (total + 63) / 64);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, p.nsplit, T3, a.CinP, a.CoutP, a.Cin, Cout, dw);

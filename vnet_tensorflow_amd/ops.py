@@ -83,6 +83,34 @@ def _same_out(n, s):
     return -(-n // s)
 
 
+# ---- gradient sinks ---------------------------------------------------------------------------------
+class GradSink(object):
+    """Registered on a Parameter by optim.FlatParams: backward kernels write that parameter's gradient
+    straight into its slice of the flat gradient buffer (no temporary, no autograd accumulate kernel) and
+    then call `ready` (the data-parallel bucket countdown).  `written` guards against a parameter that is
+    used twice in one backward pass: the second use falls back to autograd's accumulation."""
+    __slots__ = ("view", "written", "ready")
+
+    def __init__(self, view):
+        self.view, self.written, self.ready = view, False, None
+
+
+def _grad_out(p):
+    s = getattr(p, "_vnet_sink", None)
+    if s is not None and not s.written:
+        return s.view, s
+    return torch.empty_like(p), None
+
+
+def _grad_ret(t, s):
+    if s is None:
+        return t
+    s.written = True
+    if s.ready is not None:
+        s.ready()
+    return None
+
+
 # ---- optional per-launch timing (bench.py): HIP events on the launch stream ---------------------
 _PROFILE = {"on": False, "records": []}
 
@@ -154,11 +182,12 @@ def _wgrad_call(ks, stride, x0, x1, dy, dw, dims_in, dims_out):
                                 B, *dims_in, *dims_out, _ptr(ws), nb, _stream()), "vnet_conv_wgrad")
 
 
-def colsum(x2d_like, C):
+def colsum(x2d_like, C, out=None):
     """Per-channel sum over all leading axes of a channels-last tensor."""
     L = _lib.lib()
     M = x2d_like.numel() // C
-    out = torch.empty(C, dtype=torch.float32, device=x2d_like.device)
+    if out is None:
+        out = torch.empty(C, dtype=torch.float32, device=x2d_like.device)
     nb = L.vnet_colsum_ws_bytes(C)
     ws = workspace(nb, x2d_like.device)
     check(L.vnet_colsum(_ptr(x2d_like), _ptr(out), M, C, _ptr(ws), nb, _stream()), "vnet_colsum")
@@ -187,6 +216,7 @@ class _ConvFn(torch.autograd.Function):
         y = torch.empty((B,) + dims_out + (O,), dtype=torch.float32, device=x0.device)
         _conv_call(ks, stride, 1 if up else 0, x0, x1, wp, b, y, None, (Di, Hi, Wi), dims_out)
         ctx.save_for_backward(x0, x1, w)
+        ctx.params = (w, b)
         ctx.cfg = (ks, stride, up, (Di, Hi, Wi), dims_out, C0, C1, I, O)
         return y
 
@@ -197,10 +227,14 @@ class _ConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         B = x0.shape[0]
         dev = x0.device
-        db = colsum(dy, O) if ctx.needs_input_grad[3] else None
-        dw = None
+        wref, bref = ctx.params
+        db = dw = None
+        sb = sw = None
+        if ctx.needs_input_grad[3]:
+            db, sb = _grad_out(bref)
+            colsum(dy, O, out=db)
         if ctx.needs_input_grad[2]:
-            dw = torch.empty_like(w)
+            dw, sw = _grad_out(wref)
             if up:      # dw[a][o][ci] = sum_i dy[2i+a][o] * x[i][ci]  == filter grad of the 2^3 down conv (fine -> coarse)
                 _wgrad_call(2, 2, dy, None, x0, dw, dout, din)
             else:
@@ -218,7 +252,7 @@ class _ConvFn(torch.autograd.Function):
             else:
                 wp = packed_weights(w, PACK_BWD, ks ** 3, I, O)
                 _conv_call(ks, 1, 0, dy, None, wp, None, dx0, dx1, dout, din)
-        return dx0, dx1, dw, db, None, None, None, None
+        return dx0, dx1, _grad_ret(dw, sw), _grad_ret(db, sb), None, None, None, None
 
 
 def _meta(*ts):
@@ -266,6 +300,7 @@ class _BnActFn(torch.autograd.Function):
         check(L.vnet_bn_act_fwd(_ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
                                 act, _ptr(alpha), _ptr(y), _stream()), "vnet_bn_act_fwd")
         ctx.save_for_backward(x, r, gamma, beta, alpha, mean, invstd)
+        ctx.params = (gamma, beta, alpha)
         ctx.cfg = (act, bcast, M, C)
         return y
 
@@ -276,9 +311,10 @@ class _BnActFn(torch.autograd.Function):
         act, bcast, M, C = ctx.cfg
         dy = dy.contiguous()
         dev = dy.device
-        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
-        dalpha = torch.empty(C, dtype=torch.float32, device=dev) if alpha is not None else None
+        gref, bref, aref = ctx.params
+        dgamma, sg = _grad_out(gref)
+        dbeta, sbt = _grad_out(bref)
+        dalpha, sa = _grad_out(aref) if alpha is not None else (None, None)
         need_ds = ctx.needs_input_grad[0] or (r is not None and ctx.needs_input_grad[1])
         ds = torch.empty_like(dy) if need_ds else None
         nb = L.vnet_bn_ws_bytes(C)
@@ -289,7 +325,7 @@ class _BnActFn(torch.autograd.Function):
         dx = ds
         if bcast and ds is not None:
             dx = colsum_rows(ds)
-        return dx, (ds if r is not None else None), dgamma, dbeta, dalpha, None, None, None, None
+        return dx, (ds if r is not None else None), _grad_ret(dgamma, sg), _grad_ret(dbeta, sbt), _grad_ret(dalpha, sa), None, None, None, None
 
 
 def colsum_rows(ds):
@@ -375,6 +411,7 @@ class _HeadFn(torch.autograd.Function):
         y = torch.empty(x.shape[:-1] + (K,), dtype=torch.float32, device=x.device)
         check(L.vnet_head_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), M, C, K, _stream()), "vnet_head_fwd")
         ctx.save_for_backward(x, w)
+        ctx.params = (w, b)
         return y
 
     @staticmethod
@@ -385,13 +422,13 @@ class _HeadFn(torch.autograd.Function):
         M = x.numel() // C
         dy = dy.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(w)
-        db = torch.empty(K, dtype=torch.float32, device=x.device)
+        dw, sw = _grad_out(ctx.params[0])
+        db, sb = _grad_out(ctx.params[1])
         nb = L.vnet_head_ws_bytes(C, K)
         ws = workspace(nb, x.device)
         check(L.vnet_head_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), M, C, K, _ptr(ws), nb, _stream()),
               "vnet_head_bwd")
-        return dx, dw, db
+        return dx, _grad_ret(dw, sw), _grad_ret(db, sb)
 
 
 def head_conv(x, w, b):

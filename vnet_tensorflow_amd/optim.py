@@ -33,15 +33,19 @@ class FlatParams(object):
                 self.data[o:o + n].copy_(p.detach().reshape(-1))
                 p.data = self.data[o:o + n].view(p.shape)
                 p.grad = self.grad[o:o + n].view(p.shape)
+                p._vnet_sink = ops.GradSink(p.grad)      # backward kernels write here directly
         ops.invalidate_packed()
 
     def zero_grad(self):
         self.grad.zero_()
+        for p in self.params:
+            p._vnet_sink.written = False
         # autograd may have replaced .grad objects; re-point them at the flat buffer
         for p, o in zip(self.params, self.offsets):
             g = p.grad
             if g is None or g.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
+                p._vnet_sink.view = p.grad
 
     def buckets(self, bucket_bytes=32 << 20):
         """Contiguous [start, end) slices of the flat buffer, cut at variable boundaries, plus the

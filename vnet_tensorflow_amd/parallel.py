@@ -57,6 +57,9 @@ class BucketedGradAllReduce(object):
         if self.world > 1:
             for pi, p in enumerate(flat.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(pi)))
+                sink = getattr(p, "_vnet_sink", None)
+                if sink is not None:         # gradients written in place by the HIP backward kernels
+                    sink.ready = (lambda pi=pi: self._count(pi))
         self.begin_step()
 
     def begin_step(self):
@@ -74,11 +77,14 @@ class BucketedGradAllReduce(object):
                 view = self.flat.grad[o:o + param.numel()].view(param.shape)
                 view.add_(g)
                 param.grad = view
-            bi = self._bucket_of[pi]
-            self._pending[bi] -= 1
-            if self._pending[bi] == 0:
-                self._launch(bi)
+            self._count(pi)
         return hook
+
+    def _count(self, pi):
+        bi = self._bucket_of[pi]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
 
     def _launch(self, bi):
         if self._launched[bi] or self.world == 1:
