@@ -125,6 +125,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = m.train_step(images, labels)
+    host_dt = time.perf_counter() - t0           # time for the host to ENQUEUE the steps (GPU runs behind)
     barrier()
     dt = time.perf_counter() - t0
     recs = ops.profile_stop()
@@ -175,7 +176,7 @@ def main():
                "config": {"workload": "V-Net (16ch,4 levels,(1,2,3,3),3) train step fwd+Dice+bwd+Adam, %d^3 patch, %d modality, %d classes, "
                                       "batch %d/GPU (BASELINE configs[%d])" % (P, args.channels, args.classes, args.batch, 2 if world == 1 else 3),
                           "global_batch": world * args.batch, "parallelism": "dp%d" % world, "bn": "per-replica"},
-               "final_loss": round(final_loss, 6),
+               "final_loss": round(final_loss, 6), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
                "conv_ms_per_step": round(conv_ms, 3), "conv_tflops": round(conv_tf, 2),
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:

@@ -251,4 +251,4 @@ def train_step_fp32(net, images, labels, opt):
     loss, _ = loss_head(net.forward(images), labels, 'sorensen')
     loss.backward()
     opt.step()
-    return float(loss)
+    return float(loss.detach())

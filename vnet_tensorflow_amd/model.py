@@ -304,7 +304,7 @@ class image2label(object):
                     return
                 image = torch.from_numpy(image).to(self.device)
                 label = torch.from_numpy(label).to(self.device)
-                loss = float(self.train_step(image, label))
+                loss = float(self.train_step(image, label).detach())
                 self.last_loss = loss
                 self._print('{}: Segmentation training loss: {}'.format(_now(), str(loss)))
                 loss_sum += loss
@@ -321,7 +321,7 @@ class image2label(object):
                     with torch.no_grad():
                         _, tloss, _, _ = self.forward(torch.from_numpy(timage).to(self.device),
                                                       torch.from_numpy(tlabel).to(self.device), 0.0)
-                    self._print('{}: Segmentation testing loss: {}'.format(_now(), str(float(tloss))))
+                    self._print("{}: Segmentation testing loss: {}".format(_now(), str(float(tloss.detach()))))
             self._print("{}: Training of epoch {} complete, epoch loss: {}".format(_now(), epoch + 1, loss_sum / max(count, 1)))
             self.start_epoch += 1
             self._print("{}: Saving checkpoint of epoch {} at {}...".format(_now(), epoch + 1, self.ckpt_dir))
