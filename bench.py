@@ -138,7 +138,7 @@ def main():
     if rank == 0:
         # dominant kernel family: every launch of the two kernels that carry the 16-output-channel 5^3 convs at
         # full resolution -- conv_kernel<5,1,4,8,16,8,4,1> (enc1 fwd 16->16, dec1/conv_1 fwd 32->16, enc1 bwd-data)
-        # and wgrad_kernel<5,1,4,8,16,1,32> (their filter gradients): 134.2 GF / 268.6 MB algorithmic per 16->16
+        # and wgrad_kernel<5,1,4,4,16,1,16> (their filter gradients): 134.2 GF / 268.6 MB algorithmic per 16->16
         # launch, 268.4 GF / 402.9 MB per 32->16 launch at 128^3
         P = args.patch
         fam = set("%s k5 s1 %d^3x%d %d->16" % (k, P, args.batch, c) for k in ("conv", "wgrad") for c in (16, 32))
@@ -158,12 +158,12 @@ def main():
             if os.path.exists(pmc) and P == 128 and args.batch == 1:
                 ks = json.load(open(pmc))["kernels"]
                 sel = [v for k, v in ks.items() if k.startswith("conv_kernel<5, 1, 4, 8, 16, 8, 4, 1, false> grid=2097152")
-                       or k.startswith("wgrad_kernel<5, 1, 4, 8, 16, 1, 32>")]
+                       or k.startswith("wgrad_kernel<5, 1, 4, 4, 16, 1, 16>")]
                 if sel:
                     traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in sel) / sum(v["launches"] for v in sel))
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-                    "kernel": "conv_kernel<5,1,4,8,16,8,4,1> + wgrad_kernel<5,1,4,8,16,1,32>: the 5^3 convs with 16 output "
+                    "kernel": "conv_kernel<5,1,4,8,16,8,4,1> + wgrad_kernel<5,1,4,4,16,1,16>: the 5^3 convs with 16 output "
                               "channels @%d^3 (fwd, bwd-data, bwd-filter)" % P,
                     "launches": nl, "avg_ms": round(ms / nl, 4), "flops_per_launch": fl / nl, "algorithmic_bytes_per_launch": by / nl,
                     "hbm_GBps_algorithmic": round(by / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
