@@ -60,7 +60,9 @@ int vnet_pack_weights(int mode, const float* w, float* wp, int taps, int I, int 
  * and, with up=1, tf.nn.conv3d_transpose(x, w, output_shape, [1,2,2,2,1], 'SAME') + b
  * (layers2.py:73).  Also serves backward-data (conv with VNET_PACK_BWD weights; the 2^3
  * down/up pair are each other's backward-data).
- *   ks/stride : (5,1) (3,1) (1,1) (2,2);  up=1 requires ks=1 semantics internally: pass ks=2,stride=2,up=1.
+ *   ks/stride : (5,1) or (2,2); up=1 with (2,2) is the transposed conv.  kx = kernel extent along x
+ *               (0 = ks).  (ks=5,kx=1) is the 5x5x1 conv used on the x-im2col'ed 1-channel input
+ *               (vnet_tile_im2col_x): 25 taps over 16 virtual channels instead of 125 taps over 16 tiled ones.
  *   x0,C0,x1,C1 : input as the channel-concat of two NDHWC tensors (tf.concat, networks.py:325,
  *                 is never materialised); x1 may be NULL (C1=0).
  *   wp         : packed weights (vnet_pack_weights) for Cin=C0+C1 -> Cout=Cy0+Cy1.
@@ -69,8 +71,8 @@ int vnet_pack_weights(int mode, const float* w, float* wp, int taps, int I, int 
  *                 y1 may be NULL.
  *   B, Di,Hi,Wi : input spatial dims;  Do,Ho,Wo : output dims (SAME: ceil(in/stride); up: skip shape).
  *   ws         : workspace for split-K partials, >= vnet_conv_ws_bytes(...) bytes (may be NULL if 0). */
-size_t vnet_conv_ws_bytes(int ks, int stride, int up, int Cin, int Cout, int B, int Do, int Ho, int Wo);
-int vnet_conv_fwd(int ks, int stride, int up,
+size_t vnet_conv_ws_bytes(int ks, int kx, int stride, int up, int Cin, int Cout, int B, int Do, int Ho, int Wo);
+int vnet_conv_fwd(int ks, int kx, int stride, int up,
                   const float* x0, int C0, const float* x1, int C1,
                   const float* wp, const float* bias,
                   float* y0, int Cy0, float* y1, int Cy1,
@@ -81,12 +83,25 @@ int vnet_conv_fwd(int ks, int stride, int up,
  *   dw[t][ci][co] = sum_v x[v*stride + t - pad][ci] * dy[v][co]     (TF layout, unpadded)
  * x is the (possibly two-source) forward input, dy the gradient at the conv output [B,Do,Ho,Wo,Cout].
  * For the transposed 2^3 conv call it with x := dy_fine, dy := x_coarse (ks=2,stride=2). */
-size_t vnet_wgrad_ws_bytes(int ks, int stride, int Cin, int Cout, int B, int Do, int Ho, int Wo);
-int vnet_conv_wgrad(int ks, int stride,
+size_t vnet_wgrad_ws_bytes(int ks, int kx, int stride, int Cin, int Cout, int B, int Do, int Ho, int Wo);
+int vnet_conv_wgrad(int ks, int kx, int stride,
                     const float* x0, int C0, const float* x1, int C1,
                     const float* dy, int Cout, float* dw,
                     int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                     void* ws, size_t ws_bytes, void* stream);
+
+/* ---- single-modality input block (networks.py:254-259 tile + BN feeding encoder level 1 conv_1, networks.py:316)
+ * Every channel of that conv's input is an affine function of the same image, so the conv collapses to a
+ * 5x5x1 conv over 16 virtual channels = x-im2col of (image, inside-indicator):
+ *   vnet_tile_im2col_x      img [B,D,H,W,1] -> xv [B,D,H,W,16]
+ *   vnet_input_conv_fold    w [125][C][O] + BN coefficients -> wv [25][16][O] (then vnet_pack_weights FWD, taps=25)
+ *   forward  = vnet_conv_fwd(ks=5, kx=1, xv, wp) ;  G = vnet_conv_wgrad(ks=5, kx=1, xv, dy) [25][16][O]
+ *   vnet_input_conv_grads   G -> dw [125][C][O] and the conv-path parts of dgamma/dbeta (accumulate=1 adds).      */
+int vnet_tile_im2col_x(const float* img, float* xv, int B, int D, int H, int W, void* stream);
+int vnet_input_conv_fold(const float* w, const float* gamma, const float* beta, const float* mean, const float* invstd,
+                         float* wv, int C, int O, void* stream);
+int vnet_input_conv_grads(const float* G, const float* w, const float* gamma, const float* beta, const float* mean,
+                          const float* invstd, float* dw, float* dgamma, float* dbeta, int C, int O, int accumulate, void* stream);
 
 /* ---- 1x1x1 output head, networks.py:298-303 `convolution(x,[1,1,1,C,K])` (K <= 8) ---------- */
 int vnet_head_fwd(const float* x, const float* w, const float* bias, float* y, int64_t M, int C, int K, void* stream);

@@ -136,6 +136,35 @@ def test_bn_act(dev, C, act, res, tile):
     check_close(tag + " moving_var", mv, 0.99 + 0.01 * var, 1e-5)
 
 
+@pytest.mark.parametrize("shape", [(1, 8, 16, 32, 16), (2, 5, 9, 17, 16), (1, 6, 7, 9, 4), (1, 8, 8, 8, 8)])
+def test_input_block(dev, shape):
+    """conv5^3(BN(tile(img))) through the un-tiled 5x5x1 path (csrc/input_block.hip) == the oracle's tiled graph,
+    including the gradients that reach the input BN's gamma/beta through BOTH the conv and a residual use of x."""
+    from vnet_tensorflow_amd import ops
+    B, D, H, W, C = shape
+    rng = np.random.default_rng(sum(shape))
+    img = rng.standard_normal((B, D, H, W, 1)) * 40 + 120
+    gamma, beta = rng.uniform(0.5, 1.5, C), rng.standard_normal(C)
+    w = rng.standard_normal((5, 5, 5, C, C)) * 0.1
+    b = rng.standard_normal(C)
+    IMG, G_, B_, W_, Bi = O.Var(img), O.Var(gamma), O.Var(beta), O.Var(w), O.Var(b)
+    x = O.batch_norm_train(O.tile_channels(IMG, C), G_, B_)
+    y = O.add(O.convolution(x, W_, Bi, 1), x)            # conv + residual, like the first encoder block
+    dy = rng.standard_normal(y.v.shape)
+    O.backward(y, dy)
+    timg = g(img, dev)
+    tg, tb, tw, tbi = (g(a, dev).requires_grad_(True) for a in (gamma, beta, w, b))
+    tx, mean, invstd = ops.bn_act(timg, tg, tb, None, None, None, True, None, None, want_stats=True)
+    ty = ops.input_conv(timg, tg, tb, mean, invstd, tw, tbi) + tx
+    tag = "input block %s" % (shape,)
+    check_close(tag + " fwd", ty, y.v, 5e-6)
+    ty.backward(g(dy, dev))
+    check_close(tag + " dw", tw.grad, W_.g, 1e-5)
+    check_close(tag + " db", tbi.grad, Bi.g, 1e-5)
+    check_close(tag + " dgamma", tg.grad, G_.g, 5e-5)
+    check_close(tag + " dbeta", tb.grad, B_.g, 5e-5)
+
+
 @pytest.mark.parametrize("C,K", [(16, 2), (16, 5), (4, 3), (8, 8)])
 def test_head(dev, C, K):
     from vnet_tensorflow_amd import ops

@@ -25,9 +25,9 @@ def test_library_exports_every_declared_symbol():
     assert L.vnet_packed_weight_floats(0, 125, 16, 16) == 125 * 16 * 16
     assert L.vnet_packed_weight_floats(0, 125, 3, 5) == 125 * 16 * 16
     assert L.vnet_packed_weight_floats(2, 8, 32, 16) == 32 * 128
-    assert L.vnet_conv_ws_bytes(5, 1, 0, 16, 16, 1, 128, 128, 128) == 0          # no split-K at full resolution
-    assert L.vnet_conv_ws_bytes(5, 1, 0, 256, 256, 1, 8, 8, 8) > 0               # split-K at the bottom level
-    assert L.vnet_wgrad_ws_bytes(5, 1, 16, 16, 1, 128, 128, 128) > 0
+    assert L.vnet_conv_ws_bytes(5, 0, 1, 0, 16, 16, 1, 128, 128, 128) == 0          # no split-K at full resolution
+    assert L.vnet_conv_ws_bytes(5, 0, 1, 0, 256, 256, 1, 8, 8, 8) > 0               # split-K at the bottom level
+    assert L.vnet_wgrad_ws_bytes(5, 0, 1, 16, 16, 1, 128, 128, 128) > 0
 
 
 def test_no_cpu_fallback_and_argument_errors():
@@ -41,7 +41,7 @@ def test_no_cpu_fallback_and_argument_errors():
         ops.softmax_loss(torch.zeros(1, 4, 4, 4, 2), torch.zeros(1, 4, 4, 4, 1, dtype=torch.int32))
     L = _lib.lib()
     assert L.vnet_pack_weights(0, None, None, 125, 16, 16, None) == -1           # VNET_E_BADARG, no launch
-    assert L.vnet_conv_fwd(3, 1, 0, None, 16, None, 0, None, None, None, 16, None, 0, 1, 4, 4, 4, 4, 4, 4, None, 0, None) == -1
+    assert L.vnet_conv_fwd(3, 0, 1, 0, None, 16, None, 0, None, None, None, 16, None, 0, 1, 4, 4, 4, 4, 4, 4, None, 0, None) == -1
     with pytest.raises(SystemExit):
         ops.parse_loss("dice")
 

@@ -9,14 +9,17 @@ from . import ops
 from ._scope import VariableStore, current
 
 
-def convolution_block(layer_input, num_convolutions, keep_prob, activation_fn, is_training=True):
+def convolution_block(layer_input, num_convolutions, keep_prob, activation_fn, is_training=True, tiled=None):
     """reference VNet.py:26-39"""
     store = current()
     x = layer_input
     n_channels = L.get_num_channels(x)
     for i in range(num_convolutions):
         with store.variable_scope('conv_' + str(i + 1)):
-            x = L.convolution(x, [5, 5, 5, n_channels, n_channels])
+            if i == 0 and tiled is not None:
+                x = L.convolution_tiled(tiled, [5, 5, 5, n_channels, n_channels])
+            else:
+                x = L.convolution(x, [5, 5, 5, n_channels, n_channels])
             x = L.batch_normalization(x)
             res = layer_input if i == num_convolutions - 1 else None
             x = L.batch_normalization(x, activation=activation_fn, residual=res)
@@ -75,6 +78,7 @@ class VNet(object):
         if activation_fn not in ("relu", "prelu"):
             raise ValueError("activation_fn must be relu or prelu")
         self.activation_fn = activation_fn
+        self.fuse_input_block = True
         self.variables = VariableStore(device)
 
     def parameters(self):
@@ -105,8 +109,12 @@ class VNet(object):
         with store.active():
             input_channels = int(x.shape[-1])
             with store.variable_scope('vnet/input_layer'):
+                tiled = None
                 if input_channels == 1:
-                    x = L.batch_normalization(x, tile=True, channels=self.num_channels)
+                    # tile + BN; the first 5^3 conv then runs on the un-tiled image (layers2.convolution_tiled)
+                    x, tiled = L.batch_normalization(x, tile=True, channels=self.num_channels, want_stats=True)
+                    if self.num_channels > 16 or not self.fuse_input_block:
+                        tiled = None
                 else:
                     x = L.convolution(x, [5, 5, 5, input_channels, self.num_channels])
                     x = L.batch_normalization(x, activation=act)
@@ -114,7 +122,8 @@ class VNet(object):
             features = list()
             for l in range(self.num_levels):
                 with store.variable_scope('vnet/encoder/level_' + str(l + 1)):
-                    x = convolution_block(x, self.num_convolutions[l], keep_prob, activation_fn=act)
+                    x = convolution_block(x, self.num_convolutions[l], keep_prob, activation_fn=act,
+                                          tiled=tiled if l == 0 else None)
                     features.append(x)
                     with store.variable_scope('down_convolution'):
                         x = L.down_convolution(x, factor=2, kernel_size=[2, 2, 2])

@@ -19,12 +19,15 @@ SIGNATURES = {
     "vnet_version": (ctypes.c_char_p, []),
     "vnet_packed_weight_floats": (_sz, [_i, _i, _i, _i]),
     "vnet_pack_weights": (_i, [_i, _vp, _vp, _i, _i, _i, _vp]),
-    "vnet_conv_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
-    "vnet_conv_fwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i,
+    "vnet_conv_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "vnet_conv_fwd": (_i, [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i,
                            _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
-    "vnet_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
-    "vnet_conv_wgrad": (_i, [_i, _i, _vp, _i, _vp, _i, _vp, _i, _vp,
+    "vnet_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "vnet_conv_wgrad": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp,
                              _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "vnet_tile_im2col_x": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "vnet_input_conv_fold": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "vnet_input_conv_grads": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "vnet_head_fwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
     "vnet_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _sz, _vp]),
     "vnet_head_ws_bytes": (_sz, [_i, _i]),

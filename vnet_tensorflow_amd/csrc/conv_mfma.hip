@@ -28,18 +28,18 @@ struct ConvArgs {
     int CoutP;         // padded Cout (multiple of 16)
     int nchunks, cps;  // 16-channel chunks, chunks per K-split
     int nbz, nby, nbx; // bricks per axis
-    int pad;           // low-side SAME padding
+    int pad, padx;     // low-side SAME padding (z,y) and along x
     int vec_in, vec_out;
     float* part; size_t part_stride;  // split-K partials [split][vox][CoutP]
     int upO;           // UP: real output channels O (N' = 8*O)
     int nz;            // tap (dz) splits per K-split: deep levels have too few bricks to fill 256 CUs
 };
 
-template <int KS, int STRIDE, int TZ, int TY, int TX>
+template <int KS, int STRIDE, int TZ, int TY, int TX, int KX = KS>
 struct TileGeom {
     static constexpr int IZ = (TZ - 1) * STRIDE + KS;
     static constexpr int IY = (TY - 1) * STRIDE + KS;
-    static constexpr int IX = (TX - 1) * STRIDE + KS;
+    static constexpr int IX = (TX - 1) * STRIDE + KX;     // KX: kernel extent along x (1 for the x-im2col'ed input conv)
     static constexpr int NVOX_IN = IZ * IY * IX;
     static constexpr int LDS_FLOATS = NVOX_IN * 16;
 };
@@ -101,9 +101,9 @@ __device__ __forceinline__ void load_tile(float* lds, const float* __restrict__ 
     }
 }
 
-template <int KS, int STRIDE, int TZ, int TY, int TX, int WAVES, int MS, int NS, bool UP>
+template <int KS, int STRIDE, int TZ, int TY, int TX, int WAVES, int MS, int NS, bool UP, int KX = KS>
 __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
-    using G = TileGeom<KS, STRIDE, TZ, TY, TX>;
+    using G = TileGeom<KS, STRIDE, TZ, TY, TX, KX>;
     static_assert(TZ * TY * TX == WAVES * MS * 16, "brick must be WAVES*MS 16-voxel subtiles");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
 #pragma unroll
         for (int n = 0; n < NS; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int gz0 = bz * TZ * STRIDE - a.pad, gy0 = by * TY * STRIDE - a.pad, gx0 = bx * TX * STRIDE - a.pad;
+    const int gz0 = bz * TZ * STRIDE - a.pad, gy0 = by * TY * STRIDE - a.pad, gx0 = bx * TX * STRIDE - a.padx;
     const size_t tap_stride = (size_t)a.CQ * a.CoutP;   // float4 units
 
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
@@ -150,7 +150,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
             // they are software-pipelined PF taps ahead through a 5-slot register ring (5 | 25 taps per
             // dz slab keeps every ring index a compile-time constant) -- the L2 round trip hides under
             // the MFMAs of the taps in between instead of stalling each tap.
-            constexpr int T2 = KS * KS, T3 = T2 * KS, R = 5, PF = (NS == 1) ? 2 : 1;
+            constexpr int T2 = KS * KX, T3 = T2 * KS, R = 5, PF = (NS == 1) ? 2 : 1;
+            static_assert(T2 % R == 0, "ring slots must tile a dz slab");
             float4 wf[R][NS];
             float4 xf[R][MS];     // B fragments ride the same ring one tap ahead (LDS latency off the MFMA path)
 #pragma unroll
@@ -169,7 +170,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
                         for (int n = 0; n < NS; ++n) wf[(t2 + PF) % R][n] = wn[n * 16];
                         const int t2n = (t2 + 1) % T2;
                         const int dzn = min(dz + (t2 == T2 - 1 ? 1 : 0), KS - 1);
-                        const float* ln = lds + ((dzn * G::IY + t2n / KS) * G::IX + t2n % KS) * 16;
+                        const float* ln = lds + ((dzn * G::IY + t2n / KX) * G::IX + t2n % KX) * 16;
 #pragma unroll
                         for (int m = 0; m < MS; ++m) xf[(t2 + 1) % R][m] = *reinterpret_cast<const float4*>(ln + boff[m]);
                         // pin the issue point: hipcc otherwise sinks the loads to just before their first use
@@ -301,7 +302,7 @@ struct WgradArgs {
     int B, Di, Hi, Wi, Do, Ho, Wo;
     int CinP, CoutP, ncob;
     int nbz, nby, nbx, nbrick, nsplit;
-    int pad, vec_in, vec_dy;
+    int pad, padx, vec_in, vec_dy;
     float* part;   // [split][tap][CinP][CoutP]
 };
 
@@ -339,12 +340,12 @@ struct XTile {
     }
 };
 
-template <int KS, int STRIDE, int TZ, int TY, int TX, int NS, int TW>
+template <int KS, int STRIDE, int TZ, int TY, int TX, int NS, int TW, int KX = KS>
 __global__ void __launch_bounds__(512) wgrad_kernel(WgradArgs a) {
-    using G = TileGeom<KS, STRIDE, TZ, TY, TX>;
+    using G = TileGeom<KS, STRIDE, TZ, TY, TX, KX>;
     using XT = XTile<G::IZ, G::IY, G::IX, 512>;
     constexpr int NV = TZ * TY * TX;
-    constexpr int T3 = KS * KS * KS;
+    constexpr int T3 = KS * KS * KX;
     constexpr int NQD = NV * NS * 4, PERD = (NQD + 511) / 512;
     static_assert(TX % 4 == 0, "voxel groups are 4 consecutive x");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -364,7 +365,7 @@ __global__ void __launch_bounds__(512) wgrad_kernel(WgradArgs a) {
     for (int t = 0; t < TW; ++t) {
         int tap = tap0 + t;
         tap = tap < T3 ? tap : 0;
-        const int dx = tap % KS, dy = (tap / KS) % KS, dz = tap / (KS * KS);
+        const int dx = tap % KX, dy = (tap / KX) % KS, dz = tap / (KX * KS);
         toff[t] = ((dz * G::IY + dy) * G::IX + dx) * 16;
     }
 
@@ -387,7 +388,7 @@ __global__ void __launch_bounds__(512) wgrad_kernel(WgradArgs a) {
         int b, bz, by, bx;
         brick_coords(brick, b, bz, by, bx);
         XT::issue(px, a.x0, a.x1, a.C0, a.C1, chunk, b, bz * TZ * STRIDE - a.pad, by * TY * STRIDE - a.pad,
-                  bx * TX * STRIDE - a.pad, a.Di, a.Hi, a.Wi, tid);
+                  bx * TX * STRIDE - a.padx, a.Di, a.Hi, a.Wi, tid);
 #pragma unroll
         for (int k = 0; k < PERD; ++k) {
             const int q = tid + k * 512;
@@ -416,7 +417,7 @@ __global__ void __launch_bounds__(512) wgrad_kernel(WgradArgs a) {
             int b, bz, by, bx;
             brick_coords(brick, b, bz, by, bx);
             load_tile<G::IZ, G::IY, G::IX, 512>(xt, a.x0, a.x1, a.C0, a.C1, a.vec_in, chunk, b,
-                                                bz * TZ * STRIDE - a.pad, by * TY * STRIDE - a.pad, bx * TX * STRIDE - a.pad,
+                                                bz * TZ * STRIDE - a.pad, by * TY * STRIDE - a.pad, bx * TX * STRIDE - a.padx,
                                                 a.Di, a.Hi, a.Wi, tid);
             for (int q = tid; q < NQD; q += 512) {
                 const int v = q / (NS * 4), cq = q - v * (NS * 4);
@@ -579,15 +580,15 @@ ConvPlan plan_conv(int ks, int stride, int up, int Cin, int Cout, int B, int Do,
     return p;
 }
 
-template <int KS, int STRIDE, int TZ, int TY, int TX, int WAVES, int MS, bool UP>
+template <int KS, int STRIDE, int TZ, int TY, int TX, int WAVES, int MS, bool UP, int KX = KS>
 int launch_conv_ns(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
-    using G = TileGeom<KS, STRIDE, TZ, TY, TX>;
+    using G = TileGeom<KS, STRIDE, TZ, TY, TX, KX>;
     const size_t lds = (size_t)G::LDS_FLOATS * 4;
     dim3 grid(a.B * p.nbz * p.nby * p.nbx, p.ncob, p.nsplit * p.nz), block(WAVES * 64);
     int e = 0;
 #define VNET_GO(NSV)                                                                              \
     {                                                                                             \
-        auto k = conv_kernel<KS, STRIDE, TZ, TY, TX, WAVES, MS, NSV, UP>;                         \
+        auto k = conv_kernel<KS, STRIDE, TZ, TY, TX, WAVES, MS, NSV, UP, KX>;                         \
         static int attr_done = -1;                                                                \
         if (attr_done != 0) attr_done = set_lds(k, lds);                                          \
         if (attr_done != 0) return attr_done;                                                     \
@@ -622,14 +623,15 @@ int vnet_pack_weights(int mode, const float* w, float* wp, int taps, int I, int 
     return VNET_OK;
 }
 
-size_t vnet_conv_ws_bytes(int ks, int stride, int up, int Cin, int Cout, int B, int Do, int Ho, int Wo) {
+size_t vnet_conv_ws_bytes(int ks, int kx, int stride, int up, int Cin, int Cout, int B, int Do, int Ho, int Wo) {
+    (void)kx;
     const int gridW = up ? (Wo + 1) / 2 : Wo;
     ConvPlan p = plan_conv(ks, stride, up, Cin, Cout, B, up ? (Do + 1) / 2 : Do, up ? (Ho + 1) / 2 : Ho, gridW, gridW);
     if (p.nsplit * p.nz <= 1) return 0;
     return (size_t)p.nsplit * p.nz * B * Do * Ho * Wo * round_up(Cout, 16) * sizeof(float);
 }
 
-int vnet_conv_fwd(int ks, int stride, int up, const float* x0, int C0, const float* x1, int C1,
+int vnet_conv_fwd(int ks, int kx, int stride, int up, const float* x0, int C0, const float* x1, int C1,
                   const float* wp, const float* bias, float* y0, int Cy0, float* y1, int Cy1,
                   int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                   void* ws, size_t ws_bytes, void* stream) {
@@ -649,11 +651,14 @@ int vnet_conv_fwd(int ks, int stride, int up, const float* x0, int C0, const flo
     a.part = nullptr; a.part_stride = 0; a.upO = 0;
     const bool is5 = (ks == 5 && stride == 1 && !up), isdown = (ks == 2 && stride == 2 && !up), isup = (ks == 2 && stride == 2 && up);
     if (!is5 && !isdown && !isup) return VNET_E_UNSUPPORTED;
+    if (kx == 0) kx = ks;
+    if (kx != ks && !(is5 && kx == 1 && round_up(Cy0 + Cy1, 16) == 16)) return VNET_E_UNSUPPORTED;   // 5x5x1: x-im2col'ed input conv
     if (isup) {
         if (Cy1 != 0 || (Cy0 & 3)) return VNET_E_UNSUPPORTED;
-        a.CoutP = round_up(8 * Cy0, 16); a.upO = Cy0; a.pad = 0;
+        a.CoutP = round_up(8 * Cy0, 16); a.upO = Cy0; a.pad = 0; a.padx = 0;
     } else {
         a.CoutP = round_up(a.Cout, 16); a.pad = is5 ? 2 : 0;
+        a.padx = (kx - 1) / 2;
     }
     const int gD = isup ? Di : Do, gH = isup ? Hi : Ho, gW = isup ? Wi : Wo;
     ConvPlan p = plan_conv(ks, stride, up, a.Cin, isup ? Cy0 : a.Cout, B, gD, gH, gW, gW);
@@ -667,7 +672,8 @@ int vnet_conv_fwd(int ks, int stride, int up, const float* x0, int C0, const flo
     }
     int e;
     if (is5) {
-        e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 16, 8, 4, false>(a, p, st);
+        if (kx == 1) e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false, 1>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 16, 8, 4, false, 1>(a, p, st);
+        else e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 16, 8, 4, false>(a, p, st);
     } else if (isdown) {
         e = p.small ? launch_conv_ns<2, 2, 2, 8, 8, 4, 2, false>(a, p, st) : launch_conv_ns<2, 2, 2, 4, 16, 4, 2, false>(a, p, st);
     } else {
@@ -692,15 +698,15 @@ int vnet_conv_fwd(int ks, int stride, int up, const float* x0, int C0, const flo
 namespace {
 struct WgradPlan { int ns, tw, ncob, ntg, nbz, nby, nbx, nbrick, nsplit, small; };
 
-WgradPlan plan_wgrad(int ks, int stride, int Cin, int Cout, int B, int Do, int Ho, int Wo) {
+WgradPlan plan_wgrad(int ks, int kx, int stride, int Cin, int Cout, int B, int Do, int Ho, int Wo) {
     WgradPlan p{};
     const int CoutP = round_up(Cout, 16);
     p.ns = pick_ns(CoutP);
     p.ncob = CoutP / (16 * p.ns);
     p.small = Wo < 16;
-    const int T3 = ks * ks * ks;
+    const int T3 = ks * ks * kx;
     if (ks == 5) {
-        p.tw = 16 / p.ns;
+        p.tw = kx == 1 ? 4 : 16 / p.ns;
         if (p.small) { p.nbz = ceil_div(Do, 4); p.nby = ceil_div(Ho, 8); p.nbx = ceil_div(Wo, 8); }
         else { p.nbz = ceil_div(Do, 4); p.nby = ceil_div(Ho, 4); p.nbx = ceil_div(Wo, 16); }
     } else {  // ks == 2, stride 2: out brick 2x4x16 / 2x8x8
@@ -715,11 +721,11 @@ WgradPlan plan_wgrad(int ks, int stride, int Cin, int Cout, int B, int Do, int H
     return p;
 }
 
-template <int KS, int STRIDE, int TZ, int TY, int TX, int NS, int TW>
+template <int KS, int STRIDE, int TZ, int TY, int TX, int NS, int TW, int KX = KS>
 int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
-    using G = TileGeom<KS, STRIDE, TZ, TY, TX>;
+    using G = TileGeom<KS, STRIDE, TZ, TY, TX, KX>;
     const size_t lds = ((size_t)G::LDS_FLOATS + (size_t)TZ * TY * TX * NS * 16) * 4;
-    auto k = wgrad_kernel<KS, STRIDE, TZ, TY, TX, NS, TW>;
+    auto k = wgrad_kernel<KS, STRIDE, TZ, TY, TX, NS, TW, KX>;
     static int attr_done = -1;
     if (attr_done != 0) attr_done = set_lds(k, lds);
     if (attr_done != 0) return attr_done;
@@ -731,35 +737,40 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
 
 extern "C" {
 
-size_t vnet_wgrad_ws_bytes(int ks, int stride, int Cin, int Cout, int B, int Do, int Ho, int Wo) {
-    WgradPlan p = plan_wgrad(ks, stride, Cin, Cout, B, Do, Ho, Wo);
-    return (size_t)p.nsplit * ks * ks * ks * round_up(Cin, 16) * round_up(Cout, 16) * sizeof(float);
+size_t vnet_wgrad_ws_bytes(int ks, int kx, int stride, int Cin, int Cout, int B, int Do, int Ho, int Wo) {
+    if (kx == 0) kx = ks;
+    WgradPlan p = plan_wgrad(ks, kx, stride, Cin, Cout, B, Do, Ho, Wo);
+    return (size_t)p.nsplit * ks * ks * kx * round_up(Cin, 16) * round_up(Cout, 16) * sizeof(float);
 }
 
-int vnet_conv_wgrad(int ks, int stride, const float* x0, int C0, const float* x1, int C1,
+int vnet_conv_wgrad(int ks, int kx, int stride, const float* x0, int C0, const float* x1, int C1,
                     const float* dy, int Cout, float* dw,
                     int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                     void* ws, size_t ws_bytes, void* stream) {
     if (!x0 || !dy || !dw || C0 <= 0 || Cout <= 0 || B <= 0 || C1 < 0 || (C1 > 0 && !x1)) return VNET_E_BADARG;
     if (Di <= 0 || Hi <= 0 || Wi <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return VNET_E_BADARG;
     if (!((ks == 5 && stride == 1) || (ks == 2 && stride == 2))) return VNET_E_UNSUPPORTED;
+    if (kx == 0) kx = ks;
+    if (kx != ks && !(ks == 5 && kx == 1 && round_up(Cout, 16) == 16)) return VNET_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     WgradArgs a{};
     a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.dy = dy; a.Cout = Cout;
     a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
     a.CinP = round_up(a.Cin, 16); a.CoutP = round_up(Cout, 16);
-    a.pad = ks == 5 ? 2 : 0;
+    a.pad = ks == 5 ? 2 : 0; a.padx = (kx - 1) / 2;
     a.vec_in = (C0 % 4 == 0) && (C1 % 4 == 0); a.vec_dy = (Cout % 4 == 0);
-    WgradPlan p = plan_wgrad(ks, stride, a.Cin, Cout, B, Do, Ho, Wo);
+    WgradPlan p = plan_wgrad(ks, kx, stride, a.Cin, Cout, B, Do, Ho, Wo);
     a.ncob = p.ncob; a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.nbrick = p.nbrick; a.nsplit = p.nsplit;
-    const int T3 = ks * ks * ks;
+    const int T3 = ks * ks * kx;
     const size_t need = (size_t)p.nsplit * T3 * a.CinP * a.CoutP * sizeof(float);
     // one slab and no channel padding: the slab IS dw (TF layout [tap][Cin][Cout]) -> no reduce pass
     const bool direct = p.nsplit == 1 && a.CinP == a.Cin && a.CoutP == Cout;
     if (!direct && (!ws || ws_bytes < need)) return VNET_E_WORKSPACE;
     a.part = direct ? dw : reinterpret_cast<float*>(ws);
     int e;
-    if (ks == 5) {
+    if (ks == 5 && kx == 1) {
+        e = p.small ? launch_wgrad<5, 1, 4, 8, 8, 1, 4, 1>(a, p, st) : launch_wgrad<5, 1, 4, 4, 16, 1, 4, 1>(a, p, st);
+    } else if (ks == 5) {
         if (p.small) {
             e = p.ns == 4 ? launch_wgrad<5, 1, 4, 8, 8, 4, 4>(a, p, st) : p.ns == 2 ? launch_wgrad<5, 1, 4, 8, 8, 2, 8>(a, p, st)
                                                                                      : launch_wgrad<5, 1, 4, 8, 8, 1, 16>(a, p, st);

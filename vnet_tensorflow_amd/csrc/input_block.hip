@@ -1,0 +1,124 @@
+// input_block.hip -- the single-modality input block of the V-Net without the 16x redundant work.
+//
+// Reference networks.py:254-259: a 1-channel image is tf.tile'd to num_channels and batch-normalised, so every
+// channel of the first 5x5x5 convolution's input (networks.py:316, encoder level 1 conv_1) is an affine function
+// of the SAME image:  x_c = a_c * img + b_c  with  a_c = gamma_c * invstd,  b_c = beta_c - mean * a_c.  Hence
+//     conv(x, w)[v][o] = sum_tap (sum_c w[tap][c][o] a_c) img[v+tap] + sum_{tap: v+tap inside} (sum_c w[tap][c][o] b_c)
+// i.e. a 2-channel convolution of (img, inside-indicator) with folded filters.  The x taps of those two channels
+// are im2col'ed into 10 of 16 "virtual channels" so the MFMA kernel runs 25 taps x 16 channels (conv 5x5x1)
+// instead of 125 x 16: 5x fewer matrix instructions forward, the same for the filter gradient, and the
+// backward-data convolution disappears altogether because only its per-channel reductions are needed
+// (d gamma_c, d beta_c of the input batch-norm), which follow from the 2-channel filter gradient G:
+//     dw[tap][c][o]   = a_c G1[tap][o] + b_c G2[tap][o]
+//     d beta_c  (+)=  sum_{tap,o} w[tap][c][o] G2[tap][o]
+//     d gamma_c (+)=  sum_{tap,o} w[tap][c][o] invstd_c (G1[tap][o] - mean_c G2[tap][o])
+// Exact in exact arithmetic; in fp32 it differs from the tiled computation only by summation order.
+#include "common.h"
+
+namespace {
+
+// xv[v][2*dx + 0] = img[z][y][x+dx-2] (0 outside), xv[v][2*dx + 1] = 1 if x+dx-2 inside else 0, channels 10..15 = 0
+__global__ void __launch_bounds__(256) im2col_x_kernel(const float* __restrict__ img, float* __restrict__ xv, size_t nvox, int W) {
+    const size_t nq = nvox * 4;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t v = q >> 2;
+        const int cq = (int)(q & 3);
+        const int x = (int)(v % W);
+        float e[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ch = cq * 4 + k, dx = ch >> 1;
+            const int xx = x + dx - 2;
+            const bool in = ch < 10 && xx >= 0 && xx < W;
+            e[k] = !in ? 0.f : ((ch & 1) ? 1.f : img[v + dx - 2]);
+        }
+        reinterpret_cast<float4*>(xv)[q] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+}
+
+// wv[t25][vch][o]: vch = 2*dx + {0: folded with a_c, 1: folded with b_c}
+__global__ void __launch_bounds__(256) fold_weights_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, float* __restrict__ wv, int C, int O) {
+    const int total = 25 * 16 * O;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int o = idx % O, vch = (idx / O) % 16, t25 = idx / (16 * O);
+        float s = 0.f;
+        if (vch < 10) {
+            const int dx = vch >> 1, tap = t25 * 5 + dx;
+            for (int c = 0; c < C; ++c) {
+                const float a = gamma[c] * invstd[c];
+                const float coef = (vch & 1) ? (beta[c] - mean[c] * a) : a;
+                s += w[((size_t)tap * C + c) * O + o] * coef;
+            }
+        }
+        wv[idx] = s;
+    }
+}
+
+// one workgroup per input channel c: dw[:, c, :] and the conv-path parts of d gamma_c / d beta_c
+__global__ void __launch_bounds__(256) input_grads_kernel(const float* __restrict__ G, const float* __restrict__ w,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          float* __restrict__ dw, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          int C, int O, int accumulate) {
+    __shared__ double sh[2][4];
+    const int c = blockIdx.x;
+    const float a = gamma[c] * invstd[c], b = beta[c] - mean[c] * a;
+    double sg = 0.0, sb = 0.0;
+    for (int idx = threadIdx.x; idx < 125 * O; idx += blockDim.x) {
+        const int o = idx % O, tap = idx / O;
+        const int t25 = tap / 5, dx = tap - t25 * 5;
+        const float g1 = G[((size_t)t25 * 16 + 2 * dx) * O + o], g2 = G[((size_t)t25 * 16 + 2 * dx + 1) * O + o];
+        const size_t wi = ((size_t)tap * C + c) * O + o;
+        const float wt = w[wi];
+        dw[wi] = a * g1 + b * g2;
+        sg += (double)wt * (double)(invstd[c] * (g1 - mean[c] * g2));
+        sb += (double)wt * (double)g2;
+    }
+    sg = wave_sum_d(sg); sb = wave_sum_d(sb);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = sg; sh[1][threadIdx.x >> 6] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tg = (float)(sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+        const float tb = (float)(sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+        dgamma[c] = accumulate ? dgamma[c] + tg : tg;
+        dbeta[c] = accumulate ? dbeta[c] + tb : tb;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vnet_tile_im2col_x(const float* img, float* xv, int B, int D, int H, int W, void* stream) {
+    if (!img || !xv || B <= 0 || D <= 0 || H <= 0 || W <= 0) return VNET_E_BADARG;
+    const size_t nvox = (size_t)B * D * H * W;
+    const size_t nq = nvox * 4;
+    const int blocks = (int)(nq / 256 / 4 + 1 > 4096 ? 4096 : nq / 256 / 4 + 1);
+    hipLaunchKernelGGL(im2col_x_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, xv, nvox, W);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_input_conv_fold(const float* w, const float* gamma, const float* beta, const float* mean, const float* invstd,
+                         float* wv, int C, int O, void* stream) {
+    if (!w || !gamma || !beta || !mean || !invstd || !wv || C <= 0 || O <= 0) return VNET_E_BADARG;
+    if (O > 16) return VNET_E_UNSUPPORTED;
+    hipLaunchKernelGGL(fold_weights_kernel, dim3(ceil_div(25 * 16 * O, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w, gamma, beta, mean, invstd, wv, C, O);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_input_conv_grads(const float* G, const float* w, const float* gamma, const float* beta, const float* mean,
+                          const float* invstd, float* dw, float* dgamma, float* dbeta, int C, int O, int accumulate, void* stream) {
+    if (!G || !w || !gamma || !beta || !mean || !invstd || !dw || !dgamma || !dbeta || C <= 0 || O <= 0) return VNET_E_BADARG;
+    if (O > 16) return VNET_E_UNSUPPORTED;
+    hipLaunchKernelGGL(input_grads_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, G, w, gamma, beta, mean, invstd,
+                       dw, dgamma, dbeta, C, O, accumulate);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+}  // extern "C"

@@ -39,6 +39,7 @@ class VNet(object):
         if activation_fn not in ("relu", "prelu", "lrelu"):
             raise ValueError("activation_fn must be relu, prelu or lrelu")
         self.activation_fn = activation_fn
+        self.fuse_input_block = True       # single-modality input: skip the 16x redundant work of the tiled conv
         self.variables = VariableStore(device)
 
     # -- torch.nn.Module-like conveniences -------------------------------------------------
@@ -78,8 +79,12 @@ class VNet(object):
                 raise NotImplementedError("only 3-D PatchShape is built (2-D is out of scope, SURVEY section 2 row 11)")
             input_channels = int(x.shape[-1])
             with store.variable_scope('vnet/input_layer'):
+                tiled = None
                 if input_channels == 1:
-                    x = L.batch_normalization(x, tile=True, channels=self.num_channels)
+                    # tile + BN; the first 5^3 conv then runs on the un-tiled image (layers2.convolution_tiled)
+                    x, tiled = L.batch_normalization(x, tile=True, channels=self.num_channels, want_stats=True)
+                    if self.num_channels > 16 or not self.fuse_input_block:
+                        tiled = None
                 else:
                     x = L.convolution(x, [5, 5, 5, input_channels, self.num_channels])
                     x = L.batch_normalization(x, activation=act)
@@ -87,7 +92,8 @@ class VNet(object):
             features = list()
             for l in range(self.num_levels):
                 with store.variable_scope('vnet/encoder/level_' + str(l + 1)):
-                    x = self.convolution_block(x, self.num_convolutions[l], dropout_rate, act)
+                    x = self.convolution_block(x, self.num_convolutions[l], dropout_rate, act,
+                                               tiled=tiled if l == 0 else None)
                     features.append(x)
                     with store.variable_scope('down_convolution'):
                         x = L.down_convolution(x, factor=2, kernel_size=[2, 2, 2])
@@ -110,14 +116,17 @@ class VNet(object):
         return logits
 
     # -- reference networks.py:307-322 ---------------------------------------------------------
-    def convolution_block(self, layer_input, num_convolutions, dropout_rate, activation_fn, is_training=True):
+    def convolution_block(self, layer_input, num_convolutions, dropout_rate, activation_fn, is_training=True, tiled=None):
         from . import ops
         store = self.variables
         x = layer_input
         n_channels = L.get_num_channels(x)
         for i in range(num_convolutions):
             with store.variable_scope('conv_' + str(i + 1)):
-                x = L.convolution(x, [5, 5, 5, n_channels, n_channels])
+                if i == 0 and tiled is not None:
+                    x = L.convolution_tiled(tiled, [5, 5, 5, n_channels, n_channels])
+                else:
+                    x = L.convolution(x, [5, 5, 5, n_channels, n_channels])
                 res = layer_input if i == num_convolutions - 1 else None          # x = x + layer_input
                 x = L.batch_normalization(x, activation=activation_fn, residual=res)
                 x = ops.dropout(x, dropout_rate)

@@ -147,38 +147,39 @@ class _Timed(object):
 
 
 # ---- convolution family ----------------------------------------------------------------------------
-def _conv_call(ks, stride, up, x0, x1, wp, bias, y0, y1, dims_in, dims_out):
+def _conv_call(ks, stride, up, x0, x1, wp, bias, y0, y1, dims_in, dims_out, kx=0):
     L = _lib.lib()
     B = x0.shape[0]
     C0, C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
     Cy0, Cy1 = y0.shape[-1], (y1.shape[-1] if y1 is not None else 0)
-    nb = L.vnet_conv_ws_bytes(ks, stride, up, C0 + C1, Cy0 + Cy1, B, *dims_out)
+    nb = L.vnet_conv_ws_bytes(ks, kx, stride, up, C0 + C1, Cy0 + Cy1, B, *dims_out)
     ws = workspace(nb, x0.device) if nb else None
     nin, nout = B * dims_in[0] * dims_in[1] * dims_in[2], B * dims_out[0] * dims_out[1] * dims_out[2]
-    taps = 8 if up else ks ** 3
+    taps = 8 if up else ks * ks * (kx or ks)
     mac_vox = nin if up else nout          # the transposed conv does its 8 taps per INPUT voxel
     flops = 2.0 * mac_vox * taps * (C0 + C1) * (Cy0 + Cy1)
     nbytes = 4.0 * (nin * (C0 + C1) + nout * (Cy0 + Cy1) + taps * (C0 + C1) * (Cy0 + Cy1) + (Cy0 + Cy1))
-    tag = "conv k%d s%d%s %d^3x%d %d->%d" % (ks, stride, " up" if up else "", dims_out[2], B, C0 + C1, Cy0 + Cy1)
+    tag = "conv k%d%s s%d%s %d^3x%d %d->%d" % (ks, "x%d" % kx if kx else "", stride, " up" if up else "", dims_out[2], B, C0 + C1, Cy0 + Cy1)
     with _Timed(tag, flops, nbytes):
-        check(L.vnet_conv_fwd(ks, stride, up, _ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias),
+        check(L.vnet_conv_fwd(ks, kx, stride, up, _ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias),
                               _ptr(y0), Cy0, _ptr(y1), Cy1, B, *dims_in, *dims_out,
                               _ptr(ws), nb, _stream()), "vnet_conv_fwd")
 
 
-def _wgrad_call(ks, stride, x0, x1, dy, dw, dims_in, dims_out):
+def _wgrad_call(ks, stride, x0, x1, dy, dw, dims_in, dims_out, kx=0):
     L = _lib.lib()
     B = x0.shape[0]
     C0, C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
     Co = dy.shape[-1]
-    nb = L.vnet_wgrad_ws_bytes(ks, stride, C0 + C1, Co, B, *dims_out)
+    nb = L.vnet_wgrad_ws_bytes(ks, kx, stride, C0 + C1, Co, B, *dims_out)
     ws = workspace(nb, x0.device)
     nin, nout = B * dims_in[0] * dims_in[1] * dims_in[2], B * dims_out[0] * dims_out[1] * dims_out[2]
-    flops = 2.0 * nout * ks ** 3 * (C0 + C1) * Co
-    nbytes = 4.0 * (nin * (C0 + C1) + nout * Co + ks ** 3 * (C0 + C1) * Co)
-    tag = "wgrad k%d s%d %d^3x%d %d->%d" % (ks, stride, dims_out[2], B, C0 + C1, Co)
+    taps = ks * ks * (kx or ks)
+    flops = 2.0 * nout * taps * (C0 + C1) * Co
+    nbytes = 4.0 * (nin * (C0 + C1) + nout * Co + taps * (C0 + C1) * Co)
+    tag = "wgrad k%d%s s%d %d^3x%d %d->%d" % (ks, "x%d" % kx if kx else "", stride, dims_out[2], B, C0 + C1, Co)
     with _Timed(tag, flops, nbytes):
-        check(L.vnet_conv_wgrad(ks, stride, _ptr(x0), C0, _ptr(x1), C1, _ptr(dy), Co, _ptr(dw),
+        check(L.vnet_conv_wgrad(ks, kx, stride, _ptr(x0), C0, _ptr(x1), C1, _ptr(dy), Co, _ptr(dw),
                                 B, *dims_in, *dims_out, _ptr(ws), nb, _stream()), "vnet_conv_wgrad")
 
 
@@ -259,6 +260,60 @@ def _meta(*ts):
     return any(t is not None and t.device.type == "meta" for t in ts)
 
 
+class _InputConvFn(torch.autograd.Function):
+    """conv5^3(BN(tile(img))) + b for a 1-channel image without the 16x redundant work (csrc/input_block.hip):
+    forward = 5x5x1 conv over the x-im2col of (img, inside-indicator) with BN-folded filters; backward needs only
+    the 2-channel filter gradient G -- dw, and the conv-path parts of the input BN's dgamma/dbeta follow from it."""
+
+    @staticmethod
+    def forward(ctx, img, gamma, beta, mean, invstd, w, b):
+        L = _lib.lib()
+        img = img.contiguous()
+        B, D, H, W, _ = img.shape
+        C, O = w.shape[-2], w.shape[-1]
+        dev = img.device
+        xv = torch.empty((B, D, H, W, 16), dtype=torch.float32, device=dev)
+        check(L.vnet_tile_im2col_x(_ptr(img), _ptr(xv), B, D, H, W, _stream()), "vnet_tile_im2col_x")
+        wv = torch.empty((25, 16, O), dtype=torch.float32, device=dev)
+        check(L.vnet_input_conv_fold(_ptr(w), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(wv), C, O, _stream()),
+              "vnet_input_conv_fold")
+        wp = torch.empty(L.vnet_packed_weight_floats(PACK_FWD, 25, 16, O), dtype=torch.float32, device=dev)
+        check(L.vnet_pack_weights(PACK_FWD, _ptr(wv), _ptr(wp), 25, 16, O, _stream()), "vnet_pack_weights")
+        y = torch.empty((B, D, H, W, O), dtype=torch.float32, device=dev)
+        _conv_call(5, 1, 0, xv, None, wp, b, y, None, (D, H, W), (D, H, W), kx=1)
+        ctx.save_for_backward(xv, gamma, beta, mean, invstd, w)
+        ctx.params = (w, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        xv, gamma, beta, mean, invstd, w = ctx.saved_tensors
+        wref, bref = ctx.params
+        dy = dy.contiguous()
+        B, D, H, W, _ = xv.shape
+        C, O = w.shape[-2], w.shape[-1]
+        dev = dy.device
+        db, sb = _grad_out(bref)
+        colsum(dy, O, out=db)
+        G = torch.empty((25, 16, O), dtype=torch.float32, device=dev)
+        _wgrad_call(5, 1, xv, None, dy, G, (D, H, W), (D, H, W), kx=1)
+        dw, sw = _grad_out(wref)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        check(L.vnet_input_conv_grads(_ptr(G), _ptr(w), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(dw),
+                                      _ptr(dgamma), _ptr(dbeta), C, O, 0, _stream()), "vnet_input_conv_grads")
+        return None, dgamma, dbeta, None, None, _grad_ret(dw, sw), _grad_ret(db, sb)
+
+
+def input_conv(img, gamma, beta, mean, invstd, w, b):
+    """convolution(BN(tf.tile(img)), [5,5,5,C,C]) for a 1-channel `img` (networks.py:254-259 + 316)."""
+    if _meta(img):
+        return torch.empty(img.shape[:-1] + (w.shape[-1],), device="meta")
+    _need_gpu(img, "input_conv")
+    return _InputConvFn.apply(img, gamma, beta, mean, invstd, w, b)
+
+
 def conv(x0, w, b, ks, stride=1, x1=None):
     """tf.nn.convolution(concat(x0,x1), w, 'SAME', strides) + b (reference layers2.py:63)."""
     if x0.dim() != 5:
@@ -302,10 +357,11 @@ class _BnActFn(torch.autograd.Function):
         ctx.save_for_backward(x, r, gamma, beta, alpha, mean, invstd)
         ctx.params = (gamma, beta, alpha)
         ctx.cfg = (act, bcast, M, C)
-        return y
+        ctx.mark_non_differentiable(mean, invstd)
+        return y, mean, invstd
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _gmean, _ginvstd):
         L = _lib.lib()
         x, r, gamma, beta, alpha, mean, invstd = ctx.saved_tensors
         act, bcast, M, C = ctx.cfg
@@ -335,16 +391,18 @@ def colsum_rows(ds):
     return ds.sum(dim=-1, keepdim=True)
 
 
-def bn_act(x, gamma, beta, act=None, alpha=None, residual=None, tile=False, moving_mean=None, moving_var=None):
+def bn_act(x, gamma, beta, act=None, alpha=None, residual=None, tile=False, moving_mean=None, moving_var=None, want_stats=False):
     """tf.layers.batch_normalization(x (+ residual), training=True) followed by `act`.
     tile=True: x has one channel and is broadcast to gamma.numel() channels (tf.tile, networks.py:258)."""
     a = ACT[act]
     if _meta(x):
-        return torch.empty(x.shape[:-1] + (gamma.numel(),), device="meta")
+        y = torch.empty(x.shape[:-1] + (gamma.numel(),), device="meta")
+        return (y, None, None) if want_stats else y
     _need_gpu(x, "bn_act")
     if a == 2 and alpha is None:
         raise VnetHipError("prelu needs alpha")
-    return _BnActFn.apply(x, residual, gamma, beta, alpha if a == 2 else None, a, bool(tile), moving_mean, moving_var)
+    y, mean, invstd = _BnActFn.apply(x, residual, gamma, beta, alpha if a == 2 else None, a, bool(tile), moving_mean, moving_var)
+    return (y, mean, invstd) if want_stats else y
 
 
 def bn_update_only(x, C, moving_mean, moving_var):
