@@ -44,43 +44,63 @@ struct TileGeom {
     static constexpr int LDS_FLOATS = NVOX_IN * 16;
 };
 
-// Stage one 16-channel chunk of the input brick (+halo) into LDS as [iz][iy][ix][16].
-template <int IZ, int IY, int IX, int NT, int MAXB = 16>
+// Tile staging, split in two halves so a tile's global loads can fly while MFMAs run:
+//   issue  : every thread puts ALL of its 16-byte loads in flight into registers (unconditional loads from
+//            clamped addresses + select: a branch around a load would make hipcc wait vmcnt(0) per element);
+//   commit : registers -> LDS image [iz][iy][ix][16 channels].
+// Each thread owns one (x, channel-quad) column of the tile and walks the (z,y) rows, so the per-load address
+// arithmetic is a handful of integer ops (a flat quad index would cost ~60 VALU per load in div/mod + 64-bit mads).
+template <int IZ, int IY, int IX, int NT>
+struct XTile {
+    static constexpr int COLS = IX * 4;
+    static constexpr int RPI = NT / COLS;
+    static constexpr int ROWS = IZ * IY;
+    static constexpr int PER = (ROWS + RPI - 1) / RPI;
+    static_assert(RPI >= 1, "tile row wider than the workgroup");
+    __device__ static __forceinline__ void issue(float4 (&v)[PER], const float* __restrict__ x0, const float* __restrict__ x1,
+                                                 int C0, int C1, int chunk, int b, int gz0, int gy0, int gx0,
+                                                 int Di, int Hi, int Wi, int tid) {
+        const int r0 = tid / COLS, col = tid - r0 * COLS;
+        const int ix = col >> 2, cq = col & 3;
+        const int c = chunk * 16 + cq * 4;
+        const int gx = gx0 + ix;
+        const bool colok = r0 < RPI && (unsigned)gx < (unsigned)Wi && c < C0 + C1;
+        const bool first = c < C0 || !colok;
+        const float* src = first ? x0 + (colok ? c : 0) : x1 + (c - C0);
+        const int Cs = first ? C0 : C1;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int row = r0 + k * RPI;
+            const int iz = row / IY, iy = row - iz * IY;
+            const int gz = gz0 + iz, gy = gy0 + iy;
+            const bool ok = colok && row < ROWS && (unsigned)gz < (unsigned)Di && (unsigned)gy < (unsigned)Hi;
+            const size_t off = ok ? (((size_t)(b * Di + gz) * Hi + gy) * Wi + gx) * Cs : 0;
+            const float4 t = *reinterpret_cast<const float4*>(src + off);
+            v[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ static __forceinline__ void commit(float* lds, const float4 (&v)[PER], int tid) {
+        const int r0 = tid / COLS, col = tid - r0 * COLS;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int row = r0 + k * RPI;
+            if (r0 < RPI && row < ROWS) *reinterpret_cast<float4*>(lds + ((size_t)row * IX) * 16 + col * 4) = v[k];
+        }
+    }
+};
+
+// Synchronous staging of one 16-channel chunk of the input brick (+halo) into LDS as [iz][iy][ix][16].
+template <int IZ, int IY, int IX, int NT>
 __device__ __forceinline__ void load_tile(float* lds, const float* __restrict__ x0, const float* __restrict__ x1,
                                           int C0, int C1, int vec_in, int chunk, int b, int gz0, int gy0, int gx0,
                                           int Di, int Hi, int Wi, int tid) {
     constexpr int NQ = IZ * IY * IX * 4;
-    constexpr int PER = (NQ + NT - 1) / NT;
-    constexpr int NB = (PER + MAXB - 1) / MAXB, BATCH = (PER + NB - 1) / NB;
     const int Cin = C0 + C1;
     if (vec_in) {
-        // Every thread issues a whole batch of 16-byte loads before the first LDS store: the stage is
-        // latency-bound (one L2/HBM round trip per load), so the loads must be in flight together.
-#pragma unroll
-        for (int k0 = 0; k0 < PER; k0 += BATCH) {
-            float4 v[BATCH];
-#pragma unroll
-            for (int kb = 0; kb < BATCH; ++kb) {
-                const int q = tid + (k0 + kb) * NT;
-                const int vox = q >> 2, cq = q & 3;
-                const int ix = vox % IX, iy = (vox / IX) % IY, iz = vox / (IX * IY);
-                const int gz = gz0 + iz, gy = gy0 + iy, gx = gx0 + ix;
-                const int c = chunk * 16 + cq * 4;
-                // unconditional load from a clamped (always valid) address + select: a branch around each
-                // load would make hipcc wait vmcnt(0) per element and serialise the whole batch
-                const bool ok = q < NQ && (unsigned)gz < (unsigned)Di && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi && c < Cin;
-                const size_t gv = ok ? ((size_t)(b * Di + gz) * Hi + gy) * Wi + gx : 0;
-                const int cc = ok ? c : 0;
-                const float* p = (cc < C0) ? x0 + gv * C0 + cc : x1 + gv * C1 + (cc - C0);
-                const float4 t = *reinterpret_cast<const float4*>(p);
-                v[kb] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int kb = 0; kb < BATCH; ++kb) {
-                const int q = tid + (k0 + kb) * NT;
-                if (q < NQ) *reinterpret_cast<float4*>(lds + (size_t)q * 4) = v[kb];
-            }
-        }
+        using XT = XTile<IZ, IY, IX, NT>;
+        float4 v[XT::PER];
+        XT::issue(v, x0, x1, C0, C1, chunk, b, gz0, gy0, gx0, Di, Hi, Wi, tid);
+        XT::commit(lds, v, tid);
         return;
     }
     for (int q = tid; q < NQ; q += NT) {      // channel counts that are not multiples of 4: scalar gather
@@ -304,40 +324,6 @@ struct WgradArgs {
     int nbz, nby, nbx, nbrick, nsplit;
     int pad, padx, vec_in, vec_dy;
     float* part;   // [split][tap][CinP][CoutP]
-};
-
-// Split staging: tile_issue puts a whole tile's 16-byte global loads in flight into registers,
-// tile_commit writes them to LDS later -- so the NEXT brick's loads overlap the CURRENT brick's MFMAs.
-template <int IZ, int IY, int IX, int NT>
-struct XTile {
-    static constexpr int NQ = IZ * IY * IX * 4;
-    static constexpr int PER = (NQ + NT - 1) / NT;
-    __device__ static __forceinline__ void issue(float4 (&v)[PER], const float* __restrict__ x0, const float* __restrict__ x1,
-                                                 int C0, int C1, int chunk, int b, int gz0, int gy0, int gx0,
-                                                 int Di, int Hi, int Wi, int tid) {
-        const int Cin = C0 + C1;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int q = tid + k * NT;
-            const int vox = q >> 2, cq = q & 3;
-            const int ix = vox % IX, iy = (vox / IX) % IY, iz = vox / (IX * IY);
-            const int gz = gz0 + iz, gy = gy0 + iy, gx = gx0 + ix;
-            const int c = chunk * 16 + cq * 4;
-            const bool ok = q < NQ && (unsigned)gz < (unsigned)Di && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi && c < Cin;
-            const size_t gv = ok ? ((size_t)(b * Di + gz) * Hi + gy) * Wi + gx : 0;
-            const int cc = ok ? c : 0;
-            const float* p = (cc < C0) ? x0 + gv * C0 + cc : x1 + gv * C1 + (cc - C0);
-            const float4 t = *reinterpret_cast<const float4*>(p);
-            v[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    __device__ static __forceinline__ void commit(float* lds, const float4 (&v)[PER], int tid) {
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int q = tid + k * NT;
-            if (q < NQ) *reinterpret_cast<float4*>(lds + (size_t)q * 4) = v[k];
-        }
-    }
 };
 
 template <int KS, int STRIDE, int TZ, int TY, int TX, int NS, int TW, int KX = KS>
@@ -717,7 +703,7 @@ WgradPlan plan_wgrad(int ks, int kx, int stride, int Cin, int Cout, int B, int D
     p.ntg = ceil_div(T3, 8 * p.tw);
     p.nbrick = B * p.nbz * p.nby * p.nbx;
     const int base = (round_up(Cin, 16) / 16) * p.ncob * p.ntg;
-    p.nsplit = max(1, min(p.nbrick, ceil_div(512, base)));
+    p.nsplit = max(1, min(p.nbrick, ceil_div(256, base)));
     return p;
 }
 
