@@ -557,6 +557,17 @@ ConvPlan plan_conv(int ks, int stride, int up, int Cin, int Cout, int B, int Do,
     if (stride == 2 && !up) { if (p.small) brick_counts<2, 8, 8>(Do, Ho, Wo, p); else brick_counts<2, 4, 16>(Do, Ho, Wo, p); }
     else { if (p.small) brick_counts<8, 8, 8>(Do, Ho, Wo, p); else brick_counts<4, 8, 16>(Do, Ho, Wo, p); }
     const int nchunks = round_up(Cin, 16) / 16;
+    // deep levels have few bricks: prefer more, narrower cout blocks (each a full workgroup of equal work) until
+    // bricks x cout-blocks x channel-chunks fills the 256 CUs in one round, before resorting to tap splits
+    if (ks == 5 && !up) {
+        const long nb = (long)B * p.nbz * p.nby * p.nbx;
+        const int ncob1 = p.ns * p.ncob;                      // cout blocks at NS = 1
+        if (nb * p.ncob < 256 && nb * ncob1 >= 256) {         // fill the chip WITHOUT split-K if a narrower block can
+            while (nb * p.ncob < 256) { p.ns /= 2; p.ncob *= 2; }
+        } else {
+            while (p.ns > 1 && nb * p.ncob * nchunks < 256) { p.ns /= 2; p.ncob *= 2; }
+        }
+    }
     const int nwg = B * p.nbz * p.nby * p.nbx * p.ncob;
     p.nsplit = 1;
     if (!up && nwg < 256 && nchunks > 1) p.nsplit = min(nchunks, ceil_div(512, nwg));
