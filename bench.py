@@ -137,9 +137,10 @@ def main():
 
     if rank == 0:
         # dominant kernel family: every launch of the two kernels that carry the 16-output-channel 5^3 convs at
-        # full resolution -- conv_kernel<5,1,4,8,16,8,4,1> (enc1 fwd 16->16, dec1/conv_1 fwd 32->16, enc1 bwd-data)
-        # and wgrad_kernel<5,1,4,4,16,1,16> (their filter gradients): 134.2 GF / 268.6 MB algorithmic per 16->16
-        # launch, 268.4 GF / 402.9 MB per 32->16 launch at 128^3
+        # full resolution -- conv_kernel<5,1,4,8,16,8,4,1> (dec1/conv_1 fwd 32->16; 16->16 launches when the
+        # single-modality input block is not fused) and wgrad_kernel<5,1,4,4,16,1,16> (their filter gradients):
+        # 134.2 GF / 268.6 MB algorithmic per 16->16 launch, 268.4 GF / 402.9 MB per 32->16 launch at 128^3
+        # 
         P = args.patch
         fam = set("%s k5 s1 %d^3x%d %d->16" % (k, P, args.batch, c) for k in ("conv", "wgrad") for c in (16, 32))
         fl = by = ms = 0.0
@@ -157,8 +158,8 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
             if os.path.exists(pmc) and P == 128 and args.batch == 1:
                 ks = json.load(open(pmc))["kernels"]
-                sel = [v for k, v in ks.items() if k.startswith("conv_kernel<5, 1, 4, 8, 16, 8, 4, 1, false> grid=2097152")
-                       or k.startswith("wgrad_kernel<5, 1, 4, 4, 16, 1, 16>")]
+                sel = [v for k, v in ks.items() if k.startswith("conv_kernel<5, 1, 4, 8, 16, 8, 4, 1, false, 5> grid=2097152")
+                       or k.startswith("wgrad_kernel<5, 1, 4, 4, 16, 1, 16, 5>")]
                 if sel:
                     traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in sel) / sum(v["launches"] for v in sel))
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",

@@ -358,6 +358,7 @@ class _BnActFn(torch.autograd.Function):
         ctx.params = (gamma, beta, alpha)
         ctx.cfg = (act, bcast, M, C)
         ctx.mark_non_differentiable(mean, invstd)
+        ctx.set_materialize_grads(False)      # no zero-filled gradients for the (non-differentiable) statistics outputs
         return y, mean, invstd
 
     @staticmethod
@@ -534,6 +535,7 @@ class _LossFn(torch.autograd.Function):
         ctx.save_for_backward(logits, labels, weights, coef)
         ctx.cfg = (kind, alpha, B, V, K)
         ctx.mark_non_differentiable(dice)
+        ctx.set_materialize_grads(False)
         outs = [loss, dice]
         if sm is not None:
             ctx.mark_non_differentiable(sm)
