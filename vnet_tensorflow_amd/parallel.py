@@ -21,6 +21,8 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
+            backend = os.environ.get("VNET_DIST_BACKEND")          # test hook: gloo with GPU tensors on a 1-GPU box
+        if backend is None:
             backend = "nccl" if torch.cuda.device_count() > 0 else "gloo"   # device_count() does not initialise the GPU
         if backend == "nccl":
             torch.cuda.set_device(local)
@@ -54,6 +56,8 @@ class BucketedGradAllReduce(object):
         self._launched = [False] * len(self.buckets)
         self._handles = []
         self._hooks = []
+        self._expected = None
+        self._events = []
         if self.world > 1:
             for pi, p in enumerate(flat.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(pi)))
@@ -63,8 +67,14 @@ class BucketedGradAllReduce(object):
         self.begin_step()
 
     def begin_step(self):
+        """Per step.  A bucket is launched when every gradient EVENT of its variables has arrived.  A variable can
+        receive more than one event per backward pass (e.g. the input batch-norm's gamma/beta get a direct kernel
+        write from their own layer AND an autograd accumulation from the fused input conv), so the event counts are
+        calibrated on the first step (no early launches) and checked on every later one."""
+        n = len(self.flat.params)
+        self._events = [0] * n
         for bi, (_, _, first, last) in enumerate(self.buckets):
-            self._pending[bi] = last - first
+            self._pending[bi] = (sum(self._expected[first:last]) if self._expected is not None else -1)
             self._launched[bi] = False
         self._handles = []
 
@@ -81,6 +91,9 @@ class BucketedGradAllReduce(object):
         return hook
 
     def _count(self, pi):
+        self._events[pi] += 1
+        if self._expected is None:
+            return                      # calibration step: everything is reduced in finish()
         bi = self._bucket_of[pi]
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
@@ -100,10 +113,17 @@ class BucketedGradAllReduce(object):
             self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
-        """Flush buckets whose variables never received a gradient (dead batch-norms), then make the
-        compute stream wait for every all-reduce.  The optimiser divides by world (gscale)."""
+        """Flush buckets that are still pending (calibration step; variables that never receive a gradient such as
+        the dead batch-norms), then make the compute stream wait for every all-reduce.  The optimiser divides by
+        world (gscale)."""
         if self.world == 1:
             return
+        if self._expected is not None and self._events != self._expected:
+            early = [bi for bi, (_, _, f, l) in enumerate(self.buckets)
+                     if self._launched[bi] and any(self._events[pi] > self._expected[pi] for pi in range(f, l))]
+            if early:
+                raise RuntimeError("gradient events changed between steps (dynamic graph?): buckets %s were all-reduced "
+                                   "before their last gradient arrived" % early)
         for bi in range(len(self.buckets)):
             self._launch(bi)
         for h in self._handles:
@@ -111,6 +131,7 @@ class BucketedGradAllReduce(object):
         if self.overlap:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._handles = []
+        self._expected = list(self._events)
 
     def remove(self):
         for h in self._hooks:
