@@ -355,6 +355,12 @@ __global__ void __launch_bounds__(512) wgrad_kernel(WgradArgs a) {
         toff[t] = ((dz * G::IY + dy) * G::IX + dx) * 16;
     }
 
+    // loop-invariant LDS read pointers: lane part (voxel kk of a group, channel i) + this wave's tap offsets
+    const float* pt[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) pt[t] = xt + kk * STRIDE * 16 + i + toff[t];
+    const float* pa = dyt + kk * (NS * 16) + i;
+
     f32x4 acc[TW][NS];
 #pragma unroll
     for (int t = 0; t < TW; ++t)
@@ -424,47 +430,40 @@ __global__ void __launch_bounds__(512) wgrad_kernel(WgradArgs a) {
             issue(brick + a.nsplit);             // next brick's loads fly while this brick's MFMAs run
             __builtin_amdgcn_sched_barrier(0);
         }
-        // The TW taps of a voxel group are processed in sub-blocks of CH taps with two register sets in
-        // ping-pong: the LDS reads of the next sub-block are issued (pinned by sched_barrier) before the
-        // MFMAs of the current one.  Left alone, hipcc serialises read -> wait -> MFMA through one register.
+        // Inner loop, fully unrolled over the brick's voxel groups so that every LDS read is
+        //   ds_read_b32 v, <per-tap address register> offset:<compile-time group offset>
+        // with NO address VALU (on CDNA4 every non-MFMA VALU instruction of a wave costs MFMA issue time;
+        // 1.6 VALU per MFMA measured 16 % -- SQ_INSTS_VALU / SQ_INSTS_MFMA).  Two register sets in ping-pong:
+        // the next group's reads are issued (pinned by sched_barrier) before the current group's MFMAs.
         constexpr int NG = NV / 4;
-        constexpr int CH = TW < 16 ? TW : 16, SB = TW / CH, GPI = (SB % 2 == 0) ? 1 : 2;
-        static_assert(TW % CH == 0 && NG % GPI == 0, "sub-block tiling");
-        auto fetch = [&](int g, int sb, float (&av)[NS], float (&bv)[CH]) {
-            g = min(g, NG - 1);
-            const int v = g * 4 + kk;
-            const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
-            const float* xb = xt + ((vz * STRIDE * G::IY + vy * STRIDE) * G::IX + vx * STRIDE) * 16 + i;
+        static_assert(NG % 2 == 0, "voxel groups are processed in pairs");
+        auto fetch = [&](int g, float (&av)[NS], float (&bv)[TW]) {      // g is a literal after unrolling
+            const int v0 = g * 4;
+            const int vx0 = v0 % TX, vy = (v0 / TX) % TY, vz = v0 / (TX * TY);
+            const int go = ((vz * STRIDE * G::IY + vy * STRIDE) * G::IX + vx0 * STRIDE) * 16;
 #pragma unroll
-            for (int n = 0; n < NS; ++n) av[n] = dyt[v * (NS * 16) + n * 16 + i];
+            for (int n = 0; n < NS; ++n) av[n] = pa[v0 * (NS * 16) + n * 16];
 #pragma unroll
-            for (int t = 0; t < CH; ++t) bv[t] = xb[toff[sb * CH + t]];
+            for (int t = 0; t < TW; ++t) bv[t] = pt[t][go];
         };
-        float avA[NS], bvA[CH], avB[NS], bvB[CH];
-        fetch(0, 0, avA, bvA);
-        for (int g = 0; g < NG; g += GPI) {
+        float avA[NS], bvA[TW], avB[NS], bvB[TW];
+        fetch(0, avA, bvA);
 #pragma unroll
-            for (int u = 0; u < GPI * SB; ++u) {
-                const int sb = u % SB;
-                const int gn = g + (u + 1) / SB, sbn = (u + 1) % SB;
-                if (u % 2 == 0) {
-                    fetch(gn, sbn, avB, bvB);
-                    __builtin_amdgcn_sched_barrier(0);
+        for (int g = 0; g < NG; g += 2) {
+            fetch(g + 1, avB, bvB);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int t = 0; t < CH; ++t)
+            for (int t = 0; t < TW; ++t)
 #pragma unroll
-                        for (int n = 0; n < NS; ++n)
-                            acc[sb * CH + t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(avA[n], bvA[t], acc[sb * CH + t][n], 0, 0, 0);
-                } else {
-                    fetch(gn, sbn, avA, bvA);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int n = 0; n < NS; ++n)
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(avA[n], bvA[t], acc[t][n], 0, 0, 0);
+            if (g + 2 < NG) fetch(g + 2, avA, bvA);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int t = 0; t < CH; ++t)
+            for (int t = 0; t < TW; ++t)
 #pragma unroll
-                        for (int n = 0; n < NS; ++n)
-                            acc[sb * CH + t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(avB[n], bvB[t], acc[sb * CH + t][n], 0, 0, 0);
-                }
-            }
+                for (int n = 0; n < NS; ++n)
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(avB[n], bvB[t], acc[t][n], 0, 0, 0);
         }
     }
     // lane holds dW[tap][ci = chunk*16 + i][co = co0 + n*16 + 4*kk + {0..3}]
