@@ -55,6 +55,10 @@ const char* vnet_version(void);
  * floats = vnet_packed_weight_floats(mode, taps, I, O). */
 size_t vnet_packed_weight_floats(int mode, int taps, int I, int O);
 int vnet_pack_weights(int mode, const float* w, float* wp, int taps, int I, int O, void* stream);
+/* Same for every filter of a network in ONE launch (called after each optimiser step): `descs_dev` is a DEVICE
+ * array of n records of 8 int64 {w ptr, wp ptr, mode, taps, I, O, CQ, NP} (CQ, NP from vnet_packed_dims). */
+int vnet_packed_dims(int mode, int taps, int I, int O, int* CQ, int* NP);
+int vnet_pack_weights_batched(const void* descs_dev, int n, void* stream);
 
 /* ---- N-D convolution, replaces tf.nn.convolution(x, w, 'SAME', strides) + b  (layers2.py:63)
  * and, with up=1, tf.nn.conv3d_transpose(x, w, output_shape, [1,2,2,2,1], 'SAME') + b

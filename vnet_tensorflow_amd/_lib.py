@@ -19,6 +19,8 @@ SIGNATURES = {
     "vnet_version": (ctypes.c_char_p, []),
     "vnet_packed_weight_floats": (_sz, [_i, _i, _i, _i]),
     "vnet_pack_weights": (_i, [_i, _vp, _vp, _i, _i, _i, _vp]),
+    "vnet_packed_dims": (_i, [_i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "vnet_pack_weights_batched": (_i, [_vp, _i, _vp]),
     "vnet_conv_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "vnet_conv_fwd": (_i, [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i,
                            _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),

@@ -528,6 +528,30 @@ __global__ void pack_kernel(int mode, const float* __restrict__ w, float* __rest
     }
 }
 
+// all filters of a network in ONE launch (after every optimiser step): blockIdx.y selects the descriptor
+// {w, wp, mode, T, I, O, CQ, NP} (8 x int64 in device memory)
+__global__ void __launch_bounds__(256) pack_batched_kernel(const long long* __restrict__ descs) {
+    const long long* d = descs + (size_t)blockIdx.y * 8;
+    const float* w = reinterpret_cast<const float*>(d[0]);
+    float* wp = reinterpret_cast<float*>(d[1]);
+    const int mode = (int)d[2], T = (int)d[3], I = (int)d[4], O = (int)d[5];
+    const int CQ = (int)d[6], NP = (int)d[7];
+    const size_t total = (size_t)(mode == VNET_PACK_UP ? 1 : T) * CQ * NP * 4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(idx & 3);
+        size_t q = idx >> 2;
+        const int n = (int)(q % NP); q /= NP;
+        const int cq = (int)(q % CQ);
+        const int t = (int)(q / CQ);
+        const int k = cq * 4 + r;
+        float v = 0.f;
+        if (mode == VNET_PACK_FWD) { if (k < I && n < O) v = w[((size_t)t * I + k) * O + n]; }
+        else if (mode == VNET_PACK_BWD) { if (k < O && n < I) v = w[((size_t)(T - 1 - t) * I + n) * O + k]; }
+        else { if (k < I && n < 8 * O) v = w[(size_t)n * I + k]; }
+        wp[idx] = v;
+    }
+}
+
 void packed_dims(int mode, int T, int I, int O, int* Tp, int* CQ, int* NP) {
     if (mode == VNET_PACK_FWD) { *Tp = T; *CQ = round_up(I, 16) / 4; *NP = round_up(O, 16); }
     else if (mode == VNET_PACK_BWD) { *Tp = T; *CQ = round_up(O, 16) / 4; *NP = round_up(I, 16); }
@@ -615,6 +639,19 @@ int vnet_pack_weights(int mode, const float* w, float* wp, int taps, int I, int 
     const size_t total = (size_t)Tp * CQ * NP * 4;
     const int blocks = (int)min((size_t)4096, (total + 255) / 256);
     hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mode, w, wp, taps, I, O, CQ, NP, total);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_packed_dims(int mode, int taps, int I, int O, int* CQ, int* NP) {
+    if (mode < 0 || mode > 2 || !CQ || !NP) return VNET_E_BADARG;
+    int Tp; packed_dims(mode, taps, I, O, &Tp, CQ, NP);
+    return VNET_OK;
+}
+
+int vnet_pack_weights_batched(const void* descs_dev, int n, void* stream) {
+    if (!descs_dev || n <= 0) return VNET_E_BADARG;
+    hipLaunchKernelGGL(pack_batched_kernel, dim3(512, n), dim3(256), 0, (hipStream_t)stream, (const long long*)descs_dev);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
 }

@@ -7,6 +7,7 @@ for shape inference only, so a network can create its variables before the first
 """
 import ctypes
 import math
+import weakref
 
 import torch
 
@@ -52,11 +53,16 @@ def workspace(nbytes, device):
 
 # ---- packed-weight cache -------------------------------------------------------------------------
 _PACK_EPOCH = [0]
+_PACK_REG = {"entries": [], "descs": None, "device": None}     # every (filter, mode) ever packed: repacked in one launch
 
 
 def invalidate_packed():
     """Call after parameters change outside autograd's version counter (optimiser kernels)."""
     _PACK_EPOCH[0] += 1
+
+
+def _pack_tag(w):
+    return (_PACK_EPOCH[0], w._version, w.data_ptr())
 
 
 def packed_weights(w, mode, taps, I, O):
@@ -68,15 +74,52 @@ def packed_weights(w, mode, taps, I, O):
         w._vnet_packed = cache
     key = (mode, taps, I, O)
     ent = cache.get(key)
-    tag = (_PACK_EPOCH[0], w._version, w.data_ptr())
+    tag = _pack_tag(w)
     if ent is not None and ent[0] == tag:
         return ent[1]
     L = _lib.lib()
-    n = L.vnet_packed_weight_floats(mode, taps, I, O)
-    wp = ent[1] if ent is not None else torch.empty(n, dtype=torch.float32, device=w.device)
+    if ent is None:
+        wp = torch.empty(L.vnet_packed_weight_floats(mode, taps, I, O), dtype=torch.float32, device=w.device)
+        if isinstance(w, torch.nn.Parameter):                  # long-lived filter: join the batched repack
+            _PACK_REG["entries"].append((weakref.ref(w), key, wp))
+            _PACK_REG["descs"] = None
+    else:
+        wp = ent[1]
     check(L.vnet_pack_weights(mode, _ptr(w), _ptr(wp), taps, I, O, _stream()), "vnet_pack_weights")
     cache[key] = (tag, wp)
     return wp
+
+
+def repack_registered():
+    """After an optimiser step: refresh the packed copy of every registered filter in ONE kernel launch
+    (instead of ~58 small launches spread over the next forward/backward pass)."""
+    reg = _PACK_REG
+    alive = [(r(), key, wp) for r, key, wp in reg["entries"]]
+    if any(w is None for w, _, _ in alive):                     # networks that were garbage-collected
+        reg["entries"] = [(r, key, wp) for (r, key, wp), (w, _, _) in zip(reg["entries"], alive) if w is not None]
+        reg["descs"] = None
+    ents = [e for e in alive if e[0] is not None]
+    if not ents:
+        return
+    L = _lib.lib()
+    dev = ents[0][0].device
+    ptrs = tuple(w.data_ptr() for w, _, _ in ents)
+    if reg["descs"] is None or reg.get("ptrs") != ptrs:
+        rows = []
+        for w, (mode, taps, I, O), wp in ents:
+            cq, npad = ctypes.c_int(), ctypes.c_int()
+            check(L.vnet_packed_dims(mode, taps, I, O, ctypes.byref(cq), ctypes.byref(npad)), "vnet_packed_dims")
+            rows.append([w.data_ptr(), wp.data_ptr(), mode, taps, I, O, cq.value, npad.value])
+        reg["descs"] = torch.tensor(rows, dtype=torch.int64).to(dev)
+        reg["ptrs"] = ptrs
+    check(L.vnet_pack_weights_batched(_ptr(reg["descs"]), len(ents), _stream()), "vnet_pack_weights_batched")
+    for w, key, wp in ents:
+        w._vnet_packed[key] = (_pack_tag(w), wp)
+
+
+def clear_pack_registry():
+    _PACK_REG["entries"] = []
+    _PACK_REG["descs"] = None
 
 
 def _same_out(n, s):

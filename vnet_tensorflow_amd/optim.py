@@ -82,6 +82,7 @@ class GradientDescentOptimizer(_Base):
     def apply(self, lr):
         ops.sgd_apply(self.flat.data, self.flat.grad, lr, self.gscale)
         ops.invalidate_packed()
+        ops.repack_registered()
 
 
 class AdamOptimizer(_Base):
@@ -99,6 +100,7 @@ class AdamOptimizer(_Base):
         lr_t = lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
         ops.adam_apply(self.flat.data, self.flat.grad, self.m, self.v, lr_t, self.b1, self.b2, self.eps, self.gscale)
         ops.invalidate_packed()
+        ops.repack_registered()
 
     def state_dict(self):
         return {"t": self.t, "m": self.m, "v": self.v}
@@ -120,6 +122,7 @@ class MomentumOptimizer(_Base):
     def apply(self, lr):
         ops.momentum_apply(self.flat.data, self.flat.grad, self.acc, lr, self.momentum, self.nesterov, self.gscale)
         ops.invalidate_packed()
+        ops.repack_registered()
 
     def state_dict(self):
         return {"acc": self.acc}
