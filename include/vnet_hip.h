@@ -185,6 +185,12 @@ int vnet_sgd_apply(float* p, const float* g, int64_t n, float lr, float gscale, 
 int vnet_momentum_apply(float* p, const float* g, float* acc, int64_t n, float lr, float momentum,
                         int nesterov, float gscale, void* stream);
 
+/* ---- hard metrics (model.py:588-626): K x K confusion matrix cm[label][prediction] as float64 counts;
+ * accuracy, per-class tp/tn/fp/fn, sensitivity, specificity and hard Dice 2tp/(2tp+fp+fn) follow on the host. */
+size_t vnet_confusion_ws_bytes(int K);
+int vnet_confusion_matrix(const int64_t* pred, const int32_t* labels, int64_t n, int K, double* cm_out,
+                          void* ws, size_t ws_bytes, void* stream);
+
 /* ---- sliding-window accumulation for evaluate (model.py:919-929) ----------------------------- */
 int vnet_accumulate_patch(const float* patch, float* vol, float* count, int K,
                           int pz, int py, int px, int z0, int y0, int x0, int D, int H, int W, void* stream);

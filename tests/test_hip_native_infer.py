@@ -1,0 +1,55 @@
+"""-m gpu: the native C++ sliding-window driver (csrc/vnet_infer.cpp, the MI355X counterpart of the reference's cxx/
+demo) against the Python evaluate path (model.py:866-937 mirror): same weights, same volume, same patch/stride/batch
+-> identical label map and probabilities to fp32 round-off."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "vnet_tensorflow_amd", "vnet_infer")
+
+
+@pytest.mark.parametrize("cin,K,levels,convs,bottom,batch", [(1, 2, 2, [1, 2], 1, 2), (2, 3, 3, [1, 2, 3], 2, 3)])
+def test_native_driver_matches_python_evaluate(tmp_path, dev, cin, K, levels, convs, bottom, batch):
+    from vnet_tensorflow_amd import model as M
+    from oracle.vnet_oracle import synthetic_batch
+    assert os.path.exists(BIN), "run __graft_entry__.build() first"
+    cfg = {"TrainingSetting": {"Data": {"TrainingDataDirectory": "", "TestingDataDirectory": "",
+                                        "ImageFilenames": ["i%d.npy" % c for c in range(cin)], "LabelFilename": "l.npy"},
+                               "SegmentationClasses": list(range(K)), "BatchSize": 1, "PatchShape": [16, 16, 16],
+                               "Networks": {"Name": "VNet", "Dropout": 0.0, "NumChannel": 8, "NumLevels": levels,
+                                            "NumCovolutions": convs, "BottomConvolutions": bottom},
+                               "Optimizer": {"Name": "Adam", "InitialLearningRate": 1e-3, "Decay": {"Factor": 0.99, "Steps": 100}},
+                               "Loss": {"Name": "sorensen"}},
+           "EvaluationSetting": {"Stride": [8, 12, 16], "BatchSize": batch, "ProbabilityOutput": True}}
+    np.random.seed(3)
+    m = M.image2label(None, cfg, device=dev, verbose=False)
+    m.read_config()
+    m.build_model_graph()
+    # non-trivial BN/PReLU parameters so a wiring mistake cannot hide behind gamma=1, beta=0
+    import torch
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(0)
+        for name, p in m.network.named_parameters():
+            if not name.endswith("weights"):
+                p.add_(0.2 * torch.randn(p.shape, generator=g).to(p.device))
+    vol, _ = synthetic_batch(1, 24, cin, K, seed=9)
+    vol = np.ascontiguousarray(vol[0][:, :22, :20])
+    label_py, prob_py = m.evaluate_single_3D(vol)
+
+    wpath, ipath = str(tmp_path / "net.vnetw"), str(tmp_path / "vol.npy")
+    M.export_weights(m.network, wpath)
+    np.save(ipath, vol.astype(np.float32))
+    out = subprocess.run([BIN, "--weights", wpath, "--image", ipath, "--label-out", str(tmp_path / "lab.npy"),
+                          "--prob-out", str(tmp_path / "prob.npy"), "--classes", str(K), "--channels", "8",
+                          "--levels", str(levels), "--convs", ",".join(map(str, convs)), "--bottom", str(bottom),
+                          "--patch", "16,16,16", "--stride", "8,12,16", "--batch", str(batch)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:] + out.stdout[-1000:]
+    label_cc, prob_cc = np.load(tmp_path / "lab.npy"), np.load(tmp_path / "prob.npy")
+    assert label_cc.shape == label_py.shape and prob_cc.shape == prob_py.shape
+    assert np.abs(prob_cc - prob_py).max() < 2e-5, np.abs(prob_cc - prob_py).max()
+    assert (label_cc == label_py).mean() > 0.9999

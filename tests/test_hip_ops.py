@@ -248,6 +248,23 @@ def test_activation_standalone(dev):
     check_close("prelu dalpha", ta.grad, A_.g, 2e-6)
 
 
+def test_hard_metrics(dev):
+    """reference model.py:588-626: accuracy / tp,tn,fp,fn / sensitivity / specificity / hard dice vs a numpy count."""
+    from vnet_tensorflow_amd import ops
+    rng = np.random.default_rng(2)
+    K = 3
+    lab = rng.integers(0, K, size=(2, 9, 10, 11))
+    pred = np.where(rng.uniform(size=lab.shape) < 0.8, lab, rng.integers(0, K, size=lab.shape))
+    m = ops.hard_metrics(g(pred, dev, torch.int64), g(lab, dev, torch.int32), K)
+    assert abs(m["accuracy"] - (pred == lab).mean()) < 1e-12
+    ref = O.hard_dice(pred, lab, K)
+    for c in range(K):
+        p, t = pred == c, lab == c
+        assert m[c]["tp"] == (p & t).sum() and m[c]["fp"] == (p & ~t).sum() and m[c]["fn"] == (~p & t).sum() and m[c]["tn"] == (~p & ~t).sum()
+        assert abs(m[c]["dice"] - ref[c]) < 1e-12
+        assert abs(m[c]["sensitivity"] - (p & t).sum() / t.sum()) < 1e-12 and abs(m[c]["specificity"] - (~p & ~t).sum() / (~t).sum()) < 1e-12
+
+
 def test_dropout(dev):
     from vnet_tensorflow_amd import ops
     x = torch.ones(4, 8, 8, 8, 16, device=dev, requires_grad=True)

@@ -52,6 +52,8 @@ SIGNATURES = {
     "vnet_adam_apply": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp]),
     "vnet_sgd_apply": (_i, [_vp, _vp, _i64, _f, _f, _vp]),
     "vnet_momentum_apply": (_i, [_vp, _vp, _vp, _i64, _f, _f, _i, _f, _vp]),
+    "vnet_confusion_ws_bytes": (_sz, [_i]),
+    "vnet_confusion_matrix": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
     "vnet_accumulate_patch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
 }
 

@@ -9,7 +9,7 @@
 namespace {
 
 constexpr int EW_BLOCK = 256;
-constexpr int EW_MAXBLK = 1024;   // partial rows per reduction
+constexpr int EW_MAXBLK = 2048;   // partial rows per reduction
 constexpr int MAXC = 1024;
 
 inline int ew_blocks(size_t work_items) {

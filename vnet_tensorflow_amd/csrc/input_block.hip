@@ -122,3 +122,49 @@ int vnet_input_conv_grads(const float* G, const float* w, const float* gamma, co
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------
+// hard segmentation metrics (reference model.py:588-626): K x K confusion matrix of (label, prediction);
+// accuracy / per-class tp, tn, fp, fn / sensitivity / specificity / hard Dice follow on the host.
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) confusion_kernel(const long long* __restrict__ pred, const int32_t* __restrict__ labels,
+                                                        size_t n, int K, float* __restrict__ partial) {
+    __shared__ unsigned int cm[64];
+    if (threadIdx.x < 64) cm[threadIdx.x] = 0u;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int l = labels[i], p = (int)pred[i];
+        if (l >= 0 && l < K && p >= 0 && p < K) atomicAdd(&cm[l * K + p], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < K * K) partial[(size_t)blockIdx.x * K * K + threadIdx.x] = (float)cm[threadIdx.x];
+}
+__global__ void __launch_bounds__(256) confusion_finalize_kernel(const float* __restrict__ partial, int nblk, int KK, double* __restrict__ out) {
+    __shared__ double shd[4];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) s += (double)partial[(size_t)b * KK + c];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[c] = shd[0] + shd[1] + shd[2] + shd[3];
+}
+}  // namespace
+
+extern "C" {
+size_t vnet_confusion_ws_bytes(int K) { return (size_t)1024 * K * K * sizeof(float); }
+
+int vnet_confusion_matrix(const int64_t* pred, const int32_t* labels, int64_t n, int K, double* cm_out,
+                          void* ws, size_t ws_bytes, void* stream) {
+    if (!pred || !labels || !cm_out || n <= 0 || K <= 0) return VNET_E_BADARG;
+    if (K > 8) return VNET_E_UNSUPPORTED;
+    if (!ws || ws_bytes < vnet_confusion_ws_bytes(K)) return VNET_E_WORKSPACE;
+    const int nblk = (int)((n + 256 * 16 - 1) / (256 * 16) > 1024 ? 1024 : (n + 256 * 16 - 1) / (256 * 16));
+    hipLaunchKernelGGL(confusion_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const long long*)pred, labels, (size_t)n, K, (float*)ws);
+    VNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(confusion_finalize_kernel, dim3(K * K), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nblk, K * K, cm_out);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+}  // extern "C"

@@ -75,6 +75,23 @@ def prepare_batch(image_ijk_patch_indices_dict):
     return np.asarray([images[p[0]:p[1], p[2]:p[3], p[4]:p[5], :] for p in ijk])
 
 
+def export_weights(network, path):
+    """Write every trainable variable of `network` (TF names) as the blob the native driver loads
+    (csrc/vnet_infer.cpp): 'VNETW1\\0\\0', u32 nvars, then {u32 name_len, name, u32 ndim, u32 dims[], f32 data}.
+    The counterpart of the reference's meta_to_pb.py (checkpoint -> graph.pb for cxx/)."""
+    import struct
+    items = network.named_parameters()
+    with open(path, "wb") as f:
+        f.write(b"VNETW1\0\0")
+        f.write(struct.pack("<I", len(items)))
+        for name, p in items:
+            arr = np.ascontiguousarray(p.detach().cpu().numpy(), dtype=np.float32)
+            nb = name.encode()
+            f.write(struct.pack("<I", len(nb)) + nb)
+            f.write(struct.pack("<I", arr.ndim) + struct.pack("<%dI" % arr.ndim, *arr.shape))
+            f.write(arr.tobytes())
+
+
 def _now():
     return datetime.datetime.now()
 
@@ -319,8 +336,13 @@ class image2label(object):
                         test_iter = iter(test_set)
                         timage, tlabel = next(test_iter)
                     with torch.no_grad():
-                        _, tloss, _, _ = self.forward(torch.from_numpy(timage).to(self.device),
-                                                      torch.from_numpy(tlabel).to(self.device), 0.0)
+                        tl = torch.from_numpy(tlabel).to(self.device)
+                        _, tloss, _, tpred = self.forward(torch.from_numpy(timage).to(self.device), tl, 0.0, want_pred=True)
+                        # accuracy / per-class sensitivity, specificity, hard dice (reference model.py:588-626)
+                        self.last_metrics = ops.hard_metrics(tpred, tl[..., 0], self.output_channel_num)
+                    self._print('{}: Segmentation testing accuracy: {:.4f} dice: {}'.format(
+                        _now(), self.last_metrics["accuracy"],
+                        [round(self.last_metrics[c]["dice"], 4) for c in range(self.output_channel_num)]))
                     self._print("{}: Segmentation testing loss: {}".format(_now(), str(float(tloss.detach()))))
             self._print("{}: Training of epoch {} complete, epoch loss: {}".format(_now(), epoch + 1, loss_sum / max(count, 1)))
             self.start_epoch += 1

@@ -675,6 +675,28 @@ def momentum_apply(p, g, acc, lr, momentum, nesterov=False, gscale=1.0):
           "vnet_momentum_apply")
 
 
+def hard_metrics(pred, labels, K):
+    """Accuracy and per-class tp/tn/fp/fn, sensitivity, specificity, hard Dice (reference model.py:588-626) from
+    the K x K confusion matrix computed on the GPU.  pred int64 [...], labels int32 [...] (class indices)."""
+    L = _lib.lib()
+    pred = pred.contiguous().reshape(-1)
+    labels = labels.to(torch.int32).contiguous().reshape(-1)
+    cm = torch.empty(K * K, dtype=torch.float64, device=pred.device)
+    nb = L.vnet_confusion_ws_bytes(K)
+    ws = workspace(nb, pred.device)
+    check(L.vnet_confusion_matrix(_ptr(pred), _ptr(labels), pred.numel(), K, _ptr(cm), _ptr(ws), nb, _stream()),
+          "vnet_confusion_matrix")
+    cm = cm.cpu().numpy().reshape(K, K)
+    n = cm.sum()
+    out = {"accuracy": float(cm.trace() / max(n, 1.0)), "confusion": cm}
+    for c in range(K):
+        tp = cm[c, c]; fn = cm[c].sum() - tp; fp = cm[:, c].sum() - tp; tn = n - tp - fn - fp
+        out[c] = {"tp": tp, "tn": tn, "fp": fp, "fn": fn,
+                  "sensitivity": float(tp / max(tp + fn, 1e-30)), "specificity": float(tn / max(tn + fp, 1e-30)),
+                  "dice": float(2 * tp / max(2 * tp + fp + fn, 1e-30))}
+    return out
+
+
 def accumulate_patch(patch, vol, count, origin):
     """vol[z0:z0+pz, ...] += patch ; count += 1 (reference model.py:919-929)."""
     pz, py, px, K = patch.shape
