@@ -140,6 +140,27 @@ int vnet_bn_act_bwd(const float* dy, const float* x, const float* r, int bcast, 
                     float* dgamma, float* dbeta, float* dalpha, float* ds,
                     void* ws, size_t ws_bytes, void* stream);
 
+/* Cross-replica ("sync") batch-norm, SURVEY 8(e)(ii): the reference on one device with BatchSize=N reduces
+ * the statistics over the batch axis too (networks.py:319); with one patch per GPU the same numbers need the
+ * per-replica raw moments summed over ranks.  The host all-reduces the small vectors between the pieces:
+ *   vnet_bn_moments  -> sums[2C] = (sum s, sum s^2) as doubles      [all-reduce(sum)]
+ *   vnet_bn_finalize -> mean/invstd (+ moving averages) from the global sums and M_total rows
+ *   vnet_bn_act_bwd_reduce -> this replica's dgamma/dbeta/dalpha     [all-reduce(sum) of copies of dbeta,dgamma]
+ *   vnet_bn_act_bwd_apply  -> ds from the GLOBAL sum_dz (= sum of dbeta) and sum_dz_xhat (= sum of dgamma).
+ * vnet_bn_stats == moments + finalize with M_total = M; vnet_bn_act_bwd == reduce + apply with local sums. */
+int vnet_bn_moments(const float* x, const float* r, int bcast, int64_t M, int C, double* sums,
+                    void* ws, size_t ws_bytes, void* stream);
+int vnet_bn_finalize(const double* sums, double M_total, int C, float eps, float momentum,
+                     float* mean, float* invstd, float* moving_mean, float* moving_var, void* stream);
+int vnet_bn_act_bwd_reduce(const float* dy, const float* x, const float* r, int bcast, int64_t M, int C,
+                           const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           int act, const float* alpha, float* dgamma, float* dbeta, float* dalpha,
+                           void* ws, size_t ws_bytes, void* stream);
+int vnet_bn_act_bwd_apply(const float* dy, const float* x, const float* r, int bcast, int64_t M, int C,
+                          const float* mean, const float* invstd, const float* gamma, const float* beta,
+                          int act, const float* alpha, const float* sum_dz, const float* sum_dz_xhat, double M_total,
+                          float* ds, void* stream);
+
 /* ---- stand-alone activation, layers2.py:97-99 prelu / tf.nn.relu / tf.nn.leaky_relu -------------
  * (inside the networks the activation is fused into vnet_bn_act_*; this is the unfused API form) */
 int vnet_act_fwd(const float* x, int64_t M, int C, int act, const float* alpha, float* y, void* stream);

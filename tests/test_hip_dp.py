@@ -38,6 +38,61 @@ def _batch(rank, dev):
     return torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
 
 
+def _sync_bn_worker(rank, world, port, out):
+    """Cross-replica batch-norm: one patch per rank, statistics over both."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", VNET_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from vnet_tensorflow_amd import ops, optim, parallel
+    parallel.init_from_env()
+    ops.set_sync_batch_norm()
+    dev = torch.device("cuda", 0)
+    net = _build(dev, seed=100)                        # same seed: identical replicas
+    flat = optim.FlatParams(net.named_parameters())
+    sync = parallel.BucketedGradAllReduce(flat, bucket_bytes=16 << 10)
+    x, lab = _batch(rank, dev)
+    for step in range(2):
+        flat.zero_grad()
+        sync.begin_step()
+        logits = net.GetNetwork(x)
+        loss, _, _, _ = ops.softmax_loss(logits, lab, "sorensen")
+        loss.backward()
+        sync.finish()
+        torch.cuda.synchronize()
+    mm = dict(net.named_buffers()) if hasattr(net, "named_buffers") else {}
+    torch.save({"gsum": flat.grad.cpu(), "logits": logits.detach().cpu(), "loss": float(loss.detach()),
+                "moving": {k: v.cpu() for k, v in mm.items()}}, os.path.join(out, "s%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_sync_batch_norm_equals_single_device_batch(tmp_path, dev):
+    """2 ranks x 1 patch with cross-replica statistics == the single-device BatchSize=2 step of the reference
+    (networks.py:319 reduces the batch axis too): same logits per patch, loss = mean, gradient sum = 2 x."""
+    from vnet_tensorflow_amd import ops, optim
+    mp.spawn(_sync_bn_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(tmp_path / ("s%d.pt" % k)) for k in range(2)]
+    assert torch.equal(r[0]["gsum"], r[1]["gsum"])
+    net = _build(dev, seed=100)
+    flat = optim.FlatParams(net.named_parameters())
+    xs, labs = zip(*[_batch(k, dev) for k in range(2)])
+    x, lab = torch.cat(xs), torch.cat(labs)
+    flat.zero_grad()
+    logits = net.GetNetwork(x)
+    loss, _, _, _ = ops.softmax_loss(logits, lab, "sorensen")
+    loss.backward()
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert float((logits[k:k + 1].detach().cpu() - r[k]["logits"]).abs().max()) < 1e-4
+    assert abs(float(loss.detach()) - 0.5 * (r[0]["loss"] + r[1]["loss"])) < 1e-6
+    ref = 2.0 * flat.grad.cpu()
+    err = float((r[0]["gsum"] - ref).norm() / ref.norm())
+    assert err < 1e-4, err
+    # and it is NOT what per-replica statistics give (the two modes differ measurably on this input)
+    net1 = _build(dev, seed=100)
+    l0 = net1.GetNetwork(xs[0]).detach().cpu()
+    assert float((l0 - r[0]["logits"]).abs().max()) > 1e-3
+
+
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", VNET_DIST_BACKEND="gloo")

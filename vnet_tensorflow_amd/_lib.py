@@ -11,8 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvnet_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-_vp, _i, _i64, _f, _sz, _u64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
-                                ctypes.c_size_t, ctypes.c_uint64)
+_vp, _i, _i64, _f, _sz, _u64, _d = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
+                                    ctypes.c_size_t, ctypes.c_uint64, ctypes.c_double)
 
 # name -> (restype, argtypes) : must list every symbol include/vnet_hip.h declares
 SIGNATURES = {
@@ -37,6 +37,10 @@ SIGNATURES = {
     "vnet_colsum": (_i, [_vp, _vp, _i64, _i, _vp, _sz, _vp]),
     "vnet_bn_ws_bytes": (_sz, [_i]),
     "vnet_bn_stats": (_i, [_vp, _vp, _i, _i64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vnet_bn_moments": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _sz, _vp]),
+    "vnet_bn_finalize": (_i, [_vp, _d, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "vnet_bn_act_bwd_reduce": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vnet_bn_act_bwd_apply": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp]),
     "vnet_bn_act_fwd": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "vnet_bn_act_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp,
                              _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

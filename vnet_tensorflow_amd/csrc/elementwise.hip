@@ -156,6 +156,27 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restric
     }
 }
 
+// cross-replica batch-norm: per-replica raw moments (doubles) so that the host can all-reduce them
+__global__ void __launch_bounds__(256) bn_moments_kernel(const float* __restrict__ partial, int nblk, int Cs, int C, double* __restrict__ sums) {
+    const int c = blockIdx.x;
+    const int cs = (Cs == 1) ? 0 : c;
+    const double s = block_colsum_d(partial, nblk, 2 * Cs, cs);
+    const double q = block_colsum_d(partial, nblk, 2 * Cs, Cs + cs);
+    if (threadIdx.x == 0) { sums[c] = s; sums[C + c] = q; }
+}
+__global__ void __launch_bounds__(256) bn_finalize_sums_kernel(const double* __restrict__ sums, int C, double M, float eps, float momentum,
+                                                               float* mean, float* invstd, float* mm, float* mv) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const double mu = sums[c] / M;
+        double var = sums[C + c] / M - mu * mu;
+        var = var > 0.0 ? var : 0.0;
+        mean[c] = (float)mu;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (mm) mm[c] = mm[c] - (mm[c] - (float)mu) * (1.f - momentum);
+        if (mv) mv[c] = mv[c] - (mv[c] - (float)var) * (1.f - momentum);
+    }
+}
+
 __global__ void __launch_bounds__(256) sum_finalize_kernel(const float* __restrict__ partial, int nblk, int nacc, int C,
                                                            float* o0, float* o1, float* o2) {
     const int c = blockIdx.x;
@@ -732,14 +753,7 @@ size_t vnet_colsum_ws_bytes(int C) { return (size_t)EW_MAXBLK * (C > 8 ? C : 8) 
 size_t vnet_head_ws_bytes(int C, int K) { return (size_t)EW_MAXBLK * (C * K + K) * sizeof(float); }
 size_t vnet_loss_ws_bytes(int B, int K) { return (size_t)B * EW_MAXBLK * (3 * K + 1) * sizeof(float) + (size_t)B * (3 * K + 1) * sizeof(double) + 16; }
 
-int vnet_bn_stats(const float* x, const float* r, int bcast, int64_t M, int C, float eps, float momentum,
-                  float* mean, float* invstd, float* moving_mean, float* moving_var,
-                  void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !mean || !invstd || M <= 0 || C <= 0 || C > MAXC) return VNET_E_BADARG;
-    if (bcast && r) return VNET_E_UNSUPPORTED;
-    if (!ws || ws_bytes < vnet_bn_ws_bytes(C)) return VNET_E_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    float* partial = (float*)ws;
+static int bn_partial_moments(const float* x, const float* r, int bcast, int64_t M, int C, float* partial, hipStream_t st, int* nblk_out) {
     const int Cs = bcast ? 1 : C;
     const int mode = red_mode(Cs);
     int nblk;
@@ -755,7 +769,45 @@ int vnet_bn_stats(const float* x, const float* r, int bcast, int64_t M, int C, f
         hipLaunchKernelGGL(bn_stats_generic_kernel, dim3(nblk), dim3(EW_BLOCK), 0, st, x, r, (size_t)M * Cs, Cs, partial);
     }
     VNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, Cs, C, (double)M, eps, momentum,
+    *nblk_out = nblk;
+    return VNET_OK;
+}
+
+int vnet_bn_stats(const float* x, const float* r, int bcast, int64_t M, int C, float eps, float momentum,
+                  float* mean, float* invstd, float* moving_mean, float* moving_var,
+                  void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !mean || !invstd || M <= 0 || C <= 0 || C > MAXC) return VNET_E_BADARG;
+    if (bcast && r) return VNET_E_UNSUPPORTED;
+    if (!ws || ws_bytes < vnet_bn_ws_bytes(C)) return VNET_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)ws;
+    int nblk;
+    const int rc = bn_partial_moments(x, r, bcast, M, C, partial, st, &nblk);
+    if (rc != VNET_OK) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, bcast ? 1 : C, C, (double)M, eps, momentum,
+                       mean, invstd, moving_mean, moving_var);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_bn_moments(const float* x, const float* r, int bcast, int64_t M, int C, double* sums,
+                    void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !sums || M <= 0 || C <= 0 || C > MAXC) return VNET_E_BADARG;
+    if (bcast && r) return VNET_E_UNSUPPORTED;
+    if (!ws || ws_bytes < vnet_bn_ws_bytes(C)) return VNET_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int nblk;
+    const int rc = bn_partial_moments(x, r, bcast, M, C, (float*)ws, st, &nblk);
+    if (rc != VNET_OK) return rc;
+    hipLaunchKernelGGL(bn_moments_kernel, dim3(C), dim3(256), 0, st, (const float*)ws, nblk, bcast ? 1 : C, C, sums);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_bn_finalize(const double* sums, double M_total, int C, float eps, float momentum,
+                     float* mean, float* invstd, float* moving_mean, float* moving_var, void* stream) {
+    if (!sums || !mean || !invstd || M_total <= 0.0 || C <= 0 || C > MAXC) return VNET_E_BADARG;
+    hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, C, M_total, eps, momentum,
                        mean, invstd, moving_mean, moving_var);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
@@ -776,16 +828,23 @@ int vnet_bn_act_fwd(const float* x, const float* r, int bcast, int64_t M, int C,
     return VNET_OK;
 }
 
-int vnet_bn_act_bwd(const float* dy, const float* x, const float* r, int bcast, int64_t M, int C,
-                    const float* mean, const float* invstd, const float* gamma, const float* beta,
-                    int act, const float* alpha, float* dgamma, float* dbeta, float* dalpha, float* ds,
-                    void* ws, size_t ws_bytes, void* stream) {
+static int bn_bwd_fill(BnP& p, const float* dy, const float* x, const float* r, int bcast, int64_t M, int C,
+                       const float* mean, const float* invstd, const float* gamma, const float* beta, int act, const float* alpha) {
+    p.x = x; p.r = r; p.dy = dy; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.alpha = alpha;
+    p.M = (size_t)M; p.C = C; p.bcast = bcast; p.act = act;
+    return VNET_OK;
+}
+
+int vnet_bn_act_bwd_reduce(const float* dy, const float* x, const float* r, int bcast, int64_t M, int C,
+                           const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           int act, const float* alpha, float* dgamma, float* dbeta, float* dalpha,
+                           void* ws, size_t ws_bytes, void* stream) {
     if (!dy || !x || !mean || !invstd || !gamma || !beta || !dgamma || !dbeta || M <= 0 || C <= 0 || C > MAXC) return VNET_E_BADARG;
     if (act == VNET_ACT_PRELU && (!alpha || !dalpha)) return VNET_E_BADARG;
     if (!ws || ws_bytes < vnet_bn_ws_bytes(C)) return VNET_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    BnP p{}; p.x = x; p.r = r; p.dy = dy; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.alpha = alpha;
-    p.partial = (float*)ws; p.M = (size_t)M; p.C = C; p.bcast = bcast; p.act = act; p.invM = (float)(1.0 / (double)M);
+    BnP p{}; bn_bwd_fill(p, dy, x, r, bcast, M, C, mean, invstd, gamma, beta, act, alpha);
+    p.partial = (float*)ws;
     const int mode = red_mode(C);
     int nblk;
     if (mode == 0) { nblk = ew_blocks((size_t)M * C / 4 / 4 + 1); hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<0>, dim3(nblk), dim3(EW_BLOCK), 0, st, p); }
@@ -795,13 +854,34 @@ int vnet_bn_act_bwd(const float* dy, const float* x, const float* r, int bcast, 
     hipLaunchKernelGGL(sum_finalize_kernel, dim3(C), dim3(256), 0, st, p.partial, nblk, 3, C, dbeta, dgamma,
                        act == VNET_ACT_PRELU ? dalpha : (float*)nullptr);
     VNET_LAUNCH_CHECK();
-    if (ds) {
-        p.out = ds; p.dgamma = dgamma; p.dbeta = dbeta;
-        if (C % 4 == 0) hipLaunchKernelGGL(bn_act_bwd_apply_kernel<true>, dim3(ew_blocks((size_t)M * C / 4 / 4 + 1)), dim3(EW_BLOCK), 0, st, p);
-        else hipLaunchKernelGGL(bn_act_bwd_apply_kernel<false>, dim3(ew_blocks((size_t)M * C / 4 + 1)), dim3(EW_BLOCK), 0, st, p);
-        VNET_LAUNCH_CHECK();
-    }
     return VNET_OK;
+}
+
+int vnet_bn_act_bwd_apply(const float* dy, const float* x, const float* r, int bcast, int64_t M, int C,
+                          const float* mean, const float* invstd, const float* gamma, const float* beta,
+                          int act, const float* alpha, const float* sum_dz, const float* sum_dz_xhat, double M_total,
+                          float* ds, void* stream) {
+    if (!dy || !x || !mean || !invstd || !gamma || !beta || !sum_dz || !sum_dz_xhat || !ds || M <= 0 || M_total <= 0.0 || C <= 0 || C > MAXC)
+        return VNET_E_BADARG;
+    if (act == VNET_ACT_PRELU && !alpha) return VNET_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    BnP p{}; bn_bwd_fill(p, dy, x, r, bcast, M, C, mean, invstd, gamma, beta, act, alpha);
+    p.invM = (float)(1.0 / M_total);
+    p.out = ds; p.dgamma = sum_dz_xhat; p.dbeta = sum_dz;
+    if (C % 4 == 0) hipLaunchKernelGGL(bn_act_bwd_apply_kernel<true>, dim3(ew_blocks((size_t)M * C / 4 / 4 + 1)), dim3(EW_BLOCK), 0, st, p);
+    else hipLaunchKernelGGL(bn_act_bwd_apply_kernel<false>, dim3(ew_blocks((size_t)M * C / 4 + 1)), dim3(EW_BLOCK), 0, st, p);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_bn_act_bwd(const float* dy, const float* x, const float* r, int bcast, int64_t M, int C,
+                    const float* mean, const float* invstd, const float* gamma, const float* beta,
+                    int act, const float* alpha, float* dgamma, float* dbeta, float* dalpha, float* ds,
+                    void* ws, size_t ws_bytes, void* stream) {
+    const int rc = vnet_bn_act_bwd_reduce(dy, x, r, bcast, M, C, mean, invstd, gamma, beta, act, alpha, dgamma, dbeta, dalpha,
+                                          ws, ws_bytes, stream);
+    if (rc != VNET_OK || !ds) return rc;
+    return vnet_bn_act_bwd_apply(dy, x, r, bcast, M, C, mean, invstd, gamma, beta, act, alpha, dbeta, dgamma, (double)M, ds, stream);
 }
 
 int vnet_act_fwd(const float* x, int64_t M, int C, int act, const float* alpha, float* y, void* stream) {

@@ -131,6 +131,7 @@ class image2label(object):
         self.image_filenames = T['Data']['ImageFilenames']
         self.label_filename = T['Data']['LabelFilename']
         self.synthetic = T['Data'].get('Synthetic')            # extension: synthetic generator (no NIfTI shipped)
+        self.sync_batch_norm = bool(T.get('SyncBatchNorm', False))   # extension: cross-replica BN statistics
         self.batch_size = T['BatchSize']
         self.patch_shape = T['PatchShape']
         self.dimension = len(T['PatchShape'])
@@ -240,6 +241,10 @@ class image2label(object):
             parallel.broadcast_parameters(self.flat.data)
             self.optimizer.gscale = 1.0 / self.world
             self.sync = parallel.BucketedGradAllReduce(self.flat)
+            if getattr(self, "sync_batch_norm", False):
+                # single-device BatchSize = world x per-rank batch semantics of the reference (networks.py:319);
+                # the default (per-replica statistics) equals the reference run on each rank's batch alone
+                ops.set_sync_batch_norm()
 
     def train_step(self, images, labels, dropout=None):
         """reference model.py:743-748: one fwd + loss + bwd + optimiser step; returns the loss tensor."""

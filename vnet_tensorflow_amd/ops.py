@@ -379,6 +379,43 @@ def conv_transpose2(x, w, b, out_spatial):
 
 
 # ---- batch-norm (+residual, +tile, +activation) -------------------------------------------------------
+# ---- cross-replica batch-norm ---------------------------------------------------------
+# Default data-parallel semantics are per-replica statistics (== the reference run with BatchSize=1 per patch).
+# With a group set here every batch-norm reduces its moments over all ranks, which reproduces the reference's
+# single-device BatchSize=N numbers (networks.py:319 reduces over the batch axis as well).  Every rank must hold
+# the same number of rows per layer (equal per-rank batch), as data-parallel training does.
+_SYNC_BN = None      # (all_reduce callable, world size) or None
+
+
+def set_sync_batch_norm(group=None, enabled=True):
+    """Enable (or, with enabled=False, disable) cross-replica batch-norm statistics over `group`
+    (default: the world group of torch.distributed)."""
+    global _SYNC_BN
+    if not enabled:
+        _SYNC_BN = None
+        return
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        raise VnetHipError("set_sync_batch_norm needs an initialised torch.distributed process group")
+    world = dist.get_world_size(group)
+    _SYNC_BN = ((lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)), world) if world > 1 else None
+
+
+def _bn_statistics(L, x, r, bcast, M, C, mean, invstd, mm, mv, ws, nb):
+    """mean/invstd (+ moving-average update) of s = x (+ r); returns the row count the statistics cover."""
+    if _SYNC_BN is None:
+        check(L.vnet_bn_stats(_ptr(x), _ptr(r), int(bcast), M, C, BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(invstd),
+                              _ptr(mm), _ptr(mv), _ptr(ws), nb, _stream()), "vnet_bn_stats")
+        return float(M)
+    all_reduce, world = _SYNC_BN
+    sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    check(L.vnet_bn_moments(_ptr(x), _ptr(r), int(bcast), M, C, _ptr(sums), _ptr(ws), nb, _stream()), "vnet_bn_moments")
+    all_reduce(sums)
+    check(L.vnet_bn_finalize(_ptr(sums), float(M) * world, C, BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(invstd),
+                             _ptr(mm), _ptr(mv), _stream()), "vnet_bn_finalize")
+    return float(M) * world
+
+
 class _BnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, r, gamma, beta, alpha, act, bcast, mm, mv):
@@ -392,8 +429,8 @@ class _BnActFn(torch.autograd.Function):
         invstd = torch.empty(C, dtype=torch.float32, device=dev)
         nb = L.vnet_bn_ws_bytes(C)
         ws = workspace(nb, dev)
-        check(L.vnet_bn_stats(_ptr(x), _ptr(r), int(bcast), M, C, BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(invstd),
-                              _ptr(mm), _ptr(mv), _ptr(ws), nb, _stream()), "vnet_bn_stats")
+        ctx.m_total = _bn_statistics(L, x, r, bcast, M, C, mean, invstd, mm, mv, ws, nb)
+        ctx.sync = _SYNC_BN
         y = torch.empty(x.shape[:-1] + (C,), dtype=torch.float32, device=dev)
         check(L.vnet_bn_act_fwd(_ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
                                 act, _ptr(alpha), _ptr(y), _stream()), "vnet_bn_act_fwd")
@@ -419,9 +456,22 @@ class _BnActFn(torch.autograd.Function):
         ds = torch.empty_like(dy) if need_ds else None
         nb = L.vnet_bn_ws_bytes(C)
         ws = workspace(nb, dev)
-        check(L.vnet_bn_act_bwd(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd), _ptr(gamma),
-                                _ptr(beta), act, _ptr(alpha), _ptr(dgamma), _ptr(dbeta), _ptr(dalpha), _ptr(ds),
-                                _ptr(ws), nb, _stream()), "vnet_bn_act_bwd")
+        if ctx.sync is None:
+            check(L.vnet_bn_act_bwd(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                    _ptr(beta), act, _ptr(alpha), _ptr(dgamma), _ptr(dbeta), _ptr(dalpha), _ptr(ds),
+                                    _ptr(ws), nb, _stream()), "vnet_bn_act_bwd")
+        else:
+            # this replica's parameter gradients stay local (the gradient all-reduce averages them);
+            # the data gradient needs the sums over the whole cross-replica batch
+            check(L.vnet_bn_act_bwd_reduce(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd),
+                                           _ptr(gamma), _ptr(beta), act, _ptr(alpha), _ptr(dgamma), _ptr(dbeta),
+                                           _ptr(dalpha), _ptr(ws), nb, _stream()), "vnet_bn_act_bwd_reduce")
+            if ds is not None:
+                tot = torch.cat([dbeta.reshape(-1), dgamma.reshape(-1)])
+                ctx.sync[0](tot)
+                check(L.vnet_bn_act_bwd_apply(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd),
+                                              _ptr(gamma), _ptr(beta), act, _ptr(alpha), _ptr(tot), _ptr(tot[C:]),
+                                              ctx.m_total, _ptr(ds), _stream()), "vnet_bn_act_bwd_apply")
         dx = ds
         if bcast and ds is not None:
             dx = colsum_rows(ds)
@@ -461,8 +511,7 @@ def bn_update_only(x, C, moving_mean, moving_var):
     invstd = torch.empty(C, dtype=torch.float32, device=x.device)
     nb = L.vnet_bn_ws_bytes(C)
     ws = workspace(nb, x.device)
-    check(L.vnet_bn_stats(_ptr(x), None, 0, M, C, BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(invstd),
-                          _ptr(moving_mean), _ptr(moving_var), _ptr(ws), nb, _stream()), "vnet_bn_stats")
+    _bn_statistics(L, x, None, False, M, C, mean, invstd, moving_mean, moving_var, ws, nb)
 
 
 # ---- stand-alone activation (API parity with layers2.prelu; the networks use the fused bn_act) ------------
