@@ -39,6 +39,10 @@ extern "C" {
 #define VNET_PACK_BWD  1       /* conv backward-data:  wp[t][co/4][ci][co%4] = w[T-1-t][ci][co]             */
 #define VNET_PACK_UP   2       /* 2x2x2 transposed:    wp[0][ci/4][a*O+o][ci%4] = w[a][o][ci], w=[8][O][I]  */
 
+/* bf16 filter images for vnet_conv_fwd_bf16: [cin chunk 16][tap][cout block 32][cin half][32 cout][8 cin] */
+#define VNET_PACK_FWD_BF16 3   /* conv forward, operands rounded to bf16 (RNE)                              */
+#define VNET_PACK_BWD_BF16 4   /* conv backward-data (flipped taps, cin<->cout), bf16                       */
+
 /* loss kinds for vnet_softmax_dice_* (model.py:495-558) */
 #define VNET_LOSS_SORENSEN 0
 #define VNET_LOSS_JACCARD  1
@@ -82,6 +86,16 @@ int vnet_conv_fwd(int ks, int kx, int stride, int up,
                   float* y0, int Cy0, float* y1, int Cy1,
                   int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                   void* ws, size_t ws_bytes, void* stream);
+
+/* ---- bf16-operand 5x5x5 stride-1 convolution (BASELINE config C5: bf16 compute, fp32 accumulate) ----------
+ * Same contract as vnet_conv_fwd(ks=5, stride=1): fp32 NDHWC tensors in and out, two-source input, split output,
+ * bias; x and the filter are rounded to bf16 (round-to-nearest-even) on the way into the matrix cores and the
+ * products are accumulated in fp32 (v_mfma_f32_32x32x16_bf16).  wp: vnet_pack_weights(VNET_PACK_FWD_BF16) for the
+ * forward conv, VNET_PACK_BWD_BF16 for backward-data (then Cin/Cout are those of the backward problem). */
+size_t vnet_conv_bf16_ws_bytes(int Cin, int Cout, int B, int D, int H, int W);
+int vnet_conv_fwd_bf16(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
+                       float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
+                       void* ws, size_t ws_bytes, void* stream);
 
 /* ---- convolution filter gradient (the Conv3DBackpropFilterV2 autodiff builds at model.py:660)
  *   dw[t][ci][co] = sum_v x[v*stride + t - pad][ci] * dy[v][co]     (TF layout, unpadded)

@@ -95,6 +95,15 @@ def _pad_spatial(x, pads):
     return np.pad(x, cfg)
 
 
+def round_bf16(a):
+    """Round-to-nearest-even to bfloat16 (8 exponent, 7 mantissa bits), returned as float64.  This is the operand
+    rounding of the bf16-compute mode (BASELINE config C5; the matrix cores then accumulate exactly-representable
+    products in fp32) -- v_cvt_pk_bf16_f32 on gfx950.  Inputs are taken through float32 first, as the device does."""
+    u = np.ascontiguousarray(np.asarray(a, dtype=np.float32)).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).astype(np.float64).reshape(np.shape(a))
+
+
 def conv_nd_fwd(x, w, stride):
     """tf.nn.convolution(x, w, 'SAME', strides) -- cross-correlation, no bias.
     x [B,*S,Ci]; w [*k,Ci,Co]; stride int.  Works for 2-D and 3-D."""

@@ -504,6 +504,29 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     }
 }
 
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// bf16 filter image: [cin chunk of 16][tap][cout block of 32][cin half][32 cout][8 cin]
+__device__ __forceinline__ void pack_bf16_elem(int mode, const float* __restrict__ w, unsigned short* __restrict__ wp,
+                                               int T, int I, int O, int ncob, size_t idx) {
+    const int e = (int)(idx & 7);
+    size_t q = idx >> 3;
+    const int m = (int)(q & 31); q >>= 5;
+    const int hf = (int)(q & 1); q >>= 1;
+    const int cob = (int)(q % ncob); q /= ncob;
+    const int t = (int)(q % T);
+    const int chunk = (int)(q / T);
+    const int k = chunk * 16 + hf * 8 + e, n = cob * 32 + m;
+    float v = 0.f;
+    if (mode == VNET_PACK_FWD_BF16) { if (k < I && n < O) v = w[((size_t)t * I + k) * O + n]; }
+    else { if (k < O && n < I) v = w[((size_t)(T - 1 - t) * I + n) * O + k]; }
+    wp[idx] = (unsigned short)(pk_bf16(v, 0.f) & 0xffffu);
+}
+
 // ------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------
@@ -536,6 +559,12 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const long long* __re
     float* wp = reinterpret_cast<float*>(d[1]);
     const int mode = (int)d[2], T = (int)d[3], I = (int)d[4], O = (int)d[5];
     const int CQ = (int)d[6], NP = (int)d[7];
+    if (mode == VNET_PACK_FWD_BF16 || mode == VNET_PACK_BWD_BF16) {      // here CQ = cin chunks, NP = cout blocks
+        const size_t tot = (size_t)CQ * T * NP * 512;
+        for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x)
+            pack_bf16_elem(mode, w, reinterpret_cast<unsigned short*>(wp), T, I, O, NP, idx);
+        return;
+    }
     const size_t total = (size_t)(mode == VNET_PACK_UP ? 1 : T) * CQ * NP * 4;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(idx & 3);
@@ -620,6 +649,266 @@ int launch_conv_ns(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
     return e;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// bf16-operand variant of the 5x5x5 convolution (BASELINE config C5: "bf16 compute, fp32 accumulate").
+// Activations stay fp32 NDHWC in HBM; they are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) while the brick
+// is staged into LDS, the filter is packed as bf16, and v_mfma_f32_32x32x16_bf16 accumulates in fp32:
+//   D[row = cout (32)][col = voxel (32)] += A[cout][k = 16 cin] * B[k][voxel]
+//   * same 512-voxel brick as the fp32 kernel; 8 waves x MS=2 subtiles of 32 voxels, NSB blocks of 32 cout;
+//   * LDS tile = two planes [cin half][voxel][8 bf16]: a B fragment is ONE 16-byte ds_read_b128 whose
+//     address is lane_base + compile-time tap offset; voxel order inside a subtile is rotated on the second
+//     x row so that every ds_read_b128 lane group ({0-3,12-15,20-27}, ...) covers 16 distinct 16-byte slots;
+//   * at bf16 rates the filter can no longer stream from L2 per wave (64 B/clk/CU): one dz plane of it
+//     (25 taps x NSB KB) is staged in LDS, the next plane prefetched into registers during the MFMAs.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int TZ, int TY, int TX>
+struct Bf16Geom {
+    static constexpr int IZ = TZ + 4, IY = TY + 4, IX = TX + 4;
+    static constexpr int NV = IZ * IY * IX;
+    static constexpr int PLANE = NV * 16;                  // bytes of one cin-half plane
+    static constexpr int TILE_BYTES = 2 * PLANE;
+};
+
+template <int TZ, int TY, int TX, int NSB>
+__global__ void __launch_bounds__(512) conv5_bf16_kernel(ConvArgs a) {
+    using G = Bf16Geom<TZ, TY, TX>;
+    constexpr int MS = 2, NT = 512;
+    static_assert(TZ * TY * TX == 8 * MS * 32, "brick = 16 subtiles of 32 voxels");
+    constexpr int WUNITS = 25 * NSB * 64;                  // 16-byte units of one dz plane of the filter slab
+    constexpr int WPER = (WUNITS + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* tile = smem;
+    uint4* wl = reinterpret_cast<uint4*>(smem + G::TILE_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p32 = lane & 31, half = lane >> 5;
+    // voxel of this lane inside a 32-voxel subtile (see header: bank-conflict-free rotation of the 2nd row)
+    const int q32 = (TX == 16 && p32 >= 16) ? 16 + ((p32 + 12) & 15) : p32;
+
+    const int nbrick = a.B * a.nbz * a.nby * a.nbx;
+    int brick = xcd_remap(blockIdx.x, nbrick);
+    const int bx = brick % a.nbx; brick /= a.nbx;
+    const int by = brick % a.nby; brick /= a.nby;
+    const int bz = brick % a.nbz; const int b = brick / a.nbz;
+    const int ncob = a.CoutP / 32;
+    const int cob0 = blockIdx.y * NSB;
+    const int co0 = cob0 * 32;
+    const int split = blockIdx.z / a.nz, zsplit = blockIdx.z - split * a.nz;
+    const int dz0 = zsplit * 5 / a.nz, dz1 = (zsplit + 1) * 5 / a.nz;
+    const int c_begin = split * a.cps;
+    const int c_end = min(a.nchunks, c_begin + a.cps);
+
+    int boff[MS];
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+        const int v = (wave * MS + m) * 32 + q32;
+        const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+        boff[m] = half * G::PLANE + ((vz * G::IY + vy) * G::IX + vx) * 16;
+    }
+    const int aoff = half * 32 + p32;                       // uint4 units inside one (tap, cout block) KB
+
+    f32x16 acc[MS][NSB];
+#pragma unroll
+    for (int m = 0; m < MS; ++m)
+#pragma unroll
+        for (int n = 0; n < NSB; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int gz0 = bz * TZ - 2, gy0 = by * TY - 2, gx0 = bx * TX - 2;
+    const uint4* wg = reinterpret_cast<const uint4*>(a.wp);
+    using XT = XTile<G::IZ, G::IY, G::IX, NT>;
+
+    uint4 wreg[WPER];
+    auto w_issue = [&](int chunk, int dz) {
+        const uint4* src = wg + ((size_t)(chunk * 125 + dz * 25) * ncob + cob0) * 64;
+#pragma unroll
+        for (int k = 0; k < WPER; ++k) {
+            const int idx = min(tid + k * NT, WUNITS - 1);
+            const int t = idx / (NSB * 64), j = idx - t * (NSB * 64);
+            wreg[k] = src[(size_t)t * ncob * 64 + j];
+        }
+    };
+    auto w_commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < WPER; ++k) {
+            const int idx = tid + k * NT;
+            if (idx < WUNITS) wl[idx] = wreg[k];
+        }
+    };
+    auto stage_tile = [&](int chunk) {
+        if (a.vec_in) {
+            float4 v[XT::PER];
+            XT::issue(v, a.x0, a.x1, a.C0, a.C1, chunk, b, gz0, gy0, gx0, a.Di, a.Hi, a.Wi, tid);
+            const int r0 = tid / XT::COLS, col = tid - r0 * XT::COLS;
+            const int ix = col >> 2, cq = col & 3;
+#pragma unroll
+            for (int k = 0; k < XT::PER; ++k) {
+                const int row = r0 + k * XT::RPI;
+                if (r0 < XT::RPI && row < XT::ROWS) {
+                    uint2 pk = make_uint2(pk_bf16(v[k].x, v[k].y), pk_bf16(v[k].z, v[k].w));
+                    *reinterpret_cast<uint2*>(tile + (cq >> 1) * G::PLANE + (row * G::IX + ix) * 16 + (cq & 1) * 8) = pk;
+                }
+            }
+        } else {
+            const int Cin = a.C0 + a.C1;
+            for (int q = tid; q < G::NV * 4; q += NT) {       // channel counts that are not multiples of 4
+                const int vox = q >> 2, cq = q & 3;
+                const int ix = vox % G::IX, iy = (vox / G::IX) % G::IY, iz = vox / (G::IX * G::IY);
+                const int gz = gz0 + iz, gy = gy0 + iy, gx = gx0 + ix;
+                const int c = chunk * 16 + cq * 4;
+                float e[4] = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)gz < (unsigned)a.Di && (unsigned)gy < (unsigned)a.Hi && (unsigned)gx < (unsigned)a.Wi && c < Cin) {
+                    const size_t gv = ((size_t)(b * a.Di + gz) * a.Hi + gy) * a.Wi + gx;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int ck = c + k;
+                        if (ck < Cin) e[k] = (ck < a.C0) ? a.x0[gv * a.C0 + ck] : a.x1[gv * a.C1 + (ck - a.C0)];
+                    }
+                }
+                *reinterpret_cast<uint2*>(tile + (cq >> 1) * G::PLANE + vox * 16 + (cq & 1) * 8) =
+                    make_uint2(pk_bf16(e[0], e[1]), pk_bf16(e[2], e[3]));
+            }
+        }
+    };
+
+    if (c_begin < c_end) {
+        w_issue(c_begin, dz0);
+        stage_tile(c_begin);
+        w_commit();
+    }
+    __syncthreads();
+
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        for (int dz = dz0; dz < dz1; ++dz) {
+            // prefetch the next filter plane (this chunk's next dz, or the next chunk's first) into registers
+            const bool last_dz = (dz + 1 == dz1);
+            const bool more = !(last_dz && chunk + 1 == c_end);
+            if (more) w_issue(last_dz ? chunk + 1 : chunk, last_dz ? dz0 : dz + 1);
+
+            const unsigned char* tp = tile + dz * (G::IY * G::IX * 16);
+            const uint4* wa = wl + aoff;
+            bf16x8 bf[2][MS], af[2][NSB];
+#pragma unroll
+            for (int m = 0; m < MS; ++m) bf[0][m] = *reinterpret_cast<const bf16x8*>(tp + boff[m]);
+#pragma unroll
+            for (int n = 0; n < NSB; ++n) af[0][n] = *reinterpret_cast<const bf16x8*>(wa + n * 64);
+#pragma unroll
+            for (int t = 0; t < 25; ++t) {
+                if (t + 1 < 25) {
+                    const int tn = t + 1;
+                    const int o = ((tn / 5) * G::IX + (tn % 5)) * 16;
+#pragma unroll
+                    for (int m = 0; m < MS; ++m) bf[tn & 1][m] = *reinterpret_cast<const bf16x8*>(tp + boff[m] + o);
+#pragma unroll
+                    for (int n = 0; n < NSB; ++n) af[tn & 1][n] = *reinterpret_cast<const bf16x8*>(wa + (tn * NSB + n) * 64);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int m = 0; m < MS; ++m)
+#pragma unroll
+                    for (int n = 0; n < NSB; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][n], bf[t & 1][m], acc[m][n], 0, 0, 0);
+            }
+            __syncthreads();                       // every wave is done with this filter plane (and, on the last dz, the tile)
+            if (more) {
+                if (last_dz) stage_tile(chunk + 1);
+                w_commit();
+            }
+            __syncthreads();
+        }
+    }
+
+    // epilogue: register r of lane = cout co0 + n*32 + 8*(r/4) + 4*half + r%4 of voxel (m, q32)
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+        const int v = (wave * MS + m) * 32 + q32;
+        const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+        const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
+        if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
+        const size_t ov = ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+        for (int n = 0; n < NSB; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = co0 + n * 32 + g * 8 + half * 4;
+                float e[4] = {acc[m][n][g * 4], acc[m][n][g * 4 + 1], acc[m][n][g * 4 + 2], acc[m][n][g * 4 + 3]};
+                if (a.part) {
+                    *reinterpret_cast<float4*>(a.part + blockIdx.z * a.part_stride + ov * a.CoutP + co) = make_float4(e[0], e[1], e[2], e[3]);
+                    continue;
+                }
+                if (co >= a.Cout) continue;
+                if (a.vec_out && co + 3 < a.Cout) {
+                    if (a.bias) { e[0] += a.bias[co]; e[1] += a.bias[co + 1]; e[2] += a.bias[co + 2]; e[3] += a.bias[co + 3]; }
+                    float* p = (co < a.Cy0) ? a.y0 + ov * a.Cy0 + co : a.y1 + ov * a.Cy1 + (co - a.Cy0);
+                    *reinterpret_cast<float4*>(p) = make_float4(e[0], e[1], e[2], e[3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int ck = co + k;
+                        if (ck >= a.Cout) break;
+                        const float val = e[k] + (a.bias ? a.bias[ck] : 0.f);
+                        if (ck < a.Cy0) a.y0[ov * a.Cy0 + ck] = val; else a.y1[ov * a.Cy1 + (ck - a.Cy0)] = val;
+                    }
+                }
+            }
+    }
+}
+
+__global__ void pack_bf16_kernel(int mode, const float* __restrict__ w, unsigned short* __restrict__ wp, int T, int I, int O,
+                                 int ncob, size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
+        pack_bf16_elem(mode, w, wp, T, I, O, ncob, idx);
+}
+
+void packed_dims_bf16(int mode, int I, int O, int* nchunk, int* ncob) {
+    const int K = (mode == VNET_PACK_FWD_BF16) ? I : O, N = (mode == VNET_PACK_FWD_BF16) ? O : I;
+    *nchunk = round_up(K, 16) / 16; *ncob = round_up(N, 32) / 32;
+}
+
+struct Bf16Plan { int nsb, ncobg, nbz, nby, nbx, nsplit, cps, small, nz; };
+
+Bf16Plan plan_conv_bf16(int Cin, int Cout, int B, int Do, int Ho, int Wo) {
+    Bf16Plan p{};
+    const int ncob = round_up(Cout, 32) / 32, nchunks = round_up(Cin, 16) / 16;
+    p.small = Wo < 16;
+    if (p.small) { p.nbz = ceil_div(Do, 8); p.nby = ceil_div(Ho, 8); p.nbx = ceil_div(Wo, 8); }
+    else { p.nbz = ceil_div(Do, 4); p.nby = ceil_div(Ho, 8); p.nbx = ceil_div(Wo, 16); }
+    const long nb = (long)B * p.nbz * p.nby * p.nbx;
+    p.nsb = (ncob % 2 == 0 && nb * (ncob / 2) >= 256) ? 2 : 1;
+    p.ncobg = ncob / p.nsb;
+    const long nwg = nb * p.ncobg;
+    p.nsplit = 1;
+    if (nwg < 256 && nchunks > 1) p.nsplit = (int)min((long)nchunks, (long)ceil_div(512, (int)nwg));
+    p.cps = ceil_div(nchunks, p.nsplit);
+    p.nsplit = ceil_div(nchunks, p.cps);
+    p.nz = (nwg * p.nsplit < 256) ? 5 : 1;
+    return p;
+}
+
+template <int TZ, int TY, int TX>
+int launch_conv_bf16(const ConvArgs& a, const Bf16Plan& p, hipStream_t st) {
+    using G = Bf16Geom<TZ, TY, TX>;
+    dim3 grid(a.B * p.nbz * p.nby * p.nbx, p.ncobg, p.nsplit * p.nz), block(512);
+#define VNET_GO(NSBV)                                                                             \
+    {                                                                                             \
+        auto k = conv5_bf16_kernel<TZ, TY, TX, NSBV>;                                             \
+        const size_t lds = (size_t)G::TILE_BYTES + (size_t)25 * NSBV * 1024;                      \
+        static int attr_done = -1;                                                                \
+        if (attr_done != 0) attr_done = set_lds(k, lds);                                          \
+        if (attr_done != 0) return attr_done;                                                     \
+        hipLaunchKernelGGL(k, grid, block, lds, st, a);                                           \
+    }
+    if (p.nsb == 2) VNET_GO(2) else VNET_GO(1)
+#undef VNET_GO
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
@@ -627,12 +916,25 @@ extern "C" {
 const char* vnet_version(void) { return "vnet_hip 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
 
 size_t vnet_packed_weight_floats(int mode, int taps, int I, int O) {
+    if (mode == VNET_PACK_FWD_BF16 || mode == VNET_PACK_BWD_BF16) {     // bf16 image, size still quoted in floats
+        int nchunk, ncob; packed_dims_bf16(mode, I, O, &nchunk, &ncob);
+        return (size_t)nchunk * taps * ncob * 512 / 2;
+    }
     int Tp, CQ, NP; packed_dims(mode, taps, I, O, &Tp, &CQ, &NP);
     return (size_t)Tp * CQ * NP * 4;
 }
 
 int vnet_pack_weights(int mode, const float* w, float* wp, int taps, int I, int O, void* stream) {
     if (!w || !wp || taps <= 0 || I <= 0 || O <= 0) return VNET_E_BADARG;
+    if (mode == VNET_PACK_FWD_BF16 || mode == VNET_PACK_BWD_BF16) {
+        int nchunk, ncob; packed_dims_bf16(mode, I, O, &nchunk, &ncob);
+        const size_t total = (size_t)nchunk * taps * ncob * 512;
+        const int blocks = (int)min((size_t)4096, (total + 255) / 256);
+        hipLaunchKernelGGL(pack_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mode, w,
+                           reinterpret_cast<unsigned short*>(wp), taps, I, O, ncob, total);
+        VNET_LAUNCH_CHECK();
+        return VNET_OK;
+    }
     if (mode < 0 || mode > 2) return VNET_E_UNSUPPORTED;
     if (mode == VNET_PACK_UP && (taps != 8 || (O & 3))) return VNET_E_UNSUPPORTED;
     int Tp, CQ, NP; packed_dims(mode, taps, I, O, &Tp, &CQ, &NP);
@@ -644,7 +946,9 @@ int vnet_pack_weights(int mode, const float* w, float* wp, int taps, int I, int 
 }
 
 int vnet_packed_dims(int mode, int taps, int I, int O, int* CQ, int* NP) {
-    if (mode < 0 || mode > 2 || !CQ || !NP) return VNET_E_BADARG;
+    if (!CQ || !NP) return VNET_E_BADARG;
+    if (mode == VNET_PACK_FWD_BF16 || mode == VNET_PACK_BWD_BF16) { packed_dims_bf16(mode, I, O, CQ, NP); return VNET_OK; }   // (chunks, cout blocks)
+    if (mode < 0 || mode > 2) return VNET_E_BADARG;
     int Tp; packed_dims(mode, taps, I, O, &Tp, CQ, NP);
     return VNET_OK;
 }
@@ -712,6 +1016,50 @@ int vnet_conv_fwd(int ks, int kx, int stride, int up, const float* x0, int C0, c
     } else {
         e = p.small ? launch_conv_ns<1, 1, 8, 8, 8, 8, 4, true>(a, p, st) : launch_conv_ns<1, 1, 4, 8, 16, 8, 4, true>(a, p, st);
     }
+    if (e) return e;
+    if (nslab > 1) {
+        const size_t total = nvox * a.Cout;
+        const int blocks = (int)min((size_t)2048, (total + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, a.part_stride, nslab, bias,
+                           y0, y1, Cy0, Cy1, a.CoutP, nvox);
+        VNET_LAUNCH_CHECK();
+    }
+    return VNET_OK;
+}
+
+
+size_t vnet_conv_bf16_ws_bytes(int Cin, int Cout, int B, int D, int H, int W) {
+    Bf16Plan p = plan_conv_bf16(Cin, Cout, B, D, H, W);
+    if (p.nsplit * p.nz <= 1) return 0;
+    return (size_t)p.nsplit * p.nz * B * D * H * W * round_up(Cout, 32) * sizeof(float);
+}
+
+int vnet_conv_fwd_bf16(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
+                       float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
+                       void* ws, size_t ws_bytes, void* stream) {
+    if (!x0 || !wp || !y0 || C0 <= 0 || Cy0 <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return VNET_E_BADARG;
+    if ((C1 > 0 && !x1) || (Cy1 > 0 && !y1) || C1 < 0 || Cy1 < 0) return VNET_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    ConvArgs a{};
+    a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1;
+    a.wp = reinterpret_cast<const float4*>(wp); a.bias = bias;
+    a.y0 = y0; a.y1 = y1; a.Cy0 = Cy0; a.Cy1 = Cy1; a.Cout = Cy0 + Cy1;
+    a.B = B; a.Di = D; a.Hi = H; a.Wi = W; a.Do = D; a.Ho = H; a.Wo = W;
+    a.nchunks = round_up(a.Cin, 16) / 16; a.CQ = a.nchunks * 4;
+    a.CoutP = round_up(a.Cout, 32);
+    a.vec_in = (C0 % 4 == 0) && (C1 % 4 == 0);
+    a.vec_out = (Cy0 % 4 == 0) && (Cy1 % 4 == 0);
+    a.pad = 2; a.padx = 2;
+    Bf16Plan p = plan_conv_bf16(a.Cin, a.Cout, B, D, H, W);
+    a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.cps = p.cps; a.nz = p.nz;
+    const int nslab = p.nsplit * p.nz;
+    const size_t nvox = (size_t)B * D * H * W;
+    if (nslab > 1) {
+        const size_t need = (size_t)nslab * nvox * a.CoutP * sizeof(float);
+        if (!ws || ws_bytes < need) return VNET_E_WORKSPACE;
+        a.part = reinterpret_cast<float*>(ws); a.part_stride = nvox * a.CoutP;
+    }
+    const int e = p.small ? launch_conv_bf16<8, 8, 8>(a, p, st) : launch_conv_bf16<4, 8, 16>(a, p, st);
     if (e) return e;
     if (nslab > 1) {
         const size_t total = nvox * a.Cout;

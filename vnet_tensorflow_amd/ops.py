@@ -18,7 +18,22 @@ BN_EPS = 1e-3        # reference networks.py:259 epsilon=0.001
 BN_MOMENTUM = 0.99   # reference networks.py:259 momentum=0.99
 
 ACT = {None: 0, "none": 0, "relu": 1, "prelu": 2, "lrelu": 3}
-PACK_FWD, PACK_BWD, PACK_UP = 0, 1, 2
+PACK_FWD, PACK_BWD, PACK_UP, PACK_FWD_BF16, PACK_BWD_BF16 = 0, 1, 2, 3, 4
+
+# Arithmetic of the 5x5x5 convolutions (forward and backward-data): "fp32" = exact fp32 MFMA (the reference's
+# arithmetic), "bf16" = operands rounded to bf16, fp32 accumulation (BASELINE config C5).  Everything else
+# (filter gradients, batch-norm, loss, optimiser) is fp32 in both modes.
+_COMPUTE = {"dtype": "fp32"}
+
+
+def set_compute_dtype(dtype):
+    if dtype not in ("fp32", "bf16"):
+        raise VnetHipError("compute dtype must be 'fp32' or 'bf16', got %r" % (dtype,))
+    _COMPUTE["dtype"] = dtype
+
+
+def get_compute_dtype():
+    return _COMPUTE["dtype"]
 LOSS_KIND = {"sorensen": 0, "jaccard": 1, "xent": 2}
 LOSS_WEIGHTED, LOSS_MIXED = 16, 32
 
@@ -209,6 +224,23 @@ def _conv_call(ks, stride, up, x0, x1, wp, bias, y0, y1, dims_in, dims_out, kx=0
                               _ptr(ws), nb, _stream()), "vnet_conv_fwd")
 
 
+def _conv_bf16_call(x0, x1, wp, bias, y0, y1, dims):
+    """5^3 stride-1 conv with bf16 operands / fp32 accumulation (vnet_conv_fwd_bf16)."""
+    L = _lib.lib()
+    B = x0.shape[0]
+    C0, C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
+    Cy0, Cy1 = y0.shape[-1], (y1.shape[-1] if y1 is not None else 0)
+    nb = L.vnet_conv_bf16_ws_bytes(C0 + C1, Cy0 + Cy1, B, *dims)
+    ws = workspace(nb, x0.device) if nb else None
+    nvox = B * dims[0] * dims[1] * dims[2]
+    flops = 2.0 * nvox * 125 * (C0 + C1) * (Cy0 + Cy1)
+    nbytes = 4.0 * nvox * (C0 + C1 + Cy0 + Cy1) + 2.0 * 125 * (C0 + C1) * (Cy0 + Cy1)
+    tag = "conv-bf16 k5 s1 %d^3x%d %d->%d" % (dims[2], B, C0 + C1, Cy0 + Cy1)
+    with _Timed(tag, flops, nbytes):
+        check(L.vnet_conv_fwd_bf16(_ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias), _ptr(y0), Cy0, _ptr(y1), Cy1,
+                                   B, *dims, _ptr(ws), nb, _stream()), "vnet_conv_fwd_bf16")
+
+
 def _wgrad_call(ks, stride, x0, x1, dy, dw, dims_in, dims_out, kx=0):
     L = _lib.lib()
     B = x0.shape[0]
@@ -254,14 +286,21 @@ class _ConvFn(torch.autograd.Function):
         else:
             I, O = w.shape[-2], w.shape[-1]
             dims_out = (_same_out(Di, stride), _same_out(Hi, stride), _same_out(Wi, stride))
-            wp = packed_weights(w, PACK_FWD, ks ** 3, I, O)
+            wp = None
         if I != C0 + C1:
             raise VnetHipError("conv: filter expects %d input channels, got %d" % (I, C0 + C1))
         y = torch.empty((B,) + dims_out + (O,), dtype=torch.float32, device=x0.device)
-        _conv_call(ks, stride, 1 if up else 0, x0, x1, wp, b, y, None, (Di, Hi, Wi), dims_out)
+        bf16 = (not up) and ks == 5 and stride == 1 and _COMPUTE["dtype"] == "bf16"
+        if bf16:
+            _conv_bf16_call(x0, x1, packed_weights(w, PACK_FWD_BF16, 125, I, O), b, y, None, dims_out)
+        else:
+            if wp is None:
+                wp = packed_weights(w, PACK_FWD, ks ** 3, I, O)
+            _conv_call(ks, stride, 1 if up else 0, x0, x1, wp, b, y, None, (Di, Hi, Wi), dims_out)
         ctx.save_for_backward(x0, x1, w)
         ctx.params = (w, b)
         ctx.cfg = (ks, stride, up, (Di, Hi, Wi), dims_out, C0, C1, I, O)
+        ctx.bf16 = bf16
         return y
 
     @staticmethod
@@ -293,6 +332,8 @@ class _ConvFn(torch.autograd.Function):
             elif stride == 2:   # backward-data of the down conv = the 2^3 transposed conv with the same filter
                 wp = packed_weights(w, PACK_UP, 8, O, I)
                 _conv_call(2, 2, 1, dy, None, wp, None, dx0, None, dout, din)
+            elif ctx.bf16:
+                _conv_bf16_call(dy, None, packed_weights(w, PACK_BWD_BF16, 125, I, O), None, dx0, dx1, din)
             else:
                 wp = packed_weights(w, PACK_BWD, ks ** 3, I, O)
                 _conv_call(ks, 1, 0, dy, None, wp, None, dx0, dx1, dout, din)
