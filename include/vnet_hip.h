@@ -97,6 +97,12 @@ int vnet_conv_fwd_bf16(const float* x0, int C0, const float* x1, int C1, const v
                        float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* filter gradient of the same convolution with x and dy rounded to bf16, fp32 accumulation
+ * (v_mfma_f32_16x16x32_bf16 fed by LDS transpose reads); dw is fp32 in TF layout [125][Cin][Cout]. */
+size_t vnet_wgrad_bf16_ws_bytes(int Cin, int Cout, int B, int D, int H, int W);
+int vnet_conv_wgrad_bf16(const float* x0, int C0, const float* x1, int C1, const float* dy, int Cout, float* dw,
+                         int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- convolution filter gradient (the Conv3DBackpropFilterV2 autodiff builds at model.py:660)
  *   dw[t][ci][co] = sum_v x[v*stride + t - pad][ci] * dy[v][co]     (TF layout, unpadded)
  * x is the (possibly two-source) forward input, dy the gradient at the conv output [B,Do,Ho,Wo,Cout].

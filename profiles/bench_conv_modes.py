@@ -18,4 +18,13 @@ for mode in ('bf16', 'fp32'):
             e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
         fl = 2.0 * P**3 * 125 * ci * co
-        print("%s %3d^3 %3d->%3d  %.3f ms  %.1f TF/s" % (mode, P, ci, co, ms, fl / ms / 1e9), flush=True)
+        dy = torch.randn_like(y); dw = torch.empty_like(w)
+        for _ in range(3):
+            (ops._wgrad_bf16_call(x, None, dy, dw, (P, P, P)) if mode == 'bf16' else ops._wgrad_call(5, 1, x, None, dy, dw, (P, P, P), (P, P, P)))
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            (ops._wgrad_bf16_call(x, None, dy, dw, (P, P, P)) if mode == 'bf16' else ops._wgrad_call(5, 1, x, None, dy, dw, (P, P, P), (P, P, P)))
+        e1.record(); torch.cuda.synchronize()
+        ms2 = e0.elapsed_time(e1) / 10
+        print("%s %3d^3 %3d->%3d  conv %.3f ms %.1f TF/s | wgrad %.3f ms %.1f TF/s" % (mode, P, ci, co, ms, fl / ms / 1e9, ms2, fl / ms2 / 1e9), flush=True)

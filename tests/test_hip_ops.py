@@ -65,7 +65,7 @@ def test_conv5(dev, shape):
 ])
 def test_conv5_bf16(dev, shape):
     """bf16-compute mode: operands rounded to bf16 (RNE), fp32 accumulation -- against the oracle convolution of the
-    ROUNDED operands, so the tolerance stays fp32-roundoff class (2e-6); the filter gradient stays exact fp32."""
+    ROUNDED operands (x, w / dy, w / x, dy), so the tolerance stays fp32-roundoff class (2e-6)."""
     from vnet_tensorflow_amd import ops
     B, D, H, W, C0, C1, Co = shape
     rng = np.random.default_rng(sum(shape) + 7)
@@ -77,7 +77,7 @@ def test_conv5_bf16(dev, shape):
     y_ref = O.conv_nd_fwd(O.round_bf16(xcat), O.round_bf16(w), 1) + b
     dy = rng.standard_normal(y_ref.shape)
     dx_ref, _ = O.conv_nd_bwd(xcat, O.round_bf16(w), O.round_bf16(dy), 1)
-    _, dw_ref = O.conv_nd_bwd(xcat, w, dy, 1)
+    _, dw_ref = O.conv_nd_bwd(O.round_bf16(xcat), w, O.round_bf16(dy), 1)
     tx0 = g(x0, dev).requires_grad_(True)
     tx1 = g(x1, dev).requires_grad_(True) if C1 else None
     tw, tb = g(w, dev).requires_grad_(True), g(b, dev).requires_grad_(True)

@@ -871,6 +871,213 @@ void packed_dims_bf16(int mode, int I, int O, int* nchunk, int* ncob) {
     *nchunk = round_up(K, 16) / 16; *ncob = round_up(N, 32) / 32;
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16-operand filter gradient of the 5x5x5 convolution:  v_mfma_f32_16x16x32_bf16,
+//   D[row = cout][col = cin] += A[cout][k = 32 voxels] * B[32 voxels][cin(tap-shifted)]
+// Both operands are k-strided in NDHWC memory (k = voxel), which is what the gfx950 LDS transpose read is for:
+// the tiles stay [voxel][16 channels] (32-byte rows, bf16) and ds_read_b64_tr_b16 hands lane (i, g) channel i of
+// 4 consecutive voxels; two reads = the 8 k-values of lane group g.  A tap shift is a whole number of rows, so it
+// is a plain address offset (no alignment constraint) -- per-tap base register + compile-time k-step offset.
+// Lane group g of a k-step takes 8 consecutive x; groups 0/1 (one LDS service half) sit on rows y and y+1, whose
+// pitch (TX+4 voxels = 640 or 384 bytes) is 128 mod 256, so their 128-byte row quartets use disjoint banks.
+// Same work split as the fp32 kernel: 8 waves, wave w owns TW taps x NS cout blocks of one 16-cin chunk.
+// ------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p, int off) {
+    typedef s16x4 __attribute__((address_space(3))) * lp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p + off));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p + off + 128));     // rows +4..7
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int TZ, int TY, int TX, int NS, int TW>
+__global__ void __launch_bounds__(512) wgrad5_bf16_kernel(WgradArgs a) {
+    using G = TileGeom<5, 1, TZ, TY, TX, 5>;
+    using XT = XTile<G::IZ, G::IY, G::IX, 512>;
+    constexpr int NV = TZ * TY * TX, T3 = 125;
+    constexpr int TXP = TX + 4;                                  // dy row pitch (voxels): same bank argument as the x tile
+    constexpr int XBYTES = G::NVOX_IN * 32;
+    constexpr int DYPLANE = TZ * TY * TXP * 32;
+    constexpr int NQD = NV * NS * 4, PERD = (NQD + 511) / 512;
+    static_assert(NV % 32 == 0 && (TX == 16 || TX == 8), "k-steps are 32 voxels: 2 rows of 16 or 4 rows of 8");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xt = smem;
+    unsigned char* dyt = smem + XBYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int split = blockIdx.x;
+    const int chunk = blockIdx.y / a.ncob, cob = blockIdx.y - chunk * a.ncob;
+    const int co0 = cob * NS * 16;
+    const int tap0 = (blockIdx.z * 8 + wave) * TW;
+
+    // lane part of every transpose read: voxel row (group's first voxel + i/4), 8-byte column quad i%4
+    const int gx = (TX == 16) ? ((g & 1) * G::IX + (g >> 1) * 8) : g * G::IX;
+    const int gd = (TX == 16) ? ((g & 1) * TXP + (g >> 1) * 8) : g * TXP;
+    const unsigned char* pt[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        int tap = tap0 + t;
+        tap = tap < T3 ? tap : 0;
+        const int dx = tap % 5, dy = (tap / 5) % 5, dz = tap / 25;
+        pt[t] = xt + (((dz * G::IY + dy) * G::IX + dx) + gx + (i >> 2)) * 32 + (i & 3) * 8;
+    }
+    const unsigned char* pa = dyt + (gd + (i >> 2)) * 32 + (i & 3) * 8;
+
+    f32x4 acc[TW][NS];
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const bool pre = a.vec_in && a.vec_dy;
+    float4 px[XT::PER];
+    float4 pd[PERD];
+
+    auto brick_coords = [&](int brick, int& b, int& bz, int& by, int& bx) {
+        bx = brick % a.nbx; brick /= a.nbx;
+        by = brick % a.nby; brick /= a.nby;
+        bz = brick % a.nbz; b = brick / a.nbz;
+    };
+    auto issue = [&](int brick) {
+        int b, bz, by, bx;
+        brick_coords(brick, b, bz, by, bx);
+        XT::issue(px, a.x0, a.x1, a.C0, a.C1, chunk, b, bz * TZ - 2, by * TY - 2, bx * TX - 2, a.Di, a.Hi, a.Wi, tid);
+#pragma unroll
+        for (int k = 0; k < PERD; ++k) {
+            const int q = tid + k * 512;
+            const int v = q / (NS * 4), cq = q - v * (NS * 4);
+            const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+            const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
+            const int c = co0 + cq * 4;
+            const bool ok = q < NQD && oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout;
+            const size_t ov = ok ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
+            const float4 t = *reinterpret_cast<const float4*>(a.dy + ov * a.Cout + (ok ? c : 0));
+            pd[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto dy_addr = [&](int q) -> unsigned char* {
+        const int v = q / (NS * 4), cq = q - v * (NS * 4);
+        const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+        return dyt + (cq >> 2) * DYPLANE + (((vz * TY + vy) * TXP + vx) * 32) + (cq & 3) * 8;
+    };
+
+    if (pre && split < a.nbrick) issue(split);
+    for (int brick = split; brick < a.nbrick; brick += a.nsplit) {
+        __syncthreads();
+        if (pre) {
+            const int r0 = tid / XT::COLS, col = tid - r0 * XT::COLS;
+#pragma unroll
+            for (int k = 0; k < XT::PER; ++k) {
+                const int row = r0 + k * XT::RPI;
+                if (r0 < XT::RPI && row < XT::ROWS)
+                    *reinterpret_cast<uint2*>(xt + (row * G::IX + (col >> 2)) * 32 + (col & 3) * 8) =
+                        make_uint2(pk_bf16(px[k].x, px[k].y), pk_bf16(px[k].z, px[k].w));
+            }
+#pragma unroll
+            for (int k = 0; k < PERD; ++k) {
+                const int q = tid + k * 512;
+                if (q < NQD) *reinterpret_cast<uint2*>(dy_addr(q)) = make_uint2(pk_bf16(pd[k].x, pd[k].y), pk_bf16(pd[k].z, pd[k].w));
+            }
+        } else {
+            int b, bz, by, bx;
+            brick_coords(brick, b, bz, by, bx);
+            const int Cin = a.C0 + a.C1;
+            for (int q = tid; q < G::NVOX_IN * 4; q += 512) {
+                const int vox = q >> 2, cq = q & 3;
+                const int ix = vox % G::IX, iy = (vox / G::IX) % G::IY, iz = vox / (G::IX * G::IY);
+                const int gz = bz * TZ - 2 + iz, gy = by * TY - 2 + iy, gxx = bx * TX - 2 + ix;
+                const int c = chunk * 16 + cq * 4;
+                float e[4] = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)gz < (unsigned)a.Di && (unsigned)gy < (unsigned)a.Hi && (unsigned)gxx < (unsigned)a.Wi && c < Cin) {
+                    const size_t gv = ((size_t)(b * a.Di + gz) * a.Hi + gy) * a.Wi + gxx;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int ck = c + k;
+                        if (ck < Cin) e[k] = (ck < a.C0) ? a.x0[gv * a.C0 + ck] : a.x1[gv * a.C1 + (ck - a.C0)];
+                    }
+                }
+                *reinterpret_cast<uint2*>(xt + vox * 32 + cq * 8) = make_uint2(pk_bf16(e[0], e[1]), pk_bf16(e[2], e[3]));
+            }
+            for (int q = tid; q < NQD; q += 512) {
+                const int v = q / (NS * 4), cq = q - v * (NS * 4);
+                const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+                const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
+                const int c = co0 + cq * 4;
+                float e[4] = {0.f, 0.f, 0.f, 0.f};
+                if (oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout) {
+                    const float* p = a.dy + (((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.Cout + c;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (c + k < a.Cout) e[k] = p[k];
+                }
+                *reinterpret_cast<uint2*>(dy_addr(q)) = make_uint2(pk_bf16(e[0], e[1]), pk_bf16(e[2], e[3]));
+            }
+        }
+        __syncthreads();
+        if (pre && brick + a.nsplit < a.nbrick) {
+            issue(brick + a.nsplit);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        constexpr int NK = NV / 32;
+        auto fetch = [&](int s, bf16x8 (&av)[NS], bf16x8 (&bv)[TW]) {      // s is a literal after unrolling
+            const int v0 = s * 32;
+            const int vy = (v0 / TX) % TY, vz = v0 / (TX * TY);
+            const int xo = ((vz * G::IY + vy) * G::IX) * 32, dyo = ((vz * TY + vy) * TXP) * 32;
+#pragma unroll
+            for (int n = 0; n < NS; ++n) av[n] = tr_frag(pa, n * DYPLANE + dyo);
+#pragma unroll
+            for (int t = 0; t < TW; ++t) bv[t] = tr_frag(pt[t], xo);
+        };
+        bf16x8 avA[NS], bvA[TW], avB[NS], bvB[TW];
+        fetch(0, avA, bvA);
+#pragma unroll
+        for (int s = 0; s < NK; s += 2) {
+            fetch(s + 1, avB, bvB);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+#pragma unroll
+                for (int n = 0; n < NS; ++n)
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(avA[n], bvA[t], acc[t][n], 0, 0, 0);
+            if (s + 2 < NK) fetch(s + 2, avA, bvA);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+#pragma unroll
+                for (int n = 0; n < NS; ++n)
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(avB[n], bvB[t], acc[t][n], 0, 0, 0);
+        }
+    }
+    // lane holds dW[tap][ci = chunk*16 + i][co = co0 + n*16 + 4*g + {0..3}]
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        const int tap = tap0 + t;
+        if (tap >= T3) continue;
+        float* dst = a.part + ((size_t)(split * T3 + tap) * a.CinP + chunk * 16 + i) * a.CoutP + co0 + g * 4;
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            const f32x4 r = acc[t][n];
+            *reinterpret_cast<float4*>(dst + n * 16) = make_float4(r.x, r.y, r.z, r.w);
+        }
+    }
+}
+
+template <int TZ, int TY, int TX, int NS, int TW>
+int launch_wgrad_bf16(const WgradArgs& a, int nsplit, int ncob, int ntg, hipStream_t st) {
+    using G = TileGeom<5, 1, TZ, TY, TX, 5>;
+    const size_t lds = (size_t)G::NVOX_IN * 32 + (size_t)NS * TZ * TY * (TX + 4) * 32;
+    auto k = wgrad5_bf16_kernel<TZ, TY, TX, NS, TW>;
+    static int attr_done = -1;
+    if (attr_done != 0) attr_done = set_lds(k, lds);
+    if (attr_done != 0) return attr_done;
+    dim3 grid(nsplit, (a.CinP / 16) * ncob, ntg);
+    hipLaunchKernelGGL(k, grid, dim3(512), lds, st, a);
+    return (int)hipGetLastError();
+}
+
 struct Bf16Plan { int nsb, ncobg, nbz, nby, nbx, nsplit, cps, small, nz; };
 
 Bf16Plan plan_conv_bf16(int Cin, int Cout, int B, int Do, int Ho, int Wo) {
@@ -1173,6 +1380,46 @@ int vnet_conv_wgrad(int ks, int kx, int stride, const float* x0, int C0, const f
     const size_t total = (size_t)T3 * a.Cin * Cout;
     const int blocks = (int)min((size_t)4096, (total + 63) / 64);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, p.nsplit, T3, a.CinP, a.CoutP, a.Cin, Cout, dw);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+size_t vnet_wgrad_bf16_ws_bytes(int Cin, int Cout, int B, int D, int H, int W) {
+    return vnet_wgrad_ws_bytes(5, 5, 1, Cin, Cout, B, D, H, W);
+}
+
+int vnet_conv_wgrad_bf16(const float* x0, int C0, const float* x1, int C1, const float* dy, int Cout, float* dw,
+                         int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    if (!x0 || !dy || !dw || C0 <= 0 || Cout <= 0 || B <= 0 || C1 < 0 || (C1 > 0 && !x1)) return VNET_E_BADARG;
+    if (D <= 0 || H <= 0 || W <= 0) return VNET_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    WgradArgs a{};
+    a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.dy = dy; a.Cout = Cout;
+    a.B = B; a.Di = D; a.Hi = H; a.Wi = W; a.Do = D; a.Ho = H; a.Wo = W;
+    a.CinP = round_up(a.Cin, 16); a.CoutP = round_up(Cout, 16);
+    a.pad = 2; a.padx = 2;
+    a.vec_in = (C0 % 4 == 0) && (C1 % 4 == 0); a.vec_dy = (Cout % 4 == 0);
+    WgradPlan p = plan_wgrad(5, 5, 1, a.Cin, Cout, B, D, H, W);
+    a.ncob = p.ncob; a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.nbrick = p.nbrick; a.nsplit = p.nsplit;
+    const size_t need = (size_t)p.nsplit * 125 * a.CinP * a.CoutP * sizeof(float);
+    const bool direct = p.nsplit == 1 && a.CinP == a.Cin && a.CoutP == Cout;
+    if (!direct && (!ws || ws_bytes < need)) return VNET_E_WORKSPACE;
+    a.part = direct ? dw : reinterpret_cast<float*>(ws);
+    int e;
+    if (p.small) {
+        e = p.ns == 4 ? launch_wgrad_bf16<4, 8, 8, 4, 4>(a, p.nsplit, p.ncob, p.ntg, st)
+          : p.ns == 2 ? launch_wgrad_bf16<4, 8, 8, 2, 8>(a, p.nsplit, p.ncob, p.ntg, st)
+                      : launch_wgrad_bf16<4, 8, 8, 1, 16>(a, p.nsplit, p.ncob, p.ntg, st);
+    } else {
+        e = p.ns == 4 ? launch_wgrad_bf16<4, 4, 16, 4, 4>(a, p.nsplit, p.ncob, p.ntg, st)
+          : p.ns == 2 ? launch_wgrad_bf16<4, 4, 16, 2, 8>(a, p.nsplit, p.ncob, p.ntg, st)
+                      : launch_wgrad_bf16<4, 4, 16, 1, 16>(a, p.nsplit, p.ncob, p.ntg, st);
+    }
+    if (e) return e;
+    if (direct) return VNET_OK;
+    const size_t total = (size_t)125 * a.Cin * Cout;
+    const int blocks = (int)min((size_t)4096, (total + 63) / 64);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, p.nsplit, 125, a.CinP, a.CoutP, a.Cin, Cout, dw);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
 }

@@ -20,9 +20,9 @@ BN_MOMENTUM = 0.99   # reference networks.py:259 momentum=0.99
 ACT = {None: 0, "none": 0, "relu": 1, "prelu": 2, "lrelu": 3}
 PACK_FWD, PACK_BWD, PACK_UP, PACK_FWD_BF16, PACK_BWD_BF16 = 0, 1, 2, 3, 4
 
-# Arithmetic of the 5x5x5 convolutions (forward and backward-data): "fp32" = exact fp32 MFMA (the reference's
+# Arithmetic of the 5x5x5 convolutions (forward, backward-data and filter gradient): "fp32" = exact fp32 MFMA (the reference's
 # arithmetic), "bf16" = operands rounded to bf16, fp32 accumulation (BASELINE config C5).  Everything else
-# (filter gradients, batch-norm, loss, optimiser) is fp32 in both modes.
+# (2^3 down/up convolutions, the fused 1-channel input block, batch-norm, loss, optimiser) is fp32 in both modes.
 _COMPUTE = {"dtype": "fp32"}
 
 
@@ -241,6 +241,23 @@ def _conv_bf16_call(x0, x1, wp, bias, y0, y1, dims):
                                    B, *dims, _ptr(ws), nb, _stream()), "vnet_conv_fwd_bf16")
 
 
+def _wgrad_bf16_call(x0, x1, dy, dw, dims):
+    """Filter gradient of the 5^3 stride-1 conv with bf16 operands / fp32 accumulation (vnet_conv_wgrad_bf16)."""
+    L = _lib.lib()
+    B = x0.shape[0]
+    C0, C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
+    Co = dy.shape[-1]
+    nb = L.vnet_wgrad_bf16_ws_bytes(C0 + C1, Co, B, *dims)
+    ws = workspace(nb, x0.device)
+    nvox = B * dims[0] * dims[1] * dims[2]
+    flops = 2.0 * nvox * 125 * (C0 + C1) * Co
+    nbytes = 4.0 * (nvox * (C0 + C1 + Co) + 125 * (C0 + C1) * Co)
+    tag = "wgrad-bf16 k5 s1 %d^3x%d %d->%d" % (dims[2], B, C0 + C1, Co)
+    with _Timed(tag, flops, nbytes):
+        check(L.vnet_conv_wgrad_bf16(_ptr(x0), C0, _ptr(x1), C1, _ptr(dy), Co, _ptr(dw), B, *dims,
+                                     _ptr(ws), nb, _stream()), "vnet_conv_wgrad_bf16")
+
+
 def _wgrad_call(ks, stride, x0, x1, dy, dw, dims_in, dims_out, kx=0):
     L = _lib.lib()
     B = x0.shape[0]
@@ -320,6 +337,8 @@ class _ConvFn(torch.autograd.Function):
             dw, sw = _grad_out(wref)
             if up:      # dw[a][o][ci] = sum_i dy[2i+a][o] * x[i][ci]  == filter grad of the 2^3 down conv (fine -> coarse)
                 _wgrad_call(2, 2, dy, None, x0, dw, dout, din)
+            elif ctx.bf16:
+                _wgrad_bf16_call(x0, x1, dy, dw, din)
             else:
                 _wgrad_call(ks, stride, x0, x1, dy, dw, din, dout)
         dx0 = dx1 = None
