@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3     # MI355X fp32 matrix = vector peak (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -36,6 +37,9 @@ def parse():
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-patch", type=int, default=64)
+    ap.add_argument("--compute", choices=("fp32", "bf16"), default="fp32",
+                    help="arithmetic of the 5^3 convolutions: fp32 = the reference's (headline metric); bf16 = operands rounded "
+                         "to bf16, fp32 accumulate (BASELINE config C5 with --channels 4 --classes 5)")
     return ap.parse_args()
 
 
@@ -45,6 +49,7 @@ def config(args):
                  "ImageFilenames": ["image%d.nii" % i for i in range(args.channels)], "LabelFilename": "label.nii",
                  "Synthetic": {"Cases": 1}},
         "SegmentationClasses": list(range(args.classes)), "BatchSize": args.batch, "PatchShape": [args.patch] * 3,
+        "ComputeDtype": args.compute,
         "Networks": {"Name": "VNet", "Dropout": 0.0, "NumChannel": 16, "NumLevels": 4, "NumConvolutions": [1, 2, 3, 3],
                      "BottomConvolutions": 3},
         "Optimizer": {"Name": "Adam", "InitialLearningRate": 1e-2, "Decay": {"Factor": 0.99, "Steps": 100}},
@@ -142,7 +147,9 @@ def main():
         # 134.2 GF / 268.6 MB algorithmic per 16->16 launch, 268.4 GF / 402.9 MB per 32->16 launch at 128^3
         # 
         P = args.patch
-        fam = set("%s k5 s1 %d^3x%d %d->16" % (k, P, args.batch, c) for k in ("conv", "wgrad") for c in (16, 32))
+        bf16 = args.compute == "bf16"
+        fam = set("%s k5 s1 %d^3x%d %d->16" % (k, P, args.batch, c) for k in (("conv-bf16", "wgrad-bf16") if bf16 else ("conv", "wgrad"))
+                  for c in (16, 32))
         fl = by = ms = 0.0
         nl = 0
         per = {}
@@ -156,26 +163,30 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-            if os.path.exists(pmc) and P == 128 and args.batch == 1:
+            if os.path.exists(pmc) and P == 128 and args.batch == 1 and not bf16:
                 ks = json.load(open(pmc))["kernels"]
                 sel = [v for k, v in ks.items() if k.startswith("conv_kernel<5, 1, 4, 8, 16, 8, 4, 1, false, 5> grid=2097152")
                        or k.startswith("wgrad_kernel<5, 1, 4, 4, 16, 1, 16, 5>")]
                 if sel:
                     traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in sel) / sum(v["launches"] for v in sel))
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-                    "kernel": "conv_kernel<5,1,4,8,16,8,4,1> + wgrad_kernel<5,1,4,4,16,1,16>: the 5^3 convs with 16 output "
-                              "channels @%d^3 (fwd, bwd-data, bwd-filter)" % P,
+            peak = PEAK_BF16_TFLOPS if bf16 else PEAK_FP32_TFLOPS
+            kname = ("conv5_bf16_kernel<4,8,16,1> + wgrad5_bf16_kernel<4,4,16,1,16>" if bf16
+                     else "conv_kernel<5,1,4,8,16,8,4,1> + wgrad_kernel<5,1,4,4,16,1,16>")
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": traffic,
+                    "kernel": kname + ": the 5^3 convs with 16 output channels @%d^3 (fwd, bwd-data, bwd-filter)" % P,
                     "launches": nl, "avg_ms": round(ms / nl, 4), "flops_per_launch": fl / nl, "algorithmic_bytes_per_launch": by / nl,
                     "hbm_GBps_algorithmic": round(by / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
         conv_ms = sum(v[3] for v in per.values()) / args.steps
         conv_tf = sum(v[1] for v in per.values()) / max(sum(v[3] for v in per.values()) * 1e-3, 1e-12) / 1e12
-        out = {"metric": "training patches/sec (128^3x1ch fp32)", "value": round(world * args.batch * args.steps / dt, 4),
+        metric = "training patches/sec (128^3x1ch fp32)" if not bf16 else \
+            "training patches/sec (%d^3x%dch, bf16 compute / fp32 accumulate)" % (P, args.channels)
+        out = {"metric": metric, "value": round(world * args.batch * args.steps / dt, 4),
                "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
                "config": {"workload": "V-Net (16ch,4 levels,(1,2,3,3),3) train step fwd+Dice+bwd+Adam, %d^3 patch, %d modality, %d classes, "
-                                      "batch %d/GPU (BASELINE configs[%d])" % (P, args.channels, args.classes, args.batch, 2 if world == 1 else 3),
+                                      "batch %d/GPU (BASELINE configs[%d])" % (P, args.channels, args.classes, args.batch, 4 if bf16 else (2 if world == 1 else 3)),
                           "global_batch": world * args.batch, "parallelism": "dp%d" % world, "bn": "per-replica"},
                "final_loss": round(final_loss, 6), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
                "conv_ms_per_step": round(conv_ms, 3), "conv_tflops": round(conv_tf, 2),

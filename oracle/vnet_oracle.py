@@ -182,13 +182,23 @@ def _unbroadcast(g, shape):
     return g.reshape(shape)
 
 
+# BASELINE config C5 ("bf16 compute, fp32 Dice accumulate"): the three GEMMs of every 5^k stride-1 convolution
+# (forward x*w, backward-data dy*w, backward-filter x*dy) take their two operands rounded to bfloat16 and accumulate
+# exactly-representable products in a wide accumulator; everything else stays full precision.  None = the reference's
+# fp32 arithmetic (restated here in float64).
+CONV5_OPERAND_ROUNDING = None
+
+
 def convolution(x, w, b, stride=1):
     """layers2.py:59-63: tf.nn.convolution(x, w, 'SAME', strides) + b."""
-    y = conv_nd_fwd(x.v, w.v, stride) + b.v
+    rb = (lambda a: a)
+    if CONV5_OPERAND_ROUNDING == "bf16" and stride == 1 and w.v.shape[0] == 5:
+        rb = round_bf16
+    y = conv_nd_fwd(rb(x.v), rb(w.v), stride) + b.v
     out = Var(y, (x, w, b))
 
     def bw(g):
-        dx, dw = conv_nd_bwd(x.v, w.v, g, stride)
+        dx, dw = conv_nd_bwd(rb(x.v), rb(w.v), rb(g), stride)
         x._acc(dx)
         w._acc(dw)
         b._acc(g.reshape(-1, g.shape[-1]).sum(0))

@@ -21,6 +21,9 @@ SMALL = {
 }
 
 
+# same nets with the bf16-operand arithmetic of BASELINE config C5 (oracle.CONV5_OPERAND_ROUNDING = "bf16")
+SMALL_BF16 = {"small_networks_c4k5_bf16": SMALL["small_networks_c4k5"]}
+
 COMPACT = ("small_networks_l3",)   # weights by recipe (rng 11, perturb .15), only norms of the gradients stored
 
 
@@ -72,4 +75,8 @@ def make_c1():
 if __name__ == "__main__":
     for n, c in SMALL.items():
         make_small(n, c)
+    O.CONV5_OPERAND_ROUNDING = "bf16"
+    for n, c in SMALL_BF16.items():
+        make_small(n, c)
+    O.CONV5_OPERAND_ROUNDING = None
     make_c1()

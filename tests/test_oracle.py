@@ -140,3 +140,32 @@ def test_golden_vectors_reproduce():
     assert np.abs(r["logits"] - z["logits"]).max() < 1e-4
     for k in ps.vars:
         assert np.abs(r["grads"][k] - z["grad:" + k]).max() <= 1e-5 * max(1.0, np.abs(z["grad:" + k]).max()), k
+
+
+def test_bf16_operand_rounding_mode():
+    """BASELINE config C5 arithmetic in the oracle: round-to-nearest-even to bfloat16 known answers, agreement
+    with torch's own bf16 cast, and the committed bf16 fixture reproduces (and differs from the exact one by a
+    bf16-sized amount, not more)."""
+    import torch
+    from tests.golden.make_golden import SMALL_BF16
+    assert O.round_bf16(1.0) == 1.0 and O.round_bf16(-2.5) == -2.5
+    assert O.round_bf16(1.0 + 2.0 ** -8) == 1.0                     # tie -> even mantissa
+    assert O.round_bf16(1.0 + 3 * 2.0 ** -8) == 1.0 + 2.0 ** -6     # tie -> even (up)
+    assert O.round_bf16(1.0 + 2.0 ** -8 + 2.0 ** -20) == 1.0 + 2.0 ** -7
+    a = np.random.default_rng(5).standard_normal(20000) * np.exp(np.random.default_rng(6).uniform(-20, 20, 20000))
+    assert np.array_equal(O.round_bf16(a), torch.tensor(a, dtype=torch.float32).to(torch.bfloat16).double().numpy())
+    name = "small_networks_c4k5_bf16"
+    variant, cin, K, P, B, C0, levels, ncv, nb, loss, wts = SMALL_BF16[name]
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    ps = O.ParamStore(values={k[6:]: z[k].astype(np.float64) for k in z.files if k.startswith("param:")})
+    net = O.VNetOracle(K, 0.0, C0, levels, ncv, nb, "prelu", variant, ps)
+    O.CONV5_OPERAND_ROUNDING = "bf16"
+    try:
+        r = O.run_step(z["images"].astype(np.float64), z["labels"], net, loss, wts, 0.7)
+    finally:
+        O.CONV5_OPERAND_ROUNDING = None
+    assert abs(r["loss"] - float(z["loss"])) < 1e-7
+    assert np.abs(r["logits"] - z["logits"]).max() < 1e-4
+    exact = np.load(os.path.join(GOLD, "small_networks_c4k5.npz"))
+    d = np.linalg.norm(exact["logits"] - z["logits"]) / np.linalg.norm(exact["logits"])
+    assert 1e-3 < d < 5e-2, d

@@ -131,6 +131,7 @@ class image2label(object):
         self.image_filenames = T['Data']['ImageFilenames']
         self.label_filename = T['Data']['LabelFilename']
         self.synthetic = T['Data'].get('Synthetic')            # extension: synthetic generator (no NIfTI shipped)
+        self.compute_dtype = T.get('ComputeDtype', 'fp32')            # extension: 'bf16' = BASELINE config C5 arithmetic
         self.sync_batch_norm = bool(T.get('SyncBatchNorm', False))   # extension: cross-replica BN statistics
         self.batch_size = T['BatchSize']
         self.patch_shape = T['PatchShape']
@@ -192,6 +193,7 @@ class image2label(object):
         self.input_batch_shape = (self.batch_size,) + tuple(self.patch_shape) + (self.input_channel_num,)
         self.output_batch_shape = (self.batch_size,) + tuple(self.patch_shape) + (1,)
         self.dropout_placeholder = self.dropout_rate     # stand-in for "dropout_placeholder" (model.py:312)
+        ops.set_compute_dtype(getattr(self, "compute_dtype", "fp32"))
         if self.network_name == "VNet":
             self.network = networks.VNet(
                 num_classes=self.output_channel_num,
