@@ -1,0 +1,39 @@
+"""Micro-benchmark of ONE 5^3 convolution problem in one mode (for rocprofv3 --pmc passes):
+   python profiles/bench_one.py <conv|wgrad> <fp32|bf16> P Cin Cout [iters]"""
+import sys
+import torch
+sys.path.insert(0, '.')
+from vnet_tensorflow_amd import ops
+
+kind, mode, P, ci, co = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+iters = int(sys.argv[6]) if len(sys.argv) > 6 else 10
+dev = torch.device('cuda', 0)
+ops.set_compute_dtype(mode)
+x = torch.randn(1, P, P, P, ci, device=dev)
+w = torch.nn.Parameter(torch.randn(5, 5, 5, ci, co, device=dev) * 0.05)
+b = torch.zeros(co, device=dev)
+dy = torch.randn(1, P, P, P, co, device=dev)
+dw = torch.empty(5, 5, 5, ci, co, device=dev)
+
+
+def run():
+    if kind == 'conv':
+        with torch.no_grad():
+            ops._ConvFn.apply(x, None, w, b, 5, 1, False, None)
+    elif mode == 'bf16':
+        ops._wgrad_bf16_call(x, None, dy, dw, (P, P, P))
+    else:
+        ops._wgrad_call(5, 1, x, None, dy, dw, (P, P, P), (P, P, P))
+
+
+for _ in range(3):
+    run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(iters):
+    run()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / iters
+print("%s %s %d^3 %d->%d  %.3f ms  %.1f TF/s" % (kind, mode, P, ci, co, ms, 2.0 * P ** 3 * 125 * ci * co / ms / 1e9))

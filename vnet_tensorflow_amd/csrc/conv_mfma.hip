@@ -79,6 +79,30 @@ struct XTile {
             v[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    // rows k = K0 .. K0+KN-1 of this thread's column only (staging in batches keeps fewer registers in flight)
+    template <int K0, int KN>
+    __device__ static __forceinline__ void issue_part(float4 (&v)[KN], const float* __restrict__ x0, const float* __restrict__ x1,
+                                                      int C0, int C1, int chunk, int b, int gz0, int gy0, int gx0,
+                                                      int Di, int Hi, int Wi, int tid) {
+        const int r0 = tid / COLS, col = tid - r0 * COLS;
+        const int ix = col >> 2, cq = col & 3;
+        const int c = chunk * 16 + cq * 4;
+        const int gx = gx0 + ix;
+        const bool colok = r0 < RPI && (unsigned)gx < (unsigned)Wi && c < C0 + C1;
+        const bool first = c < C0 || !colok;
+        const float* src = first ? x0 + (colok ? c : 0) : x1 + (c - C0);
+        const int Cs = first ? C0 : C1;
+#pragma unroll
+        for (int k = 0; k < KN; ++k) {
+            const int row = r0 + (K0 + k) * RPI;
+            const int iz = row / IY, iy = row - iz * IY;
+            const int gz = gz0 + iz, gy = gy0 + iy;
+            const bool ok = colok && row < ROWS && (unsigned)gz < (unsigned)Di && (unsigned)gy < (unsigned)Hi;
+            const size_t off = ok ? (((size_t)(b * Di + gz) * Hi + gy) * Wi + gx) * Cs : 0;
+            const float4 t = *reinterpret_cast<const float4*>(src + off);
+            v[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     __device__ static __forceinline__ void commit(float* lds, const float4 (&v)[PER], int tid) {
         const int r0 = tid / COLS, col = tid - r0 * COLS;
 #pragma unroll
@@ -673,6 +697,44 @@ struct Bf16Geom {
     static constexpr int TILE_BYTES = 2 * PLANE;
 };
 
+// filter-plane prefetch: WPER 16-byte units per thread, global -> registers (issue) -> LDS (commit)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int NSB, int WPER>
+__device__ __forceinline__ void bf16_w_issue(u32x4 (&wreg)[WPER], const u32x4* __restrict__ src, int ncob, int tid) {
+    constexpr int WUNITS = 25 * NSB * 64;
+#pragma unroll
+    for (int k = 0; k < WPER; ++k) {
+        const int idx = min(tid + k * 512, WUNITS - 1);
+        const int t = idx / (NSB * 64), j = idx - t * (NSB * 64);
+        wreg[k] = src[(size_t)t * ncob * 64 + j];
+    }
+}
+template <int NSB, int WPER>
+__device__ __forceinline__ void bf16_w_commit(u32x4* wl, const u32x4 (&wreg)[WPER], int tid) {
+    constexpr int WUNITS = 25 * NSB * 64;
+#pragma unroll
+    for (int k = 0; k < WPER; ++k) {
+        const int idx = tid + k * 512;
+        wl[idx < WUNITS ? idx : WUNITS] = wreg[k];          // WUNITS = one spare 16-byte dump slot behind the slab
+    }
+}
+// brick (+halo) of one 16-channel chunk: fp32 NDHWC -> two bf16 planes [cin half][voxel][8]
+template <typename G, typename XT, int K0, int KN>
+__device__ __forceinline__ void bf16_tile_commit(unsigned char* tile, unsigned char* dump, const float4 (&v)[KN], int tid) {
+    const int r0 = tid / XT::COLS, col = tid - r0 * XT::COLS;
+    const int ix = col >> 2, cq = col & 3;
+    unsigned char* base = tile + (cq >> 1) * G::PLANE + ix * 16 + (cq & 1) * 8;
+#pragma unroll
+    for (int k = 0; k < KN; ++k) {
+        const int row = r0 + (K0 + k) * XT::RPI;
+        const bool ok = r0 < XT::RPI && row < XT::ROWS;
+        // select on the ADDRESS, not a branch around the store: a branch would pull the global load of v[k] inside it
+        // and every load would then wait for the previous one
+        unsigned char* dst = ok ? base + row * (G::IX * 16) : dump;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(pk_bf16(v[k].x, v[k].y), pk_bf16(v[k].z, v[k].w));
+    }
+}
+
 template <int TZ, int TY, int TX, int NSB>
 __global__ void __launch_bounds__(512) conv5_bf16_kernel(ConvArgs a) {
     using G = Bf16Geom<TZ, TY, TX>;
@@ -682,7 +744,7 @@ __global__ void __launch_bounds__(512) conv5_bf16_kernel(ConvArgs a) {
     constexpr int WPER = (WUNITS + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* tile = smem;
-    uint4* wl = reinterpret_cast<uint4*>(smem + G::TILE_BYTES);
+    u32x4* wl = reinterpret_cast<u32x4*>(smem + G::TILE_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -721,39 +783,27 @@ __global__ void __launch_bounds__(512) conv5_bf16_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     const int gz0 = bz * TZ - 2, gy0 = by * TY - 2, gx0 = bx * TX - 2;
-    const uint4* wg = reinterpret_cast<const uint4*>(a.wp);
+    const u32x4* wg = reinterpret_cast<const u32x4*>(a.wp);
     using XT = XTile<G::IZ, G::IY, G::IX, NT>;
 
-    uint4 wreg[WPER];
-    auto w_issue = [&](int chunk, int dz) {
-        const uint4* src = wg + ((size_t)(chunk * 125 + dz * 25) * ncob + cob0) * 64;
-#pragma unroll
-        for (int k = 0; k < WPER; ++k) {
-            const int idx = min(tid + k * NT, WUNITS - 1);
-            const int t = idx / (NSB * 64), j = idx - t * (NSB * 64);
-            wreg[k] = src[(size_t)t * ncob * 64 + j];
-        }
-    };
-    auto w_commit = [&]() {
-#pragma unroll
-        for (int k = 0; k < WPER; ++k) {
-            const int idx = tid + k * NT;
-            if (idx < WUNITS) wl[idx] = wreg[k];
-        }
-    };
+    u32x4 wreg[WPER];
+    unsigned char* dump = smem + G::TILE_BYTES + WUNITS * 16 + (tid & 63) * 16;       // per-lane slot for masked-off stores
+    auto wsrc = [&](int chunk, int dz) { return wg + ((size_t)(chunk * 125 + dz * 25) * ncob + cob0) * 64; };
     auto stage_tile = [&](int chunk) {
         if (a.vec_in) {
-            float4 v[XT::PER];
-            XT::issue(v, a.x0, a.x1, a.C0, a.C1, chunk, b, gz0, gy0, gx0, a.Di, a.Hi, a.Wi, tid);
-            const int r0 = tid / XT::COLS, col = tid - r0 * XT::COLS;
-            const int ix = col >> 2, cq = col & 3;
-#pragma unroll
-            for (int k = 0; k < XT::PER; ++k) {
-                const int row = r0 + k * XT::RPI;
-                if (r0 < XT::RPI && row < XT::ROWS) {
-                    uint2 pk = make_uint2(pk_bf16(v[k].x, v[k].y), pk_bf16(v[k].z, v[k].w));
-                    *reinterpret_cast<uint2*>(tile + (cq >> 1) * G::PLANE + (row * G::IX + ix) * 16 + (cq & 1) * 8) = pk;
-                }
+            constexpr int H0 = XT::PER / 2, H1 = XT::PER - H0;       // two batches: half the staging registers
+            {
+                float4 v[H0];
+                XT::template issue_part<0, H0>(v, a.x0, a.x1, a.C0, a.C1, chunk, b, gz0, gy0, gx0, a.Di, a.Hi, a.Wi, tid);
+                __builtin_amdgcn_sched_barrier(0);
+                bf16_tile_commit<G, XT, 0, H0>(tile, dump, v, tid);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                float4 v[H1];
+                XT::template issue_part<H0, H1>(v, a.x0, a.x1, a.C0, a.C1, chunk, b, gz0, gy0, gx0, a.Di, a.Hi, a.Wi, tid);
+                __builtin_amdgcn_sched_barrier(0);
+                bf16_tile_commit<G, XT, H0, H1>(tile, dump, v, tid);
             }
         } else {
             const int Cin = a.C0 + a.C1;
@@ -778,9 +828,9 @@ __global__ void __launch_bounds__(512) conv5_bf16_kernel(ConvArgs a) {
     };
 
     if (c_begin < c_end) {
-        w_issue(c_begin, dz0);
+        bf16_w_issue<NSB, WPER>(wreg, wsrc(c_begin, dz0), ncob, tid);
         stage_tile(c_begin);
-        w_commit();
+        bf16_w_commit<NSB, WPER>(wl, wreg, tid);
     }
     __syncthreads();
 
@@ -789,10 +839,13 @@ __global__ void __launch_bounds__(512) conv5_bf16_kernel(ConvArgs a) {
             // prefetch the next filter plane (this chunk's next dz, or the next chunk's first) into registers
             const bool last_dz = (dz + 1 == dz1);
             const bool more = !(last_dz && chunk + 1 == c_end);
-            if (more) w_issue(last_dz ? chunk + 1 : chunk, last_dz ? dz0 : dz + 1);
+            if (more) {
+                bf16_w_issue<NSB, WPER>(wreg, wsrc(last_dz ? chunk + 1 : chunk, last_dz ? dz0 : dz + 1), ncob, tid);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 
             const unsigned char* tp = tile + dz * (G::IY * G::IX * 16);
-            const uint4* wa = wl + aoff;
+            const u32x4* wa = wl + aoff;
             bf16x8 bf[2][MS], af[2][NSB];
 #pragma unroll
             for (int m = 0; m < MS; ++m) bf[0][m] = *reinterpret_cast<const bf16x8*>(tp + boff[m]);
@@ -818,7 +871,7 @@ __global__ void __launch_bounds__(512) conv5_bf16_kernel(ConvArgs a) {
             __syncthreads();                       // every wave is done with this filter plane (and, on the last dz, the tile)
             if (more) {
                 if (last_dz) stage_tile(chunk + 1);
-                w_commit();
+                bf16_w_commit<NSB, WPER>(wl, wreg, tid);
             }
             __syncthreads();
         }
@@ -1021,34 +1074,37 @@ __global__ void __launch_bounds__(512) wgrad5_bf16_kernel(WgradArgs a) {
             issue(brick + a.nsplit);
             __builtin_amdgcn_sched_barrier(0);
         }
-        constexpr int NK = NV / 32;
-        auto fetch = [&](int s, bf16x8 (&av)[NS], bf16x8 (&bv)[TW]) {      // s is a literal after unrolling
-            const int v0 = s * 32;
+        // K loop in phases: phase p = (k-step p/PH, tap group p%PH).  The reads of phase p+1 are issued before the
+        // MFMAs of phase p (ping-pong over TW/PH B fragments; the A fragments change once per k-step).  Short phases
+        // keep the fragment registers small: with the next brick's prefetch registers live across this loop, anything
+        // above 256 VGPRs spills loop-invariant address parts, and their scratch reloads serialise the prefetch loads
+        // (scratch and global loads share vmcnt) -- measured 24 us per brick instead of 2.
+        constexpr int NK = NV / 32, PH = (TW >= 16) ? 4 : 2, TH = TW / PH, NP = PH * NK;
+        static_assert(TW % PH == 0, "taps are processed in PH groups");
+        bf16x8 av[2][NS], bv[2][TH];
+        auto fetch = [&](int ph) {                                 // ph is a literal after unrolling
+            const int ks = ph / PH, h = ph % PH;
+            const int v0 = ks * 32;
             const int vy = (v0 / TX) % TY, vz = v0 / (TX * TY);
             const int xo = ((vz * G::IY + vy) * G::IX) * 32, dyo = ((vz * TY + vy) * TXP) * 32;
+            if (h == 0) {
 #pragma unroll
-            for (int n = 0; n < NS; ++n) av[n] = tr_frag(pa, n * DYPLANE + dyo);
+                for (int n = 0; n < NS; ++n) av[ks & 1][n] = tr_frag(pa, n * DYPLANE + dyo);
+            }
 #pragma unroll
-            for (int t = 0; t < TW; ++t) bv[t] = tr_frag(pt[t], xo);
+            for (int t = 0; t < TH; ++t) bv[ph & 1][t] = tr_frag(pt[h * TH + t], xo);
         };
-        bf16x8 avA[NS], bvA[TW], avB[NS], bvB[TW];
-        fetch(0, avA, bvA);
+        fetch(0);
 #pragma unroll
-        for (int s = 0; s < NK; s += 2) {
-            fetch(s + 1, avB, bvB);
+        for (int ph = 0; ph < NP; ++ph) {
+            if (ph + 1 < NP) fetch(ph + 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < TW; ++t)
+            for (int t = 0; t < TH; ++t)
 #pragma unroll
                 for (int n = 0; n < NS; ++n)
-                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(avA[n], bvA[t], acc[t][n], 0, 0, 0);
-            if (s + 2 < NK) fetch(s + 2, avA, bvA);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < TW; ++t)
-#pragma unroll
-                for (int n = 0; n < NS; ++n)
-                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(avB[n], bvB[t], acc[t][n], 0, 0, 0);
+                    acc[(ph % PH) * TH + t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[(ph / PH) & 1][n], bv[ph & 1][t],
+                                                                                         acc[(ph % PH) * TH + t][n], 0, 0, 0);
         }
     }
     // lane holds dW[tap][ci = chunk*16 + i][co = co0 + n*16 + 4*g + {0..3}]
@@ -1105,7 +1161,7 @@ int launch_conv_bf16(const ConvArgs& a, const Bf16Plan& p, hipStream_t st) {
 #define VNET_GO(NSBV)                                                                             \
     {                                                                                             \
         auto k = conv5_bf16_kernel<TZ, TY, TX, NSBV>;                                             \
-        const size_t lds = (size_t)G::TILE_BYTES + (size_t)25 * NSBV * 1024;                      \
+        const size_t lds = (size_t)G::TILE_BYTES + (size_t)25 * NSBV * 1024 + 16 + 64 * 16;       \
         static int attr_done = -1;                                                                \
         if (attr_done != 0) attr_done = set_lds(k, lds);                                          \
         if (attr_done != 0) return attr_done;                                                     \
@@ -1286,10 +1342,11 @@ int vnet_conv_fwd_bf16(const float* x0, int C0, const float* x1, int C1, const v
 namespace {
 struct WgradPlan { int ns, tw, ncob, ntg, nbz, nby, nbx, nbrick, nsplit, small; };
 
-WgradPlan plan_wgrad(int ks, int kx, int stride, int Cin, int Cout, int B, int Do, int Ho, int Wo) {
+WgradPlan plan_wgrad(int ks, int kx, int stride, int Cin, int Cout, int B, int Do, int Ho, int Wo, bool bf16 = false) {
     WgradPlan p{};
     const int CoutP = round_up(Cout, 16);
     p.ns = pick_ns(CoutP);
+    if (bf16 && p.ns == 4) p.ns = 2;      // the 4-block variant of the bf16 kernel does not fit 256 VGPRs next to the prefetch registers
     p.ncob = CoutP / (16 * p.ns);
     p.small = Wo < 16;
     const int T3 = ks * ks * kx;
@@ -1385,7 +1442,8 @@ int vnet_conv_wgrad(int ks, int kx, int stride, const float* x0, int C0, const f
 }
 
 size_t vnet_wgrad_bf16_ws_bytes(int Cin, int Cout, int B, int D, int H, int W) {
-    return vnet_wgrad_ws_bytes(5, 5, 1, Cin, Cout, B, D, H, W);
+    WgradPlan p = plan_wgrad(5, 5, 1, Cin, Cout, B, D, H, W, true);
+    return (size_t)p.nsplit * 125 * round_up(Cin, 16) * round_up(Cout, 16) * sizeof(float);
 }
 
 int vnet_conv_wgrad_bf16(const float* x0, int C0, const float* x1, int C1, const float* dy, int Cout, float* dw,
@@ -1399,7 +1457,7 @@ int vnet_conv_wgrad_bf16(const float* x0, int C0, const float* x1, int C1, const
     a.CinP = round_up(a.Cin, 16); a.CoutP = round_up(Cout, 16);
     a.pad = 2; a.padx = 2;
     a.vec_in = (C0 % 4 == 0) && (C1 % 4 == 0); a.vec_dy = (Cout % 4 == 0);
-    WgradPlan p = plan_wgrad(5, 5, 1, a.Cin, Cout, B, D, H, W);
+    WgradPlan p = plan_wgrad(5, 5, 1, a.Cin, Cout, B, D, H, W, true);
     a.ncob = p.ncob; a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.nbrick = p.nbrick; a.nsplit = p.nsplit;
     const size_t need = (size_t)p.nsplit * 125 * a.CinP * a.CoutP * sizeof(float);
     const bool direct = p.nsplit == 1 && a.CinP == a.Cin && a.CoutP == Cout;
@@ -1407,12 +1465,10 @@ int vnet_conv_wgrad_bf16(const float* x0, int C0, const float* x1, int C1, const
     a.part = direct ? dw : reinterpret_cast<float*>(ws);
     int e;
     if (p.small) {
-        e = p.ns == 4 ? launch_wgrad_bf16<4, 8, 8, 4, 4>(a, p.nsplit, p.ncob, p.ntg, st)
-          : p.ns == 2 ? launch_wgrad_bf16<4, 8, 8, 2, 8>(a, p.nsplit, p.ncob, p.ntg, st)
+        e = p.ns == 2 ? launch_wgrad_bf16<4, 8, 8, 2, 8>(a, p.nsplit, p.ncob, p.ntg, st)
                       : launch_wgrad_bf16<4, 8, 8, 1, 16>(a, p.nsplit, p.ncob, p.ntg, st);
     } else {
-        e = p.ns == 4 ? launch_wgrad_bf16<4, 4, 16, 4, 4>(a, p.nsplit, p.ncob, p.ntg, st)
-          : p.ns == 2 ? launch_wgrad_bf16<4, 4, 16, 2, 8>(a, p.nsplit, p.ncob, p.ntg, st)
+        e = p.ns == 2 ? launch_wgrad_bf16<4, 4, 16, 2, 8>(a, p.nsplit, p.ncob, p.ntg, st)
                       : launch_wgrad_bf16<4, 4, 16, 1, 16>(a, p.nsplit, p.ncob, p.ntg, st);
     }
     if (e) return e;
