@@ -151,3 +151,26 @@ def test_two_ranks_share_one_gpu(tmp_path, dev):
     err = float((r0["gsum"] - ref).norm() / ref.norm())
     assert err < 1e-4, err
     assert float((flat.data.cpu() - r0["data"]).abs().max()) < 1e-5
+
+
+def test_bench_contract_two_ranks(tmp_path):
+    """bench.py launched the way the driver launches it for N>1 (torch.distributed.run, one rank per GPU) -- here two
+    ranks share the single device over gloo: barrier + max-over-ranks timing, rank 0 prints ONE JSON line whose value
+    is the whole-job rate."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VNET_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "2", "--patch", "32"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 2
+    assert abs(out["value"] - 2 * 1 * 1000.0 / out["ms_per_step"]) < 1e-2 * out["value"]
+    assert out["roofline"] is None or out["roofline"]["frac"] > 0
+    assert "cpu_baseline" not in out                     # rank 0 at N=1 only

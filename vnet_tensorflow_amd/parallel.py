@@ -22,6 +22,8 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = os.environ.get("VNET_DIST_BACKEND")          # test hook: gloo with GPU tensors on a 1-GPU box
+        if backend == "gloo" and 0 < torch.cuda.device_count() <= local:
+            local %= torch.cuda.device_count()                      # test hook only: several ranks share one device
         if backend is None:
             backend = "nccl" if torch.cuda.device_count() > 0 else "gloo"   # device_count() does not initialise the GPU
         if backend == "nccl":
