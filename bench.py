@@ -142,7 +142,7 @@ def main():
 
     if rank == 0:
         # dominant kernel family: every launch of the two kernels that carry the 16-output-channel 5^3 convs at
-        # full resolution -- conv_kernel<5,1,4,8,16,8,4,1> (dec1/conv_1 fwd 32->16; 16->16 launches when the
+        # full resolution -- conv_kernel<5,1,4,8,8,4,4,1> (dec1/conv_1 fwd 32->16; 16->16 launches when the
         # single-modality input block is not fused) and wgrad_kernel<5,1,4,4,16,1,16> (their filter gradients):
         # 134.2 GF / 268.6 MB algorithmic per 16->16 launch, 268.4 GF / 402.9 MB per 32->16 launch at 128^3
         # 
@@ -171,7 +171,7 @@ def main():
                     traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in sel) / sum(v["launches"] for v in sel))
             peak = PEAK_BF16_TFLOPS if bf16 else PEAK_FP32_TFLOPS
             kname = ("conv5_bf16_kernel<4,8,16,1> + wgrad5_bf16_kernel<4,4,16,1,16>" if bf16
-                     else "conv_kernel<5,1,4,8,16,8,4,1> + wgrad_kernel<5,1,4,4,16,1,16>")
+                     else "conv_kernel<5,1,4,8,8,4,4,1> + wgrad_kernel<5,1,4,4,16,1,16>")
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic,
                     "kernel": kname + ": the 5^3 convs with 16 output channels @%d^3 (fwd, bwd-data, bwd-filter)" % P,

@@ -618,12 +618,14 @@ int set_lds(K kernel, size_t bytes) {
 
 int pick_ns(int CoutP) { return (CoutP % 64 == 0) ? 4 : (CoutP % 32 == 0) ? 2 : 1; }
 
-struct ConvPlan { int ns, ncob, nbz, nby, nbx, nsplit, cps, small, nz; };
+struct ConvPlan { int ns, ncob, nbz, nby, nbx, nsplit, cps, small, nz, half; };
 
 template <int TZ, int TY, int TX>
 void brick_counts(int Do, int Ho, int Wo, ConvPlan& p) { p.nbz = ceil_div(Do, TZ); p.nby = ceil_div(Ho, TY); p.nbx = ceil_div(Wo, TX); }
 
-// brick shapes: "wide" for W >= 16, "cube" otherwise
+// brick shapes: 5^3 stride-1 convs on W >= 16 use 4x8x8 bricks with 4-wave workgroups: the 74 KB tile lets TWO workgroups
+// share a CU, so one's tile staging and barriers overlap the other's MFMAs (+2..8 % over a 4x8x16 brick with 8 waves
+// and one workgroup per CU, measured); W < 16 uses the 8x8x8 cube, the 2^3 kernels their own shapes
 ConvPlan plan_conv(int ks, int stride, int up, int Cin, int Cout, int B, int Do, int Ho, int Wo, int gridW) {
     ConvPlan p{};
     const int CoutP = up ? round_up(8 * Cout, 16) : round_up(Cout, 16);
@@ -631,6 +633,7 @@ ConvPlan plan_conv(int ks, int stride, int up, int Cin, int Cout, int B, int Do,
     p.ncob = CoutP / (16 * p.ns);
     p.small = gridW < 16;
     if (stride == 2 && !up) { if (p.small) brick_counts<2, 8, 8>(Do, Ho, Wo, p); else brick_counts<2, 4, 16>(Do, Ho, Wo, p); }
+    else if (ks == 5 && !up && !p.small) { p.half = 1; brick_counts<4, 8, 8>(Do, Ho, Wo, p); }
     else { if (p.small) brick_counts<8, 8, 8>(Do, Ho, Wo, p); else brick_counts<4, 8, 16>(Do, Ho, Wo, p); }
     const int nchunks = round_up(Cin, 16) / 16;
     // deep levels have few bricks: prefer more, narrower cout blocks (each a full workgroup of equal work) until
@@ -1272,8 +1275,8 @@ int vnet_conv_fwd(int ks, int kx, int stride, int up, const float* x0, int C0, c
     }
     int e;
     if (is5) {
-        if (kx == 1) e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false, 1>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 16, 8, 4, false, 1>(a, p, st);
-        else e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 16, 8, 4, false>(a, p, st);
+        if (kx == 1) e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false, 1>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 8, 4, 4, false, 1>(a, p, st);
+        else e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 8, 4, 4, false>(a, p, st);
     } else if (isdown) {
         e = p.small ? launch_conv_ns<2, 2, 2, 8, 8, 4, 2, false>(a, p, st) : launch_conv_ns<2, 2, 2, 4, 16, 4, 2, false>(a, p, st);
     } else {
