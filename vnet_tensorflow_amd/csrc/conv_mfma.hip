@@ -702,22 +702,22 @@ struct Bf16Geom {
 
 // filter-plane prefetch: WPER 16-byte units per thread, global -> registers (issue) -> LDS (commit)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-template <int NSB, int WPER>
+template <int NSB, int WPER, int NT>
 __device__ __forceinline__ void bf16_w_issue(u32x4 (&wreg)[WPER], const u32x4* __restrict__ src, int ncob, int tid) {
     constexpr int WUNITS = 25 * NSB * 64;
 #pragma unroll
     for (int k = 0; k < WPER; ++k) {
-        const int idx = min(tid + k * 512, WUNITS - 1);
+        const int idx = min(tid + k * NT, WUNITS - 1);
         const int t = idx / (NSB * 64), j = idx - t * (NSB * 64);
         wreg[k] = src[(size_t)t * ncob * 64 + j];
     }
 }
-template <int NSB, int WPER>
+template <int NSB, int WPER, int NT>
 __device__ __forceinline__ void bf16_w_commit(u32x4* wl, const u32x4 (&wreg)[WPER], int tid) {
     constexpr int WUNITS = 25 * NSB * 64;
 #pragma unroll
     for (int k = 0; k < WPER; ++k) {
-        const int idx = tid + k * 512;
+        const int idx = tid + k * NT;
         wl[idx < WUNITS ? idx : WUNITS] = wreg[k];          // WUNITS = one spare 16-byte dump slot behind the slab
     }
 }
@@ -738,11 +738,11 @@ __device__ __forceinline__ void bf16_tile_commit(unsigned char* tile, unsigned c
     }
 }
 
-template <int TZ, int TY, int TX, int NSB>
-__global__ void __launch_bounds__(512) conv5_bf16_kernel(ConvArgs a) {
+template <int TZ, int TY, int TX, int NSB, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) conv5_bf16_kernel(ConvArgs a) {
     using G = Bf16Geom<TZ, TY, TX>;
-    constexpr int MS = 2, NT = 512;
-    static_assert(TZ * TY * TX == 8 * MS * 32, "brick = 16 subtiles of 32 voxels");
+    constexpr int MS = 2, NT = WAVES * 64;
+    static_assert(TZ * TY * TX == WAVES * MS * 32, "brick = WAVES*MS subtiles of 32 voxels");
     constexpr int WUNITS = 25 * NSB * 64;                  // 16-byte units of one dz plane of the filter slab
     constexpr int WPER = (WUNITS + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -753,7 +753,16 @@ __global__ void __launch_bounds__(512) conv5_bf16_kernel(ConvArgs a) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p32 = lane & 31, half = lane >> 5;
     // voxel of this lane inside a 32-voxel subtile (see header: bank-conflict-free rotation of the 2nd row)
-    const int q32 = (TX == 16 && p32 >= 16) ? 16 + ((p32 + 12) & 15) : p32;
+    int q32;
+    if (TX == 16) {
+        q32 = (p32 >= 16) ? 16 + ((p32 + 12) & 15) : p32;
+    } else {
+        // TX == 8 (row pitch 12 voxels): a subtile is 4 rows of 8; ds_read_b128 lane group {0-3,12-15,20-27} takes rows
+        // 0 and 2, group {4-11,16-19,28-31} rows 1 and 3 -> tile indices 0..7,24..31 / 12..19,36..43 are distinct mod 16
+        const bool ga = p32 < 4 || (p32 >= 12 && p32 < 16) || (p32 >= 20 && p32 < 28);
+        const int j = ga ? (p32 < 4 ? p32 : p32 < 16 ? p32 - 8 : p32 - 12) : (p32 < 12 ? p32 - 4 : p32 < 20 ? p32 - 8 : p32 - 16);
+        q32 = ((j >> 3) * 2 + (ga ? 0 : 1)) * 8 + (j & 7);
+    }
 
     const int nbrick = a.B * a.nbz * a.nby * a.nbx;
     int brick = xcd_remap(blockIdx.x, nbrick);
@@ -831,9 +840,9 @@ __global__ void __launch_bounds__(512) conv5_bf16_kernel(ConvArgs a) {
     };
 
     if (c_begin < c_end) {
-        bf16_w_issue<NSB, WPER>(wreg, wsrc(c_begin, dz0), ncob, tid);
+        bf16_w_issue<NSB, WPER, NT>(wreg, wsrc(c_begin, dz0), ncob, tid);
         stage_tile(c_begin);
-        bf16_w_commit<NSB, WPER>(wl, wreg, tid);
+        bf16_w_commit<NSB, WPER, NT>(wl, wreg, tid);
     }
     __syncthreads();
 
@@ -843,7 +852,7 @@ __global__ void __launch_bounds__(512) conv5_bf16_kernel(ConvArgs a) {
             const bool last_dz = (dz + 1 == dz1);
             const bool more = !(last_dz && chunk + 1 == c_end);
             if (more) {
-                bf16_w_issue<NSB, WPER>(wreg, wsrc(last_dz ? chunk + 1 : chunk, last_dz ? dz0 : dz + 1), ncob, tid);
+                bf16_w_issue<NSB, WPER, NT>(wreg, wsrc(last_dz ? chunk + 1 : chunk, last_dz ? dz0 : dz + 1), ncob, tid);
                 __builtin_amdgcn_sched_barrier(0);
             }
 
@@ -874,7 +883,7 @@ __global__ void __launch_bounds__(512) conv5_bf16_kernel(ConvArgs a) {
             __syncthreads();                       // every wave is done with this filter plane (and, on the last dz, the tile)
             if (more) {
                 if (last_dz) stage_tile(chunk + 1);
-                bf16_w_commit<NSB, WPER>(wl, wreg, tid);
+                bf16_w_commit<NSB, WPER, NT>(wl, wreg, tid);
             }
             __syncthreads();
         }
@@ -1137,14 +1146,17 @@ int launch_wgrad_bf16(const WgradArgs& a, int nsplit, int ncob, int ntg, hipStre
     return (int)hipGetLastError();
 }
 
-struct Bf16Plan { int nsb, ncobg, nbz, nby, nbx, nsplit, cps, small, nz; };
+struct Bf16Plan { int nsb, ncobg, nbz, nby, nbx, nsplit, cps, small, nz, half; };
 
 Bf16Plan plan_conv_bf16(int Cin, int Cout, int B, int Do, int Ho, int Wo) {
     Bf16Plan p{};
     const int ncob = round_up(Cout, 32) / 32, nchunks = round_up(Cin, 16) / 16;
     p.small = Wo < 16;
+    // few wide bricks (32^3 and below): 4x8x8 bricks with 4-wave workgroups double the workgroup count (+21 % at 32^3
+    // 64->64); with many bricks the two shapes measure the same, the wide one stages less halo
+    p.half = !p.small && (long)B * ceil_div(Do, 4) * ceil_div(Ho, 8) * ceil_div(Wo, 16) <= 256;
     if (p.small) { p.nbz = ceil_div(Do, 8); p.nby = ceil_div(Ho, 8); p.nbx = ceil_div(Wo, 8); }
-    else { p.nbz = ceil_div(Do, 4); p.nby = ceil_div(Ho, 8); p.nbx = ceil_div(Wo, 16); }
+    else { p.nbz = ceil_div(Do, 4); p.nby = ceil_div(Ho, 8); p.nbx = ceil_div(Wo, p.half ? 8 : 16); }
     const long nb = (long)B * p.nbz * p.nby * p.nbx;
     p.nsb = (ncob % 2 == 0 && nb * (ncob / 2) >= 256) ? 2 : 1;
     p.ncobg = ncob / p.nsb;
@@ -1157,13 +1169,13 @@ Bf16Plan plan_conv_bf16(int Cin, int Cout, int B, int Do, int Ho, int Wo) {
     return p;
 }
 
-template <int TZ, int TY, int TX>
+template <int TZ, int TY, int TX, int WAVES>
 int launch_conv_bf16(const ConvArgs& a, const Bf16Plan& p, hipStream_t st) {
     using G = Bf16Geom<TZ, TY, TX>;
-    dim3 grid(a.B * p.nbz * p.nby * p.nbx, p.ncobg, p.nsplit * p.nz), block(512);
+    dim3 grid(a.B * p.nbz * p.nby * p.nbx, p.ncobg, p.nsplit * p.nz), block(WAVES * 64);
 #define VNET_GO(NSBV)                                                                             \
     {                                                                                             \
-        auto k = conv5_bf16_kernel<TZ, TY, TX, NSBV>;                                             \
+        auto k = conv5_bf16_kernel<TZ, TY, TX, NSBV, WAVES>;                                      \
         const size_t lds = (size_t)G::TILE_BYTES + (size_t)25 * NSBV * 1024 + 16 + 64 * 16;       \
         static int attr_done = -1;                                                                \
         if (attr_done != 0) attr_done = set_lds(k, lds);                                          \
@@ -1325,7 +1337,8 @@ int vnet_conv_fwd_bf16(const float* x0, int C0, const float* x1, int C1, const v
         if (!ws || ws_bytes < need) return VNET_E_WORKSPACE;
         a.part = reinterpret_cast<float*>(ws); a.part_stride = nvox * a.CoutP;
     }
-    const int e = p.small ? launch_conv_bf16<8, 8, 8>(a, p, st) : launch_conv_bf16<4, 8, 16>(a, p, st);
+    const int e = p.small ? launch_conv_bf16<8, 8, 8, 8>(a, p, st)
+                : p.half  ? launch_conv_bf16<4, 8, 8, 4>(a, p, st) : launch_conv_bf16<4, 8, 16, 8>(a, p, st);
     if (e) return e;
     if (nslab > 1) {
         const size_t total = nvox * a.Cout;
