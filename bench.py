@@ -165,7 +165,7 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
             if os.path.exists(pmc) and P == 128 and args.batch == 1 and not bf16:
                 ks = json.load(open(pmc))["kernels"]
-                sel = [v for k, v in ks.items() if k.startswith("conv_kernel<5, 1, 4, 8, 16, 8, 4, 1, false, 5> grid=2097152")
+                sel = [v for k, v in ks.items() if k.startswith("conv_kernel<5, 1, 4, 8, 8, 4, 4, 1, false, 5> grid=2097152")
                        or k.startswith("wgrad_kernel<5, 1, 4, 4, 16, 1, 16, 5>")]
                 if sel:
                     traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in sel) / sum(v["launches"] for v in sel))
