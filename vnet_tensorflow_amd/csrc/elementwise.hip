@@ -139,12 +139,37 @@ __device__ __forceinline__ double block_colsum_d(const float* __restrict__ parti
     return shd[0] + shd[1] + shd[2] + shd[3];
 }
 
+// up to three columns (col0 + a*col_step) in ONE sweep over the partial rows and one block reduction
+template <int NA>
+__device__ __forceinline__ void block_colsum_multi(const float* __restrict__ partial, int nblk, size_t row_stride, size_t col0,
+                                                   size_t col_step, double (&out)[NA]) {
+    __shared__ double shm[4][NA];
+    double s[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) s[a] = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
+        const float* row = partial + (size_t)b * row_stride + col0;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) s[a] += (double)row[a * col_step];
+    }
+#pragma unroll
+    for (int a = 0; a < NA; ++a) s[a] = wave_sum_d(s[a]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < NA; ++a) shm[threadIdx.x >> 6][a] = s[a];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NA; ++a) out[a] = shm[0][a] + shm[1][a] + shm[2][a] + shm[3][a];
+}
+
 __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ partial, int nblk, int Cs, int C, double M, float eps,
                                                           float momentum, float* mean, float* invstd, float* mm, float* mv) {
     const int c = blockIdx.x;
     const int cs = (Cs == 1) ? 0 : c;
-    const double s = block_colsum_d(partial, nblk, 2 * Cs, cs);
-    const double q = block_colsum_d(partial, nblk, 2 * Cs, Cs + cs);
+    double sq[2];
+    block_colsum_multi<2>(partial, nblk, 2 * Cs, cs, Cs, sq);
+    const double s = sq[0], q = sq[1];
     if (threadIdx.x == 0) {
         const double mu = s / M;
         double var = q / M - mu * mu;
@@ -160,9 +185,9 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restric
 __global__ void __launch_bounds__(256) bn_moments_kernel(const float* __restrict__ partial, int nblk, int Cs, int C, double* __restrict__ sums) {
     const int c = blockIdx.x;
     const int cs = (Cs == 1) ? 0 : c;
-    const double s = block_colsum_d(partial, nblk, 2 * Cs, cs);
-    const double q = block_colsum_d(partial, nblk, 2 * Cs, Cs + cs);
-    if (threadIdx.x == 0) { sums[c] = s; sums[C + c] = q; }
+    double sq[2];
+    block_colsum_multi<2>(partial, nblk, 2 * Cs, cs, Cs, sq);
+    if (threadIdx.x == 0) { sums[c] = sq[0]; sums[C + c] = sq[1]; }
 }
 __global__ void __launch_bounds__(256) bn_finalize_sums_kernel(const double* __restrict__ sums, int C, double M, float eps, float momentum,
                                                                float* mean, float* invstd, float* mm, float* mv) {
@@ -180,6 +205,16 @@ __global__ void __launch_bounds__(256) bn_finalize_sums_kernel(const double* __r
 __global__ void __launch_bounds__(256) sum_finalize_kernel(const float* __restrict__ partial, int nblk, int nacc, int C,
                                                            float* o0, float* o1, float* o2) {
     const int c = blockIdx.x;
+    if (nacc == 3) {
+        double s[3];
+        block_colsum_multi<3>(partial, nblk, (size_t)3 * C, c, C, s);
+        if (threadIdx.x == 0) {
+            if (o0) o0[c] = (float)s[0];
+            if (o1) o1[c] = (float)s[1];
+            if (o2) o2[c] = (float)s[2];
+        }
+        return;
+    }
     for (int a = 0; a < nacc; ++a) {
         float* o = a == 0 ? o0 : (a == 1 ? o1 : o2);
         if (!o) continue;
