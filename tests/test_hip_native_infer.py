@@ -12,8 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "vnet_tensorflow_amd", "vnet_infer")
 
 
-@pytest.mark.parametrize("cin,K,levels,convs,bottom,batch", [(1, 2, 2, [1, 2], 1, 2), (2, 3, 3, [1, 2, 3], 2, 3)])
-def test_native_driver_matches_python_evaluate(tmp_path, dev, cin, K, levels, convs, bottom, batch):
+@pytest.mark.parametrize("cin,K,levels,convs,bottom,batch,compute", [(1, 2, 2, [1, 2], 1, 2, "fp32"), (2, 3, 3, [1, 2, 3], 2, 3, "fp32"),
+                                                                     (4, 5, 2, [2, 2], 1, 2, "bf16")])
+def test_native_driver_matches_python_evaluate(tmp_path, dev, cin, K, levels, convs, bottom, batch, compute):
     from vnet_tensorflow_amd import model as M
     from oracle.vnet_oracle import synthetic_batch
     assert os.path.exists(BIN), "run __graft_entry__.build() first"
@@ -22,6 +23,7 @@ def test_native_driver_matches_python_evaluate(tmp_path, dev, cin, K, levels, co
                                "SegmentationClasses": list(range(K)), "BatchSize": 1, "PatchShape": [16, 16, 16],
                                "Networks": {"Name": "VNet", "Dropout": 0.0, "NumChannel": 8, "NumLevels": levels,
                                             "NumCovolutions": convs, "BottomConvolutions": bottom},
+                               "ComputeDtype": compute,
                                "Optimizer": {"Name": "Adam", "InitialLearningRate": 1e-3, "Decay": {"Factor": 0.99, "Steps": 100}},
                                "Loss": {"Name": "sorensen"}},
            "EvaluationSetting": {"Stride": [8, 12, 16], "BatchSize": batch, "ProbabilityOutput": True}}
@@ -39,6 +41,8 @@ def test_native_driver_matches_python_evaluate(tmp_path, dev, cin, K, levels, co
     vol, _ = synthetic_batch(1, 24, cin, K, seed=9)
     vol = np.ascontiguousarray(vol[0][:, :22, :20])
     label_py, prob_py = m.evaluate_single_3D(vol)
+    from vnet_tensorflow_amd import ops
+    ops.set_compute_dtype("fp32")
 
     wpath, ipath = str(tmp_path / "net.vnetw"), str(tmp_path / "vol.npy")
     M.export_weights(m.network, wpath)
@@ -46,7 +50,7 @@ def test_native_driver_matches_python_evaluate(tmp_path, dev, cin, K, levels, co
     out = subprocess.run([BIN, "--weights", wpath, "--image", ipath, "--label-out", str(tmp_path / "lab.npy"),
                           "--prob-out", str(tmp_path / "prob.npy"), "--classes", str(K), "--channels", "8",
                           "--levels", str(levels), "--convs", ",".join(map(str, convs)), "--bottom", str(bottom),
-                          "--patch", "16,16,16", "--stride", "8,12,16", "--batch", str(batch)],
+                          "--patch", "16,16,16", "--stride", "8,12,16", "--batch", str(batch), "--compute", compute],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:] + out.stdout[-1000:]
     label_cc, prob_cc = np.load(tmp_path / "lab.npy"), np.load(tmp_path / "prob.npy")

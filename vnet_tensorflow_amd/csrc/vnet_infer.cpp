@@ -150,6 +150,7 @@ struct Config {
     int patch[3] = {64, 64, 64}, stride[3] = {64, 64, 64};
     std::string weights, image, label_out, prob_out;
     bool normalise = true;
+    bool bf16 = false;       // --compute bf16: bf16 operands / fp32 accumulation in the 5^3 convolutions (BASELINE config C5)
 };
 
 class VNetForward {
@@ -242,6 +243,13 @@ private:
         const int Cin = x0.C + (x1 ? x1->C : 0);
         const int Do = (x0.D + stride - 1) / stride, Ho = (x0.H + stride - 1) / stride, Wo = (x0.W + stride - 1) / stride;
         Tensor y = alloc(x0.B, Do, Ho, Wo, Cout);
+        if (cfg.bf16 && ks == 5 && stride == 1) {
+            float* wpb = pack(sc + "/weights", VNET_PACK_FWD_BF16, 125, Cin, Cout);
+            if (vnet_conv_bf16_ws_bytes(Cin, Cout, x0.B, Do, Ho, Wo) > ws_bytes_) { std::fprintf(stderr, "workspace too small\n"); std::exit(1); }
+            ABI_OK(vnet_conv_fwd_bf16(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, wpb, var(sc + "/biases").dev,
+                                      y.p, Cout, nullptr, 0, x0.B, x0.D, x0.H, x0.W, ws_, ws_bytes_, st_));
+            return y;
+        }
         float* wp = pack(sc + "/weights", VNET_PACK_FWD, ks * ks * ks, Cin, Cout);
         size_t need = vnet_conv_ws_bytes(ks, 0, stride, 0, Cin, Cout, x0.B, Do, Ho, Wo);
         if (need > ws_bytes_) { std::fprintf(stderr, "workspace too small\n"); std::exit(1); }
@@ -331,11 +339,12 @@ static Config parse(int argc, char** argv) {
         else if (a == "--patch") { auto v = ints(next()); for (int k = 0; k < 3; ++k) c.patch[k] = v[k]; }
         else if (a == "--stride") { auto v = ints(next()); for (int k = 0; k < 3; ++k) c.stride[k] = v[k]; }
         else if (a == "--no-normalise") c.normalise = false;
+        else if (a == "--compute") { const std::string v = next(); if (v != "fp32" && v != "bf16") { std::fprintf(stderr, "--compute fp32|bf16\n"); std::exit(1); } c.bf16 = (v == "bf16"); }
         else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); std::exit(1); }
     }
     if (c.weights.empty() || c.image.empty() || c.label_out.empty() || (int)c.convs.size() != c.levels) {
         std::fprintf(stderr, "usage: vnet_infer --weights W --image I.npy --label-out L.npy [--prob-out P.npy] --classes K --channels C "
-                             "--levels L --convs a,b,.. --bottom n --patch x,y,z --stride x,y,z --batch b\n");
+                             "--levels L --convs a,b,.. --bottom n --patch x,y,z --stride x,y,z --batch b [--compute fp32|bf16]\n");
         std::exit(1);
     }
     return c;
