@@ -57,29 +57,9 @@ struct XTile {
     static constexpr int ROWS = IZ * IY;
     static constexpr int PER = (ROWS + RPI - 1) / RPI;
     static_assert(RPI >= 1, "tile row wider than the workgroup");
-    __device__ static __forceinline__ void issue(float4 (&v)[PER], const float* __restrict__ x0, const float* __restrict__ x1,
-                                                 int C0, int C1, int chunk, int b, int gz0, int gy0, int gx0,
-                                                 int Di, int Hi, int Wi, int tid) {
-        const int r0 = tid / COLS, col = tid - r0 * COLS;
-        const int ix = col >> 2, cq = col & 3;
-        const int c = chunk * 16 + cq * 4;
-        const int gx = gx0 + ix;
-        const bool colok = r0 < RPI && (unsigned)gx < (unsigned)Wi && c < C0 + C1;
-        const bool first = c < C0 || !colok;
-        const float* src = first ? x0 + (colok ? c : 0) : x1 + (c - C0);
-        const int Cs = first ? C0 : C1;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int row = r0 + k * RPI;
-            const int iz = row / IY, iy = row - iz * IY;
-            const int gz = gz0 + iz, gy = gy0 + iy;
-            const bool ok = colok && row < ROWS && (unsigned)gz < (unsigned)Di && (unsigned)gy < (unsigned)Hi;
-            const size_t off = ok ? (((size_t)(b * Di + gz) * Hi + gy) * Wi + gx) * Cs : 0;
-            const float4 t = *reinterpret_cast<const float4*>(src + off);
-            v[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    // rows k = K0 .. K0+KN-1 of this thread's column only (staging in batches keeps fewer registers in flight)
+    // Address arithmetic is the VALU cost of staging (every non-MFMA VALU instruction takes MFMA issue time): one 64-bit
+    // per-thread base (source tensor, batch, x, channel) and a 32-bit row offset gz*Hi*Wi*Cs + gy*Wi*Cs per load (one
+    // sample's volume x channels stays below 2^31 elements), rows stepped incrementally (RPI rows per load).
     template <int K0, int KN>
     __device__ static __forceinline__ void issue_part(float4 (&v)[KN], const float* __restrict__ x0, const float* __restrict__ x1,
                                                       int C0, int C1, int chunk, int b, int gz0, int gy0, int gx0,
@@ -90,18 +70,27 @@ struct XTile {
         const int gx = gx0 + ix;
         const bool colok = r0 < RPI && (unsigned)gx < (unsigned)Wi && c < C0 + C1;
         const bool first = c < C0 || !colok;
-        const float* src = first ? x0 + (colok ? c : 0) : x1 + (c - C0);
         const int Cs = first ? C0 : C1;
+        const int rowstride = Wi * Cs, planestride = Hi * rowstride;
+        const float* bp = (first ? x0 + (colok ? c : 0) : x1 + (c - C0)) + (size_t)b * Di * planestride + (colok ? gx * Cs : 0);
+        constexpr int DIZ = RPI / IY, DIY = RPI % IY;
+        int row = r0 + K0 * RPI;
+        int iz = row / IY, iy = row - iz * IY;
 #pragma unroll
         for (int k = 0; k < KN; ++k) {
-            const int row = r0 + (K0 + k) * RPI;
-            const int iz = row / IY, iy = row - iz * IY;
             const int gz = gz0 + iz, gy = gy0 + iy;
             const bool ok = colok && row < ROWS && (unsigned)gz < (unsigned)Di && (unsigned)gy < (unsigned)Hi;
-            const size_t off = ok ? (((size_t)(b * Di + gz) * Hi + gy) * Wi + gx) * Cs : 0;
-            const float4 t = *reinterpret_cast<const float4*>(src + off);
+            const int off = ok ? gz * planestride + gy * rowstride : 0;
+            const float4 t = *reinterpret_cast<const float4*>(bp + off);
             v[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            row += RPI; iy += DIY; iz += DIZ;
+            if (iy >= IY) { iy -= IY; ++iz; }
         }
+    }
+    __device__ static __forceinline__ void issue(float4 (&v)[PER], const float* __restrict__ x0, const float* __restrict__ x1,
+                                                 int C0, int C1, int chunk, int b, int gz0, int gy0, int gx0,
+                                                 int Di, int Hi, int Wi, int tid) {
+        issue_part<0, PER>(v, x0, x1, C0, C1, chunk, b, gz0, gy0, gx0, Di, Hi, Wi, tid);
     }
     __device__ static __forceinline__ void commit(float* lds, const float4 (&v)[PER], int tid) {
         const int r0 = tid / COLS, col = tid - r0 * COLS;
@@ -739,7 +728,7 @@ __device__ __forceinline__ void bf16_tile_commit(unsigned char* tile, unsigned c
 }
 
 template <int TZ, int TY, int TX, int NSB, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64) conv5_bf16_kernel(ConvArgs a) {
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) conv5_bf16_kernel(ConvArgs a) {
     using G = Bf16Geom<TZ, TY, TX>;
     constexpr int MS = 2, NT = WAVES * 64;
     static_assert(TZ * TY * TX == WAVES * MS * 32, "brick = WAVES*MS subtiles of 32 voxels");
