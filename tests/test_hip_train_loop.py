@@ -66,20 +66,30 @@ def test_train_checkpoint_restore_evaluate(tmp_path, dev):
     assert np.allclose(p0 + p1, 1.0, atol=1e-5) and ((p1 > p0) == (lab == 1)).mean() > 0.999
 
 
-def test_loss_decreases_on_fixed_batch(dev):
-    """Sanity of the whole fwd/bwd/Adam loop: 12 steps on one synthetic batch reduce the Dice loss."""
+@pytest.mark.parametrize("compute,cin,K", [("fp32", 1, 2), ("bf16", 4, 5)])
+def test_loss_decreases_on_fixed_batch(dev, compute, cin, K):
+    """Sanity of the whole fwd/bwd/Adam loop: 12 steps on one synthetic batch reduce the Dice loss -- in the
+    reference's fp32 arithmetic and in the bf16-compute mode of BASELINE config C5 (4 modalities, 5 classes; this also
+    runs the batched bf16 filter repack after every optimiser step)."""
+    from vnet_tensorflow_amd import ops
     from vnet_tensorflow_amd.model import image2label
     from oracle.vnet_oracle import synthetic_batch
     import pathlib
     np.random.seed(1)
-    m = image2label(None, _cfg(pathlib.Path("/tmp")), device=dev, verbose=False)
-    m.read_config()
-    m.build_model_graph()
-    m._setup_training()
-    x, lab = synthetic_batch(2, 16, 1, 2, seed=11)
-    xt, lt = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
-    losses = [float(m.train_step(xt, lt, dropout=0.0)) for _ in range(12)]
-    assert losses[-1] < losses[0] - 0.05, losses
+    cfg = _cfg(pathlib.Path("/tmp"), ComputeDtype=compute, SegmentationClasses=list(range(K)))
+    cfg["TrainingSetting"]["Data"]["ImageFilenames"] = ["image%d.npy" % i for i in range(cin)]
+    m = image2label(None, cfg, device=dev, verbose=False)
+    try:
+        m.read_config()
+        m.build_model_graph()
+        assert ops.get_compute_dtype() == compute
+        m._setup_training()
+        x, lab = synthetic_batch(2, 16, cin, K, seed=11)
+        xt, lt = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
+        losses = [float(m.train_step(xt, lt, dropout=0.0)) for _ in range(12)]
+    finally:
+        ops.set_compute_dtype("fp32")
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 0.05, losses
 
 
 def test_main_cli(tmp_path):
