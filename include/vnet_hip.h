@@ -179,7 +179,30 @@ int vnet_bn_act_bwd_reduce(const float* dy, const float* x, const float* r, int 
 int vnet_bn_act_bwd_apply(const float* dy, const float* x, const float* r, int bcast, int64_t M, int C,
                           const float* mean, const float* invstd, const float* gamma, const float* beta,
                           int act, const float* alpha, const float* sum_dz, const float* sum_dz_xhat, double M_total,
+                          const float* xhat_coef /* NULL, or [C]: ds += xhat * xhat_coef (batch-norm chains) */,
                           float* ds, void* stream);
+
+/* Batch-norm CHAINS of the decoder, evaluated in closed form on ONE tensor x (the convolution output):
+ *   kind 0 (networks.py:333-337, block with one convolution): y1 = BN1(x); y2 = BN2(y1); out = act(BN3(y1 + y2))
+ *   kind 1 (networks.py:358-361, last convolution of a block): r = BNa(x); out = act(BNb(x + r))
+ * Every tensor in a chain is a per-channel affine function of xhat = (x - mean) * invstd, and the batch moments of such
+ * a function are known exactly (mean(xhat) = 0, var(xhat) = var/(var+eps)), so the chain equals
+ *   out = act(ceff * xhat + deff)
+ * i.e. vnet_bn_stats(x) + vnet_bn_chain_coef_fwd + vnet_bn_act_fwd(x, mean, invstd, gamma := ceff, beta := deff): two passes
+ * over x instead of eleven, identical in exact arithmetic.  coef_fwd also applies the moving-average updates of the
+ * derived layers (mm2/mv2: BN2 or BNb, mm3/mv3: BN3; NULL to skip) from their closed-form moments.
+ * Backward: vnet_bn_act_bwd_reduce(gamma := ceff, beta := deff) gives dC = sum dz*xhat and dD = sum dz;
+ * vnet_bn_chain_coef_bwd turns them into the gradients of every gamma/beta of the chain (db of the inner layers is
+ * exactly 0) and into xhat_coef, the extra term of ds that comes from ceff depending on the batch variance;
+ * vnet_bn_act_bwd_apply(..., xhat_coef) then writes ds.  With cross-replica statistics dC_global is the all-reduced dC.
+ * kind 1 uses (g1,b1) := BNa and (g2,b2) := BNb; g3/b3/dg3/db3/mm3/mv3 are ignored. */
+int vnet_bn_chain_coef_fwd(int kind, int C, float eps, float momentum, const float* mean, const float* invstd,
+                           const float* g1, const float* b1, const float* g2, const float* b2, const float* g3, const float* b3,
+                           float* ceff, float* deff, float* mm2, float* mv2, float* mm3, float* mv3, void* stream);
+int vnet_bn_chain_coef_bwd(int kind, int C, float eps, double M_total, const float* mean, const float* invstd,
+                           const float* g1, const float* g2, const float* g3,
+                           const float* dC_local, const float* dD_local, const float* dC_global,
+                           float* dg1, float* db1, float* dg2, float* db2, float* dg3, float* db3, float* xhat_coef, void* stream);
 
 /* ---- stand-alone activation, layers2.py:97-99 prelu / tf.nn.relu / tf.nn.leaky_relu -------------
  * (inside the networks the activation is fused into vnet_bn_act_*; this is the unfused API form) */

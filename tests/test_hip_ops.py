@@ -182,6 +182,62 @@ def test_bn_act(dev, C, act, res, tile):
     check_close(tag + " moving_var", mv, 0.99 + 0.01 * var, 1e-5)
 
 
+@pytest.mark.parametrize("kind,C,act", [(0, 16, "prelu"), (0, 32, "relu"), (0, 5, None), (1, 16, "prelu"), (1, 64, "lrelu"), (1, 6, None)])
+def test_bn_chain(dev, kind, C, act):
+    """The decoder's batch-norm chains evaluated in closed form as ONE normalisation of x (ops.bn_chain) against the
+    oracle's layer-by-layer graph: kind 0 = act(BN3(BN1(x) + BN2(BN1(x)))), kind 1 = act(BNb(x + BNa(x)));
+    gammas of both signs and small magnitude, a per-channel variance spread over 3 decades (so var is not >> eps)."""
+    from vnet_tensorflow_amd import ops
+    rng = np.random.default_rng(100 * kind + C)
+    shp = (2, 5, 6, 7)
+    scale = np.exp(rng.uniform(np.log(0.02), np.log(20.0), C))
+    x = rng.standard_normal(shp + (C,)) * scale * (1.0 + rng.standard_normal(C) * 0.5)     # |mean| stays ~std: fp32 BN is conditioned by |mean|/std
+    x = x.astype(np.float32).astype(np.float64)
+    nl = 3 if kind == 0 else 2
+    gam = [rng.uniform(0.3, 1.5, C) * rng.choice([-1.0, 1.0], C) for _ in range(nl)]
+    bet = [rng.standard_normal(C) for _ in range(nl)]
+    alpha = rng.uniform(0.05, 0.3, C)
+    X, A_ = O.Var(x), O.Var(alpha)
+    G_ = [O.Var(v) for v in gam]
+    B_ = [O.Var(v) for v in bet]
+    st = [[], [], []]
+    if kind == 0:
+        y1 = O.batch_norm_train(X, G_[0], B_[0], stats_out=st[0])
+        y2 = O.batch_norm_train(y1, G_[1], B_[1], stats_out=st[1])
+        y = O.batch_norm_train(O.add(y1, y2), G_[2], B_[2], stats_out=st[2])
+    else:
+        r = O.batch_norm_train(X, G_[0], B_[0], stats_out=st[0])
+        y = O.batch_norm_train(O.add(X, r), G_[1], B_[1], stats_out=st[1])
+    y = O.prelu(y, A_) if act == "prelu" else O.relu(y) if act == "relu" else O.leaky_relu(y) if act == "lrelu" else y
+    dy = rng.standard_normal(y.v.shape)
+    O.backward(y, dy)
+    tx = g(x, dev).requires_grad_(True)
+    tg = [g(v, dev).requires_grad_(True) for v in gam]
+    tb = [g(v, dev).requires_grad_(True) for v in bet]
+    ta = g(alpha, dev).requires_grad_(True)
+    mov = []
+    for _ in range(3):
+        mov += [torch.zeros(C, device=dev), torch.ones(C, device=dev)]
+    if kind == 1:
+        mov[4] = mov[5] = None
+    ty = ops.bn_chain(tx, kind, act, ta if act == "prelu" else None, tg[0], tb[0], tg[1], tb[1],
+                      tg[2] if kind == 0 else None, tb[2] if kind == 0 else None, tuple(mov))
+    tag = "bn_chain kind%d C%d %s" % (kind, C, act)
+    check_close(tag + " fwd", ty, y.v, 1e-5)
+    ty.backward(g(dy, dev))
+    check_close(tag + " dx", tx.grad, X.g, 5e-5, atol=1e-5)
+    for k in range(nl):
+        check_close(tag + " dgamma%d" % k, tg[k].grad, G_[k].g, 5e-5, atol=1e-5)
+        # the inner layers' beta gradients are analytically zero (the oracle holds fp64 roundoff there)
+        check_close(tag + " dbeta%d" % k, tb[k].grad, B_[k].g, 2e-5, atol=1e-6)
+    if act == "prelu":
+        check_close(tag + " dalpha", ta.grad, A_.g, 2e-5)
+    for k in range(nl):
+        mu, var = st[k][0]
+        check_close(tag + " moving_mean%d" % k, mov[2 * k], 0.01 * mu, 1e-5, atol=1e-7)
+        check_close(tag + " moving_var%d" % k, mov[2 * k + 1], 0.99 + 0.01 * var, 1e-5)
+
+
 @pytest.mark.parametrize("shape", [(1, 8, 16, 32, 16), (2, 5, 9, 17, 16), (1, 6, 7, 9, 4), (1, 8, 8, 8, 8)])
 def test_input_block(dev, shape):
     """conv5^3(BN(tile(img))) through the un-tiled 5x5x1 path (csrc/input_block.hip) == the oracle's tiled graph,

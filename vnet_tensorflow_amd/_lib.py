@@ -44,7 +44,9 @@ SIGNATURES = {
     "vnet_bn_moments": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _sz, _vp]),
     "vnet_bn_finalize": (_i, [_vp, _d, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "vnet_bn_act_bwd_reduce": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "vnet_bn_act_bwd_apply": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp]),
+    "vnet_bn_act_bwd_apply": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp, _vp]),
+    "vnet_bn_chain_coef_fwd": (_i, [_i, _i, _f, _f] + [_vp] * 14 + [_vp]),
+    "vnet_bn_chain_coef_bwd": (_i, [_i, _i, _f, _d] + [_vp] * 15 + [_vp]),
     "vnet_bn_act_fwd": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "vnet_bn_act_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp,
                              _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

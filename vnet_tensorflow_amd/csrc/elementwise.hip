@@ -223,6 +223,85 @@ __global__ void __launch_bounds__(256) sum_finalize_kernel(const float* __restri
     }
 }
 
+// ---- batch-norm chains of the decoder (networks.py:333-337 and :358-361) ----------------------------------------
+// Both chains are a per-channel AFFINE function of xhat = (x - mean) * invstd of ONE tensor x (the conv output):
+//   kind 0 (block with one convolution):  y1 = BN1(x);  y2 = BN2(y1);  out = act(BN3(y1 + y2))
+//   kind 1 (last convolution of a block): r = BNa(x);   out = act(BNb(x + r))
+// because the batch moments of an affine function of xhat are known in closed form (mean(xhat) = 0,
+// var(xhat) = vh = var/(var+eps)).  With A the slope of the summed tensor in xhat,
+//   out = act(Ceff * xhat + Deff),  Ceff = g_last * A / sqrt(A^2 vh + eps),  Deff = b_last,
+//   kind 0: A = g1 + g2 g1 / sqrt(g1^2 vh + eps)          kind 1: A = sqrt(var + eps) + ga
+// so the whole chain costs one statistics pass and one normalise pass instead of three of each, and its backward one
+// reduce + one apply pass.  The derived layers' moving statistics are updated from the closed-form moments.
+struct ChainP {
+    int kind, C; float eps, momentum; double M;
+    const float* mean; const float* invstd;
+    const float* g1; const float* b1; const float* g2; const float* b2; const float* g3;   // kind 1: (g1,b1) = a, (g2,b2) = b
+    float* ceff; float* deff; const float* b3;
+    float* mm2; float* mv2; float* mm3; float* mv3;
+    const float* dC_local; const float* dD_local; const float* dC_global;
+    float* dg1; float* db1; float* dg2; float* db2; float* dg3; float* db3; float* extra;
+};
+
+__global__ void bn_chain_fwd_kernel(ChainP p) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.C) return;
+    const double eps = p.eps, is = p.invstd[c], vh = fmax(0.0, 1.0 - eps * is * is), mu = p.mean[c];
+    const float keep = 1.f - p.momentum;
+    if (p.kind == 0) {
+        const double g1 = p.g1[c], g2 = p.g2[c], g3 = p.g3[c];
+        const double v2 = g1 * g1 * vh, a2 = g2 * g1 / sqrt(v2 + eps);
+        const double A = g1 + a2, v3 = A * A * vh;
+        p.ceff[c] = (float)(g3 * A / sqrt(v3 + eps));
+        p.deff[c] = p.b3[c];
+        if (p.mm2) { p.mm2[c] -= (p.mm2[c] - p.b1[c]) * keep; p.mv2[c] -= (p.mv2[c] - (float)v2) * keep; }
+        if (p.mm3) { p.mm3[c] -= (p.mm3[c] - (p.b1[c] + p.b2[c])) * keep; p.mv3[c] -= (p.mv3[c] - (float)v3) * keep; }
+    } else {
+        const double ga = p.g1[c], gb = p.g2[c];
+        const double A = 1.0 / is + ga, vs = A * A * vh;
+        p.ceff[c] = (float)(gb * A / sqrt(vs + eps));
+        p.deff[c] = p.b2[c];
+        if (p.mm2) { p.mm2[c] -= (p.mm2[c] - (float)(mu + p.b1[c])) * keep; p.mv2[c] -= (p.mv2[c] - (float)vs) * keep; }
+    }
+}
+
+// parameter gradients from dCeff = sum dz*xhat (this replica's sum) and dDeff = sum dz; `extra` = coefficient of xhat
+// that the variance dependence of Ceff adds to ds (from the cross-replica sum when statistics are shared)
+__global__ void bn_chain_bwd_kernel(ChainP p) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.C) return;
+    const double eps = p.eps, is = p.invstd[c], vh = fmax(0.0, 1.0 - eps * is * is);
+    const double dvh_dvar = eps * is * is * is * is;                 // d vh / d var = eps / (var+eps)^2
+    if (p.kind == 0) {
+        const double g1 = p.g1[c], g2 = p.g2[c], g3 = p.g3[c];
+        const double q2 = g1 * g1 * vh + eps, r2 = 1.0 / sqrt(q2);
+        const double A = g1 + g2 * g1 * r2, q3 = A * A * vh + eps, r3 = 1.0 / sqrt(q3);
+        // Ceff = g3 A r3
+        const double dC_dA = g3 * eps * r3 * r3 * r3, dC_dvh3 = -0.5 * g3 * A * A * A * r3 * r3 * r3;
+        const double dA_dg1 = 1.0 + g2 * eps * r2 * r2 * r2, dA_dg2 = g1 * r2, dA_dvh = -0.5 * g2 * g1 * g1 * g1 * r2 * r2 * r2;
+        const double dCl = p.dC_local[c], dCg = p.dC_global[c];
+        p.dg3[c] = (float)(dCl * A * r3);
+        p.dg2[c] = (float)(dCl * dC_dA * dA_dg2);
+        p.dg1[c] = (float)(dCl * dC_dA * dA_dg1);
+        p.db1[c] = 0.f; p.db2[c] = 0.f;                            // BN3 removes the mean of y1 + y2
+        p.db3[c] = p.dD_local[c];
+        const double dvar = dCg * (dC_dvh3 + dC_dA * dA_dvh) * dvh_dvar;
+        p.extra[c] = (float)(2.0 * dvar / (is * p.M));              // d var / d x_i = 2 (x_i - mean) / M = 2 xhat_i / (invstd M)
+    } else {
+        const double ga = p.g1[c], gb = p.g2[c];
+        const double A = 1.0 / is + ga, q = A * A * vh + eps, r = 1.0 / sqrt(q);
+        const double dC_dA = gb * eps * r * r * r, dC_dvh = -0.5 * gb * A * A * A * r * r * r;
+        const double dCl = p.dC_local[c], dCg = p.dC_global[c];
+        p.dg2[c] = (float)(dCl * A * r);
+        p.dg1[c] = (float)(dCl * dC_dA);
+        p.db1[c] = 0.f;                                            // BNb removes the mean of x + r
+        p.db2[c] = p.dD_local[c];
+        const double dsigma_dvar = 0.5 * is;                        // sigma = sqrt(var+eps)
+        const double dvar = dCg * (dC_dvh * dvh_dvar + dC_dA * dsigma_dvar);
+        p.extra[c] = (float)(2.0 * dvar / (is * p.M));
+    }
+}
+
 // ---- BN apply (+residual, +tile broadcast, +activation) -------------------------------------
 struct BnP {
     const float* x; const float* r; const float* dy;
@@ -230,6 +309,7 @@ struct BnP {
     const float* dgamma; const float* dbeta;
     float* out; float* partial;
     size_t M; int C; int bcast; int act; float invM; int identity;
+    const float* extra;      // optional per-channel coefficient of xhat added to ds (batch-norm chains: variance-dependent scale)
 };
 
 __device__ __forceinline__ void bn_load_coef(const BnP& p, float* sc, float* sf, float* al) {
@@ -347,11 +427,12 @@ __global__ void __launch_bounds__(EW_BLOCK) bn_act_bwd_reduce_kernel(BnP p) {
 // backward pass 2: ds = gamma*invstd*(dz - dbeta/M - xhat*dgamma/M)
 template <bool VEC>
 __global__ void __launch_bounds__(EW_BLOCK) bn_act_bwd_apply_kernel(BnP p) {
-    __shared__ float sc[MAXC], sf[MAXC], al[MAXC], k1[MAXC], k2[MAXC], mu[MAXC], is[MAXC];
+    __shared__ float sc[MAXC], sf[MAXC], al[MAXC], k1[MAXC], k2[MAXC], mu[MAXC], is[MAXC], ex[MAXC];
     bn_load_coef(p, sc, sf, al);
     for (int c = threadIdx.x; c < p.C; c += EW_BLOCK) {
         if (p.identity) { k1[c] = 0.f; k2[c] = 0.f; mu[c] = 0.f; is[c] = 1.f; }
         else { k1[c] = p.dbeta[c] * p.invM; k2[c] = p.dgamma[c] * p.invM; mu[c] = p.mean[c]; is[c] = p.invstd[c]; }
+        ex[c] = p.extra ? p.extra[c] : 0.f;
     }
     __syncthreads();
     const size_t stride = (size_t)gridDim.x * EW_BLOCK;
@@ -373,7 +454,7 @@ __global__ void __launch_bounds__(EW_BLOCK) bn_act_bwd_apply_kernel(BnP p) {
                 const float z = vv[k] * sc[c + k] + sf[c + k];
                 const float dz = gg[k] * act_grad(z, p.act, al[c + k]);
                 const float xh = (vv[k] - mu[c + k]) * is[c + k];
-                o[k] = sc[c + k] * (dz - k1[c + k] - xh * k2[c + k]);
+                o[k] = sc[c + k] * (dz - k1[c + k] - xh * k2[c + k]) + xh * ex[c + k];
             }
             reinterpret_cast<float4*>(p.out)[idx] = make_float4(o[0], o[1], o[2], o[3]);
         }
@@ -385,7 +466,8 @@ __global__ void __launch_bounds__(EW_BLOCK) bn_act_bwd_apply_kernel(BnP p) {
             if (p.r) v += p.r[idx];
             const float z = v * sc[c] + sf[c];
             const float dz = p.dy[idx] * act_grad(z, p.act, al[c]);
-            p.out[idx] = sc[c] * (dz - k1[c] - (v - mu[c]) * is[c] * k2[c]);
+            const float xh = (v - mu[c]) * is[c];
+            p.out[idx] = sc[c] * (dz - k1[c] - xh * k2[c]) + xh * ex[c];
         }
     }
 }
@@ -895,13 +977,14 @@ int vnet_bn_act_bwd_reduce(const float* dy, const float* x, const float* r, int 
 int vnet_bn_act_bwd_apply(const float* dy, const float* x, const float* r, int bcast, int64_t M, int C,
                           const float* mean, const float* invstd, const float* gamma, const float* beta,
                           int act, const float* alpha, const float* sum_dz, const float* sum_dz_xhat, double M_total,
-                          float* ds, void* stream) {
+                          const float* xhat_coef, float* ds, void* stream) {
     if (!dy || !x || !mean || !invstd || !gamma || !beta || !sum_dz || !sum_dz_xhat || !ds || M <= 0 || M_total <= 0.0 || C <= 0 || C > MAXC)
         return VNET_E_BADARG;
     if (act == VNET_ACT_PRELU && !alpha) return VNET_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     BnP p{}; bn_bwd_fill(p, dy, x, r, bcast, M, C, mean, invstd, gamma, beta, act, alpha);
     p.invM = (float)(1.0 / M_total);
+    p.extra = xhat_coef;
     p.out = ds; p.dgamma = sum_dz_xhat; p.dbeta = sum_dz;
     if (C % 4 == 0) hipLaunchKernelGGL(bn_act_bwd_apply_kernel<true>, dim3(ew_blocks((size_t)M * C / 4 / 4 + 1)), dim3(EW_BLOCK), 0, st, p);
     else hipLaunchKernelGGL(bn_act_bwd_apply_kernel<false>, dim3(ew_blocks((size_t)M * C / 4 + 1)), dim3(EW_BLOCK), 0, st, p);
@@ -916,7 +999,38 @@ int vnet_bn_act_bwd(const float* dy, const float* x, const float* r, int bcast, 
     const int rc = vnet_bn_act_bwd_reduce(dy, x, r, bcast, M, C, mean, invstd, gamma, beta, act, alpha, dgamma, dbeta, dalpha,
                                           ws, ws_bytes, stream);
     if (rc != VNET_OK || !ds) return rc;
-    return vnet_bn_act_bwd_apply(dy, x, r, bcast, M, C, mean, invstd, gamma, beta, act, alpha, dbeta, dgamma, (double)M, ds, stream);
+    return vnet_bn_act_bwd_apply(dy, x, r, bcast, M, C, mean, invstd, gamma, beta, act, alpha, dbeta, dgamma, (double)M, nullptr, ds, stream);
+}
+
+int vnet_bn_chain_coef_fwd(int kind, int C, float eps, float momentum, const float* mean, const float* invstd,
+                           const float* g1, const float* b1, const float* g2, const float* b2, const float* g3, const float* b3,
+                           float* ceff, float* deff, float* mm2, float* mv2, float* mm3, float* mv3, void* stream) {
+    if (kind < 0 || kind > 1) return VNET_E_UNSUPPORTED;
+    if (!mean || !invstd || !g1 || !b1 || !g2 || !b2 || !ceff || !deff || C <= 0 || C > MAXC) return VNET_E_BADARG;
+    if (kind == 0 && (!g3 || !b3)) return VNET_E_BADARG;
+    if ((mm2 && !mv2) || (mm3 && !mv3)) return VNET_E_BADARG;
+    ChainP p{}; p.kind = kind; p.C = C; p.eps = eps; p.momentum = momentum; p.mean = mean; p.invstd = invstd;
+    p.g1 = g1; p.b1 = b1; p.g2 = g2; p.b2 = b2; p.g3 = g3; p.b3 = b3; p.ceff = ceff; p.deff = deff;
+    p.mm2 = mm2; p.mv2 = mv2; p.mm3 = mm3; p.mv3 = mv3;
+    hipLaunchKernelGGL(bn_chain_fwd_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, p);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_bn_chain_coef_bwd(int kind, int C, float eps, double M_total, const float* mean, const float* invstd,
+                           const float* g1, const float* g2, const float* g3,
+                           const float* dC_local, const float* dD_local, const float* dC_global,
+                           float* dg1, float* db1, float* dg2, float* db2, float* dg3, float* db3, float* xhat_coef, void* stream) {
+    if (kind < 0 || kind > 1) return VNET_E_UNSUPPORTED;
+    if (!mean || !invstd || !g1 || !g2 || !dC_local || !dD_local || !dC_global || !dg1 || !db1 || !dg2 || !db2 || !xhat_coef ||
+        C <= 0 || C > MAXC || M_total <= 0.0) return VNET_E_BADARG;
+    if (kind == 0 && (!g3 || !dg3 || !db3)) return VNET_E_BADARG;
+    ChainP p{}; p.kind = kind; p.C = C; p.eps = eps; p.M = M_total; p.mean = mean; p.invstd = invstd;
+    p.g1 = g1; p.g2 = g2; p.g3 = g3; p.dC_local = dC_local; p.dD_local = dD_local; p.dC_global = dC_global;
+    p.dg1 = dg1; p.db1 = db1; p.dg2 = dg2; p.db2 = db2; p.dg3 = dg3; p.db3 = db3; p.extra = xhat_coef;
+    hipLaunchKernelGGL(bn_chain_bwd_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, p);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
 }
 
 int vnet_act_fwd(const float* x, int64_t M, int C, int act, const float* alpha, float* y, void* stream) {

@@ -238,6 +238,27 @@ private:
         ABI_OK(vnet_bn_act_fwd(x.p, res ? res->p : nullptr, tile ? 1 : 0, x.rows(), C, mean, invstd, g.dev, b.dev, act, alpha, y.p, st_));
         return y;
     }
+    // the decoder's batch-norm chains in closed form (include/vnet_hip.h, vnet_bn_chain_coef_fwd): one fused normalisation of x
+    //   kind 0: x = BN(x); r = BN(x); out = prelu(BN(x + r))      kind 1: r = BN(x); out = prelu(BN(x + r))
+    Tensor bn_chain(const Tensor& x, int kind) {
+        const std::string sc = scope();
+        const float* gp[3] = {nullptr, nullptr, nullptr};
+        const float* bp[3] = {nullptr, nullptr, nullptr};
+        int C = 0;
+        for (int k = 0; k < (kind == 0 ? 3 : 2); ++k) {
+            int n = bn_count_[sc]++;
+            const std::string name = sc + "/batch_normalization" + (n ? "_" + std::to_string(n) : "");
+            Var& g = var(name + "/gamma"); Var& b = var(name + "/beta");
+            gp[k] = g.dev; bp[k] = b.dev; C = (int)g.n;
+        }
+        Tensor y = alloc(x.B, x.D, x.H, x.W, C);
+        float* mean = stat_; float* invstd = stat_ + 1024; float* ceff = stat_ + 2048; float* deff = stat_ + 3072;
+        ABI_OK(vnet_bn_stats(x.p, nullptr, 0, x.rows(), C, 1e-3f, 0.99f, mean, invstd, nullptr, nullptr, ws_, ws_bytes_, st_));
+        ABI_OK(vnet_bn_chain_coef_fwd(kind, C, 1e-3f, 0.99f, mean, invstd, gp[0], bp[0], gp[1], bp[1], gp[2], bp[2], ceff, deff,
+                                      nullptr, nullptr, nullptr, nullptr, st_));
+        ABI_OK(vnet_bn_act_fwd(x.p, nullptr, 0, x.rows(), C, mean, invstd, ceff, deff, VNET_ACT_PRELU, var(sc + "/alpha").dev, y.p, st_));
+        return y;
+    }
     Tensor conv(const Tensor& x0, const Tensor* x1, int ks, int stride, int Cout) {
         const std::string sc = scope();
         const int Cin = x0.C + (x1 ? x1->C : 0);
@@ -299,9 +320,7 @@ private:
         scope_.push_back("conv_1");
         Tensor x = conv(up, &skip, 5, 1, C);
         if (n == 1) {
-            x = bn(x, VNET_ACT_NONE, nullptr, false);
-            Tensor r = bn(x, VNET_ACT_NONE, nullptr, false);
-            x = bn(x, VNET_ACT_PRELU, &r, false);
+            x = bn_chain(x, 0);
             scope_.pop_back();
             return x;
         }
@@ -311,8 +330,7 @@ private:
             scope_.push_back("conv_" + std::to_string(i + 1));
             x = conv(x, nullptr, 5, 1, C);
             if (i == n - 1) {
-                Tensor r = bn(x, VNET_ACT_NONE, nullptr, false);
-                x = bn(x, VNET_ACT_PRELU, &r, false);
+                x = bn_chain(x, 1);
             } else {
                 bn_count_[scope()]++;                       // the unused residual-branch BN still owns the first layer name
                 x = bn(x, VNET_ACT_PRELU, nullptr, false);

@@ -167,3 +167,30 @@ def batch_normalization(x, activation=None, residual=None, tile=False, channels=
         y, mean, invstd = ops.bn_act(x, gamma, beta, activation, alpha, residual, tile, mm, mv, want_stats=True)
         return y, (x, gamma, beta, mean, invstd)
     return ops.bn_act(x, gamma, beta, activation, alpha, residual, tile, mm, mv)
+
+
+def _bn_variables(C):
+    """gamma, beta, moving_mean, moving_variance of the next auto-uniquified 'batch_normalization[_N]' layer scope."""
+    store = current()
+    with variable_scope(store.unique_layer_name("batch_normalization")):
+        gamma = get_variable('gamma', initializer=lambda: np.ones((C,), np.float32))
+        beta = get_variable('beta', initializer=lambda: np.zeros((C,), np.float32))
+        mm = get_variable('moving_mean', initializer=lambda: np.zeros((C,), np.float32), trainable=False)
+        mv = get_variable('moving_variance', initializer=lambda: np.ones((C,), np.float32), trainable=False)
+    return gamma, beta, mm, mv
+
+
+def batch_normalization_chain(x, kind, activation=None):
+    """The decoder's batch-norm chains (reference networks.py:333-337 / 358-361), each evaluated as ONE fused
+    normalisation of x (see ops.bn_chain): same variables, created in the reference's order and under its names,
+        kind 0:  x = BN(x); r = BN(x); x = act(BN(x + r))          kind 1:  r = BN(x); x = act(BN(x + r))."""
+    C = int(x.shape[-1])
+    layers = [_bn_variables(C) for _ in range(3 if kind == 0 else 2)]
+    alpha = None
+    if activation == "prelu":
+        alpha = get_variable('alpha', initializer=lambda: np.full((C,), 0.1, dtype=np.float32))
+    (g1, b1, mm1, mv1), (g2, b2, mm2, mv2) = layers[0], layers[1]
+    g3 = b3 = mm3 = mv3 = None
+    if kind == 0:
+        g3, b3, mm3, mv3 = layers[2]
+    return ops.bn_chain(x, kind, activation, alpha, g1, b1, g2, b2, g3, b3, (mm1, mv1, mm2, mv2, mm3, mv3))

@@ -40,6 +40,7 @@ class VNet(object):
             raise ValueError("activation_fn must be relu, prelu or lrelu")
         self.activation_fn = activation_fn
         self.fuse_input_block = True       # single-modality input: skip the 16x redundant work of the tiled conv
+        self.fuse_bn_chains = True         # decoder BN->BN->add->BN chains in closed form (ops.bn_chain)
         self.variables = VariableStore(device)
 
     # -- torch.nn.Module-like conveniences -------------------------------------------------
@@ -141,9 +142,13 @@ class VNet(object):
         if num_convolutions == 1:
             with store.variable_scope('conv_' + str(1)):
                 x = L.convolution_concat(layer_input, fine_grained_features, [5, 5, 5, n_channels * 2, n_channels])
-                x = L.batch_normalization(x)
-                r = L.batch_normalization(x)                                       # networks.py:335
-                x = L.batch_normalization(x, activation=activation_fn, residual=r)  # x = x + layer_input ; BN ; act
+                if self.fuse_bn_chains:
+                    # x = BN(x); r = BN(x) (networks.py:335); x = act(BN(x + r)) -- one fused normalisation of the conv output
+                    x = L.batch_normalization_chain(x, 0, activation_fn)
+                else:
+                    x = L.batch_normalization(x)
+                    r = L.batch_normalization(x)                                       # networks.py:335
+                    x = L.batch_normalization(x, activation=activation_fn, residual=r)  # x = x + layer_input ; BN ; act
                 x = ops.dropout(x, dropout_rate)
             return x
 
@@ -157,7 +162,10 @@ class VNet(object):
                 x = L.convolution(x, [5, 5, 5, n_channels, n_channels])
                 last = (i == num_convolutions - 1)
                 # networks.py:358 builds this BN for every i; its output is used only by the last conv
-                r = L.batch_normalization(x, dead=not last)
-                x = L.batch_normalization(x, activation=activation_fn, residual=r if last else None)
+                if last and self.fuse_bn_chains:
+                    x = L.batch_normalization_chain(x, 1, activation_fn)               # r = BN(x); x = act(BN(x + r))
+                else:
+                    r = L.batch_normalization(x, dead=not last)
+                    x = L.batch_normalization(x, activation=activation_fn, residual=r if last else None)
                 x = ops.dropout(x, dropout_rate)
         return x

@@ -531,11 +531,98 @@ class _BnActFn(torch.autograd.Function):
                 ctx.sync[0](tot)
                 check(L.vnet_bn_act_bwd_apply(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd),
                                               _ptr(gamma), _ptr(beta), act, _ptr(alpha), _ptr(tot), _ptr(tot[C:]),
-                                              ctx.m_total, _ptr(ds), _stream()), "vnet_bn_act_bwd_apply")
+                                              ctx.m_total, None, _ptr(ds), _stream()), "vnet_bn_act_bwd_apply")
         dx = ds
         if bcast and ds is not None:
             dx = colsum_rows(ds)
         return dx, (ds if r is not None else None), _grad_ret(dgamma, sg), _grad_ret(dbeta, sbt), _grad_ret(dalpha, sa), None, None, None, None
+
+
+class _BnChainFn(torch.autograd.Function):
+    """Decoder batch-norm chains in closed form (include/vnet_hip.h, vnet_bn_chain_*):
+    kind 0: act(BN3(BN1(x) + BN2(BN1(x))))   (networks.py:333-337)      kind 1: act(BNb(x + BNa(x)))   (networks.py:358-361)
+    One statistics pass + one normalise pass forward, one reduce + one apply pass backward."""
+
+    @staticmethod
+    def forward(ctx, x, kind, act, alpha, g1, b1, g2, b2, g3, b3, bufs):
+        L = _lib.lib()
+        x = x.contiguous()
+        C = g1.numel()
+        M = x.numel() // C
+        dev = x.device
+        mm1, mv1, mm2, mv2, mm3, mv3 = bufs
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        nb = L.vnet_bn_ws_bytes(C)
+        ws = workspace(nb, dev)
+        ctx.m_total = _bn_statistics(L, x, None, False, M, C, mean, invstd, mm1, mv1, ws, nb)
+        ctx.sync = _SYNC_BN
+        ceff = torch.empty(C, dtype=torch.float32, device=dev)
+        deff = torch.empty(C, dtype=torch.float32, device=dev)
+        check(L.vnet_bn_chain_coef_fwd(kind, C, BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(invstd), _ptr(g1), _ptr(b1), _ptr(g2), _ptr(b2),
+                                       _ptr(g3), _ptr(b3), _ptr(ceff), _ptr(deff), _ptr(mm2), _ptr(mv2), _ptr(mm3), _ptr(mv3),
+                                       _stream()), "vnet_bn_chain_coef_fwd")
+        y = torch.empty_like(x)
+        check(L.vnet_bn_act_fwd(_ptr(x), None, 0, M, C, _ptr(mean), _ptr(invstd), _ptr(ceff), _ptr(deff),
+                                act, _ptr(alpha), _ptr(y), _stream()), "vnet_bn_act_fwd")
+        ctx.save_for_backward(x, alpha, g1, g2, g3, mean, invstd, ceff, deff)
+        ctx.params = (alpha, g1, b1, g2, b2, g3, b3)
+        ctx.cfg = (kind, act, M, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, alpha, g1, g2, g3, mean, invstd, ceff, deff = ctx.saved_tensors
+        kind, act, M, C = ctx.cfg
+        aref, g1r, b1r, g2r, b2r, g3r, b3r = ctx.params
+        dy = dy.contiguous()
+        dev = dy.device
+        dC = torch.empty(C, dtype=torch.float32, device=dev)
+        dD = torch.empty(C, dtype=torch.float32, device=dev)
+        dalpha, sa = _grad_out(aref) if alpha is not None else (None, None)
+        nb = L.vnet_bn_ws_bytes(C)
+        ws = workspace(nb, dev)
+        check(L.vnet_bn_act_bwd_reduce(_ptr(dy), _ptr(x), None, 0, M, C, _ptr(mean), _ptr(invstd), _ptr(ceff), _ptr(deff),
+                                       act, _ptr(alpha), _ptr(dC), _ptr(dD), _ptr(dalpha), _ptr(ws), nb, _stream()),
+              "vnet_bn_act_bwd_reduce")
+        if ctx.sync is None:
+            tot = None
+            dCg, dDg = dC, dD
+        else:                      # cross-replica statistics: the data gradient needs the sums over every replica
+            tot = torch.cat([dD, dC])
+            ctx.sync[0](tot)
+            dDg, dCg = tot[:C], tot[C:]
+        outs = [_grad_out(r) if r is not None else (None, None) for r in (g1r, b1r, g2r, b2r, g3r, b3r)]
+        (dg1, s1), (db1, t1), (dg2, s2), (db2, t2), (dg3, s3), (db3, t3) = outs
+        extra = torch.empty(C, dtype=torch.float32, device=dev)
+        check(L.vnet_bn_chain_coef_bwd(kind, C, BN_EPS, ctx.m_total, _ptr(mean), _ptr(invstd), _ptr(g1), _ptr(g2), _ptr(g3),
+                                       _ptr(dC), _ptr(dD), _ptr(dCg), _ptr(dg1), _ptr(db1), _ptr(dg2), _ptr(db2), _ptr(dg3), _ptr(db3),
+                                       _ptr(extra), _stream()), "vnet_bn_chain_coef_bwd")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(dy)
+            check(L.vnet_bn_act_bwd_apply(_ptr(dy), _ptr(x), None, 0, M, C, _ptr(mean), _ptr(invstd), _ptr(ceff), _ptr(deff),
+                                          act, _ptr(alpha), _ptr(dDg), _ptr(dCg), ctx.m_total, _ptr(extra), _ptr(dx), _stream()),
+                  "vnet_bn_act_bwd_apply")
+        g3ret = _grad_ret(dg3, s3) if g3r is not None else None
+        b3ret = _grad_ret(db3, t3) if b3r is not None else None
+        return (dx, None, None, _grad_ret(dalpha, sa) if alpha is not None else None, _grad_ret(dg1, s1), _grad_ret(db1, t1),
+                _grad_ret(dg2, s2), _grad_ret(db2, t2), g3ret, b3ret, None)
+
+
+def bn_chain(x, kind, act, alpha, g1, b1, g2, b2, g3=None, b3=None, moving=(None,) * 6):
+    """kind 0: act(BN3(BN1(x) + BN2(BN1(x)))) with (g1,b1),(g2,b2),(g3,b3); kind 1: act(BNb(x + BNa(x))) with (g1,b1)=a, (g2,b2)=b.
+    moving = (mm1, mv1, mm2, mv2, mm3, mv3) moving-average buffers (None to skip)."""
+    a = ACT[act]
+    if _meta(x):
+        return torch.empty(x.shape, device="meta")
+    _need_gpu(x, "bn_chain")
+    if a == 2 and alpha is None:
+        raise VnetHipError("prelu needs alpha")
+    if kind == 0 and (g3 is None or b3 is None):
+        raise VnetHipError("bn_chain kind 0 needs three batch-norm layers")
+    return _BnChainFn.apply(x, int(kind), a, alpha if a == 2 else None, g1, b1, g2, b2, g3, b3, tuple(moving))
 
 
 def colsum_rows(ds):
