@@ -15,6 +15,8 @@
 //     k-group uses element j of both, i.e. hardware k-index kk <-> cin 4*kk+j (a K permutation
 //     shared by A and B);
 //   * each lane ends up with 4 consecutive cout of one voxel -> 16-byte NDHWC stores.
+// The same file holds the bf16-operand variants of the 5^3 convolution and of its filter gradient (BASELINE
+// config C5: v_mfma_f32_32x32x16_bf16 / v_mfma_f32_16x16x32_bf16 with LDS transpose reads) further down.
 #include "common.h"
 
 namespace {
@@ -1180,7 +1182,7 @@ int launch_conv_bf16(const ConvArgs& a, const Bf16Plan& p, hipStream_t st) {
 
 extern "C" {
 
-const char* vnet_version(void) { return "vnet_hip 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
+const char* vnet_version(void) { return "vnet_hip 0.2 (gfx950; fp32 MFMA 16x16x4, bf16 MFMA 32x32x16 / 16x16x32)"; }
 
 size_t vnet_packed_weight_floats(int mode, int taps, int I, int O) {
     if (mode == VNET_PACK_FWD_BF16 || mode == VNET_PACK_BWD_BF16) {     // bf16 image, size still quoted in floats
