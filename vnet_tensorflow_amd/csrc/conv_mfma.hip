@@ -1353,7 +1353,11 @@ WgradPlan plan_wgrad(int ks, int kx, int stride, int Cin, int Cout, int B, int D
     WgradPlan p{};
     const int CoutP = round_up(Cout, 16);
     p.ns = pick_ns(CoutP);
-    if (bf16 && p.ns == 4) p.ns = 2;      // the 4-block variant of the bf16 kernel does not fit 256 VGPRs next to the prefetch registers
+    // 5^3: at most two cout blocks per workgroup.  Four would halve the staging per MFMA, but the layers wide enough for it are
+    // the deep ones with few bricks, where twice the (chunk x cout-block) workgroups means half the filter slabs to reduce
+    // and a pipeline fill amortised over twice the bricks: +2.5..5 % measured (and the bf16 kernel's 4-block variant does
+    // not fit 256 VGPRs next to its prefetch registers)
+    if (ks == 5 && p.ns == 4) p.ns = 2;
     p.ncob = CoutP / (16 * p.ns);
     p.small = Wo < 16;
     const int T3 = ks * ks * kx;
@@ -1424,11 +1428,9 @@ int vnet_conv_wgrad(int ks, int kx, int stride, const float* x0, int C0, const f
         e = p.small ? launch_wgrad<5, 1, 4, 8, 8, 1, 4, 1>(a, p, st) : launch_wgrad<5, 1, 4, 4, 16, 1, 4, 1>(a, p, st);
     } else if (ks == 5) {
         if (p.small) {
-            e = p.ns == 4 ? launch_wgrad<5, 1, 4, 8, 8, 4, 4>(a, p, st) : p.ns == 2 ? launch_wgrad<5, 1, 4, 8, 8, 2, 8>(a, p, st)
-                                                                                     : launch_wgrad<5, 1, 4, 8, 8, 1, 16>(a, p, st);
+            e = p.ns == 2 ? launch_wgrad<5, 1, 4, 8, 8, 2, 8>(a, p, st) : launch_wgrad<5, 1, 4, 8, 8, 1, 16>(a, p, st);
         } else {
-            e = p.ns == 4 ? launch_wgrad<5, 1, 4, 4, 16, 4, 4>(a, p, st) : p.ns == 2 ? launch_wgrad<5, 1, 4, 4, 16, 2, 8>(a, p, st)
-                                                                                      : launch_wgrad<5, 1, 4, 4, 16, 1, 16>(a, p, st);
+            e = p.ns == 2 ? launch_wgrad<5, 1, 4, 4, 16, 2, 8>(a, p, st) : launch_wgrad<5, 1, 4, 4, 16, 1, 16>(a, p, st);
         }
     } else {
         if (p.small) {
