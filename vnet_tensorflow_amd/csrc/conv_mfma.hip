@@ -609,7 +609,7 @@ int set_lds(K kernel, size_t bytes) {
 
 int pick_ns(int CoutP) { return (CoutP % 64 == 0) ? 4 : (CoutP % 32 == 0) ? 2 : 1; }
 
-struct ConvPlan { int ns, ncob, nbz, nby, nbx, nsplit, cps, small, nz, half; };
+struct ConvPlan { int ns, ncob, nbz, nby, nbx, nsplit, cps, small, nz, half, tiny; };
 
 template <int TZ, int TY, int TX>
 void brick_counts(int Do, int Ho, int Wo, ConvPlan& p) { p.nbz = ceil_div(Do, TZ); p.nby = ceil_div(Ho, TY); p.nbx = ceil_div(Wo, TX); }
@@ -637,6 +637,17 @@ ConvPlan plan_conv(int ks, int stride, int up, int Cin, int Cout, int B, int Do,
         } else {
             while (p.ns > 1 && nb * p.ncob * nchunks < 256) { p.ns /= 2; p.ncob *= 2; }
         }
+    }
+    if (ks == 2 && !up) {                                     // 2^3 stride-2 conv at the coarse levels: narrower cout blocks first
+        const long nb = (long)B * p.nbz * p.nby * p.nbx;
+        while (p.ns > 1 && nb * p.ncob < 256) { p.ns /= 2; p.ncob *= 2; }
+    }
+    if (up) {
+        // transposed 2^3 conv = one GEMM with N = 8*Cout: the coarse levels have one or two bricks, so take narrower
+        // column blocks and, for W < 16, 2x8x8 bricks (4 waves) until the launch has ~256 workgroups
+        long nb = (long)B * p.nbz * p.nby * p.nbx;
+        while (p.ns > 1 && nb * p.ncob < 256) { p.ns /= 2; p.ncob *= 2; }
+        if (p.small && nb * p.ncob < 256) { p.tiny = 1; brick_counts<2, 8, 8>(Do, Ho, Wo, p); }
     }
     const int nwg = B * p.nbz * p.nby * p.nbx * p.ncob;
     p.nsplit = 1;
@@ -1283,7 +1294,8 @@ int vnet_conv_fwd(int ks, int kx, int stride, int up, const float* x0, int C0, c
     } else if (isdown) {
         e = p.small ? launch_conv_ns<2, 2, 2, 8, 8, 4, 2, false>(a, p, st) : launch_conv_ns<2, 2, 2, 4, 16, 4, 2, false>(a, p, st);
     } else {
-        e = p.small ? launch_conv_ns<1, 1, 8, 8, 8, 8, 4, true>(a, p, st) : launch_conv_ns<1, 1, 4, 8, 16, 8, 4, true>(a, p, st);
+        e = p.tiny ? launch_conv_ns<1, 1, 2, 8, 8, 4, 2, true>(a, p, st)
+          : p.small ? launch_conv_ns<1, 1, 8, 8, 8, 8, 4, true>(a, p, st) : launch_conv_ns<1, 1, 4, 8, 16, 8, 4, true>(a, p, st);
     }
     if (e) return e;
     if (nslab > 1) {
