@@ -18,6 +18,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -434,6 +435,7 @@ int main(int argc, char** argv) {
         HIP_OK(hipEventRecord(copied[slot], copy));
     };
     for (int s = 0; s < 2; ++s) HIP_OK(hipEventRecord(consumed[s], compute));
+    const auto t_start = std::chrono::steady_clock::now();
     crop(0, 0); upload(0, 0);
     for (size_t bi = 0; bi < batches.size(); ++bi) {
         const int slot = (int)(bi & 1);
@@ -450,6 +452,9 @@ int main(int argc, char** argv) {
         if (next.valid()) { next.get(); upload(bi + 1, (int)((bi + 1) & 1)); }
     }
     HIP_OK(hipStreamSynchronize(compute));
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    size_t npatch = 0;
+    for (auto& bt : batches) npatch += bt.size();
 
     std::vector<float> vol(nvox * K), cnt(nvox);
     HIP_OK(hipMemcpy(vol.data(), d_vol, nvox * K * 4, hipMemcpyDeviceToHost));
@@ -466,6 +471,9 @@ int main(int argc, char** argv) {
         for (size_t v = 0; v < nvox; ++v) for (int k = 0; k < K; ++k) prob[(size_t)k * nvox + v] = cfg.normalise ? vol[v * K + k] / cnt[v] : vol[v * K + k];
         write_npy(cfg.prob_out, "<f4", {K, X, Y, Z}, prob.data(), nvox * K * 4);
     }
-    std::printf("vnet_infer: %zu batches, %dx%dx%d volume, %d classes -> %s\n", batches.size(), X, Y, Z, K, cfg.label_out.c_str());
+    std::printf("vnet_infer: %zu batches (%zu patches of %dx%dx%d), %dx%dx%d volume, %d classes -> %s\n", batches.size(), npatch,
+                P0, P1, P2, X, Y, Z, K, cfg.label_out.c_str());
+    std::printf("vnet_infer: sliding window %.3f s = %.1f patches/s (crop + H2D + forward + accumulate, %s)\n", secs, npatch / secs,
+                cfg.bf16 ? "bf16 compute" : "fp32");
     return 0;
 }
