@@ -367,24 +367,41 @@ __global__ void __launch_bounds__(EW_BLOCK) bn_act_bwd_reduce_kernel(BnP p) {
         const size_t nq = p.M * CQ;
         float4 acc[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
         const int c = (int)(start % CQ) * 4;      // fixed per thread (grid*256 % CQ == 0)
-        for (size_t idx = start; idx < nq; idx += stride) {
-            float4 v;
-            if (p.bcast) { const float t = p.x[idx / CQ]; v = make_float4(t, t, t, t); }
-            else v = reinterpret_cast<const float4*>(p.x)[idx];
-            if (p.r) { const float4 t = reinterpret_cast<const float4*>(p.r)[idx]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-            const float4 g = reinterpret_cast<const float4*>(p.dy)[idx];
-            const float vv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
-            float a0[4], a1[4], a2[4];
+        float scv[4], sfv[4], alv[4], muv[4], isv[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float z = vv[k] * sc[c + k] + sf[c + k];
-                const float dz = gg[k] * act_grad(z, p.act, al[c + k]);
-                const float xh = p.identity ? 0.f : (vv[k] - p.mean[c + k]) * p.invstd[c + k];
-                a0[k] = dz; a1[k] = dz * xh; a2[k] = gg[k] * fminf(z, 0.f);
+        for (int k = 0; k < 4; ++k) {
+            scv[k] = sc[c + k]; sfv[k] = sf[c + k]; alv[k] = al[c + k];
+            muv[k] = p.identity ? 0.f : p.mean[c + k]; isv[k] = p.identity ? 0.f : p.invstd[c + k];
+        }
+        constexpr int U = 2;                       // two independent load groups in flight per thread: 612 -> 510 us per step
+        for (size_t idx = start; idx < nq; idx += U * stride) {
+            float4 v[U], g[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t j0 = idx + u * stride;
+                const bool ok = j0 < nq;
+                const size_t j = ok ? j0 : idx;
+                if (p.bcast) { const float t = p.x[j / CQ]; v[u] = make_float4(t, t, t, t); }
+                else v[u] = reinterpret_cast<const float4*>(p.x)[j];
+                if (p.r) { const float4 t = reinterpret_cast<const float4*>(p.r)[j]; v[u].x += t.x; v[u].y += t.y; v[u].z += t.z; v[u].w += t.w; }
+                g[u] = reinterpret_cast<const float4*>(p.dy)[j];
+                if (!ok) g[u] = make_float4(0.f, 0.f, 0.f, 0.f);       // dy = 0 contributes nothing to any of the three sums
             }
-            acc[0].x += a0[0]; acc[0].y += a0[1]; acc[0].z += a0[2]; acc[0].w += a0[3];
-            acc[1].x += a1[0]; acc[1].y += a1[1]; acc[1].z += a1[2]; acc[1].w += a1[3];
-            acc[2].x += a2[0]; acc[2].y += a2[1]; acc[2].z += a2[2]; acc[2].w += a2[3];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w}, gg[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
+                float a0[4], a1[4], a2[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float z = vv[k] * scv[k] + sfv[k];
+                    const float dz = gg[k] * act_grad(z, p.act, alv[k]);
+                    const float xh = (vv[k] - muv[k]) * isv[k];
+                    a0[k] = dz; a1[k] = dz * xh; a2[k] = gg[k] * fminf(z, 0.f);
+                }
+                acc[0].x += a0[0]; acc[0].y += a0[1]; acc[0].z += a0[2]; acc[0].w += a0[3];
+                acc[1].x += a1[0]; acc[1].y += a1[1]; acc[1].z += a1[2]; acc[1].w += a1[3];
+                acc[2].x += a2[0]; acc[2].y += a2[1]; acc[2].z += a2[2]; acc[2].w += a2[3];
+            }
         }
         block_reduce_vec<3>(acc, CQ, C, p.partial + (size_t)blockIdx.x * 3 * C);
     } else if (MODE == 1) {
