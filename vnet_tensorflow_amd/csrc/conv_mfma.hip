@@ -495,28 +495,64 @@ __global__ void __launch_bounds__(512) wgrad_kernel(WgradArgs a) {
     }
 }
 
-// dw = sum over splits of the partial filter gradients; 64 outputs x 4 split-lanes per workgroup
+// dw = sum over splits of the partial filter gradients; 64 output groups x 4 split-lanes per workgroup.  VEC: a group is
+// 4 consecutive cout (16-byte accesses; needs Cout % 4 == 0), otherwise one output.  Four independent partial sums per
+// lane: the slab loads of one output are 256 KB or more apart, so a serial chain would wait one HBM round trip per slab
+// (the summation order is fixed -> deterministic).
+template <bool VEC>
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int T3, int CinP, int CoutP,
                                                            int Cin, int Cout, float* __restrict__ dw) {
-    __shared__ float sh[4][64];
-    const size_t total = (size_t)T3 * Cin * Cout;
+    constexpr int W = VEC ? 4 : 1;
+    __shared__ float sh[4][64 * W];
+    const size_t total = (size_t)T3 * Cin * Cout / W;               // output groups
     const size_t sstride = (size_t)T3 * CinP * CoutP;
+    const int CoutG = Cout / W;
     const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
     for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
         const size_t idx = base + o;
-        float s = 0.f;
+        float s[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) s[j] = 0.f;
         if (idx < total) {
-            const int co = (int)(idx % Cout);
-            const size_t r = idx / Cout;
+            const int co = (int)(idx % CoutG) * W;
+            const size_t r = idx / CoutG;
             const int ci = (int)(r % Cin), t = (int)(r / Cin);
             const float* p = part + ((size_t)t * CinP + ci) * CoutP + co;
-            for (int k = sg; k < nsplit; k += 4) s += p[k * sstride];
+            float acc[4][W];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < W; ++j) acc[u][j] = 0.f;
+            auto ld = [&](int k, float (&d)[W]) {
+                if (VEC) { const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * sstride); d[0] += v.x; d[W > 1 ? 1 : 0] += v.y; d[W > 2 ? 2 : 0] += v.z; d[W > 3 ? 3 : 0] += v.w; }
+                else d[0] += p[(size_t)k * sstride];
+            };
+            int k = sg;
+            for (; k + 12 < nsplit; k += 16) { ld(k, acc[0]); ld(k + 4, acc[1]); ld(k + 8, acc[2]); ld(k + 12, acc[3]); }
+            for (; k < nsplit; k += 4) ld(k, acc[0]);
+#pragma unroll
+            for (int j = 0; j < W; ++j) s[j] = (acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j]);
         }
         __syncthreads();
-        sh[sg][o] = s;
+#pragma unroll
+        for (int j = 0; j < W; ++j) sh[sg][o * W + j] = s[j];
         __syncthreads();
-        if (sg == 0 && idx < total) dw[idx] = sh[0][o] + sh[1][o] + sh[2][o] + sh[3][o];
+        if (sg == 0 && idx < total) {
+            float out[W];
+#pragma unroll
+            for (int j = 0; j < W; ++j) out[j] = sh[0][o * W + j] + sh[1][o * W + j] + sh[2][o * W + j] + sh[3][o * W + j];
+            if (VEC) *reinterpret_cast<float4*>(dw + idx * 4) = make_float4(out[0], out[W > 1 ? 1 : 0], out[W > 2 ? 2 : 0], out[W > 3 ? 3 : 0]);
+            else dw[idx] = out[0];
+        }
     }
+}
+
+void launch_wgrad_reduce(const float* part, int nsplit, int T3, int CinP, int CoutP, int Cin, int Cout, float* dw, hipStream_t st) {
+    const bool vec = (Cout % 4 == 0) && (CoutP % 4 == 0) && ((reinterpret_cast<uintptr_t>(dw) | reinterpret_cast<uintptr_t>(part)) & 15) == 0;
+    const size_t total = (size_t)T3 * Cin * Cout / (vec ? 4 : 1);
+    const int blocks = (int)min((size_t)4096, (total + 63) / 64);
+    if (vec) hipLaunchKernelGGL(wgrad_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, part, nsplit, T3, CinP, CoutP, Cin, Cout, dw);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, part, nsplit, T3, CinP, CoutP, Cin, Cout, dw);
 }
 
 __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
@@ -1455,9 +1491,7 @@ int vnet_conv_wgrad(int ks, int kx, int stride, const float* x0, int C0, const f
     }
     if (e) return e;
     if (direct) return VNET_OK;
-    const size_t total = (size_t)T3 * a.Cin * Cout;
-    const int blocks = (int)min((size_t)4096, (total + 63) / 64);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, p.nsplit, T3, a.CinP, a.CoutP, a.Cin, Cout, dw);
+    launch_wgrad_reduce(a.part, p.nsplit, T3, a.CinP, a.CoutP, a.Cin, Cout, dw, st);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
 }
@@ -1494,9 +1528,7 @@ int vnet_conv_wgrad_bf16(const float* x0, int C0, const float* x1, int C1, const
     }
     if (e) return e;
     if (direct) return VNET_OK;
-    const size_t total = (size_t)125 * a.Cin * Cout;
-    const int blocks = (int)min((size_t)4096, (total + 63) / 64);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, p.nsplit, 125, a.CinP, a.CoutP, a.Cin, Cout, dw);
+    launch_wgrad_reduce(a.part, p.nsplit, 125, a.CinP, a.CoutP, a.Cin, Cout, dw, st);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
 }
