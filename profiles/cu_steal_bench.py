@@ -33,16 +33,32 @@ side = torch.cuda.Stream()
 for _ in range(3):
     m.train_step(images, labels)
 torch.cuda.synchronize()
-for held in (0, 16, 32, 64):
+from vnet_tensorflow_amd import ops
+TABLE = "table" in sys.argv
+for held in ((0, 16) if TABLE else (0, 16, 32, 64)):
     steps = 5
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if held:
         L.cu_steal(held, 400.0, ctypes.c_void_p(side.cuda_stream))     # outlives the timed steps
         time.sleep(0.002)
+    if TABLE:
+        ops.profile_start()
     for _ in range(steps):
         m.train_step(images, labels)
     torch.cuda.current_stream().synchronize()
     dt = (time.perf_counter() - t0) / steps * 1e3
+    if TABLE:
+        torch.cuda.current_stream().synchronize()
+        ops._PROFILE["on"] = False
+        per = {}
+        for (t, f, b, e0, e1) in ops._PROFILE["records"]:
+            per[t] = per.get(t, 0.0) + e0.elapsed_time(e1) / steps
+        ops._PROFILE["records"] = []
+        if held == 0:
+            base = per
+        else:
+            for t, v in sorted(per.items(), key=lambda kv: -(kv[1] - base.get(kv[0], 0)))[:16]:
+                print("   %-40s %7.3f -> %7.3f ms/step  x%.2f" % (t, base.get(t, 0), v, v / max(base.get(t, 1e-9), 1e-9)))
     torch.cuda.synchronize()
     print("CUs held %3d : %.2f ms/step  (ideal %.2f)" % (held, dt, 0), flush=True)
