@@ -18,3 +18,14 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     return torch.device("cuda", 0)
+
+
+@pytest.fixture(autouse=True)
+def _main_stream_param_grads():
+    """model._setup_training switches filter/bias gradients to their own stream (joined inside train_step); tests
+    that call loss.backward() themselves and read gradients right away get the plain single-stream order."""
+    yield
+    ops = sys.modules.get("vnet_tensorflow_amd.ops")
+    if ops is not None:
+        ops.join_param_grad_stream()
+        ops.set_param_grad_stream(False)

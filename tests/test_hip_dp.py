@@ -106,6 +106,7 @@ def _worker(rank, world, port, out):
     ops.invalidate_packed()
     opt = optim.AdamOptimizer(flat)
     opt.gscale = 1.0 / world
+    ops.set_param_grad_stream(True)                    # filter/bias gradients on their own stream, as in model.train_step
     sync = parallel.BucketedGradAllReduce(flat, bucket_bytes=16 << 10)
     assert len(sync.buckets) >= 3 and sync.overlap
     x, lab = _batch(rank, dev)
@@ -117,6 +118,7 @@ def _worker(rank, world, port, out):
         if step == 1:
             assert sum(sync._launched) >= len(sync.buckets) - 1      # buckets went out DURING backward
         sync.finish()
+        ops.join_param_grad_stream()
         torch.cuda.synchronize()
         gsum = flat.grad.clone()
         opt.apply(1e-2)
@@ -151,6 +153,56 @@ def test_two_ranks_share_one_gpu(tmp_path, dev):
     err = float((r0["gsum"] - ref).norm() / ref.norm())
     assert err < 1e-4, err
     assert float((flat.data.cpu() - r0["data"]).abs().max()) < 1e-5
+
+
+def _rccl_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch.distributed as dist
+    from vnet_tensorflow_amd import ops, optim, parallel
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)       # backend "nccl" IS RCCL on ROCm
+    net = _build(dev, seed=100)
+    flat = optim.FlatParams(net.named_parameters())
+    parallel.broadcast_parameters(flat.data)
+    ops.set_param_grad_stream(True)
+    sync = parallel.BucketedGradAllReduce(flat, bucket_bytes=16 << 10, force=True)
+    assert sync.active and sync.overlap and len(sync.buckets) >= 3
+    x, lab = _batch(0, dev)
+    for step in range(3):
+        flat.zero_grad()
+        sync.begin_step()
+        loss, _, _, _ = ops.softmax_loss(net.GetNetwork(x), lab, "sorensen")
+        loss.backward()
+        if step >= 1:
+            assert sum(sync._launched) >= len(sync.buckets) - 1
+        sync.finish()
+        ops.join_param_grad_stream()
+    torch.cuda.synchronize()
+    t = torch.ones(8, device=dev)
+    dist.all_reduce(t)
+    dist.barrier()
+    torch.save({"gsum": flat.grad.cpu(), "loss": float(loss.detach()), "t": t.cpu()}, os.path.join(out, "rccl.pt"))
+    dist.destroy_process_group()
+
+
+def test_rccl_group_of_one(tmp_path, dev):
+    """RCCL itself (process group "nccl", device-bound, async all-reduce of every bucket on the side stream while the
+    backward kernels run) in a group of ONE rank -- all a 1-GPU box can host: the reduced gradient must be the plain
+    single-process gradient."""
+    from vnet_tensorflow_amd import ops, optim
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(tmp_path / "rccl.pt")
+    net = _build(dev, seed=100)
+    flat = optim.FlatParams(net.named_parameters())
+    x, lab = _batch(0, dev)
+    flat.zero_grad()
+    loss, _, _, _ = ops.softmax_loss(net.GetNetwork(x), lab, "sorensen")
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - r["loss"]) < 1e-6
+    assert torch.equal(r["gsum"], flat.grad.cpu())              # same kernels, same order: bit-identical
+    assert torch.equal(r["t"], torch.ones(8))
 
 
 def test_bench_contract_two_ranks(tmp_path):

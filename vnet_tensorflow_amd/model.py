@@ -239,6 +239,8 @@ class image2label(object):
         self.flat = optim.FlatParams(self.network.named_parameters())
         self.optimizer = optim.make_optimizer(self.optimizer_name, self.flat, self.momentum)
         self.sync = None
+        pg = os.environ.get("VNET_PARAM_GRAD_STREAM")
+        ops.set_param_grad_stream(self.device.type == "cuda" and (getattr(self, "param_grad_stream", True) if pg is None else pg == "1"))
         if self.world > 1:
             parallel.broadcast_parameters(self.flat.data)
             self.optimizer.gscale = 1.0 / self.world
@@ -258,6 +260,7 @@ class image2label(object):
         loss.backward()
         if self.sync is not None:
             self.sync.finish()
+        ops.join_param_grad_stream()          # filter / bias gradients were enqueued on their own stream
         self.optimizer.apply(lr)
         self.global_step += 1
         return loss

@@ -5,6 +5,7 @@ forward and backward computation below is a call into the HIP library on the cur
 There is no CPU or eager-PyTorch fallback -- non-GPU tensors raise (meta tensors are accepted
 for shape inference only, so a network can create its variables before the first batch).
 """
+import contextlib
 import ctypes
 import math
 import weakref
@@ -58,12 +59,45 @@ _WS = {}
 
 
 def workspace(nbytes, device):
+    """One scratch buffer per (device, stream): launches on the parameter-gradient stream never share scratch
+    with the main stream's launches."""
     nbytes = int(nbytes)
-    buf = _WS.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20) * 5 // 4, dtype=torch.uint8, device=device)
-        _WS[device] = buf
+        _WS[key] = buf
     return buf
+
+
+# ---- parameter-gradient stream --------------------------------------------------------------------------
+# The backward critical path is  batch-norm backward -> backward-data conv -> next layer; filter and bias gradients
+# only feed the optimiser / the gradient all-reduce.  With this switch on they are enqueued on a second HIP stream,
+# so their MFMA work fills the chip while the critical path sits in its short HBM- and latency-bound kernels.
+# Only gradients that go straight into the flat gradient buffer (GradSink) take this route.
+_PG = {"on": False, "streams": {}, "used": set()}
+
+
+def set_param_grad_stream(on):
+    _PG["on"] = bool(on)
+
+
+def param_grad_stream(device, create=True):
+    if not _PG["on"]:
+        return None
+    st = _PG["streams"].get(device)
+    if st is None and create:
+        st = torch.cuda.Stream(device=device)
+        _PG["streams"][device] = st
+    return st
+
+
+def join_param_grad_stream(device=None):
+    """Make the current stream wait for every parameter gradient enqueued so far (call before reading gradients)."""
+    for dev in list(_PG["used"]):
+        if device is None or dev == device:
+            torch.cuda.current_stream(dev).wait_stream(_PG["streams"][dev])
+            _PG["used"].discard(dev)
 
 
 # ---- packed-weight cache -------------------------------------------------------------------------
@@ -170,11 +204,14 @@ def _grad_ret(t, s):
 
 
 # ---- optional per-launch timing (bench.py): HIP events on the launch stream ---------------------
-_PROFILE = {"on": False, "records": []}
+_PROFILE = {"on": False, "records": [], "only": None}
 
 
-def profile_start():
+def profile_start(only=None):
+    """`only`: set of launch tags to time (None = every conv-family launch).  Each timed launch costs two event
+    packets on the stream (~5.6 us of idle GPU each on MI355X), so a throughput run times only the kernels it reports."""
     _PROFILE["records"] = []
+    _PROFILE["only"] = set(only) if only is not None else None
     _PROFILE["on"] = True
 
 
@@ -190,16 +227,17 @@ def profile_stop():
 class _Timed(object):
     def __init__(self, tag, flops, nbytes):
         self.rec = (tag, flops, nbytes)
+        self.on = _PROFILE["on"] and (_PROFILE["only"] is None or tag in _PROFILE["only"])
 
     def __enter__(self):
-        if _PROFILE["on"]:
+        if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()          # torch's current stream == the stream the kernel is launched on
         return self
 
     def __exit__(self, *a):
-        if _PROFILE["on"]:
+        if self.on:
             self.e1.record()
             _PROFILE["records"].append(self.rec + (self.e0, self.e1))
 
@@ -332,15 +370,28 @@ class _ConvFn(torch.autograd.Function):
         sb = sw = None
         if ctx.needs_input_grad[3]:
             db, sb = _grad_out(bref)
-            colsum(dy, O, out=db)
         if ctx.needs_input_grad[2]:
             dw, sw = _grad_out(wref)
-            if up:      # dw[a][o][ci] = sum_i dy[2i+a][o] * x[i][ci]  == filter grad of the 2^3 down conv (fine -> coarse)
-                _wgrad_call(2, 2, dy, None, x0, dw, dout, din)
-            elif ctx.bf16:
-                _wgrad_bf16_call(x0, x1, dy, dw, din)
-            else:
-                _wgrad_call(ks, stride, x0, x1, dy, dw, din, dout)
+        side = param_grad_stream(dev)
+        if side is not None and ((db is not None and sb is None) or (dw is not None and sw is None)):
+            side = None                                  # a gradient autograd has to hand on: stay on the main stream
+        if side is not None:
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)                       # dy is complete on the main stream
+            for t in (x0, x1, dy):
+                if t is not None:
+                    t.record_stream(side)                # keep the allocator from recycling them under the side stream
+            _PG["used"].add(dev)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            if db is not None:
+                colsum(dy, O, out=db)
+            if dw is not None:
+                if up:      # dw[a][o][ci] = sum_i dy[2i+a][o] * x[i][ci]  == filter grad of the 2^3 down conv (fine -> coarse)
+                    _wgrad_call(2, 2, dy, None, x0, dw, dout, din)
+                elif ctx.bf16:
+                    _wgrad_bf16_call(x0, x1, dy, dw, din)
+                else:
+                    _wgrad_call(ks, stride, x0, x1, dy, dw, din, dout)
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
             dx0 = torch.empty_like(x0)

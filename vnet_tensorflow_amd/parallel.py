@@ -43,12 +43,14 @@ def broadcast_parameters(flat_data, src=0, group=None):
 class BucketedGradAllReduce(object):
     """All-reduces `flat.grad` bucket by bucket as soon as every variable of a bucket has its gradient."""
 
-    def __init__(self, flat, bucket_bytes=32 << 20, group=None, overlap=True):
+    def __init__(self, flat, bucket_bytes=32 << 20, group=None, overlap=True, force=False):
+        """`force`: run the collective path even in a group of one (lets a 1-GPU box exercise RCCL itself)."""
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.buckets = flat.buckets(bucket_bytes)
         self.is_cuda = flat.grad.is_cuda
-        self.overlap = overlap and self.is_cuda and self.world > 1
+        self.overlap = overlap and self.is_cuda and self.active
         self.comm_stream = torch.cuda.Stream(device=flat.grad.device) if self.overlap else None
         self._bucket_of = {}
         for bi, (_, _, first, last) in enumerate(self.buckets):
@@ -60,7 +62,7 @@ class BucketedGradAllReduce(object):
         self._hooks = []
         self._expected = None
         self._events = []
-        if self.world > 1:
+        if self.active:
             for pi, p in enumerate(flat.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(pi)))
                 sink = getattr(p, "_vnet_sink", None)
@@ -102,23 +104,31 @@ class BucketedGradAllReduce(object):
             self._launch(bi)
 
     def _launch(self, bi):
-        if self._launched[bi] or self.world == 1:
+        if self._launched[bi] or not self.active:
             return
         self._launched[bi] = True
         s, e, _, _ = self.buckets[bi]
         view = self.flat.grad[s:e]
+        pg = None
+        if self.is_cuda:
+            from . import ops
+            pg = ops.param_grad_stream(view.device, create=False)      # filter/bias gradients are written on this stream
         if self.overlap:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            if pg is not None:
+                self.comm_stream.wait_stream(pg)
             with torch.cuda.stream(self.comm_stream):
                 self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
+            if pg is not None:
+                torch.cuda.current_stream().wait_stream(pg)
             self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Flush buckets that are still pending (calibration step; variables that never receive a gradient such as
         the dead batch-norms), then make the compute stream wait for every all-reduce.  The optimiser divides by
         world (gscale)."""
-        if self.world == 1:
+        if not self.active:
             return
         if self._expected is not None and self._events != self._expected:
             early = [bi for bi, (_, _, f, l) in enumerate(self.buckets)
