@@ -616,19 +616,73 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const long long* __re
             pack_bf16_elem(mode, w, reinterpret_cast<unsigned short*>(wp), T, I, O, NP, idx);
         return;
     }
-    const size_t total = (size_t)(mode == VNET_PACK_UP ? 1 : T) * CQ * NP * 4;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int r = (int)(idx & 3);
-        size_t q = idx >> 2;
-        const int n = (int)(q % NP); q /= NP;
-        const int cq = (int)(q % CQ);
-        const int t = (int)(q / CQ);
-        const int k = cq * 4 + r;
-        float v = 0.f;
-        if (mode == VNET_PACK_FWD) { if (k < I && n < O) v = w[((size_t)t * I + k) * O + n]; }
-        else if (mode == VNET_PACK_BWD) { if (k < O && n < I) v = w[((size_t)(T - 1 - t) * I + n) * O + k]; }
-        else { if (k < I && n < 8 * O) v = w[(size_t)n * I + k]; }
-        wp[idx] = v;
+    if (mode == VNET_PACK_BWD) {
+        // backward-data image = per tap the TRANSPOSE of the [I][O] filter slice in float4 column groups: staged through LDS
+        // so that both the read (along O) and the write (along I) are >= 256 B contiguous per 16 lanes
+        __shared__ float4 tile[16][65];
+        const uint32_t tn = (NP + 63) / 64, tk = (CQ + 15) / 16, per_t = tn * tk, ntiles = (uint32_t)T * per_t;
+        const int tid = threadIdx.x;
+        float4* wp4 = reinterpret_cast<float4*>(wp);
+        for (uint32_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+            const uint32_t t = tix / per_t, rem = tix - t * per_t, in_ = rem / tk, ik = rem - in_ * tk;
+            const int n0 = (int)in_ * 64, c0 = (int)ik * 16;
+            const float* wt = w + (size_t)(T - 1 - (int)t) * I * O;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = (tid >> 4) + 16 * j, c4 = tid & 15, n = n0 + row, k0 = (c0 + c4) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < I && k0 < O) {
+                    const float* src = wt + (size_t)n * O + k0;
+                    if (k0 + 3 < O && (reinterpret_cast<uintptr_t>(src) & 15) == 0) v = *reinterpret_cast<const float4*>(src);
+                    else { v.x = src[0]; if (k0 + 1 < O) v.y = src[1]; if (k0 + 2 < O) v.z = src[2]; if (k0 + 3 < O) v.w = src[3]; }
+                }
+                tile[c4][row] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c4 = (tid >> 6) + 4 * j, row = tid & 63, n = n0 + row, cq = c0 + c4;
+                if (n < NP && cq < CQ) wp4[((size_t)t * CQ + cq) * NP + n] = tile[c4][row];
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // one float4 of the packed image (4 consecutive k of one n) per thread, 32-bit index arithmetic: the per-element
+    // 64-bit divisions of a scalar version made this launch ALU-bound (245 us for 44 M parameters)
+    const uint32_t total4 = (uint32_t)(mode == VNET_PACK_UP ? 1 : T) * CQ * NP;
+    const uint32_t uNP = NP, uCQ = CQ;
+    for (uint32_t o4 = blockIdx.x * blockDim.x + threadIdx.x; o4 < total4; o4 += gridDim.x * blockDim.x) {
+        const uint32_t q = o4 / uNP, n = o4 - q * uNP;
+        const uint32_t t = q / uCQ, cq = q - t * uCQ;
+        const int k0 = (int)cq * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (mode == VNET_PACK_FWD) {
+            if ((int)n < O) {
+                const float* src = w + ((size_t)t * I + k0) * O + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (k0 + r < I) v[r] = src[(size_t)r * O];
+            }
+        } else if (mode == VNET_PACK_BWD) {
+            if ((int)n < I) {
+                const float* src = w + ((size_t)(T - 1 - (int)t) * I + n) * O + k0;
+                if ((O & 3) == 0 && k0 + 3 < O && (reinterpret_cast<uintptr_t>(src) & 15) == 0) { const float4 f = *reinterpret_cast<const float4*>(src); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (k0 + r < O) v[r] = src[r];
+                }
+            }
+        } else {
+            if ((int)n < 8 * O) {
+                const float* src = w + (size_t)n * I + k0;
+                if ((I & 3) == 0 && k0 + 3 < I && (reinterpret_cast<uintptr_t>(src) & 15) == 0) { const float4 f = *reinterpret_cast<const float4*>(src); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (k0 + r < I) v[r] = src[r];
+                }
+            }
+        }
+        reinterpret_cast<float4*>(wp)[o4] = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
