@@ -130,8 +130,10 @@ def main():
               for c in (16, 32))
     full_table = bool(os.environ.get("BENCH_KERNEL_TABLE"))
     loss = None
+    ops.profile_start(None if full_table else fam)       # warm-up runs the same schedule as the timed steps
     for _ in range(args.warmup):
         loss = m.train_step(images, labels)
+    ops.profile_stop()
     barrier()
     ops.profile_start(None if full_table else fam)
     t0 = time.perf_counter()

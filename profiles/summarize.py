@@ -20,6 +20,8 @@ def short(name):
 def main(src, tag):
     here = os.path.dirname(os.path.abspath(__file__))
     shutil.copy(os.path.join(src, "stats_kernel_stats.csv"), os.path.join(here, tag + "_kernel_stats.csv"))
+    if os.path.exists(os.path.join(src, "serial_kernel_stats.csv")):      # VNET_PARAM_GRAD_STREAM=0: no kernels overlap
+        shutil.copy(os.path.join(src, "serial_kernel_stats.csv"), os.path.join(here, tag + "_kernel_stats_serial.csv"))
     pmc = {}
     for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         path = os.path.join(src, which + "_counter_collection.csv")

@@ -92,6 +92,37 @@ def test_loss_decreases_on_fixed_batch(dev, compute, cin, K):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 0.05, losses
 
 
+@pytest.mark.parametrize("P", [16, 32])
+def test_param_grad_stream_is_bit_identical(dev, P, monkeypatch):
+    """Filter/bias gradients on their own HIP stream (the default in image2label) vs everything on one stream: the same
+    kernels on the same data, so after 4 optimiser steps every parameter and moving statistic must match bit for bit
+    (a missing cross-stream dependency would show up as a stale or half-written gradient)."""
+    from vnet_tensorflow_amd import ops
+    from vnet_tensorflow_amd.model import image2label
+    from oracle.vnet_oracle import synthetic_batch
+    import pathlib
+    x, lab = synthetic_batch(2, P, 1, 2, seed=21)
+    xt, lt = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
+    res = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("VNET_PARAM_GRAD_STREAM", on)
+        np.random.seed(3)
+        cfg = _cfg(pathlib.Path("/tmp"), PatchShape=[P] * 3)
+        cfg["TrainingSetting"]["Networks"].update(NumChannel=8, NumLevels=3, NumConvolutions=[1, 2, 2])
+        m = image2label(None, cfg, device=dev, verbose=False)
+        m.read_config()
+        m.build_model_graph()
+        m._setup_training()
+        assert ops._PG["on"] == (on == "1")
+        losses = [float(m.train_step(xt, lt, dropout=0.0)) for _ in range(4)]
+        torch.cuda.synchronize()
+        res.append((losses, m.flat.data.clone(), {k: v.clone() for k, v in m.network.state_dict().items()}))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
+
+
 def test_main_cli(tmp_path):
     cfg = _cfg(tmp_path, Epoches=1)
     path = tmp_path / "config.json"

@@ -224,10 +224,18 @@ def profile_stop():
     return out
 
 
+def _timed_tag(tag):
+    return _PROFILE["on"] and (_PROFILE["only"] is None or tag in _PROFILE["only"])
+
+
+def _wgrad_tag(bf16, ks, kx, stride, wo, B, cin, co):
+    return "wgrad%s k%d%s s%d %d^3x%d %d->%d" % ("-bf16" if bf16 else "", ks, "x%d" % kx if kx else "", stride, wo, B, cin, co)
+
+
 class _Timed(object):
     def __init__(self, tag, flops, nbytes):
         self.rec = (tag, flops, nbytes)
-        self.on = _PROFILE["on"] and (_PROFILE["only"] is None or tag in _PROFILE["only"])
+        self.on = _timed_tag(tag)
 
     def __enter__(self):
         if self.on:
@@ -290,7 +298,7 @@ def _wgrad_bf16_call(x0, x1, dy, dw, dims):
     nvox = B * dims[0] * dims[1] * dims[2]
     flops = 2.0 * nvox * 125 * (C0 + C1) * Co
     nbytes = 4.0 * (nvox * (C0 + C1 + Co) + 125 * (C0 + C1) * Co)
-    tag = "wgrad-bf16 k5 s1 %d^3x%d %d->%d" % (dims[2], B, C0 + C1, Co)
+    tag = _wgrad_tag(True, 5, 0, 1, dims[2], B, C0 + C1, Co)
     with _Timed(tag, flops, nbytes):
         check(L.vnet_conv_wgrad_bf16(_ptr(x0), C0, _ptr(x1), C1, _ptr(dy), Co, _ptr(dw), B, *dims,
                                      _ptr(ws), nb, _stream()), "vnet_conv_wgrad_bf16")
@@ -307,7 +315,7 @@ def _wgrad_call(ks, stride, x0, x1, dy, dw, dims_in, dims_out, kx=0):
     taps = ks * ks * (kx or ks)
     flops = 2.0 * nout * taps * (C0 + C1) * Co
     nbytes = 4.0 * (nin * (C0 + C1) + nout * Co + taps * (C0 + C1) * Co)
-    tag = "wgrad k%d%s s%d %d^3x%d %d->%d" % (ks, "x%d" % kx if kx else "", stride, dims_out[2], B, C0 + C1, Co)
+    tag = _wgrad_tag(False, ks, kx, stride, dims_out[2], B, C0 + C1, Co)
     with _Timed(tag, flops, nbytes):
         check(L.vnet_conv_wgrad(ks, kx, stride, _ptr(x0), C0, _ptr(x1), C1, _ptr(dy), Co, _ptr(dw),
                                 B, *dims_in, *dims_out, _ptr(ws), nb, _stream()), "vnet_conv_wgrad")
@@ -375,6 +383,11 @@ class _ConvFn(torch.autograd.Function):
         side = param_grad_stream(dev)
         if side is not None and ((db is not None and sb is None) or (dw is not None and sw is None)):
             side = None                                  # a gradient autograd has to hand on: stay on the main stream
+        if side is not None and dw is not None and _PROFILE["on"]:
+            wtag = (_wgrad_tag(False, 2, 0, 2, din[2], B, O, I) if up else
+                    _wgrad_tag(ctx.bf16, ks, 0, stride, dout[2], B, C0 + C1, O))
+            if _timed_tag(wtag):
+                side = None                              # a launch that is being timed runs alone (bench.py roofline)
         if side is not None:
             main = torch.cuda.current_stream(dev)
             side.wait_stream(main)                       # dy is complete on the main stream
