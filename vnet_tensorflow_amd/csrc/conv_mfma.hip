@@ -272,6 +272,19 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
             for (int n = 0; n < NS; ++n) {
                 const int cop = co0 + n * 16 + kk * 4;          // index into N' = 8*O
                 if (cop >= 8 * a.upO) continue;
+                if (a.upO & 3) {        // O no multiple of 4: the lane's four values can straddle two taps -> scalar stores
+                    const float e[4] = {acc[m][n].x, acc[m][n].y, acc[m][n].z, acc[m][n].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int ck = cop + k;
+                        if (ck >= 8 * a.upO) break;
+                        const int tp = ck / a.upO, o1 = ck - tp * a.upO;
+                        const int z1 = 2 * oz + (tp >> 2), y1 = 2 * oy + ((tp >> 1) & 1), x1 = 2 * ox + (tp & 1);
+                        if (z1 >= a.Do || y1 >= a.Ho || x1 >= a.Wo) continue;
+                        a.y0[(((size_t)(b * a.Do + z1) * a.Ho + y1) * a.Wo + x1) * a.upO + o1] = e[k] + (a.bias ? a.bias[o1] : 0.f);
+                    }
+                    continue;
+                }
                 const int tap = cop / a.upO, o = cop - tap * a.upO;
                 const int zz = 2 * oz + (tap >> 2), yy = 2 * oy + ((tap >> 1) & 1), xx = 2 * ox + (tap & 1);
                 if (zz >= a.Do || yy >= a.Ho || xx >= a.Wo) continue;
@@ -1306,7 +1319,7 @@ int vnet_pack_weights(int mode, const float* w, float* wp, int taps, int I, int 
         return VNET_OK;
     }
     if (mode < 0 || mode > 2) return VNET_E_UNSUPPORTED;
-    if (mode == VNET_PACK_UP && (taps != 8 || (O & 3))) return VNET_E_UNSUPPORTED;
+    if (mode == VNET_PACK_UP && taps != 8) return VNET_E_UNSUPPORTED;
     int Tp, CQ, NP; packed_dims(mode, taps, I, O, &Tp, &CQ, &NP);
     const size_t total = (size_t)Tp * CQ * NP * 4;
     const int blocks = (int)min((size_t)4096, (total + 255) / 256);
@@ -1361,7 +1374,7 @@ int vnet_conv_fwd(int ks, int kx, int stride, int up, const float* x0, int C0, c
     if (kx == 0) kx = ks;
     if (kx != ks && !(is5 && kx == 1 && round_up(Cy0 + Cy1, 16) == 16)) return VNET_E_UNSUPPORTED;   // 5x5x1: x-im2col'ed input conv
     if (isup) {
-        if (Cy1 != 0 || (Cy0 & 3)) return VNET_E_UNSUPPORTED;
+        if (Cy1 != 0) return VNET_E_UNSUPPORTED;
         a.CoutP = round_up(8 * Cy0, 16); a.upO = Cy0; a.pad = 0; a.padx = 0;
     } else {
         a.CoutP = round_up(a.Cout, 16); a.pad = is5 ? 2 : 0;
