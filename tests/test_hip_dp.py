@@ -106,7 +106,7 @@ def _worker(rank, world, port, out):
     ops.invalidate_packed()
     opt = optim.AdamOptimizer(flat)
     opt.gscale = 1.0 / world
-    ops.set_param_grad_stream(True)                    # filter/bias gradients on their own stream, as in model.train_step
+    ops.set_param_grad_stream(os.environ.get("VNET_TEST_PG", "1") == "1")   # filter/bias gradients on their own stream, as in model.train_step
     sync = parallel.BucketedGradAllReduce(flat, bucket_bytes=16 << 10)
     assert len(sync.buckets) >= 3 and sync.overlap
     x, lab = _batch(rank, dev)

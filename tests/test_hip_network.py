@@ -173,6 +173,40 @@ def test_config_c2_live_oracle(dev):
     assert np.sqrt(num / den) < 1e-3, np.sqrt(num / den)
 
 
+@pytest.mark.parametrize("variant,cin,K,C0,levels,ncv,nb,shape,loss", [
+    ("networks", 1, 2, 6, 2, (1, 2), 1, (2, 12, 10, 14), "sorensen"),      # 6/12/24 channels: no multiple of 16, up conv 12 -> 6
+    ("networks", 3, 4, 5, 2, (2, 1), 2, (1, 8, 12, 9), "mixed_sorensen"),  # odd extent: SAME pads high, output_shape = odd skip
+    ("networks", 2, 3, 3, 3, (1, 1, 2), 1, (1, 8, 16, 12), "weighted_jaccard"),
+    ("legacy", 2, 3, 6, 2, (1, 2), 1, (1, 8, 8, 12), "jaccard"),
+])
+def test_ragged_architectures_live_oracle(dev, variant, cin, K, C0, levels, ncv, nb, shape, loss):
+    """Whole-network parity on shapes the shipped configs do not use but the reference accepts (config.json keys
+    NumChannel / NumLevels / NumConvolutions / PatchShape): channel counts that are no multiple of 4 or 16, non-cubic and odd
+    patch extents (stride-2 SAME pads the high side, the transposed conv's output_shape is the odd skip tensor's), several
+    modalities and classes, both wirings."""
+    rng = np.random.default_rng(sum(shape) + C0)
+    B = shape[0]
+    x = np.clip(127.5 + 40.0 * rng.standard_normal(shape + (cin,)), 0, 255).astype(np.float32)
+    lab = rng.integers(0, K, size=shape + (1,)).astype(np.int32)
+    wts = tuple(rng.uniform(0.2, 1.0, K))
+    ps = O.ParamStore(rng=np.random.default_rng(17), perturb=0.1)
+    ref_net = O.VNetOracle(K, 0.0, C0, levels, ncv, nb, "prelu", variant if variant == "networks" else "legacy", ps)
+    ref = O.run_step(x.astype(np.float64), lab, ref_net, loss, wts, 0.7)
+    net = _build(dev, variant, K, C0, levels, ncv, nb, {k: v.v for k, v in ps.vars.items()}, x.shape)
+    logits, l, sm, pred = _fwd_bwd(net, variant, x, lab, loss, wts, dev)
+    check_close("ragged logits", logits, ref["logits"], 1e-4, atol=1e-3)
+    assert abs(float(l.detach()) - ref["loss"]) < 1e-5, (float(l.detach()), ref["loss"])
+    num = den = 0.0
+    for n, p in net.named_parameters():
+        r = ref["grads"][n]
+        if p.grad is not None and np.linalg.norm(r) > 1e-7:
+            gq = p.grad.cpu().numpy().astype(np.float64)
+            assert rel_l2(gq, r) < 1e-2, (n, rel_l2(gq, r))
+            num += ((gq - r) ** 2).sum()
+            den += (r ** 2).sum()
+    assert np.sqrt(num / den) < 1e-3, np.sqrt(num / den)
+
+
 def test_training_steps_match_oracle_adam(dev):
     """Three optimiser steps (TF-form Adam + exponential LR decay, model.py:641-666) track the oracle."""
     from vnet_tensorflow_amd import ops, optim

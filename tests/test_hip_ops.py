@@ -315,7 +315,7 @@ def test_input_block(dev, shape):
     check_close(tag + " dbeta", tb.grad, B_.g, 5e-5)
 
 
-@pytest.mark.parametrize("C,K", [(16, 2), (16, 5), (4, 3), (8, 8)])
+@pytest.mark.parametrize("C,K", [(16, 2), (16, 5), (4, 3), (8, 8), (6, 2), (5, 3), (12, 4), (24, 1)])
 def test_head(dev, C, K):
     from vnet_tensorflow_amd import ops
     rng = np.random.default_rng(C * K)

@@ -598,6 +598,34 @@ __global__ void __launch_bounds__(EW_BLOCK) head_bwd_kernel(const float* __restr
     }
 }
 
+// any C (not a multiple of 4 / no power-of-two quad count): one thread per row, LDS accumulation of dw / db
+template <int K>
+__global__ void __launch_bounds__(EW_BLOCK) head_bwd_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                    const float* __restrict__ dy, float* __restrict__ dx,
+                                                                    size_t M, int C, float* __restrict__ partial) {
+    __shared__ float ws[1024];
+    __shared__ float acc[1024 + 8];
+    for (int t = threadIdx.x; t < C * K; t += EW_BLOCK) ws[t] = w[t];
+    for (int t = threadIdx.x; t < C * K + K; t += EW_BLOCK) acc[t] = 0.f;
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * EW_BLOCK;
+    for (size_t row = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x; row < M; row += stride) {
+        float g[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { g[k] = dy[row * K + k]; atomicAdd(&acc[C * K + k], g[k]); }
+        for (int c = 0; c < C; ++c) {
+            const float v = x[row * C + c];
+            float o = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) { o += g[k] * ws[c * K + k]; atomicAdd(&acc[c * K + k], v * g[k]); }
+            if (dx) dx[row * C + c] = o;
+        }
+    }
+    __syncthreads();
+    float* prow = partial + (size_t)blockIdx.x * (C * K + K);
+    for (int t = threadIdx.x; t < C * K + K; t += EW_BLOCK) prow[t] = acc[t];
+}
+
 // ---- fused softmax + Dice / cross-entropy ------------------------------------------------------
 struct LossP {
     const float* logits; const int32_t* labels; const float* weights;
@@ -1119,12 +1147,18 @@ int vnet_head_fwd(const float* x, const float* w, const float* bias, float* y, i
 int vnet_head_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
                   int64_t M, int C, int K, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !w || !dy || !dw || !db || M <= 0 || C <= 0 || K <= 0) return VNET_E_BADARG;
-    if (C * K > 1024 || (C & 3) || !is_pow2(C / 4) || C / 4 > EW_BLOCK) return VNET_E_UNSUPPORTED;
+    if (C * K > 1024) return VNET_E_UNSUPPORTED;
     if (!ws || ws_bytes < vnet_head_ws_bytes(C, K)) return VNET_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)ws;
-    const int nblk = ew_blocks((size_t)M * (C / 4) / 4 + 1);
-    K_SWITCH(K, hipLaunchKernelGGL(head_bwd_kernel<KK>, dim3(nblk), dim3(EW_BLOCK), 0, st, x, w, dy, dx, (size_t)M, C, partial));
+    int nblk;
+    if ((C & 3) == 0 && is_pow2(C / 4) && C / 4 <= EW_BLOCK) {
+        nblk = ew_blocks((size_t)M * (C / 4) / 4 + 1);
+        K_SWITCH(K, hipLaunchKernelGGL(head_bwd_kernel<KK>, dim3(nblk), dim3(EW_BLOCK), 0, st, x, w, dy, dx, (size_t)M, C, partial));
+    } else {
+        nblk = ew_blocks((size_t)M / 4 + 1);
+        K_SWITCH(K, hipLaunchKernelGGL(head_bwd_generic_kernel<KK>, dim3(nblk), dim3(EW_BLOCK), 0, st, x, w, dy, dx, (size_t)M, C, partial));
+    }
     VNET_LAUNCH_CHECK();
     hipLaunchKernelGGL(head_finalize_kernel, dim3(C * K + K), dim3(256), 0, st, partial, nblk, C * K, K, dw, db);
     VNET_LAUNCH_CHECK();

@@ -75,7 +75,7 @@ def workspace(nbytes, device):
 # only feed the optimiser / the gradient all-reduce.  With this switch on they are enqueued on a second HIP stream,
 # so their MFMA work fills the chip while the critical path sits in its short HBM- and latency-bound kernels.
 # Only gradients that go straight into the flat gradient buffer (GradSink) take this route.
-_PG = {"on": False, "streams": {}, "used": set()}
+_PG = {"on": False, "streams": {}, "used": set(), "keep": [], "test_delay": 0}
 
 
 def set_param_grad_stream(on):
@@ -98,6 +98,8 @@ def join_param_grad_stream(device=None):
         if device is None or dev == device:
             torch.cuda.current_stream(dev).wait_stream(_PG["streams"][dev])
             _PG["used"].discard(dev)
+    if not _PG["used"]:
+        _PG["keep"] = []
 
 
 # ---- packed-weight cache -------------------------------------------------------------------------
@@ -394,7 +396,15 @@ class _ConvFn(torch.autograd.Function):
             for t in (x0, x1, dy):
                 if t is not None:
                     t.record_stream(side)                # keep the allocator from recycling them under the side stream
+            # dy of a residual block is ALSO the gradient of the block input (one tensor, two autograd edges); once this
+            # node has returned autograd holds the last reference and accumulates the next gradient INTO it in place
+            # (input_buffer.cpp: use_count == 1), on the main stream, while the filter gradient may still be reading it.
+            # A live reference until the join makes that accumulation out of place.
+            _PG["keep"].append(dy)
             _PG["used"].add(dev)
+            if _PG["test_delay"]:
+                with torch.cuda.stream(side):
+                    torch.cuda._sleep(int(_PG["test_delay"]))    # tests: let the side stream lag far behind
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             if db is not None:
                 colsum(dy, O, out=db)
