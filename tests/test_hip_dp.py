@@ -107,6 +107,7 @@ def _worker(rank, world, port, out):
     opt = optim.AdamOptimizer(flat)
     opt.gscale = 1.0 / world
     ops.set_param_grad_stream(os.environ.get("VNET_TEST_PG", "1") == "1")   # filter/bias gradients on their own stream, as in model.train_step
+    ops._PG["test_delay"] = 200000 * rank            # rank 1's side stream lags ~0.1 ms per layer: bucket/stream ordering holes show
     sync = parallel.BucketedGradAllReduce(flat, bucket_bytes=16 << 10)
     assert len(sync.buckets) >= 3 and sync.overlap
     x, lab = _batch(rank, dev)
