@@ -174,12 +174,29 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
     const int gz0 = bz * TZ * STRIDE - a.pad, gy0 = by * TY * STRIDE - a.pad, gx0 = bx * TX * STRIDE - a.padx;
     const size_t tap_stride = (size_t)a.CQ * a.CoutP;   // float4 units
 
+    // 2^3 / transposed kernels: a brick has only 8 (1) taps of MFMA work per chunk, so an L2 round trip per tap in front of
+    // its MFMAs would dominate.  The first RG taps' weight fragments are issued BEFORE the tile staging (in flight together
+    // with the tile's HBM loads), the rest stream through the same RG-slot ring RG taps ahead.
+    constexpr int T3G = KS * KS * KS, RG = (KS == 5) ? 1 : (T3G < 4 ? T3G : 4);
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        const float4* wq = a.wp + ((size_t)(chunk * 4 + kk) * a.CoutP + co0 + i);
+        float4 wg[RG][NS];
+        if constexpr (KS == 2) {
+#pragma unroll
+            for (int j = 0; j < RG; ++j)
+#pragma unroll
+                for (int n = 0; n < NS; ++n) wg[j][n] = wq[(size_t)j * tap_stride + n * 16];
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __syncthreads();
         load_tile<G::IZ, G::IY, G::IX, WAVES * 64>(lds, a.x0, a.x1, a.C0, a.C1, a.vec_in, chunk, b, gz0, gy0, gx0,
                                                    a.Di, a.Hi, a.Wi, tid);
         __syncthreads();
-        const float4* wq = a.wp + ((size_t)(chunk * 4 + kk) * a.CoutP + co0 + i);
+        if constexpr (KS == 1) {      // transposed conv: one tap per chunk; its fragment is fetched here, together with the LDS reads
+                                      // (issuing it ahead of the staging or of the barrier measured 18-25 % slower)
+#pragma unroll
+            for (int n = 0; n < NS; ++n) wg[0][n] = wq[n * 16];
+        }
         if constexpr (KS == 5) {
             // Weight fragments come straight from L2 (the whole filter is shared by every workgroup), so
             // they are software-pipelined PF taps ahead through a 5-slot register ring (5 | 25 taps per
@@ -233,31 +250,57 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
                 }
             }
         } else {
-            for (int dz = 0; dz < KS; ++dz) {
-                for (int dy = 0; dy < KS; ++dy) {
-                    const float* lrow = lds + (dz * G::IY + dy) * G::IX * 16;
-                    const float4* wrow = wq + (size_t)((dz * KS + dy) * KS) * tap_stride;
 #pragma unroll
-                    for (int dx = 0; dx < KS; ++dx) {
-                        float4 wf[NS];
+            for (int t = 0; t < T3G; ++t) {
+                const int dz = t / (KS * KS), dy = (t / KS) % KS, dx = t % KS;
+                const float* lrow = lds + ((dz * G::IY + dy) * G::IX + dx) * 16;
+                float4 xf[MS];
 #pragma unroll
-                        for (int n = 0; n < NS; ++n) wf[n] = wrow[dx * tap_stride + n * 16];
-                        float4 xf[MS];
+                for (int m = 0; m < MS; ++m) xf[m] = *reinterpret_cast<const float4*>(lrow + boff[m]);
+                const float4* wf = wg[t % RG];
 #pragma unroll
-                        for (int m = 0; m < MS; ++m) xf[m] = *reinterpret_cast<const float4*>(lrow + boff[m] + dx * 16);
+                for (int m = 0; m < MS; ++m)
 #pragma unroll
-                        for (int m = 0; m < MS; ++m)
-#pragma unroll
-                            for (int n = 0; n < NS; ++n) {
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].x, xf[m].x, acc[m][n], 0, 0, 0);
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].y, xf[m].y, acc[m][n], 0, 0, 0);
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].z, xf[m].z, acc[m][n], 0, 0, 0);
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].w, xf[m].w, acc[m][n], 0, 0, 0);
-                            }
+                    for (int n = 0; n < NS; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].x, xf[m].x, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].y, xf[m].y, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].z, xf[m].z, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[n].w, xf[m].w, acc[m][n], 0, 0, 0);
                     }
+                if (t + RG < T3G) {
+#pragma unroll
+                    for (int n = 0; n < NS; ++n) wg[t % RG][n] = wq[(size_t)(t + RG) * tap_stride + n * 16];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
+    }
+
+    // transposed conv whose O is no multiple of 4: a lane's four values can straddle two taps -> a separate, scalar
+    // epilogue (kept out of the vector epilogue's loops: inlined there it cost the O % 4 == 0 kernels 10-18 %)
+    if (UP && (a.upO & 3)) {
+#pragma unroll
+        for (int m = 0; m < MS; ++m) {      // (static indices: a dynamic index would push acc[][] to scratch for the whole kernel)
+            const int v = (wave * MS + m) * 16 + i;
+            const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+            const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
+            if (oz >= a.Di || oy >= a.Hi || ox >= a.Wi) continue;
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {
+                const int cop = co0 + n * 16 + kk * 4;
+                const float e[4] = {acc[m][n].x, acc[m][n].y, acc[m][n].z, acc[m][n].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ck = cop + k;
+                    if (ck >= 8 * a.upO) break;
+                    const int tp = ck / a.upO, o1 = ck - tp * a.upO;
+                    const int z1 = 2 * oz + (tp >> 2), y1 = 2 * oy + ((tp >> 1) & 1), x1 = 2 * ox + (tp & 1);
+                    if (z1 >= a.Do || y1 >= a.Ho || x1 >= a.Wo) continue;
+                    a.y0[(((size_t)(b * a.Do + z1) * a.Ho + y1) * a.Wo + x1) * a.upO + o1] = e[k] + (a.bias ? a.bias[o1] : 0.f);
+                }
+            }
+        }
+        return;
     }
 
     // epilogue: lane holds cout = co0 + n*16 + 4*kk + {0..3} of voxel (m, i)
@@ -272,19 +315,6 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
             for (int n = 0; n < NS; ++n) {
                 const int cop = co0 + n * 16 + kk * 4;          // index into N' = 8*O
                 if (cop >= 8 * a.upO) continue;
-                if (a.upO & 3) {        // O no multiple of 4: the lane's four values can straddle two taps -> scalar stores
-                    const float e[4] = {acc[m][n].x, acc[m][n].y, acc[m][n].z, acc[m][n].w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int ck = cop + k;
-                        if (ck >= 8 * a.upO) break;
-                        const int tp = ck / a.upO, o1 = ck - tp * a.upO;
-                        const int z1 = 2 * oz + (tp >> 2), y1 = 2 * oy + ((tp >> 1) & 1), x1 = 2 * ox + (tp & 1);
-                        if (z1 >= a.Do || y1 >= a.Ho || x1 >= a.Wo) continue;
-                        a.y0[(((size_t)(b * a.Do + z1) * a.Ho + y1) * a.Wo + x1) * a.upO + o1] = e[k] + (a.bias ? a.bias[o1] : 0.f);
-                    }
-                    continue;
-                }
                 const int tap = cop / a.upO, o = cop - tap * a.upO;
                 const int zz = 2 * oz + (tap >> 2), yy = 2 * oy + ((tap >> 1) & 1), xx = 2 * ox + (tap & 1);
                 if (zz >= a.Do || yy >= a.Ho || xx >= a.Wo) continue;
