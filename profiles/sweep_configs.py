@@ -23,6 +23,8 @@ cases = [
     ((128, 128, 128), 1, 1, 2, "VNet", 32, 4, [1, 2, 3, 3], 3, "fp32", "sorensen", "Adam"),
     ((160, 160, 160), 1, 1, 2, "VNet", 16, 4, [1, 2, 3, 3], 3, "fp32", "sorensen", "Adam"),
     ((192, 192, 192), 1, 4, 5, "VNet", 16, 4, [1, 2, 3, 3], 3, "bf16", "sorensen", "Adam"),
+    ((60, 52, 44), 2, 1, 2, "VNet", 6, 3, [1, 2, 2], 2, "fp32", "sorensen", "Adam"),          # 6/12/24/48 channels
+    ((45, 51, 39), 1, 3, 4, "VNet", 10, 2, [2, 1], 1, "bf16", "weighted_sorensen", "Adam"),   # odd extents, 10/20 channels
 ]
 ok = True
 for (P, B, cin, K, net, nch, lev, convs, bot, comp, loss, opt) in cases:

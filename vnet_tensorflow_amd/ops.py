@@ -43,8 +43,19 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_LAUNCH_ON = [None]      # raw handle of the stream the next launches go to instead of torch's current one (parameter-gradient stream)
+
+
+def _raw_stream():
+    """Handle of the stream kernels are launched on: torch's current stream on the current device, unless the
+    parameter-gradient section redirected launches.  (torch.cuda.current_stream() builds a Stream object through three Python
+    layers, ~8 us, and a torch.cuda.stream() context costs ~20 us; this is called for every kernel launch.)"""
+    h = _LAUNCH_ON[0]
+    return h if h is not None else torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_raw_stream())
 
 
 def _need_gpu(t, what):
@@ -56,15 +67,19 @@ def _need_gpu(t, what):
 
 # ---- workspace (caller-owned, per device) -----------------------------------------------------
 _WS = {}
+_WS_RETIRED = []
 
 
 def workspace(nbytes, device):
     """One scratch buffer per (device, stream): launches on the parameter-gradient stream never share scratch
     with the main stream's launches."""
     nbytes = int(nbytes)
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, _raw_stream())
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None and _LAUNCH_ON[0] is not None:
+            _WS_RETIRED.append(buf)     # the allocator files this block under torch's current stream, not the redirected one:
+                                        # never hand it back while launches on that stream may still be using it
         buf = torch.empty(max(nbytes, 1 << 20) * 5 // 4, dtype=torch.uint8, device=device)
         _WS[key] = buf
     return buf
@@ -405,7 +420,8 @@ class _ConvFn(torch.autograd.Function):
             if _PG["test_delay"]:
                 with torch.cuda.stream(side):
                     torch.cuda._sleep(int(_PG["test_delay"]))    # tests: let the side stream lag far behind
-        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            _LAUNCH_ON[0] = side.cuda_stream             # launches (and their scratch buffer) go to the side stream
+        try:
             if db is not None:
                 colsum(dy, O, out=db)
             if dw is not None:
@@ -415,6 +431,8 @@ class _ConvFn(torch.autograd.Function):
                     _wgrad_bf16_call(x0, x1, dy, dw, din)
                 else:
                     _wgrad_call(ks, stride, x0, x1, dy, dw, din, dout)
+        finally:
+            _LAUNCH_ON[0] = None
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
             dx0 = torch.empty_like(x0)
