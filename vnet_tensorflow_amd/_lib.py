@@ -101,8 +101,21 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
+            if name.endswith("_ws_bytes") or name == "vnet_packed_weight_floats":
+                setattr(L, name, _memo(fn))    # pure size queries, asked before every launch: answer repeats from a dict
         _lib = L
     return _lib
+
+
+def _memo(fn):
+    cache = {}
+
+    def cached(*args):
+        r = cache.get(args)
+        if r is None:
+            r = cache[args] = fn(*args)
+        return r
+    return cached
 
 
 def check(code, what):

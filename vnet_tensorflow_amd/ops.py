@@ -40,7 +40,7 @@ LOSS_WEIGHTED, LOSS_MIXED = 16, 32
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    return t.data_ptr() if t is not None else None      # ctypes converts an int to the declared c_void_p itself
 
 
 _LAUNCH_ON = [None]      # raw handle of the stream the next launches go to instead of torch's current one (parameter-gradient stream)
@@ -55,7 +55,7 @@ def _raw_stream():
 
 
 def _stream():
-    return ctypes.c_void_p(_raw_stream())
+    return _raw_stream()
 
 
 def _need_gpu(t, what):
