@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
             // they are software-pipelined PF taps ahead through a 5-slot register ring (5 | 25 taps per
             // dz slab keeps every ring index a compile-time constant) -- the L2 round trip hides under
             // the MFMAs of the taps in between instead of stalling each tap.
-            constexpr int T2 = KS * KX, T3 = T2 * KS, R = 5, PF = (NS == 1) ? 2 : 1;
+            constexpr int T2 = KS * KX, T3 = T2 * KS, R = 5, PF = (NS == 1) ? 3 : 1;
             static_assert(T2 % R == 0, "ring slots must tile a dz slab");
             float4 wf[R][NS];
             float4 xf[R][MS];     // B fragments ride the same ring one tap ahead (LDS latency off the MFMA path)
