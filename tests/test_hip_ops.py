@@ -193,9 +193,30 @@ def test_conv_family_random_shapes(dev):
     (12, "prelu", False, False), (8, "prelu", False, True),
 ])
 def test_bn_act(dev, C, act, res, tile):
+    _bn_act_case(dev, C, act, res, tile, (2, 5, 6, 7), C + 7 * bool(res))
+
+
+def test_bn_act_random_cases(dev):
+    """Property test: train-mode batch-norm (+ residual | + tile) + activation on random row counts and channel counts
+    (vector path: C/4 a power of two; row path: C <= 8; generic path: everything else), forward, all gradients and the
+    moving-average update against the fp64 oracle."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(C=st.one_of(st.integers(1, 40), st.sampled_from([16, 32, 64, 128, 256])), act=st.sampled_from([None, "relu", "prelu", "lrelu"]),
+           extra=st.sampled_from(["none", "res", "tile"]), B=st.integers(1, 3), D=st.integers(1, 7), H=st.integers(1, 7),
+           W=st.integers(2, 19), seed=st.integers(0, 10 ** 6))
+    def run(C, act, extra, B, D, H, W, seed):
+        if B * D * H * W < 4:
+            W += 4                      # the batch variance of fewer than a handful of rows is all round-off
+        _bn_act_case(dev, C, act, extra == "res", extra == "tile", (B, D, H, W), seed)
+
+    run()
+
+
+def _bn_act_case(dev, C, act, res, tile, shp, seed):
     from vnet_tensorflow_amd import ops
-    rng = np.random.default_rng(C + 7 * bool(res))
-    shp = (2, 5, 6, 7)
+    rng = np.random.default_rng(seed)
     x = rng.standard_normal(shp + ((1,) if tile else (C,))) * 3.0 + 1.5
     r = rng.standard_normal(shp + (C,)) if res else None
     gamma, beta = rng.uniform(0.5, 1.5, C), rng.standard_normal(C)
