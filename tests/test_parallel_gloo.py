@@ -31,7 +31,7 @@ def _loss(params, x):
     return ((h @ p["l2/weights"] + p["l2/biases"]) ** 2).mean()      # "dead/gamma" never gets a gradient
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, hold=0.0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from vnet_tensorflow_amd import optim, parallel
     r, _, w = parallel.init_from_env("gloo")
@@ -39,7 +39,7 @@ def _worker(rank, world, port, out):
     params = _model(seed=100 + rank)                       # different init per rank ...
     flat = optim.FlatParams(params)
     parallel.broadcast_parameters(flat.data)               # ... until rank 0's weights are broadcast
-    sync = parallel.BucketedGradAllReduce(flat, bucket_bytes=64)
+    sync = parallel.BucketedGradAllReduce(flat, bucket_bytes=64, hold_fraction=hold)
     assert len(sync.buckets) >= 2
     results = []
     for step in range(2):
@@ -47,15 +47,24 @@ def _worker(rank, world, port, out):
         flat.zero_grad()
         sync.begin_step()
         _loss(params, x).backward()
+        if step == 1:            # (step 0 calibrates the event counts: nothing is launched before finish())
+            if hold > 0.0:       # held buckets go out together, in order, once `hold` of the bytes is ready -- or in finish()
+                n = sum(sync._launched)
+                assert n == 0 or sync._ready_bytes >= hold * sync._total_bytes
+                assert sync._launched == sorted(sync._launched, reverse=True) or n == 0
+            else:
+                assert sum(sync._launched) >= 1
         sync.finish()
+        assert all(sync._launched) and not sync._held
         results.append(flat.grad.clone())
     torch.save({"data": flat.data.clone(), "grads": results}, os.path.join(out, "r%d.pt" % rank))
     dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_world2(tmp_path):
+@pytest.mark.parametrize("hold", [0.0, 0.6, 1.0])
+def test_bucketed_allreduce_world2(tmp_path, hold):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), hold), nprocs=2, join=True)
     r0 = torch.load(tmp_path / "r0.pt")
     r1 = torch.load(tmp_path / "r1.pt")
     assert torch.equal(r0["data"], r1["data"])             # broadcast made the replicas identical

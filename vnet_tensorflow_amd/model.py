@@ -244,7 +244,10 @@ class image2label(object):
         if self.world > 1:
             parallel.broadcast_parameters(self.flat.data)
             self.optimizer.gscale = 1.0 / self.world
-            self.sync = parallel.BucketedGradAllReduce(self.flat)
+            # launch the bucket all-reduces once this fraction of the gradient bytes exists (parallel.py): keeps the
+            # collective off the 256-CU-planned deep-level kernels; TrainingSetting.AllReduceHoldFraction / VNET_DP_HOLD
+            hold = float(os.environ.get("VNET_DP_HOLD", getattr(self, "allreduce_hold_fraction", 0.99)))
+            self.sync = parallel.BucketedGradAllReduce(self.flat, hold_fraction=hold)
             if getattr(self, "sync_batch_norm", False):
                 # single-device BatchSize = world x per-rank batch semantics of the reference (networks.py:319);
                 # the default (per-replica statistics) equals the reference run on each rank's batch alone
