@@ -133,6 +133,8 @@ class image2label(object):
         self.synthetic = T['Data'].get('Synthetic')            # extension: synthetic generator (no NIfTI shipped)
         self.compute_dtype = T.get('ComputeDtype', 'fp32')            # extension: 'bf16' = BASELINE config C5 arithmetic
         self.sync_batch_norm = bool(T.get('SyncBatchNorm', False))   # extension: cross-replica BN statistics
+        if 'AllReduceHoldFraction' in T:                               # extension: when the gradient buckets are launched (parallel.py)
+            self.allreduce_hold_fraction = float(T['AllReduceHoldFraction'])
         self.batch_size = T['BatchSize']
         self.patch_shape = T['PatchShape']
         self.dimension = len(T['PatchShape'])
@@ -246,7 +248,9 @@ class image2label(object):
             self.optimizer.gscale = 1.0 / self.world
             # launch the bucket all-reduces once this fraction of the gradient bytes exists (parallel.py): keeps the
             # collective off the 256-CU-planned deep-level kernels; TrainingSetting.AllReduceHoldFraction / VNET_DP_HOLD
-            hold = float(os.environ.get("VNET_DP_HOLD", getattr(self, "allreduce_hold_fraction", 0.99)))
+            # (bf16 mode: the backward pass that is left after encoder level 3 is shorter than the all-reduce -> launch when ready)
+            default_hold = 0.99 if ops.get_compute_dtype() == "fp32" else 0.0
+            hold = float(os.environ.get("VNET_DP_HOLD", getattr(self, "allreduce_hold_fraction", default_hold)))
             self.sync = parallel.BucketedGradAllReduce(self.flat, hold_fraction=hold)
             if getattr(self, "sync_batch_norm", False):
                 # single-device BatchSize = world x per-rank batch semantics of the reference (networks.py:319);
