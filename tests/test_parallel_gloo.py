@@ -61,6 +61,25 @@ def _worker(rank, world, port, out, hold=0.0):
     dist.destroy_process_group()
 
 
+def test_bucketed_allreduce_world4(tmp_path):
+    """Four ranks (the driver scales to 8): every rank ends with the sum of the four per-rank gradients."""
+    mp.spawn(_worker, args=(4, _free_port(), str(tmp_path), 0.6), nprocs=4, join=True)
+    r = [torch.load(tmp_path / ("r%d.pt" % k)) for k in range(4)]
+    from vnet_tensorflow_amd import optim
+    params = _model(seed=100)
+    flat = optim.FlatParams(params)
+    for step in range(2):
+        tot = torch.zeros_like(flat.grad)
+        for rank in range(4):
+            x = torch.randn(4, 6, generator=torch.Generator().manual_seed(10 * step + rank))
+            flat.zero_grad()
+            _loss(params, x).backward()
+            tot += flat.grad
+        for k in range(4):
+            assert torch.allclose(r[k]["grads"][step], tot, atol=1e-6)
+            assert torch.equal(r[k]["data"], r[0]["data"])
+
+
 @pytest.mark.parametrize("hold", [0.0, 0.6, 1.0])
 def test_bucketed_allreduce_world2(tmp_path, hold):
     port = _free_port()
