@@ -7,10 +7,18 @@
 
 One "step" = one pass of the hot path over one batch of synthetic patches already resident in HBM:
 forward (networks.VNet, batch-statistics BN) + softmax/Sorensen-Dice + backward + gradient all-reduce
-(N>1, RCCL) + TF-form Adam.  Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events
-around every launch of the dominant kernel family (the 16-channel 5x5x5 conv at 128^3: forward,
-backward-data and filter-gradient launches); `cpu_baseline` times the CPU restatement (oracle/torch_ref.py,
-PyTorch-CPU oneDNN fp32, same graph incl. backward + Adam) on a bounded sub-patch on rank 0 at N=1.
+(N>1, RCCL) + TF-form Adam + filter repack.  The step is enqueued the way image2label.train() enqueues it: as a
+replayed hipGraph of the whole step (2 eager steps + 1 capture happen before the W warm-up steps; VNET_STEP_GRAPH=0
+gives the kernel-by-kernel eager enqueue).  Rank 0 prints ONE JSON line.
+
+`roofline`: HIP events around every launch of the dominant kernel family -- decoder level 1 / conv_1, the 5x5x5
+convolution with 16 output channels at 128^3: forward (32->16), backward-data (16->32) and filter gradient, 268.4 GF
+algorithmic each.  In graph mode the events are EXTERNAL event-record nodes of the captured step; they are read after
+each of R further replays that follow the timed region (reading needs a host sync, which the timed region must not
+contain).  `c5_bf16` (N=1 only): the same measurement for BASELINE configs[4]'s per-GPU workload (4 modalities, 5
+classes, bf16 conv operands / fp32 accumulate), outside the headline's timed region.  `cpu_baseline`: the CPU
+restatement (oracle/torch_ref.py: same graph on PyTorch-CPU oneDNN fp32 incl. backward + Adam) timed on the real
+128^3 step on rank 0 at N=1.
 """
 import argparse
 import json
@@ -36,73 +44,110 @@ def parse():
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-patch", type=int, default=64)
+    ap.add_argument("--no-c5", action="store_true", help="skip the bf16 / 4-modality / 5-class sub-measurement (N=1)")
+    ap.add_argument("--cpu-patch", type=int, default=0, help="CPU baseline patch edge (0 = the benchmarked patch itself)")
+    ap.add_argument("--pin-core", type=int, default=-1,
+                    help="pin this process to ONE host core before the GPU is initialised (host-overhead experiment)")
     ap.add_argument("--compute", choices=("fp32", "bf16"), default="fp32",
                     help="arithmetic of the 5^3 convolutions: fp32 = the reference's (headline metric); bf16 = operands rounded "
                          "to bf16, fp32 accumulate (BASELINE config C5 with --channels 4 --classes 5)")
     return ap.parse_args()
 
 
-def config(args):
+def config(patch, batch, channels, classes, compute):
     return {"TrainingSetting": {
         "Data": {"TrainingDataDirectory": "synthetic", "TestingDataDirectory": "synthetic",
-                 "ImageFilenames": ["image%d.nii" % i for i in range(args.channels)], "LabelFilename": "label.nii",
+                 "ImageFilenames": ["image%d.nii" % i for i in range(channels)], "LabelFilename": "label.nii",
                  "Synthetic": {"Cases": 1}},
-        "SegmentationClasses": list(range(args.classes)), "BatchSize": args.batch, "PatchShape": [args.patch] * 3,
-        "ComputeDtype": args.compute,
+        "SegmentationClasses": list(range(classes)), "BatchSize": batch, "PatchShape": [patch] * 3,
+        "ComputeDtype": compute,
         "Networks": {"Name": "VNet", "Dropout": 0.0, "NumChannel": 16, "NumLevels": 4, "NumConvolutions": [1, 2, 3, 3],
                      "BottomConvolutions": 3},
         "Optimizer": {"Name": "Adam", "InitialLearningRate": 1e-2, "Decay": {"Factor": 0.99, "Steps": 100}},
         "Loss": {"Name": "sorensen", "Weights": [], "Alpha": 1}}}
 
 
+def host_cpu():
+    """(model string, physical cores, logical cpus) of this host."""
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    return model, len(phys) or (os.cpu_count() or 1), os.cpu_count() or 1
+
+
 def cpu_baseline(args):
-    """CPU restatement ("port"): same graph, PyTorch-CPU ops, fp32, fwd+bwd+Adam, on a cpu_patch^3 sub-patch
-    (the conv work scales with the voxel count, so patches/s at 128^3 = measured rate * (cpu_patch/128)^3)."""
-    import numpy as np
+    """CPU restatement ("port", NOT TensorFlow 1.15): the same graph on PyTorch-CPU ops (oneDNN conv3d, fp32), fwd + Dice
+    + bwd + Adam, on the benchmarked patch itself -- one warm-up step and one or two timed steps, no extrapolation."""
     import torch
     from oracle import torch_ref as T
     from oracle import vnet_oracle as O
-    cores = torch.get_num_threads()
-    P = args.cpu_patch
-    x, lab = O.synthetic_batch(1, P, args.channels, args.classes, seed=1000)
-    torch.manual_seed(0)
-    net = T.TorchVNet(args.classes, 16, 4, (1, 2, 3, 3), 3, "prelu", "networks", dtype=torch.float32)
-    xt, lt = torch.from_numpy(x), torch.from_numpy(lab)
-    with torch.no_grad():
-        pass
-    loss, _ = T.loss_head(net.forward(xt), lt, "sorensen")       # creates the parameters
-    opt = torch.optim.Adam(list(net.p.values()), lr=1e-2, eps=1e-8)
-    T.train_step_fp32(net, xt, lt, opt)                            # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while n < 3 and (time.perf_counter() - t0) < 20.0:
-        T.train_step_fp32(net, xt, lt, opt)
-        n += 1
-    dt = (time.perf_counter() - t0) / n
+    model, phys, logical = host_cpu()
+    threads = torch.get_num_threads()
+
+    def time_patch(P, max_steps, budget_s):
+        x, lab = O.synthetic_batch(1, P, args.channels, args.classes, seed=1000)
+        torch.manual_seed(0)
+        net = T.TorchVNet(args.classes, 16, 4, (1, 2, 3, 3), 3, "prelu", "networks", dtype=torch.float32)
+        xt, lt = torch.from_numpy(x), torch.from_numpy(lab)
+        T.loss_head(net.forward(xt), lt, "sorensen")                    # creates the parameters
+        opt = torch.optim.Adam(list(net.p.values()), lr=1e-2, eps=1e-8)
+        T.train_step_fp32(net, xt, lt, opt)                             # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while n < max_steps and (n == 0 or (time.perf_counter() - t0) * (n + 1) / n < budget_s):
+            T.train_step_fp32(net, xt, lt, opt)
+            n += 1
+        return (time.perf_counter() - t0) / n, n
+
+    P = args.cpu_patch or args.patch
+    dt, n = time_patch(P, 2, 60.0)
+    dt32, n32 = time_patch(32, 3, 10.0)                                  # BASELINE configs[0] (C1): 32^3, B=1
     scale = (P / float(args.patch)) ** 3
-    return {"value": scale / dt, "unit": "patches/s", "cores": cores, "kind": "port",
-            "sample": "%d^3 sub-patch (%.4g of the %d^3 voxels), %d timed steps fwd+Dice+bwd+Adam at %.2f s/step, "
-                      "rate scaled by the voxel ratio; PyTorch-CPU oneDNN fp32 restatement, not TF1" % (P, scale, args.patch, n, dt)}
+    sample = "%d^3 patch, batch 1: 1 warm-up + %d timed training steps (fwd+Dice+bwd+Adam) at %.2f s/step" % (P, n, dt)
+    if scale != 1.0:
+        sample += ", rate scaled by the voxel ratio %.4g" % scale
+    sample += "; PyTorch-CPU oneDNN fp32 restatement of the reference graph (oracle/torch_ref.py), NOT TensorFlow 1.15; " \
+              "CPU %s, %d physical cores / %d logical, %d threads" % (model, phys, logical, threads)
+    return {"value": scale / dt, "unit": "patches/s", "cores": threads, "kind": "port", "sample": sample,
+            "cpu_model": model, "physical_cores": phys, "threads": threads, "seconds_per_step": round(dt, 3),
+            "c1_32cube": {"value": round(1.0 / dt32, 4), "unit": "patches/s", "seconds_per_step": round(dt32, 4), "steps": n32}}
 
 
-def main():
-    args = parse()
+def family_tags(P, B, bf16):
+    """Launch tags (ops._Timed) of decoder level 1 / conv_1: forward 32->16, backward-data 16->32, filter gradient."""
+    c, w = ("conv-bf16", "wgrad-bf16") if bf16 else ("conv", "wgrad")
+    return {"%s k5 s1 %d^3x%d 32->16" % (c, P, B), "%s k5 s1 %d^3x%d 16->32" % (c, P, B), "%s k5 s1 %d^3x%d 32->16" % (w, P, B)}
+
+
+def measure(args, patch, batch, channels, classes, compute, rank, local, world):
+    """Build the model, run prepare + warm-up + the timed K steps + the roofline replays.  Returns the result dict."""
+    import numpy as np
     import torch
     import torch.distributed as dist
     from vnet_tensorflow_amd import model as M
-    from vnet_tensorflow_amd import ops, parallel
+    from vnet_tensorflow_amd import ops
     from vnet_tensorflow_amd.data import synthetic_case
-    import numpy as np
 
-    rank, local, world = parallel.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    import gc
+    gc.collect()                             # a previous measurement's model (graph memory pool, packed filters) is gone
+    ops.clear_pack_registry()
+    torch.cuda.empty_cache()
     dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-
     np.random.seed(42)                       # the reference's unseeded global-NumPy Xavier init, made repeatable
-    m = M.image2label(None, config(args), device=dev, verbose=False)
+    m = M.image2label(None, config(patch, batch, channels, classes, compute), device=dev, verbose=False)
     m.rank, m.local_rank, m.world = rank, local, world
     m.read_config()
     m.build_model_graph()
@@ -110,8 +155,8 @@ def main():
 
     # synthetic batch, resident in HBM before the timed region (per-rank seed: SURVEY 8(d))
     imgs, labs = [], []
-    for b in range(args.batch):
-        im, lb = synthetic_case([args.patch] * 3, args.channels, args.classes, 1000 + rank * 64 + b)
+    for b in range(batch):
+        im, lb = synthetic_case([patch] * 3, channels, classes, 1000 + rank * 64 + b)
         imgs.append(im)
         labs.append(lb[..., None])
     images = torch.from_numpy(np.stack(imgs)).to(dev)
@@ -122,87 +167,142 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # HIP events go around the launches of the dominant kernel family only (every event packet idles the GPU for
-    # ~5.6 us; around all ~140 conv-family launches of a step that is 0.8 ms); BENCH_KERNEL_TABLE=1 times them all
-    P = args.patch
-    bf16 = args.compute == "bf16"
-    fam = set("%s k5 s1 %d^3x%d %d->16" % (k, P, args.batch, c) for k in (("conv-bf16", "wgrad-bf16") if bf16 else ("conv", "wgrad"))
-              for c in (16, 32))
+    bf16 = compute == "bf16"
+    fam = family_tags(patch, batch, bf16)
     full_table = bool(os.environ.get("BENCH_KERNEL_TABLE"))
+    graph = m._graph_mode() != "off"
+    if full_table and graph:
+        raise SystemExit("BENCH_KERNEL_TABLE times every launch with host-read events: run it with VNET_STEP_GRAPH=0")
+    ops._PROFILE["graph_records"] = []
+    # HIP events go around the launches of the dominant kernel family only (an event packet idles the GPU for ~5.6 us)
+    ops.profile_start(None if full_table else fam)
     loss = None
-    ops.profile_start(None if full_table else fam)       # warm-up runs the same schedule as the timed steps
+    for _ in range(3 if graph else 0):       # prepare: 2 eager steps + the capture (and first replay) of the step graph
+        loss = m.train_step(images, labels)
     for _ in range(args.warmup):
         loss = m.train_step(images, labels)
-    ops.profile_stop()
+    ops.profile_stop()                       # (synchronises; eager-mode records of the warm-up are dropped)
     barrier()
-    ops.profile_start(None if full_table else fam)
+    if not graph:
+        ops.profile_start(None if full_table else fam)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = m.train_step(images, labels)
     host_dt = time.perf_counter() - t0           # time for the host to ENQUEUE the steps (GPU runs behind)
     barrier()
     dt = time.perf_counter() - t0
-    recs = ops.profile_stop()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.detach())
+    if graph:
+        # roofline replays: the same graph, one host sync per step to read the external events of that replay
+        recs = []
+        for _ in range(min(args.steps, 10)):
+            m.train_step(images, labels)
+            torch.cuda.synchronize()
+            recs += ops.profile_read()
+        ops._PROFILE["graph_records"] = []
+    else:
+        recs = ops.profile_stop()
+    barrier()
 
+    res = {"value": round(world * batch * args.steps / dt, 4), "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "final_loss": round(final_loss, 6), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
+           "step_enqueue": {"off": "eager (one ctypes launch per kernel)", "whole": "hipGraph replay of the whole step",
+                            "segmented": "hipGraph(gradients) + eager RCCL bucket all-reduces + hipGraph(optimiser)",
+                            "full": "hipGraph of the whole step incl. captured RCCL all-reduces"}[m._graph_mode()],
+           "roofline": None}
+    if rank != 0:
+        return res
+    fl = by = ms = 0.0
+    nl = 0
+    per = {}
+    for tag, f, b, t in recs:
+        a = per.setdefault(tag, [0, 0.0, 0.0, 0.0])
+        a[0] += 1; a[1] += f; a[2] += b; a[3] += t
+        if tag in fam:
+            fl += f; by += b; ms += t; nl += 1
+    if nl:
+        ach = fl / (ms * 1e-3) / 1e12
+        traffic = tsrc = None
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc.json")      # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        if os.path.exists(pmc) and patch == 128 and batch == 1:
+            fams = json.load(open(pmc)).get("families", {})
+            ent = fams.get("bf16" if bf16 else "fp32")
+            if ent:
+                traffic = ent["hbm_bytes_per_launch"]
+                tsrc = "profiles/r02_pmc.json: rocprofv3 --pmc passes of this command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), not this run"
+        peak = PEAK_BF16_TFLOPS if bf16 else PEAK_FP32_TFLOPS
+        kname = ("conv5_bf16_kernel (fwd 32->16, bwd-data 16->32) + wgrad5_bf16_kernel" if bf16
+                 else "conv_kernel<5,1,4,8,8,4,4,{1,2}> (fwd 32->16, bwd-data 16->32) + wgrad_kernel<5,1,4,4,16,1,16>")
+        res["roofline"] = {
+            "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": traffic, "traffic_source": tsrc,
+            "kernel": kname + ": decoder level 1 conv_1, the 5^3 conv with 16 output channels @%d^3 -- forward, backward-data "
+                              "and filter-gradient launches" % patch,
+            "launches": nl, "avg_ms": round(ms / nl, 4), "flops_per_launch": fl / nl, "algorithmic_bytes_per_launch": by / nl,
+            "per_launch_ms": {tag: round(per[tag][3] / per[tag][0], 4) for tag in sorted(fam) if tag in per},
+            "hbm_GBps_algorithmic": round(by / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+            "measured": ("external HIP event nodes inside the replayed step graph, read after each of %d replays that follow "
+                         "the timed region" % min(args.steps, 10)) if graph else "HIP events on the launch stream inside the timed region"}
+    if full_table:
+        tot_ms = sum(v[3] for v in per.values())
+        res["conv_ms_per_step"] = round(tot_ms / args.steps, 3)
+        res["conv_tflops"] = round(sum(v[1] for v in per.values()) / max(tot_ms * 1e-3, 1e-12) / 1e12, 2)
+        for tag, v in sorted(per.items(), key=lambda kv: -kv[1][3]):
+            print("# %-40s n=%3d %8.3f ms/step %7.2f TF/s" % (tag, v[0] // args.steps, v[3] / args.steps, v[1] / (v[3] * 1e-3) / 1e12),
+                  file=sys.stderr)
+    return res
+
+
+def main():
+    args = parse()
+    if args.pin_core >= 0:
+        os.sched_setaffinity(0, {args.pin_core})     # before anything touches the GPU; no wrapper / launcher hop
+    import torch
+    import torch.distributed as dist
+    from vnet_tensorflow_amd import ops, parallel
+
+    rank, local, world = parallel.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1 and dist.get_world_size() != args.gpus:
+        raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+    torch.cuda.set_device(torch.device("cuda", local))
+
+    bf16 = args.compute == "bf16"
+    r = measure(args, args.patch, args.batch, args.channels, args.classes, args.compute, rank, local, world)
     if rank == 0:
-        # dominant kernel family: every launch of the two kernels that carry the 16-output-channel 5^3 convs at
-        # full resolution -- conv_kernel<5,1,4,8,8,4,4,1> (dec1/conv_1 fwd 32->16; 16->16 launches when the
-        # single-modality input block is not fused) and wgrad_kernel<5,1,4,4,16,1,16> (their filter gradients):
-        # 134.2 GF / 268.6 MB algorithmic per 16->16 launch, 268.4 GF / 402.9 MB per 32->16 launch at 128^3
-        # 
-        fl = by = ms = 0.0
-        nl = 0
-        per = {}
-        for tag, f, b, t in recs:
-            a = per.setdefault(tag, [0, 0.0, 0.0, 0.0])
-            a[0] += 1; a[1] += f; a[2] += b; a[3] += t
-            if tag in fam:
-                fl += f; by += b; ms += t; nl += 1
-        roof = None
-        if nl:
-            ach = fl / (ms * 1e-3) / 1e12
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-            if os.path.exists(pmc) and P == 128 and args.batch == 1 and not bf16:
-                ks = json.load(open(pmc))["kernels"]
-                sel = [v for k, v in ks.items() if k.startswith("conv_kernel<5, 1, 4, 8, 8, 4, 4, 1, false, 5> grid=2097152")
-                       or k.startswith("wgrad_kernel<5, 1, 4, 4, 16, 1, 16, 5>")]
-                if sel:
-                    traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in sel) / sum(v["launches"] for v in sel))
-            peak = PEAK_BF16_TFLOPS if bf16 else PEAK_FP32_TFLOPS
-            kname = ("conv5_bf16_kernel<4,8,16,1> + wgrad5_bf16_kernel<4,4,16,1,16>" if bf16
-                     else "conv_kernel<5,1,4,8,8,4,4,1> + wgrad_kernel<5,1,4,4,16,1,16>")
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic,
-                    "kernel": kname + ": the 5^3 convs with 16 output channels @%d^3 (fwd, bwd-data, bwd-filter)" % P,
-                    "launches": nl, "avg_ms": round(ms / nl, 4), "flops_per_launch": fl / nl, "algorithmic_bytes_per_launch": by / nl,
-                    "hbm_GBps_algorithmic": round(by / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-        conv_ms = sum(v[3] for v in per.values()) / args.steps
-        conv_tf = sum(v[1] for v in per.values()) / max(sum(v[3] for v in per.values()) * 1e-3, 1e-12) / 1e12
+        P = args.patch
         metric = "training patches/sec (128^3x1ch fp32)" if not bf16 else \
             "training patches/sec (%d^3x%dch, bf16 compute / fp32 accumulate)" % (P, args.channels)
-        out = {"metric": metric, "value": round(world * args.batch * args.steps / dt, 4),
+        out = {"metric": metric, "value": r["value"],
                "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
                "config": {"workload": "V-Net (16ch,4 levels,(1,2,3,3),3) train step fwd+Dice+bwd+Adam, %d^3 patch, %d modality, %d classes, "
                                       "batch %d/GPU (BASELINE configs[%d])" % (P, args.channels, args.classes, args.batch, 4 if bf16 else (2 if world == 1 else 3)),
-                          "global_batch": world * args.batch, "parallelism": "dp%d" % world, "bn": "per-replica"},
-               "final_loss": round(final_loss, 6), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
-               "roofline": roof}
-        if full_table:
-            out["conv_ms_per_step"], out["conv_tflops"] = round(conv_ms, 3), round(conv_tf, 2)
+                          "global_batch": world * args.batch, "parallelism": "dp%d" % world, "bn": "per-replica",
+                          "ranks": world, "backend": (dist.get_backend() if world > 1 else None)},
+               "final_loss": r["final_loss"], "host_enqueue_ms_per_step": r["host_enqueue_ms_per_step"],
+               "step_enqueue": r["step_enqueue"], "pinned_to_core": args.pin_core if args.pin_core >= 0 else None,
+               "roofline": r["roofline"]}
+        for k in ("conv_ms_per_step", "conv_tflops"):
+            if k in r:
+                out[k] = r[k]
+    if world == 1 and not bf16 and not args.no_c5 and args.patch == 128 and args.channels == 1:
+        # BASELINE configs[4] per-GPU workload on the same record (outside the headline's timed region)
+        c5 = measure(args, args.patch, args.batch, 4, 5, "bf16", rank, local, world)
+        ops.set_compute_dtype("fp32")
+        c5["metric"] = "training patches/sec (128^3x4ch, 5 classes, bf16 conv operands / fp32 accumulate), 1 GPU"
+        c5["dtype"] = "bf16"
+        c5["steps"], c5["warmup"] = args.steps, args.warmup
+        out["c5_bf16"] = c5
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        if full_table:
-            for tag, v in sorted(per.items(), key=lambda kv: -kv[1][3]):
-                print("# %-40s n=%3d %8.3f ms/step %7.2f TF/s" % (tag, v[0] // args.steps, v[3] / args.steps, v[1] / (v[3] * 1e-3) / 1e12),
-                      file=sys.stderr)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -249,6 +249,22 @@ int vnet_sgd_apply(float* p, const float* g, int64_t n, float lr, float gscale, 
 int vnet_momentum_apply(float* p, const float* g, float* acc, int64_t n, float lr, float momentum,
                         int nesterov, float gscale, void* stream);
 
+/* ---- device-resident step state: one host call per training step (model.py:743-748 is one sess.run per step) ----
+ * A hipGraph freezes kernel ARGUMENTS, not memory.  `state` is a caller-owned 32-byte device buffer
+ * {float lr; float lr_t; u32 pad[2]; u64 step; u64 pad}; vnet_step_state_set (a one-thread kernel, arguments by
+ * value, launched eagerly before each replay) writes this step's learning rate (model.py:641-644), Adam's
+ * bias-corrected lr_t and the step number.  The *_dev forms of the optimisers read lr / lr_t from it instead of
+ * from an argument and the dropout adds step * odd constant to its seed, so a captured graph of the WHOLE step
+ * (forward + loss + backward + optimiser + filter repack) is replayed unchanged every iteration. */
+int vnet_step_state_set(void* state, float lr, float lr_t, uint64_t step, void* stream);
+int vnet_adam_apply_dev(float* p, const float* g, float* m, float* v, int64_t n,
+                        const void* state, float beta1, float beta2, float eps, float gscale, void* stream);
+int vnet_sgd_apply_dev(float* p, const float* g, int64_t n, const void* state, float gscale, void* stream);
+int vnet_momentum_apply_dev(float* p, const float* g, float* acc, int64_t n, const void* state, float momentum,
+                            int nesterov, float gscale, void* stream);
+int vnet_dropout_fwd_dev(const float* x, float* y, uint8_t* mask, int64_t n, float rate, uint64_t seed,
+                         const void* state, void* stream);
+
 /* ---- hard metrics (model.py:588-626): K x K confusion matrix cm[label][prediction] as float64 counts;
  * accuracy, per-class tp/tn/fp/fn, sensitivity, specificity and hard Dice 2tp/(2tp+fp+fn) follow on the host. */
 size_t vnet_confusion_ws_bytes(int K);

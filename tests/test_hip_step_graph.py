@@ -1,0 +1,183 @@
+"""-m gpu: the whole training step as ONE hipGraph (model.image2label.train_step; reference model.py:743-748 is one
+sess.run per step).  The graph holds exactly the launches the eager step makes -- forward, loss, backward on two
+streams, fused optimiser, batched filter repack -- with the per-step scalars (learning rate, Adam's lr_t, dropout
+stream position) read from the device step state, so replay must be BIT-identical to the eager step."""
+import os
+import pathlib
+import socket
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(P=16, dropout=0.0, opt="Adam", compute="fp32", cin=1, K=2, loss="sorensen"):
+    return {"TrainingSetting": {
+        "Data": {"TrainingDataDirectory": "synthetic", "TestingDataDirectory": "synthetic",
+                 "ImageFilenames": ["image%d.npy" % i for i in range(cin)], "LabelFilename": "label.npy",
+                 "Synthetic": {"Cases": 4}},
+        "SegmentationClasses": list(range(K)), "BatchSize": 2, "PatchShape": [P] * 3, "ComputeDtype": compute,
+        "Networks": {"Name": "VNet", "Dropout": dropout, "NumChannel": 8, "NumLevels": 3, "NumConvolutions": [1, 2, 2],
+                     "BottomConvolutions": 2},
+        "Loss": {"Name": loss, "Weights": [0.3, 0.7, 1.0, 0.5, 0.2][:K], "Alpha": 0.5},
+        "Optimizer": {"Name": opt, "InitialLearningRate": 1e-2, "Momentum": 0.9, "Decay": {"Factor": 0.9, "Steps": 3}}}}
+
+
+def _run(dev, graph, steps, monkeypatch, **kw):
+    from vnet_tensorflow_amd import ops
+    from vnet_tensorflow_amd.model import image2label
+    from oracle.vnet_oracle import synthetic_batch
+    monkeypatch.setenv("VNET_STEP_GRAPH", "1" if graph else "0")
+    cfg = _cfg(**kw)
+    T = cfg["TrainingSetting"]
+    cin, K, P = len(T["Data"]["ImageFilenames"]), len(T["SegmentationClasses"]), T["PatchShape"][0]
+    np.random.seed(7)
+    m = image2label(None, cfg, device=dev, verbose=False)
+    try:
+        m.read_config()
+        m.build_model_graph()
+        m._setup_training()
+        batches = [synthetic_batch(2, P, cin, K, seed=40 + i) for i in range(2)]
+        batches = [(torch.from_numpy(x).to(dev), torch.from_numpy(l).to(dev)) for x, l in batches]
+        losses = []
+        for i in range(steps):
+            x, l = batches[i % 2]                      # the inputs change between replays: static-buffer copy is exercised
+            losses.append(float(m.train_step(x, l)))
+        torch.cuda.synchronize()
+        assert (m._graph_mode() == "whole") == graph
+        if graph:
+            assert m._graphs is not None and len(m._graphs) == 1, "the step was never captured"
+    finally:
+        ops.set_compute_dtype("fp32")
+    state = {k: v.clone() for k, v in m.network.state_dict().items()}
+    return losses, m.flat.data.clone(), state, {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in m.optimizer.state_dict().items()}
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),                                                       # Adam, no dropout (the bench configuration)
+    dict(dropout=0.05),                                           # dropout masks from the device step state
+    dict(opt="NesterovMomentum", loss="mixed_weighted_jaccard", cin=2, K=3),
+    dict(opt="SGD", compute="bf16", cin=4, K=5),                  # BASELINE config C5 arithmetic
+], ids=["adam", "dropout", "nesterov-mixed", "sgd-bf16"])
+def test_graph_replay_is_bit_identical_to_eager(dev, monkeypatch, kw):
+    """6 steps: 2 eager warm-up steps + capture + 4 replays against 6 eager steps -- same losses, parameters, moving
+    statistics and optimiser slots, bit for bit (LR decays every step, so a frozen scalar would show)."""
+    a = _run(dev, True, 6, monkeypatch, **kw)
+    b = _run(dev, False, 6, monkeypatch, **kw)
+    assert a[0] == b[0], (a[0], b[0])
+    assert torch.equal(a[1], b[1])
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+    for k in a[3]:
+        assert (torch.equal(a[3][k], b[3][k]) if isinstance(a[3][k], torch.Tensor) else a[3][k] == b[3][k]), k
+    assert a[0][-1] < a[0][0]                                      # and it trains
+
+
+def test_graph_step_is_one_host_call(dev, monkeypatch):
+    """Host cost of a replayed step: a handful of microsecond-scale calls instead of ~400 ctypes launches."""
+    from vnet_tensorflow_amd.model import image2label
+    from oracle.vnet_oracle import synthetic_batch
+    res = {}
+    for graph in (True, False):
+        monkeypatch.setenv("VNET_STEP_GRAPH", "1" if graph else "0")
+        np.random.seed(7)
+        m = image2label(None, _cfg(P=32), device=dev, verbose=False)
+        m.read_config()
+        m.build_model_graph()
+        m._setup_training()
+        x, l = synthetic_batch(2, 32, 1, 2, seed=40)
+        x, l = torch.from_numpy(x).to(dev), torch.from_numpy(l).to(dev)
+        for _ in range(4):
+            m.train_step(x, l)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            m.train_step(x, l)
+        res[graph] = (time.perf_counter() - t0) / 10
+        torch.cuda.synchronize()
+    print("host enqueue per step: graph %.3f ms, eager %.3f ms" % (res[True] * 1e3, res[False] * 1e3))
+    assert res[True] < 0.5 * res[False] or res[True] < 1e-3
+
+
+def test_timed_launches_inside_the_graph(dev, monkeypatch):
+    """bench.py's roofline leg: HIP events recorded as EXTERNAL event nodes of the captured step give the duration of
+    the tagged launches of every replay."""
+    from vnet_tensorflow_amd import ops
+    from vnet_tensorflow_amd.model import image2label
+    from oracle.vnet_oracle import synthetic_batch
+    monkeypatch.setenv("VNET_STEP_GRAPH", "1")
+    np.random.seed(7)
+    m = image2label(None, _cfg(P=32), device=dev, verbose=False)
+    m.read_config()
+    m.build_model_graph()
+    m._setup_training()
+    x, l = synthetic_batch(2, 32, 1, 2, seed=40)
+    x, l = torch.from_numpy(x).to(dev), torch.from_numpy(l).to(dev)
+    fam = {"conv k5 s1 32^3x2 16->8", "wgrad k5 s1 32^3x2 16->8"}
+    ops._PROFILE["graph_records"] = []
+    ops.profile_start(fam)
+    try:
+        for _ in range(4):
+            m.train_step(x, l)
+        torch.cuda.synchronize()
+        recs = ops.profile_read()
+    finally:
+        ops.profile_stop()
+        ops._PROFILE["graph_records"] = []
+    assert sorted(t for t, _, _, _ in recs) == sorted(fam), recs
+    for tag, fl, by, ms in recs:
+        assert 0.0 < ms < 5.0, (tag, ms)
+        assert fl == 2.0 * 2 * 32 ** 3 * 125 * 16 * 8
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, out, mode):
+    """One rank, process group "nccl" (= RCCL) on cuda:0, the data-parallel collective path forced on."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      VNET_DP_FORCE="1", VNET_DP_BUCKET_BYTES=str(16 << 10))
+    os.environ["VNET_STEP_GRAPH"] = "0" if mode == "eager" else "1"
+    os.environ["VNET_DP_GRAPH"] = "full" if mode == "full" else "segmented"
+    import torch.distributed as dist
+    from vnet_tensorflow_amd.model import image2label
+    from oracle.vnet_oracle import synthetic_batch
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    np.random.seed(7)
+    m = image2label(None, _cfg(), device=dev, verbose=False)
+    m.read_config()
+    m.build_model_graph()
+    m._setup_training()
+    assert m.sync is not None and m.sync.active and len(m.sync.buckets) >= 3
+    x, l = synthetic_batch(2, 16, 1, 2, seed=40)
+    x, l = torch.from_numpy(x).to(dev), torch.from_numpy(l).to(dev)
+    losses = [float(m.train_step(x, l)) for _ in range(5)]
+    torch.cuda.synchronize()
+    assert m._graph_mode() == {"eager": "off", "segmented": "segmented", "full": "full"}[mode]
+    if mode != "eager":
+        assert m._graphs is not None and len(m._graphs) == (2 if mode == "segmented" else 1)
+    torch.save({"losses": losses, "data": m.flat.data.cpu()}, os.path.join(out, "dp_%s.pt" % mode))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["segmented", "full"])
+def test_data_parallel_graph_modes_rccl_group_of_one(tmp_path, dev, mode):
+    """Data-parallel step with RCCL in the loop (group of one rank: all a 1-GPU box can host):
+    'segmented' = gradients graph -> eager bucket all-reduces -> optimiser graph (no collective is captured);
+    'full' = the all-reduces captured between the backward kernels.  Both must reproduce the eager step bit for bit."""
+    for md in ("eager", mode):
+        mp.spawn(_dp_worker, args=(1, _free_port(), str(tmp_path), md), nprocs=1, join=True)
+    a, b = torch.load(tmp_path / "dp_eager.pt"), torch.load(tmp_path / ("dp_%s.pt" % mode))
+    assert a["losses"] == b["losses"]
+    assert torch.equal(a["data"], b["data"])

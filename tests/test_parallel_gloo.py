@@ -103,3 +103,103 @@ def test_bucketed_allreduce_world2(tmp_path, hold):
     # the never-touched ("dead") variable stays exactly zero after the flushed all-reduce
     o = flat.offsets[flat.names.index("dead/gamma")]
     assert float(r0["grads"][0][o:o + 5].abs().sum()) == 0.0
+
+
+# ---- launch point of the held buckets (the threshold must not depend on where the size cuts fall) ----------
+def _chain_model(seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [("a", (6, 6)), ("b", (6, 6)), ("c", (6, 40)), ("d", (40, 10)), ("e", (10, 2))]     # forward order
+    return [(n, torch.nn.Parameter(0.3 * torch.randn(s, generator=g))) for n, s in shapes]
+
+
+def _chain_loss(params, x):
+    h = x
+    for _, p in params:
+        h = torch.tanh(h @ p)
+    return (h ** 2).mean()
+
+
+def _hold_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from vnet_tensorflow_amd import optim, parallel
+    parallel.init_from_env("gloo")
+    params = _chain_model(5)
+    flat = optim.FlatParams(params)          # gradient-production order: e (20), d (400), c (240), b (36), a (36) floats
+    # one size-driven bucket would hold everything; 55 % of the bytes exist once d's gradient is written
+    sync = parallel.BucketedGradAllReduce(flat, bucket_bytes=1 << 20, hold_fraction=0.55)
+    assert [(f, l) for _, _, f, l in sync.buckets] == [(0, 2), (2, 5)], sync.buckets
+    logs = []
+    for step in range(3):
+        x = torch.randn(4, 6, generator=torch.Generator().manual_seed(step))
+        flat.zero_grad()
+        sync.begin_step()
+        _chain_loss(params, x).backward()
+        logs.append(list(sync.launch_log))
+        sync.finish()
+    torch.save({"logs": logs, "grad": flat.grad.clone()}, os.path.join(out, "h%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_hold_fraction_launches_before_backward_ends(tmp_path):
+    """With hold_fraction = f the collective starts when a fraction f of the gradient BYTES exists -- here after 2 of the 5
+    gradient events -- not when the last size-driven bucket completes (which would be the end of backward)."""
+    mp.spawn(_hold_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r = torch.load(tmp_path / "h0.pt")
+    assert r["logs"][0] == []                                 # calibration step: nothing before finish()
+    for log in r["logs"][1:]:
+        assert log[0] == (0, 2), log                           # bucket 0 went out after the 2nd of 5 gradient events
+        assert log[-1] == (1, 5)
+    assert torch.equal(r["grad"], torch.load(tmp_path / "h1.pt")["grad"])
+
+
+# ---- dataset sharding (ADVICE r1: unequal step counts hang the collectives) ------------------------------------
+def _shard_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from vnet_tensorflow_amd import data, parallel
+    parallel.init_from_env("gloo")
+    ds = data.VolumeDataset("synthetic", ["image.npy"], "label.npy", [0, 1], (8, 8, 8), 1, train=True, seed=3,
+                            synthetic={"Cases": 10, "Shape": [10, 10, 10]}, rank=rank, world=world)
+    seen = []
+    for epoch in range(2):
+        n = 0
+        plan = ds.epoch_plan()
+        for cases, seeds in plan:
+            img, lab = ds.make_batch(cases, seeds)
+            assert img.shape == (1, 8, 8, 8, 1) and lab.dtype == np.int32
+            t = torch.ones(1)
+            dist.all_reduce(t)            # the per-step collective: pairs up only if every rank takes the same number of steps
+            assert float(t) == world
+            n += 1
+            seen.append((epoch, cases[0]))
+        assert n == ds.steps_per_epoch() == 10 // world
+    torch.save(seen, os.path.join(out, "d%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [3, 4])
+def test_dataset_shards_are_disjoint_and_equal_length(tmp_path, world):
+    """10 cases on 3 / 4 ranks (10 % world != 0): every rank runs floor(10/world) steps per epoch, no case is seen twice in
+    an epoch, and the per-step collective never waits for a rank that has already finished."""
+    mp.spawn(_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    seen = [torch.load(tmp_path / ("d%d.pt" % r)) for r in range(world)]
+    for epoch in range(2):
+        cases = [c for s in seen for (e, c) in s if e == epoch]
+        assert len(cases) == world * (10 // world) and len(set(cases)) == len(cases)
+    assert [c for s in seen for (e, c) in s if e == 0] != [c for s in seen for (e, c) in s if e == 1]     # reshuffled per epoch
+
+
+def test_dataset_refuses_a_rank_without_work():
+    from vnet_tensorflow_amd import data
+    with pytest.raises(ValueError):
+        data.VolumeDataset("synthetic", ["image.npy"], "label.npy", [0, 1], (8, 8, 8), 2, synthetic={"Cases": 3}, rank=0, world=2)
+
+
+def test_prefetcher_keeps_order_and_content():
+    from vnet_tensorflow_amd import data
+    mk = lambda: data.VolumeDataset("synthetic", ["image.npy"], "label.npy", [0, 1, 2], (8, 8, 8), 2, train=True, seed=1,
+                                    synthetic={"Cases": 9, "Shape": [12, 10, 9]})
+    plain = list(mk())
+    pre = list(data.Prefetcher(mk(), depth=3, workers=3, pin=False))
+    assert len(plain) == len(pre) == 4
+    for (a, b), (c, d) in zip(plain, pre):
+        assert np.array_equal(a, c.numpy()) and np.array_equal(b, d.numpy())

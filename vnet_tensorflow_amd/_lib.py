@@ -62,6 +62,11 @@ SIGNATURES = {
     "vnet_adam_apply": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp]),
     "vnet_sgd_apply": (_i, [_vp, _vp, _i64, _f, _f, _vp]),
     "vnet_momentum_apply": (_i, [_vp, _vp, _vp, _i64, _f, _f, _i, _f, _vp]),
+    "vnet_step_state_set": (_i, [_vp, _f, _f, _u64, _vp]),
+    "vnet_adam_apply_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _vp]),
+    "vnet_sgd_apply_dev": (_i, [_vp, _vp, _i64, _vp, _f, _vp]),
+    "vnet_momentum_apply_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _f, _i, _f, _vp]),
+    "vnet_dropout_fwd_dev": (_i, [_vp, _vp, _vp, _i64, _f, _u64, _vp, _vp]),
     "vnet_confusion_ws_bytes": (_sz, [_i]),
     "vnet_confusion_matrix": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
     "vnet_accumulate_patch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

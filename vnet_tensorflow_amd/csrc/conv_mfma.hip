@@ -739,6 +739,18 @@ template <typename K>
 int set_lds(K kernel, size_t bytes) {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
+// The dynamic-LDS attribute is per (kernel, device): remember per device which ones are configured (a process that
+// drives a non-zero device, or several, must configure each of them once).
+template <typename K>
+int ensure_lds(K kernel, size_t bytes, unsigned long long& done_mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done_mask & bit) return 0;
+    const int e = set_lds(kernel, bytes);
+    if (e == 0) done_mask |= bit;
+    return e;
+}
 
 int pick_ns(int CoutP) { return (CoutP % 64 == 0) ? 4 : (CoutP % 32 == 0) ? 2 : 1; }
 
@@ -800,9 +812,8 @@ int launch_conv_ns(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
 #define VNET_GO(NSV)                                                                              \
     {                                                                                             \
         auto k = conv_kernel<KS, STRIDE, TZ, TY, TX, WAVES, MS, NSV, UP, KX>;                         \
-        static int attr_done = -1;                                                                \
-        if (attr_done != 0) attr_done = set_lds(k, lds);                                          \
-        if (attr_done != 0) return attr_done;                                                     \
+        static unsigned long long attr_done = 0;                                                  \
+        if (int ae = ensure_lds(k, lds, attr_done)) return ae;                                    \
         hipLaunchKernelGGL(k, grid, block, lds, st, a);                                           \
     }
     if (p.ns == 4) VNET_GO(4) else if (p.ns == 2) VNET_GO(2) else VNET_GO(1)
@@ -1273,9 +1284,8 @@ int launch_wgrad_bf16(const WgradArgs& a, int nsplit, int ncob, int ntg, hipStre
     using G = TileGeom<5, 1, TZ, TY, TX, 5>;
     const size_t lds = (size_t)G::NVOX_IN * 32 + (size_t)NS * TZ * TY * (TX + 4) * 32;
     auto k = wgrad5_bf16_kernel<TZ, TY, TX, NS, TW>;
-    static int attr_done = -1;
-    if (attr_done != 0) attr_done = set_lds(k, lds);
-    if (attr_done != 0) return attr_done;
+    static unsigned long long attr_done = 0;
+    if (int ae = ensure_lds(k, lds, attr_done)) return ae;
     dim3 grid(nsplit, (a.CinP / 16) * ncob, ntg);
     hipLaunchKernelGGL(k, grid, dim3(512), lds, st, a);
     return (int)hipGetLastError();
@@ -1312,9 +1322,8 @@ int launch_conv_bf16(const ConvArgs& a, const Bf16Plan& p, hipStream_t st) {
     {                                                                                             \
         auto k = conv5_bf16_kernel<TZ, TY, TX, NSBV, WAVES>;                                      \
         const size_t lds = (size_t)G::TILE_BYTES + (size_t)25 * NSBV * 1024 + 16 + 64 * 16;       \
-        static int attr_done = -1;                                                                \
-        if (attr_done != 0) attr_done = set_lds(k, lds);                                          \
-        if (attr_done != 0) return attr_done;                                                     \
+        static unsigned long long attr_done = 0;                                                  \
+        if (int ae = ensure_lds(k, lds, attr_done)) return ae;                                    \
         hipLaunchKernelGGL(k, grid, block, lds, st, a);                                           \
     }
     if (p.nsb == 2) VNET_GO(2) else VNET_GO(1)
@@ -1527,9 +1536,8 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
     using G = TileGeom<KS, STRIDE, TZ, TY, TX, KX>;
     const size_t lds = ((size_t)G::LDS_FLOATS + (size_t)TZ * TY * TX * NS * 16) * 4;
     auto k = wgrad_kernel<KS, STRIDE, TZ, TY, TX, NS, TW, KX>;
-    static int attr_done = -1;
-    if (attr_done != 0) attr_done = set_lds(k, lds);
-    if (attr_done != 0) return attr_done;
+    static unsigned long long attr_done = 0;
+    if (int ae = ensure_lds(k, lds, attr_done)) return ae;
     dim3 grid(p.nsplit, (a.CinP / 16) * p.ncob, p.ntg);
     hipLaunchKernelGGL(k, grid, dim3(512), lds, st, a);
     return (int)hipGetLastError();

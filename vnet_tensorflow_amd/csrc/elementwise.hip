@@ -827,9 +827,15 @@ __device__ __forceinline__ uint32_t mix32(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
     return (uint32_t)x;
 }
+// Device-resident step state (vnet_step_state_set): lets a captured hipGraph of the whole training step be replayed with a
+// new learning rate / dropout stream every step without re-capturing (kernel arguments are frozen in a graph, memory is not).
+struct StepState { float lr, lr_t; uint32_t pad0, pad1; uint64_t step; uint64_t pad2; };
+__global__ void step_state_kernel(StepState* s, float lr, float lr_t, uint64_t step) { s->lr = lr; s->lr_t = lr_t; s->step = step; }
+
 __global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ mask,
-                                   size_t n, float rate, uint64_t seed) {
+                                   size_t n, float rate, uint64_t seed, const StepState* __restrict__ st) {
     const float sc = 1.f / (1.f - rate);
+    if (st) seed += st->step * 0xD1342543DE82EF95ULL;          // a fresh mask per replayed step
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float u = (mix32(seed * 0x9E3779B97F4A7C15ULL + i) >> 8) * (1.f / 16777216.f);
         const uint8_t keep = u >= rate;
@@ -844,7 +850,8 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
 
 // ---- optimisers ----------------------------------------------------------------------------------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            size_t n, float lr_t, float b1, float b2, float eps, float gs) {
+                            size_t n, float lr_t, float b1, float b2, float eps, float gs, const StepState* __restrict__ st) {
+    if (st) lr_t = st->lr_t;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * gs;
         const float mi = m[i] + (gi - m[i]) * (1.f - b1);
@@ -853,11 +860,13 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         p[i] -= lr_t * mi / (sqrtf(vi) + eps);
     }
 }
-__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, size_t n, float lr, float gs) {
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, size_t n, float lr, float gs, const StepState* __restrict__ st) {
+    if (st) lr = st->lr;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] -= lr * gs * g[i];
 }
 __global__ void momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ acc, size_t n,
-                                float lr, float mom, int nesterov, float gs) {
+                                float lr, float mom, int nesterov, float gs, const StepState* __restrict__ st) {
+    if (st) lr = st->lr;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * gs;
         const float a = acc[i] * mom + gi;
@@ -1235,11 +1244,22 @@ int vnet_dice_coe_bwd(const float* output, const float* target, int B, int64_t V
     return VNET_OK;
 }
 
-int vnet_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float rate, uint64_t seed, void* stream) {
-    if (!x || !y || !mask || n <= 0 || rate < 0.f || rate >= 1.f) return VNET_E_BADARG;
-    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(ew_blocks((size_t)n / 4 + 1)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, y, mask, (size_t)n, rate, seed);
+int vnet_step_state_set(void* state, float lr, float lr_t, uint64_t step, void* stream) {
+    if (!state) return VNET_E_BADARG;
+    hipLaunchKernelGGL(step_state_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (StepState*)state, lr, lr_t, step);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
+}
+
+int vnet_dropout_fwd_dev(const float* x, float* y, uint8_t* mask, int64_t n, float rate, uint64_t seed, const void* state, void* stream) {
+    if (!x || !y || !mask || n <= 0 || rate < 0.f || rate >= 1.f) return VNET_E_BADARG;
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(ew_blocks((size_t)n / 4 + 1)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, y, mask, (size_t)n, rate, seed,
+                       (const StepState*)state);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+int vnet_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float rate, uint64_t seed, void* stream) {
+    return vnet_dropout_fwd_dev(x, y, mask, n, rate, seed, nullptr, stream);
 }
 int vnet_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float rate, void* stream) {
     if (!dy || !dx || !mask || n <= 0 || rate < 0.f || rate >= 1.f) return VNET_E_BADARG;
@@ -1248,27 +1268,53 @@ int vnet_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n,
     return VNET_OK;
 }
 
-int vnet_adam_apply(float* p, const float* g, float* m, float* v, int64_t n,
-                    float lr_t, float beta1, float beta2, float eps, float gscale, void* stream) {
+static int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, const void* state,
+                       float beta1, float beta2, float eps, float gscale, void* stream) {
     if (!p || !g || !m || !v || n <= 0) return VNET_E_BADARG;
     hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks((size_t)n / 4 + 1) * 2), dim3(EW_BLOCK), 0, (hipStream_t)stream, p, g, m, v, (size_t)n,
-                       lr_t, beta1, beta2, eps, gscale);
+                       lr_t, beta1, beta2, eps, gscale, (const StepState*)state);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+int vnet_adam_apply(float* p, const float* g, float* m, float* v, int64_t n,
+                    float lr_t, float beta1, float beta2, float eps, float gscale, void* stream) {
+    return adam_launch(p, g, m, v, n, lr_t, nullptr, beta1, beta2, eps, gscale, stream);
+}
+int vnet_adam_apply_dev(float* p, const float* g, float* m, float* v, int64_t n,
+                        const void* state, float beta1, float beta2, float eps, float gscale, void* stream) {
+    if (!state) return VNET_E_BADARG;
+    return adam_launch(p, g, m, v, n, 0.f, state, beta1, beta2, eps, gscale, stream);
+}
+static int sgd_launch(float* p, const float* g, int64_t n, float lr, const void* state, float gscale, void* stream) {
+    if (!p || !g || n <= 0) return VNET_E_BADARG;
+    hipLaunchKernelGGL(sgd_kernel, dim3(ew_blocks((size_t)n / 4 + 1) * 2), dim3(EW_BLOCK), 0, (hipStream_t)stream, p, g, (size_t)n, lr, gscale,
+                       (const StepState*)state);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
 }
 int vnet_sgd_apply(float* p, const float* g, int64_t n, float lr, float gscale, void* stream) {
-    if (!p || !g || n <= 0) return VNET_E_BADARG;
-    hipLaunchKernelGGL(sgd_kernel, dim3(ew_blocks((size_t)n / 4 + 1) * 2), dim3(EW_BLOCK), 0, (hipStream_t)stream, p, g, (size_t)n, lr, gscale);
+    return sgd_launch(p, g, n, lr, nullptr, gscale, stream);
+}
+int vnet_sgd_apply_dev(float* p, const float* g, int64_t n, const void* state, float gscale, void* stream) {
+    if (!state) return VNET_E_BADARG;
+    return sgd_launch(p, g, n, 0.f, state, gscale, stream);
+}
+static int momentum_launch(float* p, const float* g, float* acc, int64_t n, float lr, const void* state, float momentum,
+                           int nesterov, float gscale, void* stream) {
+    if (!p || !g || !acc || n <= 0) return VNET_E_BADARG;
+    hipLaunchKernelGGL(momentum_kernel, dim3(ew_blocks((size_t)n / 4 + 1) * 2), dim3(EW_BLOCK), 0, (hipStream_t)stream, p, g, acc, (size_t)n,
+                       lr, momentum, nesterov, gscale, (const StepState*)state);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
 }
 int vnet_momentum_apply(float* p, const float* g, float* acc, int64_t n, float lr, float momentum,
                         int nesterov, float gscale, void* stream) {
-    if (!p || !g || !acc || n <= 0) return VNET_E_BADARG;
-    hipLaunchKernelGGL(momentum_kernel, dim3(ew_blocks((size_t)n / 4 + 1) * 2), dim3(EW_BLOCK), 0, (hipStream_t)stream, p, g, acc, (size_t)n,
-                       lr, momentum, nesterov, gscale);
-    VNET_LAUNCH_CHECK();
-    return VNET_OK;
+    return momentum_launch(p, g, acc, n, lr, nullptr, momentum, nesterov, gscale, stream);
+}
+int vnet_momentum_apply_dev(float* p, const float* g, float* acc, int64_t n, const void* state, float momentum,
+                            int nesterov, float gscale, void* stream) {
+    if (!state) return VNET_E_BADARG;
+    return momentum_launch(p, g, acc, n, 0.f, state, momentum, nesterov, gscale, stream);
 }
 
 int vnet_accumulate_patch(const float* patch, float* vol, float* count, int K,

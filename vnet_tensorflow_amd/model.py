@@ -14,6 +14,7 @@ import math
 import os
 import shutil
 import sys
+import time
 
 import numpy as np
 import torch
@@ -96,6 +97,71 @@ def _now():
     return datetime.datetime.now()
 
 
+class _DeviceFeeder(object):
+    """Double-buffered host-to-device input path of the training loop: batch t+1 is copied from pinned host memory into
+    its device slot on a COPY stream while step t runs; the compute stream only waits for the copy's event.  A slot is
+    rewritten only after the step that read it has finished (event recorded behind that step).  With this the
+    PCIe transfer (16.8 MB per 128^3 fp32 patch + int32 labels) is off the step's critical path."""
+
+    def __init__(self, device, loader):
+        self.device, self.it = device, iter(loader)
+        self.cuda = device.type == "cuda"
+        self.copy_stream = torch.cuda.Stream(device=device) if self.cuda else None
+        self.slots = [None, None]
+        self.ready = [None, None]
+        self.done = [None, None]
+        self.t = 0
+        self._stage(0)
+
+    def _stage(self, k):
+        try:
+            img, lab = next(self.it)
+        except StopIteration:
+            self.slots[k] = None
+            return
+        img = img if isinstance(img, torch.Tensor) else torch.from_numpy(img)
+        lab = lab if isinstance(lab, torch.Tensor) else torch.from_numpy(lab)
+        if not self.cuda:
+            self.slots[k] = (img.to(self.device), lab.to(self.device))
+            return
+        with torch.cuda.stream(self.copy_stream):
+            if self.done[k] is not None:
+                self.copy_stream.wait_event(self.done[k])          # the step that read this slot has finished
+            old = self.slots[k]
+            if old is not None and old[0].shape == img.shape and old[1].shape == lab.shape:
+                di, dl = old
+                di.copy_(img, non_blocking=True)
+                dl.copy_(lab, non_blocking=True)
+            else:
+                di, dl = img.to(self.device, non_blocking=True), lab.to(self.device, non_blocking=True)
+            self.slots[k] = (di, dl)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+            self.ready[k] = ev
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        k = self.t % 2
+        cur = self.slots[k]
+        if cur is None:
+            raise StopIteration
+        self._stage(1 - k)                                          # batch t+1 starts its transfer now
+        if self.cuda:
+            torch.cuda.current_stream(self.device).wait_event(self.ready[k])
+        self._cur = k
+        self.t += 1
+        return cur
+
+    def step_done(self):
+        """Call after the step that consumed the last batch has been enqueued."""
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.done[self._cur] = ev
+
+
 # ------------------------------------------------------------------------------------------------
 # image2label -- reference model.py:169-1242
 # ------------------------------------------------------------------------------------------------
@@ -118,6 +184,10 @@ class image2label(object):
     def _print(self, *a):
         if self.verbose and self.rank == 0:
             print(*a)
+
+    def _device_sync(self):
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
 
     # -- reference model.py:185-245, with the corrected key set of SURVEY.md B.3 --------------------
     def read_config(self):
@@ -192,6 +262,8 @@ class image2label(object):
             if not torch.cuda.is_available():
                 raise VnetHipError("no HIP device: the MI355X kernels are the only compute path")
             self.device = torch.device("cuda", self.local_rank)
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)     # kernels are launched on the CURRENT device's current stream (ops._raw_stream)
         self.input_batch_shape = (self.batch_size,) + tuple(self.patch_shape) + (self.input_channel_num,)
         self.output_batch_shape = (self.batch_size,) + tuple(self.patch_shape) + (1,)
         self.dropout_placeholder = self.dropout_rate     # stand-in for "dropout_placeholder" (model.py:312)
@@ -243,7 +315,8 @@ class image2label(object):
         self.sync = None
         pg = os.environ.get("VNET_PARAM_GRAD_STREAM")
         ops.set_param_grad_stream(self.device.type == "cuda" and (getattr(self, "param_grad_stream", True) if pg is None else pg == "1"))
-        if self.world > 1:
+        force = os.environ.get("VNET_DP_FORCE") == "1" and torch.distributed.is_available() and torch.distributed.is_initialized()
+        if self.world > 1 or force:      # VNET_DP_FORCE: run the collective path in a group of one (RCCL on a 1-GPU box)
             parallel.broadcast_parameters(self.flat.data)
             self.optimizer.gscale = 1.0 / self.world
             # launch the bucket all-reduces once this fraction of the gradient bytes exists (parallel.py): keeps the
@@ -251,26 +324,136 @@ class image2label(object):
             # (bf16 mode: the backward pass that is left after encoder level 3 is shorter than the all-reduce -> launch when ready)
             default_hold = 0.99 if ops.get_compute_dtype() == "fp32" else 0.0
             hold = float(os.environ.get("VNET_DP_HOLD", getattr(self, "allreduce_hold_fraction", default_hold)))
-            self.sync = parallel.BucketedGradAllReduce(self.flat, hold_fraction=hold)
+            self.sync = parallel.BucketedGradAllReduce(self.flat, hold_fraction=hold, force=force,
+                                                       bucket_bytes=int(os.environ.get("VNET_DP_BUCKET_BYTES", 32 << 20)))
             if getattr(self, "sync_batch_norm", False):
                 # single-device BatchSize = world x per-rank batch semantics of the reference (networks.py:319);
                 # the default (per-replica statistics) equals the reference run on each rank's batch alone
                 ops.set_sync_batch_norm()
 
-    def train_step(self, images, labels, dropout=None):
-        """reference model.py:743-748: one fwd + loss + bwd + optimiser step; returns the loss tensor."""
-        lr = optim.exponential_decay(self.initial_learning_rate, self.global_step, self.decay_steps, self.decay_factor)
+    # -- one training step (reference model.py:743-748: ONE sess.run per step) ------------------------------------
+    def _compute_gradients(self, images, labels, dropout):
+        """zero the flat gradient buffer, forward, loss, backward, join the parameter-gradient stream."""
         self.flat.zero_grad()
+        ops.begin_dropout_pass()
+        _, loss, _, _ = self.forward(images, labels, dropout)
+        loss.backward()
+        ops.join_param_grad_stream()          # filter / bias gradients were enqueued on their own stream
+        return loss
+
+    def _train_step_eager(self, images, labels, dropout):
+        lr = optim.exponential_decay(self.initial_learning_rate, self.global_step, self.decay_steps, self.decay_factor)
         if self.sync is not None:
             self.sync.begin_step()
-        _, loss, _, _ = self.forward(images, labels, self.dropout_rate if dropout is None else dropout)
-        loss.backward()
+        if dropout > 0.0 and self.device.type == "cuda":
+            # dropout masks from (layer position, step number in the device step state): the same stream of masks
+            # whether the step is enqueued kernel by kernel or replayed as a graph
+            st = ops.step_state(self.device)
+            ops.set_step_state(st, lr, lr, self.global_step)
+            with ops.use_step_state(st):
+                loss = self._compute_gradients(images, labels, dropout)
+        else:
+            loss = self._compute_gradients(images, labels, dropout)
         if self.sync is not None:
             self.sync.finish()
-        ops.join_param_grad_stream()          # filter / bias gradients were enqueued on their own stream
         self.optimizer.apply(lr)
         self.global_step += 1
         return loss
+
+    def _graph_mode(self):
+        """'off' | 'whole' (single process: the whole step is one hipGraph) | 'segmented' (data parallel: gradients graph ->
+        eager RCCL all-reduce of the buckets -> optimiser graph; no collective is ever captured) | 'full' (data parallel,
+        collectives captured inside the one graph, overlap with backward kept; opt-in: VNET_DP_GRAPH=full).
+        TrainingSetting.StepGraph / VNET_STEP_GRAPH = 0|1 switches the feature (default on)."""
+        want = os.environ.get("VNET_STEP_GRAPH")
+        want = getattr(self, "step_graph", True) if want is None else want not in ("0", "off", "false")
+        if not want or self.device.type != "cuda":
+            return "off"
+        if self.world > 1 or self.sync is not None:
+            if getattr(self, "sync_batch_norm", False):
+                return "off"                   # 74 small collectives inside forward/backward: eager only
+            return "full" if os.environ.get("VNET_DP_GRAPH", getattr(self, "dp_graph", "segmented")) == "full" else "segmented"
+        return "whole"
+
+    def _capture(self, fn, pool=None):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=pool, stream=self._graph_stream):
+            out = fn()
+        return g, out
+
+    def _build_step_graph(self, mode, images, labels, dropout):
+        """Capture the step on static input buffers.  Everything the host would enqueue (about 400 kernel launches on two
+        streams) becomes one hipGraphLaunch; per-step scalars come from the device step state (ops.step_state)."""
+        st = self._step_state
+        self._g_images = torch.empty_like(images, device=self.device)
+        self._g_labels = torch.empty_like(labels, device=self.device)
+        self._g_shape = (tuple(images.shape), tuple(labels.shape), float(dropout))
+        self._g_images.copy_(images, non_blocking=True)
+        self._g_labels.copy_(labels, non_blocking=True)
+
+        def grads():
+            with ops.use_step_state(st):
+                return self._compute_gradients(self._g_images, self._g_labels, dropout)
+
+        def update():
+            self.optimizer.launch(0.0, state=st)
+
+        if mode == "whole":
+            def whole():
+                loss = grads()
+                update()
+                return loss
+            g, loss = self._capture(whole)
+            self._graphs = [g]
+        elif mode == "segmented":
+            self.sync.hold_all = True            # hooks count, nothing is launched: finish() reduces every bucket after the graph
+            ga, loss = self._capture(grads)
+            gb, _ = self._capture(update, pool=ga.pool())
+            self._graphs = [ga, gb]
+        else:                                    # "full": RCCL collectives captured between the backward kernels
+            def whole_dp():
+                self.sync.begin_step()
+                loss = grads()
+                self.sync.finish()
+                update()
+                return loss
+            g, loss = self._capture(whole_dp)
+            self._graphs = [g]
+        self._g_loss = loss.detach()
+        self._g_mode = mode
+
+    def train_step(self, images, labels, dropout=None):
+        """reference model.py:743-748: one fwd + loss + bwd + optimiser step; returns the loss tensor (device scalar; in
+        graph mode it is a static buffer that the next step overwrites -- read or clone it before the next call)."""
+        dropout = float(self.dropout_rate if dropout is None else dropout)
+        mode = self._graph_mode()
+        if mode == "off":
+            return self._train_step_eager(images, labels, dropout)
+        if getattr(self, "_graph_stream", None) is None:
+            self._graph_stream = torch.cuda.Stream(device=self.device)
+            self._step_state = ops.step_state(self.device)
+            self._graphs, self._g_shape, self._g_warm = None, None, 0
+        if self._graphs is None and self._g_warm < max(1, int(os.environ.get("VNET_STEP_GRAPH_WARMUP", "2"))):
+            # eager steps first: sizes every scratch buffer, builds the packed-filter registry, calibrates the bucket counts
+            self._g_warm += 1
+            return self._train_step_eager(images, labels, dropout)
+        shape = (tuple(images.shape), tuple(labels.shape), dropout)
+        if self._graphs is not None and (shape != self._g_shape or mode != self._g_mode):
+            return self._train_step_eager(images, labels, dropout)        # e.g. an odd-sized batch: not the captured shape
+        lr = optim.exponential_decay(self.initial_learning_rate, self.global_step, self.decay_steps, self.decay_factor)
+        if self._graphs is None:
+            torch.cuda.current_stream(self.device).synchronize()
+            self._build_step_graph(mode, images, labels, dropout)
+        else:
+            self._g_images.copy_(images, non_blocking=True)
+            self._g_labels.copy_(labels, non_blocking=True)
+        ops.set_step_state(self._step_state, lr, self.optimizer.schedule(lr), self.global_step)
+        self._graphs[0].replay()
+        if mode == "segmented":
+            self.sync.reduce_all()               # every bucket: RCCL all-reduce on the communication stream, then wait
+            self._graphs[1].replay()
+        self.global_step += 1
+        return self._g_loss
 
     # -- checkpoints (reference model.py:689-702, 758-764, 806-808) ----------------------------------------
     def _ckpt_prefix(self):
@@ -292,11 +475,15 @@ class image2label(object):
         if path is None:
             with open(self._ckpt_prefix() + "-latest") as f:
                 path = os.path.join(self.ckpt_dir, f.readline().split('"')[1])
-        ck = torch.load(path, map_location="cpu", weights_only=False)
+        ck = torch.load(path, map_location="cpu", weights_only=True)      # tensors, ints and a list of names only
         self.network.load_state_dict(ck["variables"])
         ops.invalidate_packed()
         self.global_step, self.start_epoch = int(ck["global_step"]), int(ck["start_epoch"])
         if with_optimizer and getattr(self, "optimizer", None) is not None and ck.get("optimizer"):
+            if list(ck.get("opt_names", [])) != list(self.flat.names):
+                raise VnetHipError("checkpoint %s: optimiser slots were saved for a different variable layout "
+                                   "(%d names vs %d here); restore with the network configuration it was trained with"
+                                   % (path, len(ck.get("opt_names", [])), len(self.flat.names)))
             self.optimizer.load_state_dict(ck["optimizer"])
         return path
 
@@ -328,21 +515,53 @@ class image2label(object):
         if self.testing:
             test_set = self._dataset(self.test_data_dir, False)
             test_iter = iter(test_set)
+        prefetch = int(os.environ.get("VNET_PREFETCH", getattr(self, "prefetch_depth", 4)))
+        workers = int(os.environ.get("VNET_LOADER_THREADS", getattr(self, "loader_threads", 3)))
+        self.steps_timed, self.seconds_timed = 0, 0.0
 
         for epoch in range(self.start_epoch, self.epoches):
             self._print("{}: Epoch {} starts...".format(_now(), epoch + 1))
             loss_sum, count = 0.0, 0
-            for image, label in train_set:
+            pending = None                    # (pinned host scalar, event): the loss of the step before, still in flight
+            loader = vdata.Prefetcher(train_set, depth=prefetch, workers=workers) if prefetch > 0 else train_set
+            feeder = _DeviceFeeder(self.device, loader)
+
+            def flush(p):
+                # the reference prints every step's loss (model.py:749); reading it one step late keeps the host one
+                # step ahead of the GPU instead of draining the queue on every iteration
+                if p is None:
+                    return 0.0, 0
+                host, ev = p
+                if ev is not None:
+                    ev.synchronize()
+                val = float(host)
+                self.last_loss = val
+                self._print('{}: Segmentation training loss: {}'.format(_now(), str(val)))
+                return val, 1
+
+            t_epoch = None
+            for image, label in feeder:
                 if self.global_step > self.max_itr:
+                    flush(pending)
                     self._print("{}: Reach maximum iteration steps, training abort.".format(_now()))
                     return
-                image = torch.from_numpy(image).to(self.device)
-                label = torch.from_numpy(label).to(self.device)
-                loss = float(self.train_step(image, label).detach())
-                self.last_loss = loss
-                self._print('{}: Segmentation training loss: {}'.format(_now(), str(loss)))
-                loss_sum += loss
-                count += 1
+                loss_t = self.train_step(image, label)
+                feeder.step_done()
+                if self.device.type == "cuda":
+                    host = torch.empty((), dtype=torch.float32, pin_memory=True)
+                    host.copy_(loss_t.detach(), non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(self.device))
+                    now = (host, ev)
+                else:
+                    now = (loss_t.detach().clone(), None)
+                v, n = flush(pending)
+                loss_sum += v
+                count += n
+                pending = now
+                if t_epoch is None and self.global_step >= 5:      # steady-state throughput (past capture / warm-up)
+                    self._device_sync()
+                    t_epoch, s_epoch = time.perf_counter(), self.global_step
                 if self.global_step % self.log_interval == 0:
                     self._print("{}: Saving checkpoint of step {} at {}...".format(_now(), self.global_step, self.ckpt_dir))
                     self.save_checkpoint()
@@ -361,6 +580,13 @@ class image2label(object):
                         _now(), self.last_metrics["accuracy"],
                         [round(self.last_metrics[c]["dice"], 4) for c in range(self.output_channel_num)]))
                     self._print("{}: Segmentation testing loss: {}".format(_now(), str(float(tloss.detach()))))
+            v, n = flush(pending)
+            loss_sum += v
+            count += n
+            if t_epoch is not None:
+                self._device_sync()
+                self.steps_timed += self.global_step - s_epoch
+                self.seconds_timed += time.perf_counter() - t_epoch
             self._print("{}: Training of epoch {} complete, epoch loss: {}".format(_now(), epoch + 1, loss_sum / max(count, 1)))
             self.start_epoch += 1
             self._print("{}: Saving checkpoint of epoch {} at {}...".format(_now(), epoch + 1, self.ckpt_dir))

@@ -58,6 +58,35 @@ def _stream():
     return _raw_stream()
 
 
+# ---- device-resident step state (include/vnet_hip.h: vnet_step_state_set) ---------------------------------
+# A captured hipGraph freezes kernel arguments; the learning rate, Adam's bias-corrected lr_t and the dropout stream
+# position live in a 32-byte device buffer that one tiny eager kernel rewrites before each replay.
+_STEP_STATE = {"buf": {}, "active": None}
+
+
+def step_state(device):
+    buf = _STEP_STATE["buf"].get(device)
+    if buf is None:
+        buf = torch.zeros(32, dtype=torch.uint8, device=device)
+        _STEP_STATE["buf"][device] = buf
+    return buf
+
+
+def set_step_state(state, lr, lr_t, step):
+    check(_lib.lib().vnet_step_state_set(_ptr(state), float(lr), float(lr_t), int(step), _stream()), "vnet_step_state_set")
+
+
+@contextlib.contextmanager
+def use_step_state(state):
+    """Inside: dropout takes its per-step seed offset from `state` (graph-replayable) instead of a host counter."""
+    prev = _STEP_STATE["active"]
+    _STEP_STATE["active"] = state
+    try:
+        yield
+    finally:
+        _STEP_STATE["active"] = prev
+
+
 def _need_gpu(t, what):
     if not t.is_cuda:
         raise VnetHipError("%s: tensor on %s -- the HIP library is the only compute path (no CPU fallback)" % (what, t.device))
@@ -221,7 +250,7 @@ def _grad_ret(t, s):
 
 
 # ---- optional per-launch timing (bench.py): HIP events on the launch stream ---------------------
-_PROFILE = {"on": False, "records": [], "only": None}
+_PROFILE = {"on": False, "records": [], "only": None, "graph_records": []}
 
 
 def profile_start(only=None):
@@ -249,6 +278,42 @@ def _wgrad_tag(bf16, ks, kx, stride, wo, B, cin, co):
     return "wgrad%s k%d%s s%d %d^3x%d %d->%d" % ("-bf16" if bf16 else "", ks, "x%d" % kx if kx else "", stride, wo, B, cin, co)
 
 
+class _ExtEvent(object):
+    """HIP event recorded with hipEventRecordExternal: inside a stream capture it becomes an event-record NODE of the
+    graph, re-recorded by every replay and readable from outside the graph (torch.cuda.Event cannot be timed across a
+    capture).  Lets bench.py time the reported kernel family inside the replayed whole-step graph."""
+    _hip = None
+
+    @classmethod
+    def hip(cls):
+        if cls._hip is None:
+            h = ctypes.CDLL("libamdhip64.so")        # the runtime torch already loaded (same soname)
+            h.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+            h.hipEventRecordWithFlags.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
+            h.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+            h.hipEventDestroy.argtypes = [ctypes.c_void_p]
+            cls._hip = h
+        return cls._hip
+
+    def __init__(self):
+        self.h = ctypes.c_void_p()
+        check(self.hip().hipEventCreate(ctypes.byref(self.h)), "hipEventCreate")
+
+    def record(self):
+        check(self.hip().hipEventRecordWithFlags(self.h, _raw_stream(), 1), "hipEventRecordWithFlags(external)")
+
+    def elapsed_time(self, other):
+        ms = ctypes.c_float()
+        check(self.hip().hipEventElapsedTime(ctypes.byref(ms), self.h, other.h), "hipEventElapsedTime")
+        return ms.value
+
+
+def profile_read():
+    """[(tag, flops, algorithmic_bytes, milliseconds)] of the launches timed inside a captured graph, as recorded by the
+    LAST replay (synchronise first).  The records stay: every replay re-records the same events."""
+    return [(t, f, b, e0.elapsed_time(e1)) for (t, f, b, e0, e1) in _PROFILE["graph_records"]]
+
+
 class _Timed(object):
     def __init__(self, tag, flops, nbytes):
         self.rec = (tag, flops, nbytes)
@@ -256,15 +321,19 @@ class _Timed(object):
 
     def __enter__(self):
         if self.on:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.ext = torch.cuda.is_current_stream_capturing()
+            if self.ext:
+                self.e0, self.e1 = _ExtEvent(), _ExtEvent()
+            else:
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()          # torch's current stream == the stream the kernel is launched on
         return self
 
     def __exit__(self, *a):
         if self.on:
             self.e1.record()
-            _PROFILE["records"].append(self.rec + (self.e0, self.e1))
+            _PROFILE["graph_records" if self.ext else "records"].append(self.rec + (self.e0, self.e1))
 
 
 # ---- convolution family ----------------------------------------------------------------------------
@@ -415,6 +484,11 @@ class _ConvFn(torch.autograd.Function):
             # node has returned autograd holds the last reference and accumulates the next gradient INTO it in place
             # (input_buffer.cpp: use_count == 1), on the main stream, while the filter gradient may still be reading it.
             # A live reference until the join makes that accumulation out of place.
+            if not _PG["used"]:
+                # first side-stream launch of this backward pass: join when the pass ends, whoever drives it (a user
+                # loop calling loss.backward() directly would otherwise keep every dy alive and could read filter
+                # gradients before the side stream has written them)
+                torch.autograd.Variable._execution_engine.queue_callback(join_param_grad_stream)
             _PG["keep"].append(dy)
             _PG["used"].add(dev)
             if _PG["test_delay"]:
@@ -844,6 +918,19 @@ def parse_loss(name):
     return kind
 
 
+_CONST_VEC = {}
+
+
+def _const_vector(values, device):
+    """Small constant vector (Loss.Weights) on the device, uploaded once: a pageable host-to-device copy is not allowed
+    inside a stream capture."""
+    key = (tuple(float(v) for v in values), device)
+    t = _CONST_VEC.get(key)
+    if t is None:
+        t = _CONST_VEC[key] = torch.as_tensor(list(key[0]), dtype=torch.float32).to(device)
+    return t
+
+
 class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, kind, weights, alpha, smooth, want_softmax, want_pred):
@@ -897,7 +984,7 @@ def softmax_loss(logits, labels, loss_name="sorensen", weights=None, alpha=1.0, 
     if kind & LOSS_WEIGHTED:
         if weights is None or len(weights) != K:
             raise AssertionError("Length of DICE weight is {}, should be {}".format(0 if weights is None else len(weights), K))
-        wt = torch.as_tensor(list(weights), dtype=torch.float32).to(logits.device)
+        wt = _const_vector(weights, logits.device)
     if labels.dtype != torch.int32:
         labels = labels.to(torch.int32)
     return _LossFn.apply(logits, labels, kind, wt, float(alpha), float(smooth), want_softmax, want_pred)
@@ -920,7 +1007,11 @@ class _DropoutFn(torch.autograd.Function):
         x = x.contiguous()
         y = torch.empty_like(x)
         mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
-        check(L.vnet_dropout_fwd(_ptr(x), _ptr(y), _ptr(mask), x.numel(), rate, seed, _stream()), "vnet_dropout_fwd")
+        st = _STEP_STATE["active"]
+        if st is not None:
+            check(L.vnet_dropout_fwd_dev(_ptr(x), _ptr(y), _ptr(mask), x.numel(), rate, seed, _ptr(st), _stream()), "vnet_dropout_fwd_dev")
+        else:
+            check(L.vnet_dropout_fwd(_ptr(x), _ptr(y), _ptr(mask), x.numel(), rate, seed, _stream()), "vnet_dropout_fwd")
         ctx.save_for_backward(mask)
         ctx.rate = rate
         return y
@@ -935,7 +1026,7 @@ class _DropoutFn(torch.autograd.Function):
         return dx, None, None
 
 
-_DROP_SEED = [0x5EED]
+_DROP_SEED = [0x5EED, 0]
 
 
 def dropout(x, rate):
@@ -944,21 +1035,42 @@ def dropout(x, rate):
     if rate == 0.0 or _meta(x):
         return x
     _need_gpu(x, "dropout")
+    if _STEP_STATE["active"] is not None:
+        # graph-replayable: the seed of a layer is its position in the pass, the step number comes from the device state
+        _DROP_SEED[1] += 1
+        return _DropoutFn.apply(x, rate, 0x5EED0000 + _DROP_SEED[1])
     _DROP_SEED[0] += 1
     return _DropoutFn.apply(x, rate, _DROP_SEED[0])
 
 
+def begin_dropout_pass():
+    """Reset the per-pass layer counter of the state-driven dropout (called at the start of a step)."""
+    _DROP_SEED[1] = 0
+
+
 # ---- optimiser apply + sliding-window accumulate (no autograd) ----------------------------------------------------
-def adam_apply(p, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, gscale=1.0):
+def adam_apply(p, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, gscale=1.0, state=None):
+    """state: device step-state buffer holding lr_t (then the `lr_t` argument is ignored) -- the graph-replayable form."""
+    if state is not None:
+        check(_lib.lib().vnet_adam_apply_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(state), beta1, beta2, eps, gscale,
+                                             _stream()), "vnet_adam_apply_dev")
+        return
     check(_lib.lib().vnet_adam_apply(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr_t, beta1, beta2, eps, gscale, _stream()),
           "vnet_adam_apply")
 
 
-def sgd_apply(p, g, lr, gscale=1.0):
+def sgd_apply(p, g, lr, gscale=1.0, state=None):
+    if state is not None:
+        check(_lib.lib().vnet_sgd_apply_dev(_ptr(p), _ptr(g), p.numel(), _ptr(state), gscale, _stream()), "vnet_sgd_apply_dev")
+        return
     check(_lib.lib().vnet_sgd_apply(_ptr(p), _ptr(g), p.numel(), lr, gscale, _stream()), "vnet_sgd_apply")
 
 
-def momentum_apply(p, g, acc, lr, momentum, nesterov=False, gscale=1.0):
+def momentum_apply(p, g, acc, lr, momentum, nesterov=False, gscale=1.0, state=None):
+    if state is not None:
+        check(_lib.lib().vnet_momentum_apply_dev(_ptr(p), _ptr(g), _ptr(acc), p.numel(), _ptr(state), momentum, int(nesterov), gscale,
+                                                 _stream()), "vnet_momentum_apply_dev")
+        return
     check(_lib.lib().vnet_momentum_apply(_ptr(p), _ptr(g), _ptr(acc), p.numel(), lr, momentum, int(nesterov), gscale, _stream()),
           "vnet_momentum_apply")
 

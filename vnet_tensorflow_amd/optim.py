@@ -47,16 +47,26 @@ class FlatParams(object):
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
                 p._vnet_sink.view = p.grad
 
-    def buckets(self, bucket_bytes=32 << 20):
+    def buckets(self, bucket_bytes=32 << 20, cut_after=()):
         """Contiguous [start, end) slices of the flat buffer, cut at variable boundaries, plus the
-        index range of the variables each one holds."""
+        index range of the variables each one holds.  `cut_after`: variable indices that must END a bucket."""
         out, start, first = [], 0, 0
+        cut_after = set(cut_after)
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             end = o + (p.numel() + 3) // 4 * 4
-            if (end - start) * 4 >= bucket_bytes or i == len(self.params) - 1:
+            if (end - start) * 4 >= bucket_bytes or i == len(self.params) - 1 or i in cut_after:
                 out.append((start, end, first, i + 1))
                 start, first = end, i + 1
         return out
+
+    def first_index_reaching(self, fraction):
+        """Index of the variable (gradient-production order) with which the cumulative gradient bytes reach
+        `fraction` of the total."""
+        total = float(self.numel)
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            if (o + (p.numel() + 3) // 4 * 4) >= fraction * total:
+                return i
+        return len(self.params) - 1
 
 
 def exponential_decay(lr0, global_step, decay_steps, decay_rate):
@@ -65,9 +75,24 @@ def exponential_decay(lr0, global_step, decay_steps, decay_rate):
 
 
 class _Base(object):
+    """apply(lr) = schedule(lr) + launch(...).  `schedule` is the host-side scalar bookkeeping of one step (returns the
+    learning-rate scalar the kernel uses); `launch` enqueues the fused update + the batched filter repack.  With
+    `state` (ops.step_state) the kernel reads its scalar from device memory, so the launch can sit inside a captured
+    hipGraph while `schedule` + ops.set_step_state run on the host before each replay (model.image2label)."""
+
     def __init__(self, flat):
         self.flat = flat
         self.gscale = 1.0       # 1/world_size under data parallelism (mean of per-rank gradients)
+
+    def schedule(self, lr):
+        return lr
+
+    def apply(self, lr):
+        self.launch(self.schedule(lr))
+
+    def _after(self):
+        ops.invalidate_packed()
+        ops.repack_registered()
 
     def state_dict(self):
         return {}
@@ -79,10 +104,9 @@ class _Base(object):
 class GradientDescentOptimizer(_Base):
     """tf.train.GradientDescentOptimizer"""
 
-    def apply(self, lr):
-        ops.sgd_apply(self.flat.data, self.flat.grad, lr, self.gscale)
-        ops.invalidate_packed()
-        ops.repack_registered()
+    def launch(self, lr, state=None):
+        ops.sgd_apply(self.flat.data, self.flat.grad, lr, self.gscale, state=state)
+        self._after()
 
 
 class AdamOptimizer(_Base):
@@ -95,12 +119,13 @@ class AdamOptimizer(_Base):
         self.m = torch.zeros_like(flat.data)
         self.v = torch.zeros_like(flat.data)
 
-    def apply(self, lr):
+    def schedule(self, lr):
         self.t += 1
-        lr_t = lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
-        ops.adam_apply(self.flat.data, self.flat.grad, self.m, self.v, lr_t, self.b1, self.b2, self.eps, self.gscale)
-        ops.invalidate_packed()
-        ops.repack_registered()
+        return lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+
+    def launch(self, lr_t, state=None):
+        ops.adam_apply(self.flat.data, self.flat.grad, self.m, self.v, lr_t, self.b1, self.b2, self.eps, self.gscale, state=state)
+        self._after()
 
     def state_dict(self):
         return {"t": self.t, "m": self.m, "v": self.v}
@@ -119,10 +144,9 @@ class MomentumOptimizer(_Base):
         self.momentum, self.nesterov = momentum, use_nesterov
         self.acc = torch.zeros_like(flat.data)
 
-    def apply(self, lr):
-        ops.momentum_apply(self.flat.data, self.flat.grad, self.acc, lr, self.momentum, self.nesterov, self.gscale)
-        ops.invalidate_packed()
-        ops.repack_registered()
+    def launch(self, lr, state=None):
+        ops.momentum_apply(self.flat.data, self.flat.grad, self.acc, lr, self.momentum, self.nesterov, self.gscale, state=state)
+        self._after()
 
     def state_dict(self):
         return {"acc": self.acc}

@@ -53,7 +53,14 @@ class BucketedGradAllReduce(object):
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())
-        self.buckets = flat.buckets(bucket_bytes)
+        self.hold_fraction = float(hold_fraction)
+        # a bucket boundary exactly where the cumulative bytes cross hold_fraction, so the launch point does not depend
+        # on where the size-driven cuts happen to fall (without it the 0.99 threshold of the V-Net layout is only crossed
+        # by the LAST bucket and nothing overlaps backward)
+        cut = [flat.first_index_reaching(self.hold_fraction)] if 0.0 < self.hold_fraction < 1.0 else []
+        self.buckets = flat.buckets(bucket_bytes, cut_after=cut)
+        self.hold_all = False            # graph mode "segmented": hooks only count, reduce_all() launches everything
+        self.launch_log = []             # (bucket index, gradient events seen so far) per launch of the current step
         self.is_cuda = flat.grad.is_cuda
         self.overlap = overlap and self.is_cuda and self.active
         self.comm_stream = torch.cuda.Stream(device=flat.grad.device) if self.overlap else None
@@ -61,7 +68,6 @@ class BucketedGradAllReduce(object):
         for bi, (_, _, first, last) in enumerate(self.buckets):
             for pi in range(first, last):
                 self._bucket_of[pi] = bi
-        self.hold_fraction = float(hold_fraction)
         self._bytes = [4 * (e - s_) for s_, e, _, _ in self.buckets]
         self._total_bytes = float(sum(self._bytes)) or 1.0
         self._ready_bytes = 0
@@ -93,6 +99,24 @@ class BucketedGradAllReduce(object):
         self._handles = []
         self._ready_bytes = 0
         self._held = []
+        self.launch_log = []
+
+    def reduce_all(self):
+        """All-reduce every bucket now (the gradients are complete on the current stream) and make the current stream
+        wait for the result: the exchange step between the gradients graph and the optimiser graph (model.train_step,
+        'segmented' mode).  Leaves the event calibration untouched."""
+        if not self.active:
+            return
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+        self.launch_log = []
+        for bi in range(len(self.buckets)):
+            self._launch(bi)
+        for h in self._handles:
+            h.wait()
+        if self.overlap:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._handles = []
 
     def _make_hook(self, pi):
         def hook(param):
@@ -108,8 +132,8 @@ class BucketedGradAllReduce(object):
 
     def _count(self, pi):
         self._events[pi] += 1
-        if self._expected is None:
-            return                      # calibration step: everything is reduced in finish()
+        if self._expected is None or self.hold_all:
+            return                      # calibration step / segmented graph mode: everything is reduced after backward
         bi = self._bucket_of[pi]
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
@@ -126,6 +150,7 @@ class BucketedGradAllReduce(object):
         if self._launched[bi] or not self.active:
             return
         self._launched[bi] = True
+        self.launch_log.append((bi, sum(self._events)))
         s, e, _, _ = self.buckets[bi]
         view = self.flat.grad[s:e]
         pg = None
