@@ -13,9 +13,9 @@ gives the kernel-by-kernel eager enqueue).  Rank 0 prints ONE JSON line.
 
 `roofline`: HIP events around every launch of the dominant kernel family -- decoder level 1 / conv_1, the 5x5x5
 convolution with 16 output channels at 128^3: forward (32->16), backward-data (16->32) and filter gradient, 268.4 GF
-algorithmic each.  In graph mode the events are EXTERNAL event-record nodes of the captured step; they are read after
-each of R further replays that follow the timed region (reading needs a host sync, which the timed region must not
-contain).  `c5_bf16` (N=1 only): the same measurement for BASELINE configs[4]'s per-GPU workload (4 modalities, 5
+algorithmic each.  Events cannot be timed inside a replayed hipGraph on this runtime (profiles/probes/graph_event_probe.py),
+so in graph mode the family is timed in R eager steps of the same model that follow the timed region.
+`c5_bf16` (N=1 only): the same measurement for BASELINE configs[4]'s per-GPU workload (4 modalities, 5
 classes, bf16 conv operands / fp32 accumulate), outside the headline's timed region.  `cpu_baseline`: the CPU
 restatement (oracle/torch_ref.py: same graph on PyTorch-CPU oneDNN fp32 incl. backward + Adam) timed on the real
 128^3 step on rank 0 at N=1.
@@ -171,17 +171,19 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
     fam = family_tags(patch, batch, bf16)
     full_table = bool(os.environ.get("BENCH_KERNEL_TABLE"))
     graph = m._graph_mode() != "off"
-    if full_table and graph:
-        raise SystemExit("BENCH_KERNEL_TABLE times every launch with host-read events: run it with VNET_STEP_GRAPH=0")
-    ops._PROFILE["graph_records"] = []
-    # HIP events go around the launches of the dominant kernel family only (an event packet idles the GPU for ~5.6 us)
-    ops.profile_start(None if full_table else fam)
+    mode = m._graph_mode()
+    # eager enqueue: HIP events go around the launches of the dominant kernel family only (an event packet idles the GPU
+    # for ~5.6 us); graph replay: events cannot be timed inside a hipGraph on this runtime, the family is timed in eager
+    # steps right after the timed region
     loss = None
+    if not graph:
+        ops.profile_start(None if full_table else fam)
     for _ in range(3 if graph else 0):       # prepare: 2 eager steps + the capture (and first replay) of the step graph
         loss = m.train_step(images, labels)
     for _ in range(args.warmup):
         loss = m.train_step(images, labels)
-    ops.profile_stop()                       # (synchronises; eager-mode records of the warm-up are dropped)
+    if not graph:
+        ops.profile_stop()                   # (synchronises; the warm-up records are dropped)
     barrier()
     if not graph:
         ops.profile_start(None if full_table else fam)
@@ -196,23 +198,22 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.detach())
+    nroof = min(args.steps, 10)
     if graph:
-        # roofline replays: the same graph, one host sync per step to read the external events of that replay
-        recs = []
-        for _ in range(min(args.steps, 10)):
+        m.force_eager = True                     # same kernels, enqueued one by one so that events can bracket them
+        m.train_step(images, labels)
+        barrier()
+        ops.profile_start(None if full_table else fam)
+        for _ in range(nroof):
             m.train_step(images, labels)
-            torch.cuda.synchronize()
-            recs += ops.profile_read()
-        ops._PROFILE["graph_records"] = []
-    else:
-        recs = ops.profile_stop()
+    recs = ops.profile_stop()
     barrier()
 
     res = {"value": round(world * batch * args.steps / dt, 4), "ms_per_step": round(dt / args.steps * 1e3, 3),
            "final_loss": round(final_loss, 6), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
            "step_enqueue": {"off": "eager (one ctypes launch per kernel)", "whole": "hipGraph replay of the whole step",
                             "segmented": "hipGraph(gradients) + eager RCCL bucket all-reduces + hipGraph(optimiser)",
-                            "full": "hipGraph of the whole step incl. captured RCCL all-reduces"}[m._graph_mode()],
+                            "full": "hipGraph of the whole step incl. captured RCCL all-reduces"}[mode],
            "roofline": None}
     if rank != 0:
         return res
@@ -245,14 +246,16 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
             "launches": nl, "avg_ms": round(ms / nl, 4), "flops_per_launch": fl / nl, "algorithmic_bytes_per_launch": by / nl,
             "per_launch_ms": {tag: round(per[tag][3] / per[tag][0], 4) for tag in sorted(fam) if tag in per},
             "hbm_GBps_algorithmic": round(by / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-            "measured": ("external HIP event nodes inside the replayed step graph, read after each of %d replays that follow "
-                         "the timed region" % min(args.steps, 10)) if graph else "HIP events on the launch stream inside the timed region"}
+            "measured": ("HIP events on the launch stream in %d eager steps that follow the timed region (same process, same "
+                         "kernels and arguments; events cannot be timed inside a replayed hipGraph on this runtime)" % nroof)
+            if graph else "HIP events on the launch stream inside the timed region"}
     if full_table:
         tot_ms = sum(v[3] for v in per.values())
-        res["conv_ms_per_step"] = round(tot_ms / args.steps, 3)
+        res["conv_ms_per_step"] = round(tot_ms / (nroof if graph else args.steps), 3)
         res["conv_tflops"] = round(sum(v[1] for v in per.values()) / max(tot_ms * 1e-3, 1e-12) / 1e12, 2)
         for tag, v in sorted(per.items(), key=lambda kv: -kv[1][3]):
-            print("# %-40s n=%3d %8.3f ms/step %7.2f TF/s" % (tag, v[0] // args.steps, v[3] / args.steps, v[1] / (v[3] * 1e-3) / 1e12),
+            nst = nroof if graph else args.steps
+            print("# %-40s n=%3d %8.3f ms/step %7.2f TF/s" % (tag, v[0] // nst, v[3] / nst, v[1] / (v[3] * 1e-3) / 1e12),
                   file=sys.stderr)
     return res
 

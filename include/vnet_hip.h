@@ -271,6 +271,16 @@ size_t vnet_confusion_ws_bytes(int K);
 int vnet_confusion_matrix(const int64_t* pred, const int32_t* labels, int64_t n, int K, double* cm_out,
                           void* ws, size_t ws_bytes, void* stream);
 
+/* ---- tf.metrics.auc (model.py:607,613,624): per class i, labels = one_hot[..., i], predictions = softmax[..., i];
+ * TF's default is 200 thresholds {-1e-7, 1/199 ... 198/199, 1+1e-7}, ROC curve, trapezoidal summation, and it counts
+ * tp/fn/tn/fp at every threshold with `prediction > threshold` in float32.  One pass here: hist_out[0][b] (voxels of the
+ * class) and hist_out[1][b] (all others), b = number of thresholds strictly below the prediction (0..T), as float64
+ * counts; tp[t] = sum_{b > t} hist[0][b], fp[t] likewise from hist[1], and the AUC follow on the host (ops.auc_from_hist).
+ * thresholds: DEVICE float32[T], ascending.  ws >= vnet_auc_ws_bytes(T). */
+size_t vnet_auc_ws_bytes(int T);
+int vnet_auc_histogram(const float* softmax, const int32_t* labels, int64_t n, int K, int cls, const float* thresholds, int T,
+                       double* hist_out, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- sliding-window accumulation for evaluate (model.py:919-929) ----------------------------- */
 int vnet_accumulate_patch(const float* patch, float* vol, float* count, int K,
                           int pz, int py, int px, int z0, int y0, int x0, int D, int H, int W, void* stream);

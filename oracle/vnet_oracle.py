@@ -675,6 +675,26 @@ def hard_dice(pred, labels, K):
 # ----------------------------------------------------------------------------------------
 # optimiser / LR schedule -- model.py:641-666 (A.9, f-1)
 # ----------------------------------------------------------------------------------------
+def tf_metrics_auc(labels01, predictions, num_thresholds=200):
+    """tf.metrics.auc(labels, predictions) with the TF 1.15 defaults (curve='ROC', summation_method='trapezoidal'), as used
+    per class at model.py:607,613,624.  Restated from TF 1.15 metrics_impl.py (third-party, un-vendored): thresholds
+    [0 - 1e-7] + [(i + 1) / (n - 1) for i in range(n - 2)] + [1 + 1e-7] as float32; a voxel is predicted positive at
+    threshold t iff prediction > t; rec = (tp + eps) / (tp + fn + eps); fp_rate = fp / (fp + tn + eps);
+    auc = sum((x[:-1] - x[1:]) * (y[:-1] + y[1:]) / 2) with x = fp_rate, y = rec.  (TF keeps the counters in float32
+    variables; counts here are exact.)"""
+    eps = 1e-7
+    th = np.asarray([0.0 - eps] + [(i + 1) * 1.0 / (num_thresholds - 1) for i in range(num_thresholds - 2)] + [1.0 + eps], dtype=np.float32)
+    p = np.asarray(predictions, dtype=np.float32).ravel()
+    lab = np.asarray(labels01).ravel().astype(bool)
+    tp = np.array([np.count_nonzero(lab & (p > t)) for t in th], dtype=np.float64)
+    fp = np.array([np.count_nonzero(~lab & (p > t)) for t in th], dtype=np.float64)
+    fn = np.count_nonzero(lab) - tp
+    tn = np.count_nonzero(~lab) - fp
+    rec = (tp + eps) / (tp + fn + eps)
+    fpr = fp / (fp + tn + eps)
+    return float(((fpr[:-1] - fpr[1:]) * (rec[:-1] + rec[1:]) / 2.0).sum())
+
+
 def exponential_decay(lr0, step, decay_steps, decay_rate):
     return lr0 * decay_rate ** (step / float(decay_steps))
 

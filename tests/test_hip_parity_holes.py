@@ -1,0 +1,143 @@
+"""-m gpu: parity items VERDICT r1 listed as open (#8): dropout against the oracle with the kernel's own mask, the native
+C++ inference driver against the ORACLE (not against the Python HIP path), tf.metrics.auc, streaming metrics."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vnet_oracle as O
+from tests.util import g, check_close
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "vnet_tensorflow_amd", "vnet_infer")
+
+
+@pytest.mark.parametrize("rate", [0.01, 0.25, 0.6])
+def test_dropout_against_oracle_with_the_kernels_mask(dev, rate):
+    """tf.nn.dropout(x, rate) (networks.py:321): the kernel emits its keep-mask; fed to oracle.dropout(x, rate, mask) the
+    forward values and the input gradient must agree to fp32 round-off (1/(1-rate) scaling in fp32 vs fp64)."""
+    from vnet_tensorflow_amd import ops
+    rng = np.random.default_rng(3)
+    xs = rng.standard_normal((2, 6, 7, 5, 12))
+    gs = rng.standard_normal(xs.shape)
+    x = g(xs, dev).requires_grad_(True)
+    y = ops.dropout(x, rate)
+    y.backward(g(gs, dev))
+    mask = y.grad_fn.saved_tensors[0].cpu().numpy().astype(np.float64)
+    assert set(np.unique(mask)) <= {0.0, 1.0} and abs(mask.mean() - (1.0 - rate)) < 0.05
+    xv = O.Var(xs.astype(np.float32).astype(np.float64))
+    ref = O.dropout(xv, rate, mask)
+    xv.g = None
+    O.backward(ref, seed=gs.astype(np.float32).astype(np.float64))
+    check_close("dropout fwd", y, ref.v, 2e-7)
+    check_close("dropout bwd", x.grad, xv.g, 2e-7)
+    assert np.array_equal(y.detach().cpu().numpy() != 0, (mask != 0) & (xs.astype(np.float32) != 0))
+
+
+def test_dropout_streams_differ_between_layers_and_steps(dev):
+    """State-driven dropout (graph-replayable): the mask depends on (layer position in the pass, step number)."""
+    from vnet_tensorflow_amd import ops
+    x = torch.ones(1, 8, 8, 8, 16, device=dev)
+    st = ops.step_state(dev)
+    masks = []
+    for step in (5, 6):
+        ops.set_step_state(st, 0.0, 0.0, step)
+        with ops.use_step_state(st):
+            ops.begin_dropout_pass()
+            masks.append([(ops.dropout(x, 0.5) != 0).cpu() for _ in range(2)])
+    assert not torch.equal(masks[0][0], masks[0][1]) and not torch.equal(masks[0][0], masks[1][0])
+    ops.set_step_state(st, 0.0, 0.0, 5)
+    with ops.use_step_state(st):
+        ops.begin_dropout_pass()
+        assert torch.equal((ops.dropout(x, 0.5) != 0).cpu(), masks[0][0])        # reproducible for a given (layer, step)
+
+
+@pytest.mark.parametrize("K,N", [(2, 20000), (5, 50000)])
+def test_tf_metrics_auc(dev, K, N):
+    """tf.metrics.auc defaults (200 thresholds, ROC, trapezoidal; model.py:607,613,624) from the GPU histogram against the
+    oracle's direct per-threshold counts; predictions ON thresholds (k/199 as float32) exercise the strict `>`."""
+    from vnet_tensorflow_amd import ops
+    rng = np.random.default_rng(K)
+    lab = rng.integers(0, K, size=N).astype(np.int32)
+    logits = rng.standard_normal((N, K)) + 1.5 * (lab[:, None] == np.arange(K))
+    sm = np.exp(logits) / np.exp(logits).sum(-1, keepdims=True)
+    sm = sm.astype(np.float32)
+    th = ops.tf_auc_thresholds()
+    sm[:400, 1] = th[rng.integers(0, 200, size=400)]            # exactly on a threshold
+    sm[400:420, 1] = [0.0, 1.0] * 10
+    smt, labt = g(sm, dev), g(lab, dev, torch.int32)
+    for c in range(1, K):
+        hist = ops.auc_histogram(smt, labt, K, c).cpu().numpy()
+        assert hist.sum() == N and hist[0].sum() == (lab == c).sum()
+        got, ref = ops.auc_from_hist(hist), O.tf_metrics_auc(lab == c, sm[:, c])
+        assert abs(got - ref) < 1e-12, (c, got, ref)
+        assert 0.5 < got <= 1.0
+    # streaming: two updates == one update on the concatenation (TF's accumulating local variables)
+    pred = torch.from_numpy(sm.argmax(-1)).to(dev)
+    a = ops.StreamingMetrics(K).update(pred[:N // 2], labt[:N // 2], smt[:N // 2]).update(pred[N // 2:], labt[N // 2:], smt[N // 2:]).result()
+    b = ops.StreamingMetrics(K).update(pred, labt, smt).result()
+    for c in range(1, K):
+        assert abs(a[c]["auc"] - b[c]["auc"]) < 1e-12 and a[c]["tp"] == b[c]["tp"] and a[c]["fn"] == b[c]["fn"]
+        assert abs(b[c]["auc"] - O.tf_metrics_auc(lab == c, sm[:, c])) < 1e-12
+
+
+def test_native_driver_against_the_oracle(tmp_path, dev):
+    """csrc/vnet_infer.cpp (C ABI only) vs the ORACLE: per sliding-window patch the oracle's forward + softmax, accumulated
+    and counted in NumPy exactly as model.py:919-937 does (sum of softmax over overlapping patches, argmax of the sums,
+    probabilities = sums / counts) -- the duplicated last batch of model.py:903 included."""
+    cin, K, levels, convs, bottom, batch = 2, 3, 2, [1, 2], 1, 2
+    P, stride = (8, 8, 8), (4, 8, 6)
+    assert os.path.exists(BIN), "run __graft_entry__.build() first"
+    ps = O.ParamStore(rng=np.random.default_rng(4), perturb=0.2)
+    net = O.VNetOracle(K, 0.0, 4, levels, tuple(convs), bottom, "prelu", "networks", ps)
+    vol, _ = O.synthetic_batch(1, 14, cin, K, seed=12)
+    vol = np.ascontiguousarray(vol[0][:, :12, :10]).astype(np.float32)            # 14 x 12 x 10
+    dims = vol.shape[:3]
+    # patch enumeration of model.py:866-903
+    nums = [int(np.ceil((dims[a] - P[a]) / float(stride[a]))) + 1 for a in range(3)]
+    idxs = []
+    for i in range(nums[0]):
+        for j in range(nums[1]):
+            for k in range(nums[2]):
+                o = [min(n * stride[a], dims[a] - P[a]) for a, n in enumerate((i, j, k))]
+                idxs.append(o)
+    batches = [idxs[b:b + batch] for b in range(0, len(idxs), batch)]
+    batches.append(batches[-1])                                        # "for last batch" (model.py:903): appended once more
+    acc = np.zeros(dims + (K,))
+    cnt = np.zeros(dims)
+    for bt in batches:
+        xb = np.stack([vol[o[0]:o[0] + P[0], o[1]:o[1] + P[1], o[2]:o[2] + P[2]] for o in bt]).astype(np.float64)
+        sm = O.softmax(net.GetNetwork(xb)).v                           # batch statistics of THIS batch (model.py:917)
+        for o, s in zip(bt, sm):
+            acc[o[0]:o[0] + P[0], o[1]:o[1] + P[1], o[2]:o[2] + P[2]] += s
+            cnt[o[0]:o[0] + P[0], o[1]:o[1] + P[1], o[2]:o[2] + P[2]] += 1
+    lab_ref = acc.argmax(-1)
+    prob_ref = np.moveaxis(acc / cnt[..., None], -1, 0)
+
+    # weights blob of the oracle's variables (format of model.export_weights)
+    import struct
+    wpath, ipath = str(tmp_path / "net.vnetw"), str(tmp_path / "vol.npy")
+    with open(wpath, "wb") as f:
+        items = [(k, v.v) for k, v in ps.vars.items()]
+        f.write(b"VNETW1\0\0" + struct.pack("<I", len(items)))
+        for name, arr in items:
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            nb = name.encode()
+            f.write(struct.pack("<I", len(nb)) + nb + struct.pack("<I", arr.ndim) + struct.pack("<%dI" % arr.ndim, *arr.shape))
+            f.write(arr.tobytes())
+    np.save(ipath, vol)
+    out = subprocess.run([BIN, "--weights", wpath, "--image", ipath, "--label-out", str(tmp_path / "lab.npy"),
+                          "--prob-out", str(tmp_path / "prob.npy"), "--classes", str(K), "--channels", "4",
+                          "--levels", str(levels), "--convs", ",".join(map(str, convs)), "--bottom", str(bottom),
+                          "--patch", ",".join(map(str, P)), "--stride", ",".join(map(str, stride)), "--batch", str(batch)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:] + out.stdout[-1000:]
+    lab, prob = np.load(tmp_path / "lab.npy"), np.load(tmp_path / "prob.npy")
+    assert lab.shape == lab_ref.shape and prob.shape == prob_ref.shape
+    assert np.abs(prob - prob_ref).max() < 1e-4, np.abs(prob - prob_ref).max()
+    margin = np.sort(prob_ref, axis=0)
+    sure = (margin[-1] - margin[-2]) > 1e-4
+    assert (lab == lab_ref)[sure].all() and (lab == lab_ref).mean() > 0.999

@@ -104,6 +104,7 @@ def test_param_grad_stream_is_bit_identical(dev, P, monkeypatch):
     x, lab = synthetic_batch(2, P, 1, 2, seed=21)
     xt, lt = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
     res = []
+    monkeypatch.setenv("VNET_STEP_GRAPH", "0")      # the replayed step graph is captured single-stream; this is the eager two-stream path
     for on in ("1", "0"):
         monkeypatch.setenv("VNET_PARAM_GRAD_STREAM", on)
         np.random.seed(3)

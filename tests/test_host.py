@@ -194,3 +194,40 @@ def test_cli_parser():
     a = get_parser(["-p", "evaluate", "--config_json", "c.json", "--gpu", "0,1", "-v"])
     assert a.phase == "evaluate" and a.config_json == "c.json" and a.gpu == "0,1" and a.verbose
     assert get_parser([]).phase == "train"
+
+
+def test_plain_xent_exits_like_the_reference():
+    """model.py:495-560: `if name == "xent"` is followed by a separate if/elif chain whose else is sys.exit -> the reference
+    exits with "Invalid loss function" for Loss.Name == "xent".  Kept; Loss.AllowPlainXent (extension) opts out."""
+    import pytest
+    from vnet_tensorflow_amd.model import image2label
+    cfg = {"TrainingSetting": {"Data": {"TrainingDataDirectory": "", "TestingDataDirectory": "", "ImageFilenames": ["a"], "LabelFilename": "l"},
+                               "SegmentationClasses": [0, 1], "BatchSize": 1, "PatchShape": [16, 16, 16],
+                               "Networks": {"Name": "VNet", "Dropout": 0.0, "NumChannel": 4, "NumLevels": 2, "NumConvolutions": [1, 1],
+                                            "BottomConvolutions": 1},
+                               "Optimizer": {"Name": "Adam", "InitialLearningRate": 1e-3, "Decay": {"Factor": 0.99, "Steps": 100}},
+                               "Loss": {"Name": "xent"}}}
+    m = image2label(None, cfg, verbose=False)
+    m.read_config()
+    with pytest.raises(SystemExit, match="Invalid loss function"):
+        m.build_model_graph()
+    cfg["TrainingSetting"]["Loss"]["Name"] = "no_such_loss"
+    m = image2label(None, cfg, verbose=False)
+    m.read_config()
+    with pytest.raises(SystemExit, match="Invalid loss function"):
+        m.build_model_graph()
+    cfg["TrainingSetting"]["Loss"] = {"Name": "xent", "AllowPlainXent": True}
+    m = image2label(None, cfg, verbose=False)
+    m.read_config()
+    m._validate_loss()                       # no exit
+
+
+def test_tf_metrics_auc_restatement_known_answers():
+    """oracle.tf_metrics_auc against hand-derivable cases of TF's thresholded ROC (200 thresholds, trapezoid)."""
+    from oracle import vnet_oracle as O
+    lab = np.array([0, 0, 1, 1])
+    assert abs(O.tf_metrics_auc(lab, np.array([0.1, 0.2, 0.8, 0.9])) - 1.0) < 1e-6            # perfectly separated
+    assert abs(O.tf_metrics_auc(lab, np.array([0.9, 0.8, 0.2, 0.1])) - 0.0) < 1e-6            # perfectly wrong
+    assert abs(O.tf_metrics_auc(lab, np.array([0.5, 0.5, 0.5, 0.5])) - 0.5) < 1e-6            # one ROC step: area 1/2
+    # TF's doc example: labels [0,0,1,1], predictions [0.1,0.4,0.35,0.8] -> 0.75
+    assert abs(O.tf_metrics_auc(lab, np.array([0.1, 0.4, 0.35, 0.8])) - 0.75) < 1e-6

@@ -69,6 +69,8 @@ SIGNATURES = {
     "vnet_dropout_fwd_dev": (_i, [_vp, _vp, _vp, _i64, _f, _u64, _vp, _vp]),
     "vnet_confusion_ws_bytes": (_sz, [_i]),
     "vnet_confusion_matrix": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
+    "vnet_auc_ws_bytes": (_sz, [_i]),
+    "vnet_auc_histogram": (_i, [_vp, _vp, _i64, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "vnet_accumulate_patch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
 }
 

@@ -150,9 +150,59 @@ __global__ void __launch_bounds__(256) confusion_finalize_kernel(const float* __
     __syncthreads();
     if (threadIdx.x == 0) out[c] = shd[0] + shd[1] + shd[2] + shd[3];
 }
+// tf.metrics.auc (reference model.py:607,613: per class i > 0, labels = one-hot[..., i], predictions = softmax[..., i], default
+// num_thresholds = 200, ROC, trapezoidal): TF counts tp/fn/tn/fp at every threshold with `prediction > threshold` (float32).
+// Equivalent and one pass: bin(p) = number of thresholds strictly below p (0..T), one histogram for the voxels of the class
+// and one for the others; tp[t] = sum of hist_pos[b] over b > t etc. follow on the host.  Integer LDS atomics: exact counts.
+__global__ void __launch_bounds__(256) auc_hist_kernel(const float* __restrict__ sm, const int32_t* __restrict__ labels, size_t n, int K, int cls,
+                                                       const float* __restrict__ thr, int T, unsigned int* __restrict__ partial) {
+    extern __shared__ unsigned int lds_u[];
+    unsigned int* hist = lds_u;                       // [2][T + 1]
+    float* th = reinterpret_cast<float*>(lds_u + 2 * (T + 1));
+    for (int i = threadIdx.x; i < 2 * (T + 1); i += blockDim.x) hist[i] = 0u;
+    for (int i = threadIdx.x; i < T; i += blockDim.x) th[i] = thr[i];
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float p = sm[i * K + cls];
+        int lo = 0, hi = T;                           // smallest b with !(th[b] < p)  ==  count of thresholds below p
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (th[mid] < p) lo = mid + 1; else hi = mid;
+        }
+        atomicAdd(&hist[(labels[i] == cls ? 0 : T + 1) + lo], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * (T + 1); i += blockDim.x) partial[(size_t)blockIdx.x * 2 * (T + 1) + i] = hist[i];
+}
+__global__ void __launch_bounds__(256) auc_hist_finalize_kernel(const unsigned int* __restrict__ partial, int nblk, int W, double* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= W) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * W + c];
+    out[c] = s;
+}
 }  // namespace
 
 extern "C" {
+size_t vnet_auc_ws_bytes(int T) { return (size_t)256 * 2 * (T + 1) * sizeof(unsigned int); }
+
+int vnet_auc_histogram(const float* softmax, const int32_t* labels, int64_t n, int K, int cls, const float* thresholds, int T,
+                       double* hist_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!softmax || !labels || !thresholds || !hist_out || n <= 0 || K <= 0 || cls < 0 || cls >= K || T <= 0) return VNET_E_BADARG;
+    if (T > 4096) return VNET_E_UNSUPPORTED;
+    if (!ws || ws_bytes < vnet_auc_ws_bytes(T)) return VNET_E_WORKSPACE;
+    const int64_t want = (n + 256 * 16 - 1) / (256 * 16);
+    const int nblk = (int)(want > 256 ? 256 : want);
+    const size_t lds = (size_t)(2 * (T + 1) + T) * 4;
+    hipLaunchKernelGGL(auc_hist_kernel, dim3(nblk), dim3(256), lds, (hipStream_t)stream, softmax, labels, (size_t)n, K, cls, thresholds, T,
+                       (unsigned int*)ws);
+    VNET_LAUNCH_CHECK();
+    const int W = 2 * (T + 1);
+    hipLaunchKernelGGL(auc_hist_finalize_kernel, dim3((W + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const unsigned int*)ws, nblk, W, hist_out);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
 size_t vnet_confusion_ws_bytes(int K) { return (size_t)1024 * K * K * sizeof(float); }
 
 int vnet_confusion_matrix(const int64_t* pred, const int32_t* labels, int64_t n, int K, double* cm_out,

@@ -256,6 +256,7 @@ class image2label(object):
     # -- reference model.py:297-630 (network + loss head; summaries/metrics not carried) ---------------
     def build_model_graph(self):
         self._print("{}: Start to build model graph...".format(_now()))
+        self._validate_loss()
         if self.dimension != 3:
             sys.exit("Only 3D PatchShape is built (2D is out of scope)")
         if self.device is None:
@@ -282,8 +283,16 @@ class image2label(object):
         else:
             sys.exit("Invalid Network")
         self.network.build(self.input_batch_shape)
-        ops.parse_loss(self.loss_name)                   # validates Loss.Name like model.py:559-560
         self._print("{}: Core network complete".format(_now()))
+
+    def _validate_loss(self):
+        """Loss.Name check of model.py:495-560, INCLUDING its fall-through: `if name == "xent"` (model.py:495) is a
+        separate statement from the `if name == "weighted_xent" / elif ... / else: sys.exit("Invalid loss function")` chain
+        that follows (model.py:497-560), so the reference builds the xent loss and then exits.  A drop-in keeps that
+        (nobody can be training with it); `Loss.AllowPlainXent: true` (extension) runs the plain cross-entropy instead."""
+        ops.parse_loss(self.loss_name)                   # unknown names: SystemExit("Invalid loss function")
+        if self.loss_name == "xent" and not self.config['TrainingSetting']['Loss'].get('AllowPlainXent', False):
+            sys.exit("Invalid loss function")
 
     def forward(self, images, labels=None, dropout=0.0, want_softmax=False, want_pred=False):
         """One pass of the graph of model.py:444-568.  images float32 [B,*P,Cin]; labels int32 [B,*P,1]."""
@@ -358,13 +367,18 @@ class image2label(object):
             self.sync.finish()
         self.optimizer.apply(lr)
         self.global_step += 1
-        return loss
+        # detached: a caller that keeps the loss must not keep this step's autograd graph (and with it the AccumulateGrad
+        # nodes, which remember the stream they were created on -- a later stream capture of the step would then run them
+        # on the wrong stream)
+        return loss.detach()
 
     def _graph_mode(self):
         """'off' | 'whole' (single process: the whole step is one hipGraph) | 'segmented' (data parallel: gradients graph ->
         eager RCCL all-reduce of the buckets -> optimiser graph; no collective is ever captured) | 'full' (data parallel,
         collectives captured inside the one graph, overlap with backward kept; opt-in: VNET_DP_GRAPH=full).
         TrainingSetting.StepGraph / VNET_STEP_GRAPH = 0|1 switches the feature (default on)."""
+        if getattr(self, "force_eager", False):      # e.g. bench.py's per-launch timing pass (events cannot be timed in a graph)
+            return "off"
         want = os.environ.get("VNET_STEP_GRAPH")
         want = getattr(self, "step_graph", True) if want is None else want not in ("0", "off", "false")
         if not want or self.device.type != "cuda":
@@ -398,6 +412,20 @@ class image2label(object):
         def update():
             self.optimizer.launch(0.0, state=st)
 
+        # Single-stream capture: a graph with the filter-gradient branch on a second stream makes hipGraphLaunch cost as
+        # much host time as the eager enqueue (measured 18.8 ms vs 0.11 ms per replay, 128^3 step) and runs 0.9 ms slower
+        # on the GPU (the runtime schedules the branch worse than the eager two-stream order), while the side stream
+        # itself is worth 0.06 ms -- profiles/r02_step_modes.txt.
+        pg_on = ops._PG["on"]
+        ops.set_param_grad_stream(False)
+        try:
+            loss = self._capture_mode(mode, grads, update)
+        finally:
+            ops.set_param_grad_stream(pg_on)
+        self._g_loss = loss.detach()
+        self._g_mode = mode
+
+    def _capture_mode(self, mode, grads, update):
         if mode == "whole":
             def whole():
                 loss = grads()
@@ -419,8 +447,7 @@ class image2label(object):
                 return loss
             g, loss = self._capture(whole_dp)
             self._graphs = [g]
-        self._g_loss = loss.detach()
-        self._g_mode = mode
+        return loss
 
     def train_step(self, images, labels, dropout=None):
         """reference model.py:743-748: one fwd + loss + bwd + optimiser step; returns the loss tensor (device scalar; in
@@ -573,9 +600,12 @@ class image2label(object):
                         timage, tlabel = next(test_iter)
                     with torch.no_grad():
                         tl = torch.from_numpy(tlabel).to(self.device)
-                        _, tloss, _, tpred = self.forward(torch.from_numpy(timage).to(self.device), tl, 0.0, want_pred=True)
-                        # accuracy / per-class sensitivity, specificity, hard dice (reference model.py:588-626)
-                        self.last_metrics = ops.hard_metrics(tpred, tl[..., 0], self.output_channel_num)
+                        _, tloss, tsm, tpred = self.forward(torch.from_numpy(timage).to(self.device), tl, 0.0, want_softmax=True, want_pred=True)
+                        # accuracy + streaming per-class tp/tn/fp/fn, sensitivity, specificity, hard dice, ROC AUC
+                        # (tf.metrics.*, reference model.py:588-626)
+                        if getattr(self, "metrics", None) is None:
+                            self.metrics = ops.StreamingMetrics(self.output_channel_num)
+                        self.last_metrics = self.metrics.update(tpred, tl[..., 0], tsm).result()
                     self._print('{}: Segmentation testing accuracy: {:.4f} dice: {}'.format(
                         _now(), self.last_metrics["accuracy"],
                         [round(self.last_metrics[c]["dice"], 4) for c in range(self.output_channel_num)]))

@@ -250,7 +250,7 @@ def _grad_ret(t, s):
 
 
 # ---- optional per-launch timing (bench.py): HIP events on the launch stream ---------------------
-_PROFILE = {"on": False, "records": [], "only": None, "graph_records": []}
+_PROFILE = {"on": False, "records": [], "only": None}
 
 
 def profile_start(only=None):
@@ -278,62 +278,27 @@ def _wgrad_tag(bf16, ks, kx, stride, wo, B, cin, co):
     return "wgrad%s k%d%s s%d %d^3x%d %d->%d" % ("-bf16" if bf16 else "", ks, "x%d" % kx if kx else "", stride, wo, B, cin, co)
 
 
-class _ExtEvent(object):
-    """HIP event recorded with hipEventRecordExternal: inside a stream capture it becomes an event-record NODE of the
-    graph, re-recorded by every replay and readable from outside the graph (torch.cuda.Event cannot be timed across a
-    capture).  Lets bench.py time the reported kernel family inside the replayed whole-step graph."""
-    _hip = None
-
-    @classmethod
-    def hip(cls):
-        if cls._hip is None:
-            h = ctypes.CDLL("libamdhip64.so")        # the runtime torch already loaded (same soname)
-            h.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
-            h.hipEventRecordWithFlags.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
-            h.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
-            h.hipEventDestroy.argtypes = [ctypes.c_void_p]
-            cls._hip = h
-        return cls._hip
-
-    def __init__(self):
-        self.h = ctypes.c_void_p()
-        check(self.hip().hipEventCreate(ctypes.byref(self.h)), "hipEventCreate")
-
-    def record(self):
-        check(self.hip().hipEventRecordWithFlags(self.h, _raw_stream(), 1), "hipEventRecordWithFlags(external)")
-
-    def elapsed_time(self, other):
-        ms = ctypes.c_float()
-        check(self.hip().hipEventElapsedTime(ctypes.byref(ms), self.h, other.h), "hipEventElapsedTime")
-        return ms.value
-
-
-def profile_read():
-    """[(tag, flops, algorithmic_bytes, milliseconds)] of the launches timed inside a captured graph, as recorded by the
-    LAST replay (synchronise first).  The records stay: every replay re-records the same events."""
-    return [(t, f, b, e0.elapsed_time(e1)) for (t, f, b, e0, e1) in _PROFILE["graph_records"]]
-
-
 class _Timed(object):
+    """HIP events around one launch.  Not under stream capture: on this runtime (ROCm 7.0 libamdhip64 bundled with torch
+    2.10) an event recorded into a capture cannot be timed afterwards -- hipEventRecordWithFlags(hipEventRecordExternal)
+    is refused with hipErrorInvalidValue and hipEventElapsedTime on captured events returns hipErrorInvalidHandle
+    (profiles/probes/graph_event_probe.py) -- so bench.py times the reported kernel family in eager steps."""
+
     def __init__(self, tag, flops, nbytes):
         self.rec = (tag, flops, nbytes)
-        self.on = _timed_tag(tag)
+        self.on = _timed_tag(tag) and not torch.cuda.is_current_stream_capturing()
 
     def __enter__(self):
         if self.on:
-            self.ext = torch.cuda.is_current_stream_capturing()
-            if self.ext:
-                self.e0, self.e1 = _ExtEvent(), _ExtEvent()
-            else:
-                self.e0 = torch.cuda.Event(enable_timing=True)
-                self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()          # torch's current stream == the stream the kernel is launched on
         return self
 
     def __exit__(self, *a):
         if self.on:
             self.e1.record()
-            _PROFILE["graph_records" if self.ext else "records"].append(self.rec + (self.e0, self.e1))
+            _PROFILE["records"].append(self.rec + (self.e0, self.e1))
 
 
 # ---- convolution family ----------------------------------------------------------------------------
@@ -1086,7 +1051,83 @@ def hard_metrics(pred, labels, K):
     ws = workspace(nb, pred.device)
     check(L.vnet_confusion_matrix(_ptr(pred), _ptr(labels), pred.numel(), K, _ptr(cm), _ptr(ws), nb, _stream()),
           "vnet_confusion_matrix")
-    cm = cm.cpu().numpy().reshape(K, K)
+    return metrics_from_confusion(cm.cpu().numpy().reshape(K, K))
+
+
+# ---- tf.metrics.auc (reference model.py:607,613,624) ------------------------------------------------------------------
+def tf_auc_thresholds(num_thresholds=200):
+    """TF 1.15 metrics_impl.auc: kepsilon = 1e-7; [0 - eps] + [(i + 1) / (n - 1) for i in range(n - 2)] + [1 + eps], used as
+    float32 constants against float32 predictions."""
+    import numpy as np
+    eps = 1e-7
+    th = [0.0 - eps] + [(i + 1) * 1.0 / (num_thresholds - 1) for i in range(num_thresholds - 2)] + [1.0 + eps]
+    return np.asarray(th, dtype=np.float32)
+
+
+def auc_histogram(softmax, labels, K, cls, num_thresholds=200):
+    """Counts behind tf.metrics.auc(one_hot(labels)[..., cls], softmax[..., cls]): float64 [2][T+1] on the device --
+    row 0 the voxels of class `cls`, row 1 all others; bin = number of thresholds strictly below the prediction."""
+    L = _lib.lib()
+    sm = softmax.contiguous()
+    lab = labels.to(torch.int32).contiguous().reshape(-1)
+    n = lab.numel()
+    th = _const_vector(tf_auc_thresholds(num_thresholds), sm.device)
+    hist = torch.empty((2, num_thresholds + 1), dtype=torch.float64, device=sm.device)
+    nb = L.vnet_auc_ws_bytes(num_thresholds)
+    ws = workspace(nb, sm.device)
+    check(L.vnet_auc_histogram(_ptr(sm), _ptr(lab), n, K, cls, _ptr(th), num_thresholds, _ptr(hist), _ptr(ws), nb, _stream()),
+          "vnet_auc_histogram")
+    return hist
+
+
+def auc_from_hist(hist):
+    """ROC AUC the way tf.metrics.auc(curve='ROC', summation_method='trapezoidal') evaluates it from its per-threshold
+    counters: tp[t] = #{positive, p > thr[t]}, rec = (tp + eps) / (tp + fn + eps), fpr = fp / (fp + tn + eps),
+    auc = sum((fpr[:-1] - fpr[1:]) * (rec[:-1] + rec[1:]) / 2)."""
+    import numpy as np
+    h = np.asarray(hist, dtype=np.float64)
+    eps = 1e-7
+    tp = h[0][::-1].cumsum()[::-1][1:]          # tp[t] = sum_{b > t} hist_pos[b]
+    fp = h[1][::-1].cumsum()[::-1][1:]
+    fn, tn = h[0].sum() - tp, h[1].sum() - fp
+    rec = (tp + eps) / (tp + fn + eps)
+    fpr = fp / (fp + tn + eps)
+    return float(((fpr[:-1] - fpr[1:]) * (rec[:-1] + rec[1:]) / 2.0).sum())
+
+
+class StreamingMetrics(object):
+    """The tf.metrics of reference model.py:588-626: accumulating (like TF's local variables, over every update since
+    construction) confusion counts and AUC counters; result() gives accuracy of the LAST batch (model.py:590 is not
+    streaming) and per class i > 0: tp/tn/fp/fn, sensitivity, specificity, hard Dice 2tp/(2tp+fp+fn) and the ROC AUC."""
+
+    def __init__(self, K, num_thresholds=200):
+        self.K, self.T = K, num_thresholds
+        self.cm = None
+        self.hist = [None] * K
+        self.last_accuracy = None
+
+    def update(self, pred, labels, softmax=None):
+        import numpy as np
+        m = hard_metrics(pred, labels, self.K)
+        self.last_accuracy = m["accuracy"]
+        self.cm = m["confusion"] if self.cm is None else self.cm + m["confusion"]
+        if softmax is not None:
+            for c in range(1, self.K):
+                h = auc_histogram(softmax, labels, self.K, c, self.T).cpu().numpy()
+                self.hist[c] = h if self.hist[c] is None else self.hist[c] + h
+        return self
+
+    def result(self):
+        out = metrics_from_confusion(self.cm)
+        out["accuracy"] = self.last_accuracy
+        for c in range(1, self.K):
+            if self.hist[c] is not None:
+                out[c]["auc"] = auc_from_hist(self.hist[c])
+        return out
+
+
+def metrics_from_confusion(cm):
+    K = cm.shape[0]
     n = cm.sum()
     out = {"accuracy": float(cm.trace() / max(n, 1.0)), "confusion": cm}
     for c in range(K):
