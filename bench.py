@@ -178,8 +178,12 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
     loss = None
     if not graph:
         ops.profile_start(None if full_table else fam)
-    for _ in range(3 if graph else 0):       # prepare: 2 eager steps + the capture (and first replay) of the step graph
+    nprep = 3 if graph else 0                # prepare: 2 eager steps + the capture (and first replay) of the step graph
+    if mode == "segmented":
+        nprep += 10                          # + the data-parallel start-up autotune: 5 segmented-graph steps, 5 eager steps
+    for _ in range(nprep):
         loss = m.train_step(images, labels)
+    mode = m.step_mode()                     # (the autotune may have picked the eager enqueue)
     for _ in range(args.warmup):
         loss = m.train_step(images, labels)
     if not graph:
@@ -211,9 +215,9 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
 
     res = {"value": round(world * batch * args.steps / dt, 4), "ms_per_step": round(dt / args.steps * 1e3, 3),
            "final_loss": round(final_loss, 6), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
+           "dp_autotune_ms": ([round(t * 1e3, 3) for t in m._tuner.times] if getattr(m, "_tuner", None) is not None else None),
            "step_enqueue": {"off": "eager (one ctypes launch per kernel)", "whole": "hipGraph replay of the whole step",
-                            "segmented": "hipGraph(gradients) + eager RCCL bucket all-reduces + hipGraph(optimiser)",
-                            "full": "hipGraph of the whole step incl. captured RCCL all-reduces"}[mode],
+                            "segmented": "hipGraph(gradients) + eager RCCL bucket all-reduces + hipGraph(optimiser)"}[mode],
            "roofline": None}
     if rank != 0:
         return res
@@ -290,7 +294,7 @@ def main():
                           "global_batch": world * args.batch, "parallelism": "dp%d" % world, "bn": "per-replica",
                           "ranks": world, "backend": (dist.get_backend() if world > 1 else None)},
                "final_loss": r["final_loss"], "host_enqueue_ms_per_step": r["host_enqueue_ms_per_step"],
-               "step_enqueue": r["step_enqueue"], "pinned_to_core": args.pin_core if args.pin_core >= 0 else None,
+               "step_enqueue": r["step_enqueue"], "dp_autotune_ms": r.get("dp_autotune_ms"), "pinned_to_core": args.pin_core if args.pin_core >= 0 else None,
                "roofline": r["roofline"]}
         for k in ("conv_ms_per_step", "conv_tflops"):
             if k in r:

@@ -15,6 +15,22 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 NET = dict(K=2, C0=4, levels=2, ncv=(1, 2), nb=1, P=16)
 
+# Every multi-rank test runs (a) over gloo with both ranks on cuda:0 -- always possible -- and (b) over RCCL (backend
+# "nccl") with ONE RANK PER DEVICE whenever the box has at least two GPUs (skipped, and reported as skipped, otherwise):
+# rank r's loss == the single-GPU B=1 run of its patch, reduced gradient == sum of the per-rank gradients, replicas stay
+# bit-identical after Adam, sync-BN == single-device batch of N.
+BACKENDS = [pytest.param("gloo", id="gloo-2-ranks-on-one-gpu"),
+            pytest.param("nccl", id="rccl-one-rank-per-gpu",
+                         marks=pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL between devices)"))]
+
+
+def _rank_env(rank, world, port, backend):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank if backend == "nccl" else 0), VNET_DIST_BACKEND=backend)
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    return dev
+
 
 def _free_port():
     s = socket.socket()
@@ -38,15 +54,14 @@ def _batch(rank, dev):
     return torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
 
 
-def _sync_bn_worker(rank, world, port, out):
+def _sync_bn_worker(rank, world, port, out, backend="gloo"):
     """Cross-replica batch-norm: one patch per rank, statistics over both."""
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", VNET_DIST_BACKEND="gloo")
+    dev = _rank_env(rank, world, port, backend)
     import torch.distributed as dist
     from vnet_tensorflow_amd import ops, optim, parallel
     parallel.init_from_env()
+    assert dist.get_backend() == backend and dist.get_world_size() == world
     ops.set_sync_batch_norm()
-    dev = torch.device("cuda", 0)
     net = _build(dev, seed=100)                        # same seed: identical replicas
     flat = optim.FlatParams(net.named_parameters())
     sync = parallel.BucketedGradAllReduce(flat, bucket_bytes=16 << 10)
@@ -65,11 +80,12 @@ def _sync_bn_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_sync_batch_norm_equals_single_device_batch(tmp_path, dev):
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_sync_batch_norm_equals_single_device_batch(tmp_path, dev, backend):
     """2 ranks x 1 patch with cross-replica statistics == the single-device BatchSize=2 step of the reference
     (networks.py:319 reduces the batch axis too): same logits per patch, loss = mean, gradient sum = 2 x."""
     from vnet_tensorflow_amd import ops, optim
-    mp.spawn(_sync_bn_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_sync_bn_worker, args=(2, _free_port(), str(tmp_path), backend), nprocs=2, join=True)
     r = [torch.load(tmp_path / ("s%d.pt" % k)) for k in range(2)]
     assert torch.equal(r[0]["gsum"], r[1]["gsum"])
     net = _build(dev, seed=100)
@@ -93,13 +109,12 @@ def test_sync_batch_norm_equals_single_device_batch(tmp_path, dev):
     assert float((l0 - r[0]["logits"]).abs().max()) > 1e-3
 
 
-def _worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", VNET_DIST_BACKEND="gloo")
+def _worker(rank, world, port, out, backend="gloo"):
+    dev = _rank_env(rank, world, port, backend)
     import torch.distributed as dist
     from vnet_tensorflow_amd import ops, optim, parallel
     parallel.init_from_env()
-    dev = torch.device("cuda", 0)
+    assert dist.get_backend() == backend and dist.get_world_size() == world
     net = _build(dev, seed=100 + rank)                 # replicas start different ...
     flat = optim.FlatParams(net.named_parameters())
     parallel.broadcast_parameters(flat.data)           # ... rank 0's weights win
@@ -128,9 +143,10 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_share_one_gpu(tmp_path, dev):
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_two_ranks(tmp_path, dev, backend):
     from vnet_tensorflow_amd import ops, optim
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), backend), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
     assert torch.equal(r0["gsum"], r1["gsum"]) and torch.equal(r0["data"], r1["data"])     # replicas identical
     # single-process reference: per-rank gradients from rank 0's initial weights, summed
@@ -206,7 +222,8 @@ def test_rccl_group_of_one(tmp_path, dev):
     assert torch.equal(r["t"], torch.ones(8))
 
 
-def test_bench_contract_two_ranks(tmp_path):
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_bench_contract_two_ranks(tmp_path, backend):
     """bench.py launched the way the driver launches it for N>1 (torch.distributed.run, one rank per GPU) -- here two
     ranks share the single device over gloo: barrier + max-over-ranks timing, rank 0 prints ONE JSON line whose value
     is the whole-job rate."""
@@ -214,7 +231,7 @@ def test_bench_contract_two_ranks(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VNET_DIST_BACKEND="gloo")
+    env = dict(os.environ, VNET_DIST_BACKEND=backend)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "2", "--patch", "32"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
@@ -224,6 +241,8 @@ def test_bench_contract_two_ranks(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 2 and out["scaling"] == "weak"
     assert out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 2
+    assert out["config"]["ranks"] == 2 and out["config"]["backend"] == backend          # the process group really has N ranks
+    assert out["step_enqueue"].startswith(("hipGraph(gradients)", "eager")) and len(out["dp_autotune_ms"]) == 2
     assert abs(out["value"] - 2 * 1 * 1000.0 / out["ms_per_step"]) < 1e-2 * out["value"]
     assert out["roofline"] is None or out["roofline"]["frac"] > 0
     assert "cpu_baseline" not in out                     # rank 0 at N=1 only

@@ -25,8 +25,8 @@ def test_dropout_against_oracle_with_the_kernels_mask(dev, rate):
     gs = rng.standard_normal(xs.shape)
     x = g(xs, dev).requires_grad_(True)
     y = ops.dropout(x, rate)
+    mask = y.grad_fn.saved_tensors[0].cpu().numpy().astype(np.float64)       # the keep-mask the kernel wrote
     y.backward(g(gs, dev))
-    mask = y.grad_fn.saved_tensors[0].cpu().numpy().astype(np.float64)
     assert set(np.unique(mask)) <= {0.0, 1.0} and abs(mask.mean() - (1.0 - rate)) < 0.05
     xv = O.Var(xs.astype(np.float32).astype(np.float64))
     ref = O.dropout(xv, rate, mask)

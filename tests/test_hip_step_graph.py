@@ -151,7 +151,6 @@ def _dp_worker(rank, world, port, out, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                       VNET_DP_FORCE="1", VNET_DP_BUCKET_BYTES=str(16 << 10))
     os.environ["VNET_STEP_GRAPH"] = "0" if mode == "eager" else "1"
-    os.environ["VNET_DP_GRAPH"] = "full" if mode == "full" else "segmented"
     import torch.distributed as dist
     from vnet_tensorflow_amd.model import image2label
     from oracle.vnet_oracle import synthetic_batch
@@ -168,18 +167,18 @@ def _dp_worker(rank, world, port, out, mode):
     x, l = torch.from_numpy(x).to(dev), torch.from_numpy(l).to(dev)
     losses = [float(m.train_step(x, l)) for _ in range(5)]
     torch.cuda.synchronize()
-    assert m._graph_mode() == {"eager": "off", "segmented": "segmented", "full": "full"}[mode]
+    assert m._graph_mode() == {"eager": "off", "segmented": "segmented"}[mode]
     if mode != "eager":
-        assert m._graphs is not None and len(m._graphs) == (2 if mode == "segmented" else 1)
+        assert m._graphs is not None and len(m._graphs) == 2
     torch.save({"losses": losses, "data": m.flat.data.cpu()}, os.path.join(out, "dp_%s.pt" % mode))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["segmented", "full"])
-def test_data_parallel_graph_modes_rccl_group_of_one(tmp_path, dev, mode):
-    """Data-parallel step with RCCL in the loop (group of one rank: all a 1-GPU box can host):
-    'segmented' = gradients graph -> eager bucket all-reduces -> optimiser graph (no collective is captured);
-    'full' = the all-reduces captured between the backward kernels.  Both must reproduce the eager step bit for bit."""
+def test_data_parallel_segmented_graph_rccl_group_of_one(tmp_path, dev):
+    """Data-parallel step with RCCL in the loop (group of one rank: all a 1-GPU box can host): gradients graph -> eager
+    bucket all-reduces on the communication stream -> optimiser graph.  No collective is captured (a captured RCCL
+    all-reduce trips ProcessGroupNCCL's watchdog: hipErrorCapturedEvent).  Must reproduce the eager step bit for bit."""
+    mode = "segmented"
     for md in ("eager", mode):
         mp.spawn(_dp_worker, args=(1, _free_port(), str(tmp_path), md), nprocs=1, join=True)
     a, b = torch.load(tmp_path / "dp_eager.pt"), torch.load(tmp_path / ("dp_%s.pt" % mode))

@@ -203,3 +203,40 @@ def test_prefetcher_keeps_order_and_content():
     assert len(plain) == len(pre) == 4
     for (a, b), (c, d) in zip(plain, pre):
         assert np.array_equal(a, c.numpy()) and np.array_equal(b, d.numpy())
+
+
+# ---- start-up choice of the data-parallel step mode ---------------------------------------------------------------------
+def _tune_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import time
+    from vnet_tensorflow_amd import parallel
+    parallel.init_from_env("gloo")
+    cost = {"segmented": (0.003, 0.003), "off": (0.001, 0.012)}       # seconds per step on (rank 0, rank 1)
+    tuner = parallel.StepModeAutotune(["segmented", "off"], steps=4)
+    seen = []
+    for step in range(12):
+        mode = tuner.mode()
+        tuner.before()
+        time.sleep(cost[mode][rank])
+        seen.append(mode)
+        tuner.after()
+    torch.save({"seen": seen, "choice": tuner.choice, "times": tuner.times}, os.path.join(out, "t%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_step_mode_autotune_picks_the_same_winner_on_every_rank(tmp_path):
+    """Rank 0 alone would prefer 'off' (1 ms vs 3 ms per step), but rank 1 is slow in that mode (12 ms): the max over ranks
+    decides, and both ranks continue with 'segmented' after 2 x 4 measured steps."""
+    mp.spawn(_tune_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "t0.pt"), torch.load(tmp_path / "t1.pt")
+    assert r0["seen"] == r1["seen"] == ["segmented"] * 4 + ["off"] * 4 + ["segmented"] * 4
+    assert r0["choice"] == r1["choice"] == "segmented" and r0["times"] == r1["times"]
+    assert r0["times"][0] < r0["times"][1]
+
+
+def test_step_mode_autotune_single_candidate_is_free():
+    from vnet_tensorflow_amd import parallel
+    t = parallel.StepModeAutotune(["segmented"])
+    assert t.choice == "segmented" and t.mode() == "segmented"
+    t.before(); t.after()
+    assert t.times == []

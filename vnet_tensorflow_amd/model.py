@@ -374,9 +374,10 @@ class image2label(object):
 
     def _graph_mode(self):
         """'off' | 'whole' (single process: the whole step is one hipGraph) | 'segmented' (data parallel: gradients graph ->
-        eager RCCL all-reduce of the buckets -> optimiser graph; no collective is ever captured) | 'full' (data parallel,
-        collectives captured inside the one graph, overlap with backward kept; opt-in: VNET_DP_GRAPH=full).
-        TrainingSetting.StepGraph / VNET_STEP_GRAPH = 0|1 switches the feature (default on)."""
+        eager RCCL all-reduce of the buckets -> optimiser graph).  No collective is ever captured: torch's
+        ProcessGroupNCCL watchdog thread queries the work's events, and an event last recorded in a capturing stream makes
+        that query fail with hipErrorCapturedEvent and terminate the process (seen with a captured RCCL all-reduce in a
+        group of one).  TrainingSetting.StepGraph / VNET_STEP_GRAPH = 0|1 switches the feature (default on)."""
         if getattr(self, "force_eager", False):      # e.g. bench.py's per-launch timing pass (events cannot be timed in a graph)
             return "off"
         want = os.environ.get("VNET_STEP_GRAPH")
@@ -386,12 +387,14 @@ class image2label(object):
         if self.world > 1 or self.sync is not None:
             if getattr(self, "sync_batch_norm", False):
                 return "off"                   # 74 small collectives inside forward/backward: eager only
-            return "full" if os.environ.get("VNET_DP_GRAPH", getattr(self, "dp_graph", "segmented")) == "full" else "segmented"
+            return "segmented"
         return "whole"
 
     def _capture(self, fn, pool=None):
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=pool, stream=self._graph_stream):
+        # thread_local: the prefetch threads pin host memory (hipHostMalloc) while the main thread captures; in the default
+        # "global" mode such a call from ANY thread invalidates the capture (hipErrorStreamCaptureInvalidated)
+        with torch.cuda.graph(g, pool=pool, stream=self._graph_stream, capture_error_mode="thread_local"):
             out = fn()
         return g, out
 
@@ -418,6 +421,7 @@ class image2label(object):
         # itself is worth 0.06 ms -- profiles/r02_step_modes.txt.
         pg_on = ops._PG["on"]
         ops.set_param_grad_stream(False)
+        ops.settle_pack_registry()
         try:
             loss = self._capture_mode(mode, grads, update)
         finally:
@@ -433,20 +437,11 @@ class image2label(object):
                 return loss
             g, loss = self._capture(whole)
             self._graphs = [g]
-        elif mode == "segmented":
-            self.sync.hold_all = True            # hooks count, nothing is launched: finish() reduces every bucket after the graph
+        else:
+            # (sync.hold_all is set by train_step: hooks only count, reduce_all() launches every bucket after the graph)
             ga, loss = self._capture(grads)
             gb, _ = self._capture(update, pool=ga.pool())
             self._graphs = [ga, gb]
-        else:                                    # "full": RCCL collectives captured between the backward kernels
-            def whole_dp():
-                self.sync.begin_step()
-                loss = grads()
-                self.sync.finish()
-                update()
-                return loss
-            g, loss = self._capture(whole_dp)
-            self._graphs = [g]
         return loss
 
     def train_step(self, images, labels, dropout=None):
@@ -454,8 +449,42 @@ class image2label(object):
         graph mode it is a static buffer that the next step overwrites -- read or clone it before the next call)."""
         dropout = float(self.dropout_rate if dropout is None else dropout)
         mode = self._graph_mode()
+        tuner = None
+        if mode == "segmented" and getattr(self, "_graphs", None) is not None:       # (after the warm-up steps and the capture)
+            tuner = self._dp_tuner()
+            if tuner is not None:
+                mode = tuner.mode()
+                tuner.before()
+        if self.sync is not None:
+            self.sync.hold_all = (mode == "segmented")       # eager: buckets go out from the hooks, overlapping backward
         if mode == "off":
-            return self._train_step_eager(images, labels, dropout)
+            loss = self._train_step_eager(images, labels, dropout)
+        else:
+            loss = self._train_step_graph(mode, images, labels, dropout)
+        if tuner is not None:
+            tuner.after()
+        return loss
+
+    def step_mode(self):
+        """How train_step currently enqueues the step: 'off' (eager) | 'whole' | 'segmented'."""
+        t = getattr(self, "_tuner", None)
+        mode = self._graph_mode()
+        if mode == "segmented" and t is not None and t.choice is not None:
+            return t.choice
+        return mode
+
+    def _dp_tuner(self):
+        """Data parallel: 5 steps as segmented graph replay, 5 steps eager, keep the faster (parallel.StepModeAutotune);
+        TrainingSetting.DpAutotune / VNET_DP_AUTOTUNE = 0 pins the segmented graph."""
+        if getattr(self, "_tuner", None) is None:
+            on = os.environ.get("VNET_DP_AUTOTUNE")
+            on = getattr(self, "dp_autotune", True) if on is None else on not in ("0", "off", "false")
+            cands = ["segmented", "off"] if on else ["segmented"]
+            self._tuner = parallel.StepModeAutotune(cands, steps=int(os.environ.get("VNET_DP_AUTOTUNE_STEPS", "5")),
+                                                    sync=self._device_sync)
+        return self._tuner
+
+    def _train_step_graph(self, mode, images, labels, dropout):
         if getattr(self, "_graph_stream", None) is None:
             self._graph_stream = torch.cuda.Stream(device=self.device)
             self._step_state = ops.step_state(self.device)
@@ -546,6 +575,7 @@ class image2label(object):
         workers = int(os.environ.get("VNET_LOADER_THREADS", getattr(self, "loader_threads", 3)))
         self.steps_timed, self.seconds_timed = 0, 0.0
 
+        first_epoch = self.start_epoch
         for epoch in range(self.start_epoch, self.epoches):
             self._print("{}: Epoch {} starts...".format(_now(), epoch + 1))
             loss_sum, count = 0.0, 0
@@ -586,7 +616,9 @@ class image2label(object):
                 loss_sum += v
                 count += n
                 pending = now
-                if t_epoch is None and self.global_step >= 5:      # steady-state throughput (past capture / warm-up)
+                # steady-state throughput: past the capture / warm-up steps and, when there are several epochs, past the
+                # first one (which also fills the dataset's volume cache)
+                if t_epoch is None and self.global_step >= 5 and (epoch > first_epoch or self.epoches - first_epoch == 1):
                     self._device_sync()
                     t_epoch, s_epoch = time.perf_counter(), self.global_step
                 if self.global_step % self.log_interval == 0:

@@ -200,6 +200,9 @@ def repack_registered():
     dev = ents[0][0].device
     ptrs = tuple(w.data_ptr() for w, _, _ in ents)
     if reg["descs"] is None or reg.get("ptrs") != ptrs:
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise VnetHipError("the packed-filter registry changed inside a stream capture (a network was garbage-collected or "
+                               "a new filter appeared): call ops.settle_pack_registry() before capturing")
         rows = []
         for w, (mode, taps, I, O), wp in ents:
             cq, npad = ctypes.c_int(), ctypes.c_int()
@@ -210,6 +213,15 @@ def repack_registered():
     check(L.vnet_pack_weights_batched(_ptr(reg["descs"]), len(ents), _stream()), "vnet_pack_weights_batched")
     for w, key, wp in ents:
         w._vnet_packed[key] = (_pack_tag(w), wp)
+
+
+def settle_pack_registry():
+    """Before a stream capture: collect garbage (torch.cuda.graph does it on entry anyway -- a network that dies THERE would
+    change the registry inside the capture), drop dead filters and rebuild the descriptor table now, while host-to-device
+    copies are still allowed."""
+    import gc
+    gc.collect()
+    repack_registered()
 
 
 def clear_pack_registry():

@@ -193,3 +193,47 @@ class BucketedGradAllReduce(object):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+
+class StepModeAutotune(object):
+    """Start-up choice between ways of running the data-parallel step (model.image2label: 'segmented' hipGraph replay with the
+    all-reduce between the two graphs vs the eager kernel-by-kernel enqueue whose bucket all-reduces overlap backward).
+    Which one wins depends on the machine: the eager enqueue costs 6-20 ms of host time per 128^3 step (8 ranks share the
+    host's cores), the segmented graph costs no host time but exposes the all-reduce (~1-2.5 ms).  Every candidate runs
+    `steps` REAL training steps; the wall time of each block is max-reduced over the ranks, so all ranks pick the same
+    winner.  Usage per step:  mode = tuner.mode();  tuner.before();  <run the step in that mode>;  tuner.after()."""
+
+    def __init__(self, candidates, steps=5, group=None, sync=None, clock=None):
+        import time
+        self.candidates, self.steps, self.group = list(candidates), int(steps), group
+        self.sync = sync if sync is not None else (lambda: None)          # device synchronisation
+        self.clock = clock if clock is not None else time.perf_counter
+        self.times, self._i, self._n, self._t0 = [], 0, 0, None
+        self.choice = self.candidates[0] if len(self.candidates) == 1 else None
+
+    def mode(self):
+        return self.choice if self.choice is not None else self.candidates[self._i]
+
+    def before(self):
+        if self.choice is None and self._n == 0:
+            self.sync()
+            if dist.is_initialized():
+                dist.barrier(group=self.group)
+            self._t0 = self.clock()
+
+    def after(self):
+        if self.choice is not None:
+            return
+        self._n += 1
+        if self._n < self.steps:
+            return
+        self.sync()
+        t = torch.tensor([self.clock() - self._t0], dtype=torch.float64)
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+            t = t.to(dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        self.times.append(float(t.item()) / self.steps)
+        self._i, self._n = self._i + 1, 0
+        if self._i == len(self.candidates):
+            self.choice = self.candidates[min(range(len(self.times)), key=lambda k: (self.times[k], k))]
