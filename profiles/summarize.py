@@ -50,7 +50,7 @@ def main(src, tag):
         keys |= set(agg)
     for key in sorted(keys):
         name, grid = key
-        if not (name.startswith("conv_kernel<5") or name.startswith("wgrad_kernel<5")):
+        if not (name.startswith("conv_kernel<5") or name.startswith("wgrad_kernel<5") or name.startswith("conv5_bf16") or name.startswith("wgrad5_bf16")):
             continue
         e = {"grid_threads": int(grid)}
         if "FETCH_SIZE" in pmc and key in pmc["FETCH_SIZE"]:
@@ -64,6 +64,22 @@ def main(src, tag):
             e["hbm_write_bytes"] = 1024.0 * v / n
         e["hbm_bytes_per_launch"] = e.get("hbm_read_bytes", 0.0) + e.get("hbm_write_bytes", 0.0)
         out["kernels"]["%s grid=%s" % (name, grid)] = e
+    # the kernel family bench.py reports (decoder level 1 conv_1 at 128^3: forward 32->16, backward-data 16->32, filter
+    # gradient): launches on 8192 bricks x 256 threads (conv) / the one-slab filter-gradient kernels
+    fams = {"fp32": [k for k in out["kernels"] if (k.startswith("conv_kernel<5, 1, 4, 8, 8, 4, 4, 1, false, 5> grid=2097152")
+                                                     or k.startswith("conv_kernel<5, 1, 4, 8, 8, 4, 4, 2, false, 5> grid=2097152")
+                                                     or k.startswith("wgrad_kernel<5, 1, 4, 4, 16, 1, 16, 5>"))],
+            # bf16: the 128^3 launches cannot be told apart by grid -- all five conv (4->16, 16->16, 32->16 forward; 16->16,
+            # 16->32 backward-data) and three filter-gradient launches per step of the C5 network are averaged
+            "bf16": [k for k in out["kernels"] if (k.startswith("conv5_bf16_kernel<4, 8, 16, 1, 8> grid=2097152")
+                                                     or k.startswith("wgrad5_bf16_kernel<4, 4, 16, 1, 16>"))]}
+    out["families"] = {}
+    for name, keys in fams.items():
+        sel = [out["kernels"][k] for k in keys if out["kernels"][k].get("launches")]
+        if sel:
+            n = sum(e["launches"] for e in sel)
+            out["families"][name] = {"kernels": keys, "launches": n,
+                                     "hbm_bytes_per_launch": round(sum(e["launches"] * e["hbm_bytes_per_launch"] for e in sel) / n)}
     json.dump(out, open(os.path.join(here, tag + "_pmc.json"), "w"), indent=1)
     for k, e in out["kernels"].items():
         print("%-70s n=%3d read %8.1f MB write %8.1f MB  %8.1f us" % (k, e.get("launches", 0), e.get("hbm_read_bytes", 0) / 1e6,

@@ -141,3 +141,41 @@ def test_native_driver_against_the_oracle(tmp_path, dev):
     margin = np.sort(prob_ref, axis=0)
     sure = (margin[-1] - margin[-2]) > 1e-4
     assert (lab == lab_ref)[sure].all() and (lab == lab_ref).mean() > 0.999
+
+
+@pytest.mark.parametrize("variant", ["networks", "legacy"])
+def test_conv_bias_gradient_closed_form(dev, variant):
+    """Every conv bias of the V-Net feeds a train-mode batch-norm, so dLoss/dbias == 0 identically (the batch mean absorbs a
+    per-channel shift).  The networks use that closed form (ops.zero_bias_gradients); with it switched off the generic
+    column sum of dy must produce nothing but round-off (|db| <= 1e-5 * sum|dy| scale), the oracle's fp64 value is ~1e-12,
+    and every OTHER gradient is bit-identical between the two settings."""
+    from vnet_tensorflow_amd import networks, VNet, ops, optim
+    ps = O.ParamStore(rng=np.random.default_rng(8), perturb=0.2)
+    ref_net = O.VNetOracle(3, 0.0, 4, 2, (1, 2), 2, "prelu", variant, ps)
+    x, lab = O.synthetic_batch(2, 16, 2, 3, seed=77)
+    ref = O.run_step(x.astype(np.float64), lab, ref_net, "sorensen")
+    grads = {}
+    for fuse in (True, False):
+        cls = networks.VNet if variant == "networks" else VNet.VNet
+        net = cls(3, 0.0 if variant == "networks" else 1.0, 4, 2, (1, 2), 2, True, "prelu", device=dev)
+        net.fuse_zero_bias_grad = fuse
+        net.variables.values = {k: v.v for k, v in ps.vars.items()}
+        net.build(x.shape)
+        flat = optim.FlatParams(net.named_parameters())
+        flat.zero_grad()
+        logits = net.GetNetwork(g(x, dev)) if variant == "networks" else net.network_fn(g(x, dev))
+        loss, _, _, _ = ops.softmax_loss(logits, g(lab, dev, torch.int32), "sorensen")
+        loss.backward()
+        torch.cuda.synchronize()
+        grads[fuse] = {n: p.grad.detach().cpu().numpy().copy() for n, p in net.named_parameters()}
+    nb = 0
+    for n in grads[True]:
+        if n.endswith("biases"):
+            nb += 1
+            assert np.abs(ref["grads"][n]).max() < 1e-9, (n, np.abs(ref["grads"][n]).max())       # oracle: zero up to fp64 round-off
+            if not n.startswith("vnet/output_layer"):                                              # (the 1x1x1 head kernel computes db with dw)
+                assert np.abs(grads[True][n]).max() == 0.0, n                                      # closed form: exact 0
+            assert np.abs(grads[False][n]).max() < 1e-4, (n, np.abs(grads[False][n]).max())         # generic path: round-off only
+        else:
+            assert np.array_equal(grads[True][n], grads[False][n]), n
+    assert nb >= 8

@@ -79,6 +79,7 @@ class VNet(object):
             raise ValueError("activation_fn must be relu or prelu")
         self.activation_fn = activation_fn
         self.fuse_input_block = True
+        self.fuse_zero_bias_grad = True    # every conv feeds a batch-norm (VNet.py:32,36): bias gradients are identically 0
         self.variables = VariableStore(device)
 
     def parameters(self):
@@ -106,7 +107,8 @@ class VNet(object):
         store.begin_pass()
         keep_prob = float(self.keep_prob() if callable(self.keep_prob) else self.keep_prob)
         act = self.activation_fn
-        with store.active():
+        from . import ops
+        with store.active(), ops.zero_bias_gradients(self.fuse_zero_bias_grad):
             input_channels = int(x.shape[-1])
             with store.variable_scope('vnet/input_layer'):
                 tiled = None

@@ -324,6 +324,7 @@ class image2label(object):
         self.sync = None
         pg = os.environ.get("VNET_PARAM_GRAD_STREAM")
         ops.set_param_grad_stream(self.device.type == "cuda" and (getattr(self, "param_grad_stream", True) if pg is None else pg == "1"))
+        self._pg_env = pg
         force = os.environ.get("VNET_DP_FORCE") == "1" and torch.distributed.is_available() and torch.distributed.is_initialized()
         if self.world > 1 or force:      # VNET_DP_FORCE: run the collective path in a group of one (RCCL on a 1-GPU box)
             parallel.broadcast_parameters(self.flat.data)
@@ -339,6 +340,10 @@ class image2label(object):
                 # single-device BatchSize = world x per-rank batch semantics of the reference (networks.py:319);
                 # the default (per-replica statistics) equals the reference run on each rank's batch alone
                 ops.set_sync_batch_norm()
+        if self._pg_env is None and not hasattr(self, "param_grad_stream") and self._graph_mode() != "off":
+            # the replayed step graph is single-stream (see _build_step_graph); its few eager steps (warm-up, odd batch
+            # shapes) then use one stream too, so every launch of the process has the same schedule
+            ops.set_param_grad_stream(False)
 
     # -- one training step (reference model.py:743-748: ONE sess.run per step) ------------------------------------
     def _compute_gradients(self, images, labels, dropout):

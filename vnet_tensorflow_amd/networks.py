@@ -41,6 +41,7 @@ class VNet(object):
         self.activation_fn = activation_fn
         self.fuse_input_block = True       # single-modality input: skip the 16x redundant work of the tiled conv
         self.fuse_bn_chains = True         # decoder BN->BN->add->BN chains in closed form (ops.bn_chain)
+        self.fuse_zero_bias_grad = True    # conv biases feed batch-norms: their gradient is identically 0 (ops.zero_bias_gradients)
         self.variables = VariableStore(device)
 
     # -- torch.nn.Module-like conveniences -------------------------------------------------
@@ -75,7 +76,8 @@ class VNet(object):
         store.begin_pass()
         dropout_rate = self._dropout_rate()
         act = self.activation_fn
-        with store.active():
+        from . import ops
+        with store.active(), ops.zero_bias_gradients(self.fuse_zero_bias_grad):
             if x.dim() != 5:
                 raise NotImplementedError("only 3-D PatchShape is built (2-D is out of scope, SURVEY section 2 row 11)")
             input_channels = int(x.shape[-1])
