@@ -87,6 +87,17 @@ int vnet_conv_fwd(int ks, int kx, int stride, int up,
                   int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                   void* ws, size_t ws_bytes, void* stream);
 
+/* Accumulating form, y += conv(x): the backward-data pass of a tensor that has TWO consumers (the skip connection
+ * networks.py:276,325 feeds the down convolution and the decoder's concat; a block input networks.py:314-318 feeds conv_1 and
+ * the residual add) writes the second contribution on top of the first instead of leaving an add kernel to autodiff
+ * (tf.add_n in the reference's gradient graph, model.py:660).  Same arguments as vnet_conv_fwd. */
+int vnet_conv_fwd_acc(int ks, int kx, int stride, int up,
+                      const float* x0, int C0, const float* x1, int C1,
+                      const float* wp, const float* bias,
+                      float* y0, int Cy0, float* y1, int Cy1,
+                      int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                      void* ws, size_t ws_bytes, void* stream);
+
 /* ---- bf16-operand 5x5x5 stride-1 convolution (BASELINE config C5: bf16 compute, fp32 accumulate) ----------
  * Same contract as vnet_conv_fwd(ks=5, stride=1): fp32 NDHWC tensors in and out, two-source input, split output,
  * bias; x and the filter are rounded to bf16 (round-to-nearest-even) on the way into the matrix cores and the
@@ -96,6 +107,10 @@ size_t vnet_conv_bf16_ws_bytes(int Cin, int Cout, int B, int D, int H, int W);
 int vnet_conv_fwd_bf16(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
                        float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
                        void* ws, size_t ws_bytes, void* stream);
+
+int vnet_conv_fwd_bf16_acc(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
+                           float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
+                           void* ws, size_t ws_bytes, void* stream);     /* y += conv(x), see vnet_conv_fwd_acc */
 
 /* filter gradient of the same convolution with x and dy rounded to bf16, fp32 accumulation
  * (v_mfma_f32_16x16x32_bf16 fed by LDS transpose reads); dw is fp32 in TF layout [125][Cin][Cout]. */

@@ -179,3 +179,36 @@ def test_conv_bias_gradient_closed_form(dev, variant):
         else:
             assert np.array_equal(grads[True][n], grads[False][n]), n
     assert nb >= 8
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_gradient_accumulation_in_the_producing_kernel(dev, compute):
+    """Tensors with two consumers (skip connection, residual block input): the second gradient is added by the backward-data
+    kernel that produces it (y += ..., ops.fork) instead of an autodiff add kernel.  Same two fp32 numbers are added either
+    way, so every gradient is bit-identical to the unfused graph; and the fused pass really runs no add kernel."""
+    from vnet_tensorflow_amd import networks, ops, optim
+    x, lab = O.synthetic_batch(1, 32, 2, 3, seed=5)
+    grads = {}
+    ops.set_compute_dtype(compute)
+    try:
+        for fuse in (True, False):
+            np.random.seed(11)
+            net = networks.VNet(3, 0.0, 8, 3, (1, 2, 3), 2, True, "prelu", device=dev)
+            net.fuse_grad_accumulation = fuse
+            net.build(x.shape)
+            flat = optim.FlatParams(net.named_parameters())
+            flat.zero_grad()
+            from torch.profiler import profile, ProfilerActivity
+            with profile(activities=[ProfilerActivity.CPU]) as prof:
+                loss, _, _, _ = ops.softmax_loss(net.GetNetwork(g(x, dev)), g(lab, dev, torch.int32), "sorensen")
+                loss.backward()
+            torch.cuda.synchronize()
+            adds = sum(1 for e in prof.events() if e.name == "aten::add" and e.input_shapes != [])
+            big_adds = [e for e in prof.events() if e.name in ("aten::add", "aten::add_")]
+            grads[fuse] = ({n: p.grad.detach().cpu().numpy().copy() for n, p in net.named_parameters()}, len(big_adds))
+    finally:
+        ops.set_compute_dtype("fp32")
+    for n in grads[True][0]:
+        assert np.array_equal(grads[True][0][n], grads[False][0][n]), n
+    # 3 levels: 3 skip forks + residual forks at levels 2, 3 and the bottom = 6 full-tensor adds saved
+    assert grads[False][1] - grads[True][1] >= 6, (grads[False][1], grads[True][1])

@@ -24,6 +24,9 @@ SIGNATURES = {
     "vnet_conv_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "vnet_conv_fwd": (_i, [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i,
                            _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "vnet_conv_fwd_acc": (_i, [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i,
+                               _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "vnet_conv_fwd_bf16_acc": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "vnet_conv_bf16_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "vnet_conv_fwd_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "vnet_wgrad_bf16_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),

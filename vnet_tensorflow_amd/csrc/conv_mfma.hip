@@ -35,6 +35,7 @@ struct ConvArgs {
     float* part; size_t part_stride;  // split-K partials [split][vox][CoutP]
     int upO;           // UP: real output channels O (N' = 8*O)
     int nz;            // tap (dz) splits per K-split: deep levels have too few bricks to fill 256 CUs
+    int accum;         // 1: y += result (backward-data into a gradient another consumer of the same tensor already wrote)
 };
 
 template <int KS, int STRIDE, int TZ, int TY, int TX, int KX = KS>
@@ -296,7 +297,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
                     const int tp = ck / a.upO, o1 = ck - tp * a.upO;
                     const int z1 = 2 * oz + (tp >> 2), y1 = 2 * oy + ((tp >> 1) & 1), x1 = 2 * ox + (tp & 1);
                     if (z1 >= a.Do || y1 >= a.Ho || x1 >= a.Wo) continue;
-                    a.y0[(((size_t)(b * a.Do + z1) * a.Ho + y1) * a.Wo + x1) * a.upO + o1] = e[k] + (a.bias ? a.bias[o1] : 0.f);
+                    float* dst = a.y0 + (((size_t)(b * a.Do + z1) * a.Ho + y1) * a.Wo + x1) * a.upO + o1;
+                    *dst = e[k] + (a.bias ? a.bias[o1] : 0.f) + (a.accum ? *dst : 0.f);
                 }
             }
         }
@@ -321,7 +323,9 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
                 const size_t ov = ((size_t)(b * a.Do + zz) * a.Ho + yy) * a.Wo + xx;
                 f32x4 r = acc[m][n];
                 if (a.bias) { r.x += a.bias[o]; r.y += a.bias[o + 1]; r.z += a.bias[o + 2]; r.w += a.bias[o + 3]; }
-                *reinterpret_cast<float4*>(a.y0 + ov * a.upO + o) = make_float4(r.x, r.y, r.z, r.w);
+                float4* dst = reinterpret_cast<float4*>(a.y0 + ov * a.upO + o);
+                if (a.accum) { const float4 old = *dst; r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
+                *dst = make_float4(r.x, r.y, r.z, r.w);
             }
         } else {
             if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
@@ -340,14 +344,15 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
                 if (a.vec_out && co + 3 < a.Cout) {
                     if (a.bias) { e[0] += a.bias[co]; e[1] += a.bias[co + 1]; e[2] += a.bias[co + 2]; e[3] += a.bias[co + 3]; }
                     float* p = (co < a.Cy0) ? a.y0 + ov * a.Cy0 + co : a.y1 + ov * a.Cy1 + (co - a.Cy0);
+                    if (a.accum) { const float4 old = *reinterpret_cast<const float4*>(p); e[0] += old.x; e[1] += old.y; e[2] += old.z; e[3] += old.w; }
                     *reinterpret_cast<float4*>(p) = make_float4(e[0], e[1], e[2], e[3]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int ck = co + k;
                         if (ck >= a.Cout) break;
-                        const float val = e[k] + (a.bias ? a.bias[ck] : 0.f);
-                        if (ck < a.Cy0) a.y0[ov * a.Cy0 + ck] = val; else a.y1[ov * a.Cy1 + (ck - a.Cy0)] = val;
+                        float* dst = (ck < a.Cy0) ? a.y0 + ov * a.Cy0 + ck : a.y1 + ov * a.Cy1 + (ck - a.Cy0);
+                        *dst = e[k] + (a.bias ? a.bias[ck] : 0.f) + (a.accum ? *dst : 0.f);
                     }
                 }
             }
@@ -358,14 +363,15 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
 // y = sum_s part[s] + bias, scattered to the (possibly dual) NDHWC destination
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, size_t part_stride, int nsplit,
                                      const float* __restrict__ bias, float* y0, float* y1, int Cy0, int Cy1,
-                                     int CoutP, size_t nvox) {
+                                     int CoutP, size_t nvox, int accum) {
     const int Cout = Cy0 + Cy1;
     const size_t total = nvox * (size_t)Cout;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const size_t v = idx / Cout; const int c = (int)(idx - v * Cout);
         float s = bias ? bias[c] : 0.f;
         for (int k = 0; k < nsplit; ++k) s += part[k * part_stride + v * CoutP + c];
-        if (c < Cy0) y0[v * Cy0 + c] = s; else y1[v * Cy1 + (c - Cy0)] = s;
+        float* dst = (c < Cy0) ? y0 + v * Cy0 + c : y1 + v * Cy1 + (c - Cy0);
+        *dst = accum ? *dst + s : s;
     }
 }
 
@@ -1057,14 +1063,15 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
                 if (a.vec_out && co + 3 < a.Cout) {
                     if (a.bias) { e[0] += a.bias[co]; e[1] += a.bias[co + 1]; e[2] += a.bias[co + 2]; e[3] += a.bias[co + 3]; }
                     float* p = (co < a.Cy0) ? a.y0 + ov * a.Cy0 + co : a.y1 + ov * a.Cy1 + (co - a.Cy0);
+                    if (a.accum) { const float4 old = *reinterpret_cast<const float4*>(p); e[0] += old.x; e[1] += old.y; e[2] += old.z; e[3] += old.w; }
                     *reinterpret_cast<float4*>(p) = make_float4(e[0], e[1], e[2], e[3]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int ck = co + k;
                         if (ck >= a.Cout) break;
-                        const float val = e[k] + (a.bias ? a.bias[ck] : 0.f);
-                        if (ck < a.Cy0) a.y0[ov * a.Cy0 + ck] = val; else a.y1[ov * a.Cy1 + (ck - a.Cy0)] = val;
+                        float* dst = (ck < a.Cy0) ? a.y0 + ov * a.Cy0 + ck : a.y1 + ov * a.Cy1 + (ck - a.Cy0);
+                        *dst = e[k] + (a.bias ? a.bias[ck] : 0.f) + (a.accum ? *dst : 0.f);
                     }
                 }
             }
@@ -1390,10 +1397,10 @@ size_t vnet_conv_ws_bytes(int ks, int kx, int stride, int up, int Cin, int Cout,
     return (size_t)p.nsplit * p.nz * B * Do * Ho * Wo * round_up(Cout, 16) * sizeof(float);
 }
 
-int vnet_conv_fwd(int ks, int kx, int stride, int up, const float* x0, int C0, const float* x1, int C1,
-                  const float* wp, const float* bias, float* y0, int Cy0, float* y1, int Cy1,
-                  int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
-                  void* ws, size_t ws_bytes, void* stream) {
+static int conv_fwd_impl(int ks, int kx, int stride, int up, const float* x0, int C0, const float* x1, int C1,
+                         const float* wp, const float* bias, float* y0, int Cy0, float* y1, int Cy1,
+                         int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                         void* ws, size_t ws_bytes, void* stream, int accum) {
     if (!x0 || !wp || !y0 || C0 <= 0 || Cy0 <= 0 || B <= 0) return VNET_E_BADARG;
     if ((C1 > 0 && !x1) || (Cy1 > 0 && !y1) || C1 < 0 || Cy1 < 0) return VNET_E_BADARG;
     if (Di <= 0 || Hi <= 0 || Wi <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return VNET_E_BADARG;
@@ -1407,7 +1414,7 @@ int vnet_conv_fwd(int ks, int kx, int stride, int up, const float* x0, int C0, c
     a.nchunks = a.CQ / 4;
     a.vec_in = (C0 % 4 == 0) && (C1 % 4 == 0);
     a.vec_out = (Cy0 % 4 == 0) && (Cy1 % 4 == 0);
-    a.part = nullptr; a.part_stride = 0; a.upO = 0;
+    a.part = nullptr; a.part_stride = 0; a.upO = 0; a.accum = accum;
     const bool is5 = (ks == 5 && stride == 1 && !up), isdown = (ks == 2 && stride == 2 && !up), isup = (ks == 2 && stride == 2 && up);
     if (!is5 && !isdown && !isup) return VNET_E_UNSUPPORTED;
     if (kx == 0) kx = ks;
@@ -1444,12 +1451,25 @@ int vnet_conv_fwd(int ks, int kx, int stride, int up, const float* x0, int C0, c
         const size_t total = nvox * a.Cout;
         const int blocks = (int)min((size_t)2048, (total + 255) / 256);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, a.part_stride, nslab, bias,
-                           y0, y1, Cy0, Cy1, a.CoutP, nvox);
+                           y0, y1, Cy0, Cy1, a.CoutP, nvox, a.accum);
         VNET_LAUNCH_CHECK();
     }
     return VNET_OK;
 }
 
+
+int vnet_conv_fwd(int ks, int kx, int stride, int up, const float* x0, int C0, const float* x1, int C1,
+                  const float* wp, const float* bias, float* y0, int Cy0, float* y1, int Cy1,
+                  int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                  void* ws, size_t ws_bytes, void* stream) {
+    return conv_fwd_impl(ks, kx, stride, up, x0, C0, x1, C1, wp, bias, y0, Cy0, y1, Cy1, B, Di, Hi, Wi, Do, Ho, Wo, ws, ws_bytes, stream, 0);
+}
+int vnet_conv_fwd_acc(int ks, int kx, int stride, int up, const float* x0, int C0, const float* x1, int C1,
+                      const float* wp, const float* bias, float* y0, int Cy0, float* y1, int Cy1,
+                      int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                      void* ws, size_t ws_bytes, void* stream) {
+    return conv_fwd_impl(ks, kx, stride, up, x0, C0, x1, C1, wp, bias, y0, Cy0, y1, Cy1, B, Di, Hi, Wi, Do, Ho, Wo, ws, ws_bytes, stream, 1);
+}
 
 size_t vnet_conv_bf16_ws_bytes(int Cin, int Cout, int B, int D, int H, int W) {
     Bf16Plan p = plan_conv_bf16(Cin, Cout, B, D, H, W);
@@ -1457,9 +1477,9 @@ size_t vnet_conv_bf16_ws_bytes(int Cin, int Cout, int B, int D, int H, int W) {
     return (size_t)p.nsplit * p.nz * B * D * H * W * round_up(Cout, 32) * sizeof(float);
 }
 
-int vnet_conv_fwd_bf16(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
-                       float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
-                       void* ws, size_t ws_bytes, void* stream) {
+static int conv_fwd_bf16_impl(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
+                              float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
+                              void* ws, size_t ws_bytes, void* stream, int accum) {
     if (!x0 || !wp || !y0 || C0 <= 0 || Cy0 <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return VNET_E_BADARG;
     if ((C1 > 0 && !x1) || (Cy1 > 0 && !y1) || C1 < 0 || Cy1 < 0) return VNET_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -1472,7 +1492,7 @@ int vnet_conv_fwd_bf16(const float* x0, int C0, const float* x1, int C1, const v
     a.CoutP = round_up(a.Cout, 32);
     a.vec_in = (C0 % 4 == 0) && (C1 % 4 == 0);
     a.vec_out = (Cy0 % 4 == 0) && (Cy1 % 4 == 0);
-    a.pad = 2; a.padx = 2;
+    a.pad = 2; a.padx = 2; a.accum = accum;
     Bf16Plan p = plan_conv_bf16(a.Cin, a.Cout, B, D, H, W);
     a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.cps = p.cps; a.nz = p.nz;
     const int nslab = p.nsplit * p.nz;
@@ -1489,10 +1509,21 @@ int vnet_conv_fwd_bf16(const float* x0, int C0, const float* x1, int C1, const v
         const size_t total = nvox * a.Cout;
         const int blocks = (int)min((size_t)2048, (total + 255) / 256);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, a.part_stride, nslab, bias,
-                           y0, y1, Cy0, Cy1, a.CoutP, nvox);
+                           y0, y1, Cy0, Cy1, a.CoutP, nvox, a.accum);
         VNET_LAUNCH_CHECK();
     }
     return VNET_OK;
+}
+
+int vnet_conv_fwd_bf16(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
+                       float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
+                       void* ws, size_t ws_bytes, void* stream) {
+    return conv_fwd_bf16_impl(x0, C0, x1, C1, wp, bias, y0, Cy0, y1, Cy1, B, D, H, W, ws, ws_bytes, stream, 0);
+}
+int vnet_conv_fwd_bf16_acc(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
+                           float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
+                           void* ws, size_t ws_bytes, void* stream) {
+    return conv_fwd_bf16_impl(x0, C0, x1, C1, wp, bias, y0, Cy0, y1, Cy1, B, D, H, W, ws, ws_bytes, stream, 1);
 }
 
 }  // extern "C"

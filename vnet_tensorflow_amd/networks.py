@@ -41,6 +41,7 @@ class VNet(object):
         self.activation_fn = activation_fn
         self.fuse_input_block = True       # single-modality input: skip the 16x redundant work of the tiled conv
         self.fuse_bn_chains = True         # decoder BN->BN->add->BN chains in closed form (ops.bn_chain)
+        self.fuse_grad_accumulation = True # tensors with two consumers: second gradient accumulated by its producer (ops.fork)
         self.fuse_zero_bias_grad = True    # conv biases feed batch-norms: their gradient is identically 0 (ops.zero_bias_gradients)
         self.variables = VariableStore(device)
 
@@ -97,7 +98,12 @@ class VNet(object):
                 with store.variable_scope('vnet/encoder/level_' + str(l + 1)):
                     x = self.convolution_block(x, self.num_convolutions[l], dropout_rate, act,
                                                tiled=tiled if l == 0 else None)
-                    features.append(x)
+                    if self.fuse_grad_accumulation:
+                        # skip connection: decoder concat + down convolution consume x (ops.fork)
+                        skip, x = ops.fork(x)
+                        features.append(skip)
+                    else:
+                        features.append(x)
                     with store.variable_scope('down_convolution'):
                         x = L.down_convolution(x, factor=2, kernel_size=[2, 2, 2])
                         x = L.batch_normalization(x, activation=act)
@@ -124,6 +130,9 @@ class VNet(object):
         store = self.variables
         x = layer_input
         n_channels = L.get_num_channels(x)
+        if tiled is None and self.fuse_grad_accumulation:
+            # the block input feeds conv_1 and the residual add: its second gradient is accumulated in place (ops.fork)
+            x, layer_input = ops.fork(layer_input)
         for i in range(num_convolutions):
             with store.variable_scope('conv_' + str(i + 1)):
                 if i == 0 and tiled is not None:

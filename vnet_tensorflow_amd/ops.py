@@ -314,7 +314,7 @@ class _Timed(object):
 
 
 # ---- convolution family ----------------------------------------------------------------------------
-def _conv_call(ks, stride, up, x0, x1, wp, bias, y0, y1, dims_in, dims_out, kx=0):
+def _conv_call(ks, stride, up, x0, x1, wp, bias, y0, y1, dims_in, dims_out, kx=0, accum=False):
     L = _lib.lib()
     B = x0.shape[0]
     C0, C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
@@ -328,12 +328,13 @@ def _conv_call(ks, stride, up, x0, x1, wp, bias, y0, y1, dims_in, dims_out, kx=0
     nbytes = 4.0 * (nin * (C0 + C1) + nout * (Cy0 + Cy1) + taps * (C0 + C1) * (Cy0 + Cy1) + (Cy0 + Cy1))
     tag = "conv k%d%s s%d%s %d^3x%d %d->%d" % (ks, "x%d" % kx if kx else "", stride, " up" if up else "", dims_out[2], B, C0 + C1, Cy0 + Cy1)
     with _Timed(tag, flops, nbytes):
-        check(L.vnet_conv_fwd(ks, kx, stride, up, _ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias),
-                              _ptr(y0), Cy0, _ptr(y1), Cy1, B, *dims_in, *dims_out,
-                              _ptr(ws), nb, _stream()), "vnet_conv_fwd")
+        fn = L.vnet_conv_fwd_acc if accum else L.vnet_conv_fwd
+        check(fn(ks, kx, stride, up, _ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias),
+                 _ptr(y0), Cy0, _ptr(y1), Cy1, B, *dims_in, *dims_out,
+                 _ptr(ws), nb, _stream()), "vnet_conv_fwd")
 
 
-def _conv_bf16_call(x0, x1, wp, bias, y0, y1, dims):
+def _conv_bf16_call(x0, x1, wp, bias, y0, y1, dims, accum=False):
     """5^3 stride-1 conv with bf16 operands / fp32 accumulation (vnet_conv_fwd_bf16)."""
     L = _lib.lib()
     B = x0.shape[0]
@@ -346,8 +347,9 @@ def _conv_bf16_call(x0, x1, wp, bias, y0, y1, dims):
     nbytes = 4.0 * nvox * (C0 + C1 + Cy0 + Cy1) + 2.0 * 125 * (C0 + C1) * (Cy0 + Cy1)
     tag = "conv-bf16 k5 s1 %d^3x%d %d->%d" % (dims[2], B, C0 + C1, Cy0 + Cy1)
     with _Timed(tag, flops, nbytes):
-        check(L.vnet_conv_fwd_bf16(_ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias), _ptr(y0), Cy0, _ptr(y1), Cy1,
-                                   B, *dims, _ptr(ws), nb, _stream()), "vnet_conv_fwd_bf16")
+        fn = L.vnet_conv_fwd_bf16_acc if accum else L.vnet_conv_fwd_bf16
+        check(fn(_ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias), _ptr(y0), Cy0, _ptr(y1), Cy1,
+                 B, *dims, _ptr(ws), nb, _stream()), "vnet_conv_fwd_bf16")
 
 
 def _wgrad_bf16_call(x0, x1, dy, dw, dims):
@@ -396,6 +398,55 @@ def colsum(x2d_like, C, out=None):
     return out
 
 
+# ---- tensors with two consumers: the second gradient is accumulated by the kernel that produces it ---------------------
+# The skip connection (networks.py:276 -> 325: block output feeds the down convolution AND the decoder's concat) and the
+# residual blocks (networks.py:314-318: block input feeds conv_1 AND the add in front of the last batch-norm) give autodiff
+# two gradient contributions per tensor, which it sums with an add kernel (tf.add_n / torch's accumulation: 8 full-tensor
+# adds per step, 134 MB each at level 1).  `fork` hands the two consumers separate views that share a slot; the consumer
+# whose backward runs FIRST leaves its gradient tensor in the slot, the second one runs its backward-data kernel in
+# accumulate mode (y += ...) on that tensor and reports no gradient of its own, so the sum costs no extra pass.
+class _GradSlot(object):
+    __slots__ = ("first",)
+
+    def __init__(self):
+        self.first = None
+
+
+class _ForkFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if gb is None:
+            return ga
+        if ga is None:
+            return gb
+        return ga + gb           # both consumers reported a gradient (accumulation not possible there)
+
+
+def fork(x):
+    """Two handles of `x` for its two consumers (see above); plain (x, x) when no gradient is being recorded."""
+    if _meta(x) or not (torch.is_grad_enabled() and x.requires_grad):
+        return x, x
+    a, b = _ForkFn.apply(x)
+    a._vnet_slot = b._vnet_slot = _GradSlot()
+    return a, b
+
+
+def _slot_target(slot, dy, shape):
+    """The tensor an accumulating backward-data kernel may add into: the other consumer's gradient, unless the parameter-
+    gradient stream is on (its filter-gradient launches may still be reading that tensor) or it IS this kernel's input."""
+    if slot is None or slot.first is None or _PG["on"]:
+        return None
+    t = slot.first
+    if t.data_ptr() == dy.data_ptr() or tuple(t.shape) != tuple(shape) or not t.is_contiguous():
+        return None
+    return t
+
+
 # ---- conv bias in front of a batch-norm ----------------------------------------------------------------------------------
 # Every convolution of the V-Net (both wirings) feeds a train-mode batch-norm (networks.py:259...361; decoder chains
 # included), and a batch-norm's output does not change when a per-channel constant is added to its input -- the batch mean
@@ -422,6 +473,7 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x0, x1, w, b, ks, stride, up, out_spatial):
+        slot0, slot1 = getattr(x0, "_vnet_slot", None), getattr(x1, "_vnet_slot", None)
         x0 = x0.contiguous()
         x1 = x1.contiguous() if x1 is not None else None
         B, Di, Hi, Wi, C0 = x0.shape
@@ -449,6 +501,7 @@ class _ConvFn(torch.autograd.Function):
         ctx.cfg = (ks, stride, up, (Di, Hi, Wi), dims_out, C0, C1, I, O)
         ctx.bf16 = bf16
         ctx.bias_zero = _FUSE["zero_bias_grad"] and b is not None
+        ctx.slots = (slot0, slot1)
         return y
 
     @staticmethod
@@ -511,22 +564,32 @@ class _ConvFn(torch.autograd.Function):
         finally:
             _LAUNCH_ON[0] = None
         dx0 = dx1 = None
+        r0 = r1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
-            dx0 = torch.empty_like(x0)
+            slot0, slot1 = ctx.slots
+            # x0 has a second consumer whose gradient exists already: add this one into it (single-source convs only)
+            acc = _slot_target(slot0, dy, x0.shape) if x1 is None else None
+            dx0 = acc if acc is not None else torch.empty_like(x0)
             dx1 = torch.empty_like(x1) if x1 is not None else None
+            accum = acc is not None
             if up:          # backward-data of the transposed conv = the 2^3 stride-2 conv with the same filter
                 wp = packed_weights(w, PACK_FWD, 8, O, I)
-                _conv_call(2, 2, 0, dy, None, wp, None, dx0, None, dout, din)
+                _conv_call(2, 2, 0, dy, None, wp, None, dx0, None, dout, din, accum=accum)
             elif stride == 2:   # backward-data of the down conv = the 2^3 transposed conv with the same filter
                 wp = packed_weights(w, PACK_UP, 8, O, I)
-                _conv_call(2, 2, 1, dy, None, wp, None, dx0, None, dout, din)
+                _conv_call(2, 2, 1, dy, None, wp, None, dx0, None, dout, din, accum=accum)
             elif ctx.bf16:
-                _conv_bf16_call(dy, None, packed_weights(w, PACK_BWD_BF16, 125, I, O), None, dx0, dx1, din)
+                _conv_bf16_call(dy, None, packed_weights(w, PACK_BWD_BF16, 125, I, O), None, dx0, dx1, din, accum=accum)
             else:
                 wp = packed_weights(w, PACK_BWD, ks ** 3, I, O)
-                _conv_call(ks, 1, 0, dy, None, wp, None, dx0, dx1, dout, din)
+                _conv_call(ks, 1, 0, dy, None, wp, None, dx0, dx1, dout, din, accum=accum)
+            r0, r1 = (None if accum else dx0), dx1
+            if not accum and slot0 is not None and slot0.first is None:
+                slot0.first = dx0                      # first of the two gradients of a forked tensor
+            if slot1 is not None and slot1.first is None:
+                slot1.first = dx1
         gb = _grad_ret(db, sb) if (db is not None or bias_zero) else None
-        return dx0, dx1, _grad_ret(dw, sw), gb, None, None, None, None
+        return r0, r1, _grad_ret(dw, sw), gb, None, None, None, None
 
 
 def _meta(*ts):
@@ -654,6 +717,7 @@ class _BnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, r, gamma, beta, alpha, act, bcast, mm, mv):
         L = _lib.lib()
+        ctx.slot_r = getattr(r, "_vnet_slot", None)
         x = x.contiguous()
         r = r.contiguous() if r is not None else None
         C = gamma.numel()
@@ -709,6 +773,8 @@ class _BnActFn(torch.autograd.Function):
         dx = ds
         if bcast and ds is not None:
             dx = colsum_rows(ds)
+        if r is not None and ds is not None and ctx.slot_r is not None and ctx.slot_r.first is None:
+            ctx.slot_r.first = ds                      # the block input's other consumer (conv_1) adds its gradient into this
         return dx, (ds if r is not None else None), _grad_ret(dgamma, sg), _grad_ret(dbeta, sbt), _grad_ret(dalpha, sa), None, None, None, None
 
 
