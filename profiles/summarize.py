@@ -72,6 +72,7 @@ def main(src, tag):
             # bf16: the 128^3 launches cannot be told apart by grid -- all five conv (4->16, 16->16, 32->16 forward; 16->16,
             # 16->32 backward-data) and three filter-gradient launches per step of the C5 network are averaged
             "bf16": [k for k in out["kernels"] if (k.startswith("conv5_bf16_kernel<4, 8, 16, 1, 8> grid=2097152")
+                                                     or k.startswith("conv5_bf16_c16_kernel")
                                                      or k.startswith("wgrad5_bf16_kernel<4, 4, 16, 1, 16>"))]}
     out["families"] = {}
     for name, keys in fams.items():

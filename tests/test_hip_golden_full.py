@@ -116,7 +116,13 @@ def test_full_size_network_c5_bf16(dev):
     oracle run with the same operand rounding.  Operand rounding is discontinuous (a last-bit fp32 difference can move an
     operand to the neighbouring bf16 value), so the network-level bound is the measured sensitivity of the oracle itself
     (tests/test_hip_network.py::test_small_network_bf16_compute_golden), not fp32 round-off; the kernels are held to
-    2e-6 against the rounded-operand oracle in tests/test_hip_ops.py::test_conv5_bf16."""
+    2e-6 against the rounded-operand oracle in tests/test_hip_ops.py::test_conv5_bf16.
+    MEASURED at this size (profiles/oracle_bf16_sensitivity.py, recorded in profiles/r02_golden_full_errors.txt): the oracle run
+    again with its input perturbed by 1e-7 relative differs from this fixture by 1.1e-6 in the loss, 1.2e-2 (rel-L2) in the
+    logits, 24 % (median) / 29-33 % (max) per gradient tensor and 8.1 % in the whole gradient vector; the HIP path differs
+    from the fixture by 1.6e-6, <1.5e-2, 23 % / 28-32 % and <10 % -- it agrees with the oracle as well as the oracle agrees
+    with itself.  Per-tensor gradient agreement is therefore not a meaningful bf16 criterion; the bounds below are the
+    yardstick's."""
     z, net, logits, loss, sm, pred, lab, K = _run_case(dev, "c5")
     s = (slice(None),) + (slice(None, None, STRIDE),) * 3
     got, ref = logits[s].cpu().numpy(), z["logits_sample"]

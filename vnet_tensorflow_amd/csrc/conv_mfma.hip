@@ -1078,6 +1078,217 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 16-output-channel variant (round 2).  The kernel above computes D[32 cout][32 voxels]; layers with 16 output channels
+// (every 5^3 conv at full resolution: 4->16, 16->16, 32->16 forward, 16->16 backward-data) pad to 32 and waste half of
+// their MFMAs.  Here:  v_mfma_f32_16x16x32_bf16,  D[16 cout][16 voxels] += A[16 cout][k = 2 taps x 16 cin] * B[k][16 voxels]
+//   * a subtile = one x row of 16 voxels; a wave owns 4 rows adjacent in y, so the B fragment of (row m, tap dy) IS the
+//     fragment of (row m+1, tap dy-1): per (dz pair, dx) a wave reads 8 row fragments for 20 MFMAs (2.5x fewer LDS bytes
+//     than one read per MFMA, which would make this shape LDS-bound);
+//   * K = 32 pairs two taps that differ by a constant LDS offset (dz, dz+1 -> one tile plane; for dz = 4: dy, dy+1 -> one
+//     tile row), so lanes 32-63 just use a base address shifted by that constant; 260 MFMAs per subtile-quad instead of 250;
+//   * the whole 16-cin chunk of the filter (65 fragments x 1 KB, compacted from the generic packed image: only the 16 real
+//     cout) stays in LDS -- no per-plane barriers; for Cin = 16 it is loaded once per workgroup;
+//   * persistent workgroups (one per CU) walk their bricks; the next tile (and filter chunk) is prefetched global ->
+//     registers during the MFMAs and committed between two barriers.
+// ------------------------------------------------------------------------------------------
+template <int TZ, int TY, int TX>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv5_bf16_c16_kernel(ConvArgs a) {
+    using G = Bf16Geom<TZ, TY, TX>;
+    static_assert(TZ == 4 && TY == 8 && TX == 16, "8 waves x 4 rows of 16 voxels");
+    constexpr int NT = 512, NFRAG = 65, FUNITS = NFRAG * 64, FPER = (FUNITS + NT - 1) / NT;
+    constexpr int ROWB = G::IX * 16, PLANEB = G::IY * G::IX * 16;       // bytes per tile row / per tile z-plane (one cin half)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* tile = smem;
+    unsigned char* fl = smem + G::TILE_BYTES;                            // [65 fragments][64 lanes][16 B]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4, half = g & 1, hi = g >> 1;
+    const int vz = wave >> 1, vy0 = (wave & 1) * 4;
+    unsigned char* dump = smem + G::TILE_BYTES + NFRAG * 1024 + lane * 16;
+
+    const int base0 = half * G::PLANE + ((vz * G::IY + vy0) * G::IX + j) * 16;
+    const unsigned char* bZ = tile + base0 + hi * PLANEB;                // taps (dz, dz+1)
+    const unsigned char* bY = tile + base0 + hi * ROWB;                  // taps (4, dy), (4, dy+1)
+    const unsigned char* b0 = tile + base0;                              // single tap (4, 4): both lane halves read the same row
+    const unsigned char* fa = fl + lane * 16;
+
+    const int nbrick = a.B * a.nbz * a.nby * a.nbx;
+    const int G8 = gridDim.x >> 3;                                       // workgroups per XCD (grid is a multiple of 8)
+    const int per_xcd = (nbrick + 7) >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b_lo = xcd * per_xcd, b_hi = min(nbrick, b_lo + per_xcd);
+    const int nmine = (b_hi - b_lo - slot + G8 - 1) / G8;                // bricks b_lo + slot + i * G8
+    if (b_lo + slot >= b_hi) return;
+    const int nch = a.nchunks;
+    using XT = XTile<G::IZ, G::IY, G::IX, NT>;
+    const u32x4* wg = reinterpret_cast<const u32x4*>(a.wp);
+
+    auto brick_origin = [&](int i, int& b, int& bz, int& by, int& bx) {
+        int brick = b_lo + slot + i * G8;
+        bx = brick % a.nbx; brick /= a.nbx;
+        by = brick % a.nby; brick /= a.nby;
+        bz = brick % a.nbz; b = brick / a.nbz;
+    };
+    // source (16-byte unit of the generic packed image, ncob = 1) of filter fragment unit u = f * 64 + l
+    auto fsrc = [&](int u, int chunk, bool& valid) -> const u32x4* {
+        const int f = u >> 6, l = u & 63;
+        const int co = l & 15, gg = l >> 4, hf = gg & 1, up = gg >> 1;
+        int dz, dy, dx;
+        valid = u < FUNITS;
+        if (f < 50) { const int zp = f / 25, r = f - zp * 25; dx = r / 5; dy = r - dx * 5; dz = 2 * zp + up; }
+        else { const int r = f - 50; dx = r / 3; const int q = r - dx * 3; dz = 4; dy = 2 * q + up; if (q == 2 && up) valid = false; }
+        const int tap = valid ? (dz * 5 + dy) * 5 + dx : 0;
+        return wg + ((size_t)(chunk * 125 + tap) * 2 + hf) * 32 + co;
+    };
+    u32x4 freg[FPER];
+    auto filter_issue = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < FPER; ++k) {
+            bool valid;
+            const u32x4* src = fsrc(min(tid + k * NT, FUNITS - 1), chunk, valid);
+            const u32x4 t = *src;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            freg[k] = valid ? t : z;
+        }
+    };
+    auto filter_commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < FPER; ++k) {
+            const int u = tid + k * NT;
+            *reinterpret_cast<u32x4*>(u < FUNITS ? fl + (size_t)u * 16 : dump) = freg[k];
+        }
+    };
+    // Step schedule.  One chunk: bricks in order.  Two chunks: bricks in pairs (b0, b1) visited as
+    //   (b0, c), (b1, c), (b1, c'), (b0, c')  with c alternating from pair to pair,
+    // so the resident filter chunk changes once per pair (every 4th step) instead of at every step; the two bricks'
+    // accumulators live in accA / accB and are swapped (32 moves) at the second and fourth step of a pair.
+    const bool paired = nch == 2;
+    const int nsteps = paired ? (nmine >> 1) * 4 + (nmine & 1) * 2 : nmine * nch;
+    auto sched = [&](int s, int& bi, int& ch, bool& first, bool& last, bool& swap) {
+        if (!paired) { bi = s / nch; ch = s - bi * nch; first = ch == 0; last = ch == nch - 1; swap = false; return; }
+        const int q = s >> 2, r = s & 3, cf = q & 1;
+        if (2 * q + 1 >= nmine) { bi = 2 * q; ch = r == 0 ? cf : 1 - cf; first = r == 0; last = r == 1; swap = false; return; }
+        const bool second = (r == 1 || r == 2);
+        bi = 2 * q + (second ? 1 : 0); ch = r < 2 ? cf : 1 - cf; first = r < 2; last = r >= 2; swap = (r == 1 || r == 3);
+    };
+    float4 v[XT::PER];
+    uint2 pk[XT::PER];
+    auto tile_issue = [&](int bi, int ch) {
+        int b, bz, by, bx;
+        brick_origin(bi, b, bz, by, bx);
+        XT::template issue_part<0, XT::PER>(v, a.x0, a.x1, a.C0, a.C1, ch, b, bz * TZ - 2, by * TY - 2, bx * TX - 2,
+                                            a.Di, a.Hi, a.Wi, tid);
+    };
+    auto tile_pack = [&]() {            // fp32 -> bf16 (RNE) in registers; halves the registers the prefetch holds
+#pragma unroll
+        for (int k = 0; k < XT::PER; ++k) pk[k] = make_uint2(pk_bf16(v[k].x, v[k].y), pk_bf16(v[k].z, v[k].w));
+    };
+    auto tile_commit = [&]() {
+        const int r0 = tid / XT::COLS, col = tid - r0 * XT::COLS;
+        const int ix = col >> 2, cq = col & 3;
+        unsigned char* base = tile + (cq >> 1) * G::PLANE + ix * 16 + (cq & 1) * 8;
+#pragma unroll
+        for (int k = 0; k < XT::PER; ++k) {
+            const int row = r0 + k * XT::RPI;
+            const bool ok = r0 < XT::RPI && row < XT::ROWS;
+            *reinterpret_cast<uint2*>(ok ? base + row * (G::IX * 16) : dump) = pk[k];
+        }
+    };
+
+    int bi, ch; bool first, last, swp;
+    sched(0, bi, ch, first, last, swp);
+    filter_issue(ch);
+    tile_issue(bi, ch);
+    filter_commit();
+    tile_pack();
+    tile_commit();
+    __syncthreads();
+
+    f32x4 accA[4], accB[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) accB[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int step = 0; step < nsteps; ++step) {
+        sched(step, bi, ch, first, last, swp);
+        const bool more = step + 1 < nsteps;
+        int nbi = 0, nchk = ch; bool nf, nl, ns;
+        if (more) {
+            sched(step + 1, nbi, nchk, nf, nl, ns);
+            tile_issue(nbi, nchk);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (swp) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { const f32x4 t = accA[m]; accA[m] = accB[m]; accB[m] = t; }
+        }
+        if (first) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) accA[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // ---- dz pairs (0,1), (2,3) ----
+#pragma unroll
+        for (int zp = 0; zp < 2; ++zp)
+#pragma unroll
+            for (int dx = 0; dx < 5; ++dx) {
+                bf16x8 R[8], A[5];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) R[k] = *reinterpret_cast<const bf16x8*>(bZ + ((2 * zp * G::IY + k) * G::IX + dx) * 16);
+#pragma unroll
+                for (int dy = 0; dy < 5; ++dy) A[dy] = *reinterpret_cast<const bf16x8*>(fa + ((zp * 5 + dx) * 5 + dy) * 1024);
+#pragma unroll
+                for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        accA[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[dy], R[m + dy], accA[m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);     // keep the next group's 13 fragment reads from being hoisted above this
+                                                       // group's MFMAs (the allocator then runs out of registers and spills)
+            }
+        if (more) tile_pack();          // the prefetched tile has long arrived: convert now, 32 fewer live registers from here
+        // ---- dz = 4: dy pairs (0,1), (2,3) and the single tap dy = 4 ----
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+            bf16x8 P[6], S[4], A[3];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) P[k] = *reinterpret_cast<const bf16x8*>(bY + ((4 * G::IY + k) * G::IX + dx) * 16);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) S[m] = *reinterpret_cast<const bf16x8*>(b0 + ((4 * G::IY + 4 + m) * G::IX + dx) * 16);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) A[q] = *reinterpret_cast<const bf16x8*>(fa + (50 + dx * 3 + q) * 1024);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                accA[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], P[m], accA[m], 0, 0, 0);
+                accA[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], P[m + 2], accA[m], 0, 0, 0);
+                accA[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2], S[m], accA[m], 0, 0, 0);
+            }
+        }
+        if (last) {
+            // epilogue: lane holds cout 4g..4g+3 of voxel (vz, vy0 + m, x = j)
+            int b, bz, by, bx;
+            brick_origin(bi, b, bz, by, bx);
+            const int oz = bz * TZ + vz, ox = bx * TX + j, co = 4 * g;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int oy = by * TY + vy0 + m;
+                if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo || co >= a.Cout) continue;
+                const size_t ov = ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+                float e[4] = {accA[m][0], accA[m][1], accA[m][2], accA[m][3]};
+                if (a.bias) { e[0] += a.bias[co]; e[1] += a.bias[co + 1]; e[2] += a.bias[co + 2]; e[3] += a.bias[co + 3]; }
+                float* p = (co < a.Cy0) ? a.y0 + ov * a.Cy0 + co : a.y1 + ov * a.Cy1 + (co - a.Cy0);
+                if (a.accum) { const float4 old = *reinterpret_cast<const float4*>(p); e[0] += old.x; e[1] += old.y; e[2] += old.z; e[3] += old.w; }
+                *reinterpret_cast<float4*>(p) = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+        __syncthreads();                               // every wave is done reading the tile (and the filter chunk)
+        if (more) {
+            tile_commit();
+            // two chunks: the other filter chunk is loaded here, synchronously, once per brick PAIR (every 4th step) -- a
+            // register prefetch across the MFMA section does not fit next to the tile prefetch (it spilled)
+            if (nchk != ch) { filter_issue(nchk); filter_commit(); }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void pack_bf16_kernel(int mode, const float* __restrict__ w, unsigned short* __restrict__ wp, int T, int I, int O,
                                  int ncob, size_t total) {
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
@@ -1321,6 +1532,12 @@ Bf16Plan plan_conv_bf16(int Cin, int Cout, int B, int Do, int Ho, int Wo) {
     return p;
 }
 
+// 16-cout kernel: exactly the layers that would pad 16 -> 32 cout, vector-aligned channels, >= 256 bricks of 4x8x16
+bool conv_bf16_use_c16(int Cin, int Cout, int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W) {
+    if (Cout > 16 || (Cout & 3) || (C0 & 3) || (C1 & 3) || (Cy0 & 3) || (Cy1 & 3) || W < 16) return false;
+    return (long)B * ceil_div(D, 4) * ceil_div(H, 8) * ceil_div(W, 16) >= 256;
+}
+
 template <int TZ, int TY, int TX, int WAVES>
 int launch_conv_bf16(const ConvArgs& a, const Bf16Plan& p, hipStream_t st) {
     using G = Bf16Geom<TZ, TY, TX>;
@@ -1501,6 +1718,18 @@ static int conv_fwd_bf16_impl(const float* x0, int C0, const float* x1, int C1, 
         const size_t need = (size_t)nslab * nvox * a.CoutP * sizeof(float);
         if (!ws || ws_bytes < need) return VNET_E_WORKSPACE;
         a.part = reinterpret_cast<float*>(ws); a.part_stride = nvox * a.CoutP;
+    }
+    if (conv_bf16_use_c16(a.Cin, a.Cout, C0, C1, Cy0, Cy1, B, D, H, W)) {
+        // 16 output channels at a size with enough bricks for one persistent workgroup per CU: no padding to 32 cout
+        using GC = Bf16Geom<4, 8, 16>;
+        a.nbz = ceil_div(D, 4); a.nby = ceil_div(H, 8); a.nbx = ceil_div(W, 16);
+        auto k = conv5_bf16_c16_kernel<4, 8, 16>;
+        const size_t lds = (size_t)GC::TILE_BYTES + 65 * 1024 + 64 * 16;
+        static unsigned long long attr_done = 0;
+        if (int ae = ensure_lds(k, lds, attr_done)) return ae;
+        hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, st, a);
+        VNET_LAUNCH_CHECK();
+        return VNET_OK;
     }
     const int e = p.small ? launch_conv_bf16<8, 8, 8, 8>(a, p, st)
                 : p.half  ? launch_conv_bf16<4, 8, 8, 4>(a, p, st) : launch_conv_bf16<4, 8, 16, 8>(a, p, st);
