@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvnet_hip.so")
+LIB_PATH = os.environ.get("VNET_HIP_LIB") or os.path.join(_HERE, "libvnet_hip.so")      # (override: A/B of kernel builds)
 CSRC = os.path.join(_HERE, "csrc")
 
 _vp, _i, _i64, _f, _sz, _u64, _d = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,

@@ -110,13 +110,16 @@ class VolumeDataset(object):
     others blocked in RCCL).  Crop windows are drawn from a per-rank generator."""
 
     def __init__(self, data_dir, image_filenames, label_filename, classes, patch_shape, batch_size,
-                 train=True, seed=0, synthetic=None, rank=0, world=1, cache=None):
+                 train=True, seed=0, synthetic=None, rank=0, world=1, cache=None, transforms=None):
         self.image_filenames, self.label_filename = list(image_filenames), label_filename
         self.classes, self.patch, self.batch = list(classes), tuple(patch_shape), int(batch_size)
         self.train, self.seed, self.epoch = train, int(seed), 0
         self.rng = np.random.default_rng(seed + 7919 * rank)          # crop windows of this rank
         self.rank, self.world = rank, world
         self.synthetic = synthetic
+        # the reference's per-sample transform list (vnet_tensorflow_amd.transforms.build_pipeline of TrainingSetting.Pipeline);
+        # None = zero-pad + uniform RandomCrop to PatchShape
+        self.transforms = transforms
         # volumes kept in host memory after the first load (synthetic cases are a pure function of their seed;
         # regenerating a 128^3 case costs ~0.3 s, 10x a training step)
         self.cache = {} if (cache if cache is not None else synthetic is not None) else None
@@ -165,7 +168,14 @@ class VolumeDataset(object):
         imgs, labs = [], []
         for case, sd in zip(cases, seeds):
             image, label = self._load(case)
-            image, label = random_crop(image, label, self.patch, np.random.default_rng(sd))
+            if self.transforms is not None:
+                from .transforms import apply_pipeline
+                image, label = apply_pipeline(self.transforms, image, label, np.random.default_rng(sd))
+                if tuple(label.shape) != self.patch:
+                    raise ValueError("the transform pipeline produced a %s sample, PatchShape is %s (end it with a crop to "
+                                     "PatchShape, like the reference's pipeline3D.yaml)" % (tuple(label.shape), self.patch))
+            else:
+                image, label = random_crop(image, label, self.patch, np.random.default_rng(sd))
             imgs.append(image)
             labs.append(label[..., None])
         return np.stack(imgs).astype(np.float32, copy=False), np.stack(labs).astype(np.int32, copy=False)

@@ -549,9 +549,15 @@ class image2label(object):
         return path
 
     def _dataset(self, data_dir, train):
+        tf = None
+        if self.training_pipeline:
+            # TrainingSetting.Pipeline: the reference's transform YAML (model.py:340-372); the index / intensity transforms
+            # are restated on arrays (vnet_tensorflow_amd/transforms.py), SimpleITK resampling ones are refused
+            from . import transforms as vtf
+            tf = vtf.build_pipeline(self.training_pipeline, "train" if train else "test")
         return vdata.VolumeDataset(data_dir, self.image_filenames, self.label_filename, self.label_classes,
                                    self.patch_shape, self.batch_size, train=train, synthetic=self.synthetic,
-                                   rank=self.rank, world=self.world)
+                                   rank=self.rank, world=self.world, transforms=tf)
 
     # -- reference model.py:632-815 ---------------------------------------------------------------------------
     def train(self):
