@@ -98,6 +98,19 @@ int vnet_conv_fwd_acc(int ks, int kx, int stride, int up,
                       int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                       void* ws, size_t ws_bytes, void* stream);
 
+/* Batch-norm statistics in the convolution epilogue (networks.py:316-319: every convolution is followed by
+ * tf.layers.batch_normalization, optionally of conv + residual): the launch also writes, per workgroup, the partial sums of
+ * v = y (+ res) and v^2 per channel into stats[rows][2][Cout]; vnet_bn_finalize_partial turns them into mean / invstd (+ the
+ * moving averages) -- the separate statistics pass over y (vnet_bn_stats) is not needed.  rows = vnet_conv_stats_rows(...)
+ * for the same problem (0: this launch cannot do it -- transposed conv, split output, Cout % 4 != 0, or a split-K launch whose
+ * Cout does not divide 256 -- use vnet_bn_stats).  Single output tensor y [.., Cout]; res: NULL or [.., Cout] like y. */
+int vnet_conv_stats_rows(int ks, int kx, int stride, int up, int Cin, int Cy0, int Cy1, int B, int Do, int Ho, int Wo);
+int vnet_conv_stats_from_reduce(int ks, int kx, int stride, int Cin, int Cout, int B, int Do, int Ho, int Wo);   /* 1: split-K launch, the reduce kernel produces them */
+int vnet_conv_fwd_stats(int ks, int kx, int stride, const float* x0, int C0, const float* x1, int C1,
+                        const float* wp, const float* bias, float* y, int Cout,
+                        int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                        const float* res, float* stats, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- bf16-operand 5x5x5 stride-1 convolution (BASELINE config C5: bf16 compute, fp32 accumulate) ----------
  * Same contract as vnet_conv_fwd(ks=5, stride=1): fp32 NDHWC tensors in and out, two-source input, split output,
  * bias; x and the filter are rounded to bf16 (round-to-nearest-even) on the way into the matrix cores and the
@@ -111,6 +124,11 @@ int vnet_conv_fwd_bf16(const float* x0, int C0, const float* x1, int C1, const v
 int vnet_conv_fwd_bf16_acc(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
                            float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
                            void* ws, size_t ws_bytes, void* stream);     /* y += conv(x), see vnet_conv_fwd_acc */
+
+int vnet_conv_bf16_stats_rows(int Cin, int Cy0, int Cy1, int C0, int C1, int B, int D, int H, int W);
+int vnet_conv_fwd_bf16_stats(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
+                             float* y, int Cout, int B, int D, int H, int W,
+                             const float* res, float* stats, void* ws, size_t ws_bytes, void* stream);   /* see vnet_conv_fwd_stats */
 
 /* filter gradient of the same convolution with x and dy rounded to bf16, fp32 accumulation
  * (v_mfma_f32_16x16x32_bf16 fed by LDS transpose reads); dw is fp32 in TF layout [125][Cin][Cout]. */
@@ -183,6 +201,10 @@ int vnet_bn_act_bwd(const float* dy, const float* x, const float* r, int bcast, 
  *   vnet_bn_act_bwd_reduce -> this replica's dgamma/dbeta/dalpha     [all-reduce(sum) of copies of dbeta,dgamma]
  *   vnet_bn_act_bwd_apply  -> ds from the GLOBAL sum_dz (= sum of dbeta) and sum_dz_xhat (= sum of dgamma).
  * vnet_bn_stats == moments + finalize with M_total = M; vnet_bn_act_bwd == reduce + apply with local sums. */
+/* mean / invstd (+ moving averages) from `rows` partial rows [2][C] of (sum, sum of squares), e.g. those a convolution wrote
+ * in its epilogue (vnet_conv_fwd_stats); M_total = rows of the normalised tensor. */
+int vnet_bn_finalize_partial(const float* partial, int rows, int C, double M_total, float eps, float momentum,
+                             float* mean, float* invstd, float* moving_mean, float* moving_var, void* stream);
 int vnet_bn_moments(const float* x, const float* r, int bcast, int64_t M, int C, double* sums,
                     void* ws, size_t ws_bytes, void* stream);
 int vnet_bn_finalize(const double* sums, double M_total, int C, float eps, float momentum,

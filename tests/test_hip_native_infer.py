@@ -40,8 +40,14 @@ def test_native_driver_matches_python_evaluate(tmp_path, dev, cin, K, levels, co
                 p.add_(0.2 * torch.randn(p.shape, generator=g).to(p.device))
     vol, _ = synthetic_batch(1, 24, cin, K, seed=9)
     vol = np.ascontiguousarray(vol[0][:, :22, :20])
-    label_py, prob_py = m.evaluate_single_3D(vol)
     from vnet_tensorflow_amd import ops
+    # like with like: the native driver runs the separate statistics pass (vnet_bn_stats); in bf16 mode a different summation
+    # order of the batch moments flips operand roundings downstream, far beyond this test's fp32 round-off bound
+    ops.set_epilogue_bn_stats(False)
+    try:
+        label_py, prob_py = m.evaluate_single_3D(vol)
+    finally:
+        ops.set_epilogue_bn_stats(True)
     ops.set_compute_dtype("fp32")
 
     wpath, ipath = str(tmp_path / "net.vnetw"), str(tmp_path / "vol.npy")

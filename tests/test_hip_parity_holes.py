@@ -212,3 +212,52 @@ def test_gradient_accumulation_in_the_producing_kernel(dev, compute):
         assert np.array_equal(grads[True][0][n], grads[False][0][n]), n
     # 3 levels: 3 skip forks + residual forks at levels 2, 3 and the bottom = 6 full-tensor adds saved
     assert grads[False][1] - grads[True][1] >= 6, (grads[False][1], grads[True][1])
+
+
+@pytest.mark.parametrize("mode,ks,stride,shape,Cin,Cout,residual", [
+    ("fp32", 5, 1, (1, 32, 32, 32), 16, 16, True),        # one brick row per workgroup, residual added in the epilogue
+    ("fp32", 5, 1, (2, 24, 20, 28), 8, 24, False),        # ragged bricks: voxels outside the volume must not be counted
+    ("fp32", 5, 1, (1, 8, 8, 8), 64, 64, True),           # split-K: statistics come from the reduce kernel
+    ("fp32", 2, 2, (1, 32, 32, 32), 16, 32, False),       # 2^3 stride-2 down convolution
+    ("bf16", 5, 1, (1, 64, 64, 128), 16, 16, True),       # 16-output-channel bf16 kernel (persistent workgroups)
+    ("bf16", 5, 1, (1, 32, 32, 32), 32, 32, False),       # generic bf16 kernel
+    ("bf16", 5, 1, (1, 8, 8, 8), 128, 128, True),         # bf16 split-K
+])
+def test_batch_norm_statistics_from_the_conv_epilogue(dev, mode, ks, stride, shape, Cin, Cout, residual):
+    """The convolution writes per-workgroup partial sums of y (+ residual) and its square; the batch-norm behind it only
+    finalizes them (vnet_conv_fwd_stats + vnet_bn_finalize_partial).  Mean / inverse standard deviation must equal the
+    float64 moments of the tensor the batch-norm normalises, the normalised output must equal the unfused path's, and the
+    moving averages must be updated."""
+    from vnet_tensorflow_amd import ops
+    gen = torch.Generator().manual_seed(Cin * 7 + Cout)
+    B, D, H, W = shape
+    x = (torch.randn(B, D, H, W, Cin, generator=gen) * 1.5 + 0.3).to(dev)
+    w = (torch.randn(ks, ks, ks, Cin, Cout, generator=gen) * 0.05).to(dev)
+    b = torch.randn(Cout, generator=gen).to(dev)
+    od = tuple(-(-v // stride) for v in (D, H, W))
+    r = (torch.randn(B, *od, Cout, generator=gen) * 2.0).to(dev) if residual else None
+    gamma, beta = (torch.rand(Cout, generator=gen) + 0.5).to(dev), torch.randn(Cout, generator=gen).to(dev)
+    ops.set_compute_dtype(mode)
+    try:
+        outs = {}
+        for fused in (True, False):
+            ops.set_epilogue_bn_stats(fused, fp32_direct=True)
+            mm, mv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+            with torch.no_grad():
+                y = ops.conv(x, w, b, ks, stride, bn_stats=True, bn_residual=r)
+                assert (getattr(y, "_vnet_stats", None) is not None) == fused
+                z, mean, invstd = ops.bn_act(y, gamma, beta, "relu", None, r, False, mm, mv, want_stats=True)
+            outs[fused] = (y.clone(), z.clone(), mean.clone(), invstd.clone(), mm.clone(), mv.clone())
+    finally:
+        ops.set_epilogue_bn_stats(True, fp32_direct=True)
+        ops.set_compute_dtype("fp32")
+    yf, zf, mean, invstd, mm, mv = outs[True]
+    assert torch.equal(yf, outs[False][0])                                   # the convolution output itself is unchanged
+    s = yf.double() + (r.double() if residual else 0.0)
+    mu = s.mean(dim=(0, 1, 2, 3))
+    var = s.var(dim=(0, 1, 2, 3), unbiased=False)
+    check_close("mean", mean, mu.cpu().numpy(), 1e-6, atol=1e-6)
+    check_close("invstd", invstd, (1.0 / torch.sqrt(var + 1e-3)).cpu().numpy(), 1e-6)
+    check_close("normalised output", zf, outs[False][1].cpu().numpy(), 2e-6)
+    check_close("moving mean", mm, (0.01 * mu).cpu().numpy(), 1e-5, atol=1e-7)
+    check_close("moving variance", mv, (0.99 + 0.01 * var).cpu().numpy(), 1e-6)

@@ -36,7 +36,23 @@ struct ConvArgs {
     int upO;           // UP: real output channels O (N' = 8*O)
     int nz;            // tap (dz) splits per K-split: deep levels have too few bricks to fill 256 CUs
     int accum;         // 1: y += result (backward-data into a gradient another consumer of the same tensor already wrote)
+    // batch-norm statistics of the output in the epilogue (round 2): per-workgroup partial sums of v = y (+ res) and v^2 per
+    // channel, row [2][Cout] per brick (or per reduce block for split-K launches); the batch-norm that consumes y then
+    // only runs its finalize.  res: optional residual that is added in front of that batch-norm (networks.py:318).
+    float* stats; const float* res;
 };
+
+// cross-wave stage of the epilogue statistics: per-wave sums in red[wave][2 * CW] -> one row of the partial buffer
+template <int WAVES_, int CW>
+__device__ __forceinline__ void stats_row_write(const float* red, float* __restrict__ stats, size_t row, int co0, int Cout, int tid) {
+    if (tid < 2 * CW) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_; ++w) t += red[w * 2 * CW + tid];
+        const int a2 = tid / CW, c = co0 + (tid - a2 * CW);
+        if (c < Cout) stats[row * 2 * Cout + (size_t)a2 * Cout + c] = t;
+    }
+}
 
 template <int KS, int STRIDE, int TZ, int TY, int TX, int KX = KS>
 struct TileGeom {
@@ -137,7 +153,9 @@ __device__ __forceinline__ void load_tile(float* lds, const float* __restrict__ 
     }
 }
 
-template <int KS, int STRIDE, int TZ, int TY, int TX, int WAVES, int MS, int NS, bool UP, int KX = KS>
+// STATS: separate instantiation with the batch-norm statistics in the epilogue -- kept out of the plain kernels, whose main
+// loop lost 2-3 % when the (unused) epilogue code was merely present (register allocation / code placement)
+template <int KS, int STRIDE, int TZ, int TY, int TX, int WAVES, int MS, int NS, bool UP, int KX = KS, bool STATS = false>
 __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
     using G = TileGeom<KS, STRIDE, TZ, TY, TX, KX>;
     static_assert(TZ * TY * TX == WAVES * MS * 16, "brick must be WAVES*MS 16-voxel subtiles");
@@ -148,6 +166,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
 
     const int nbrick = a.B * a.nbz * a.nby * a.nbx;
     int brick = xcd_remap(blockIdx.x, nbrick);
+    const int brick_id = brick;
     const int bx = brick % a.nbx; brick /= a.nbx;
     const int by = brick % a.nby; brick /= a.nby;
     const int bz = brick % a.nbz; const int b = brick / a.nbz;
@@ -306,6 +325,12 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
     }
 
     // epilogue: lane holds cout = co0 + n*16 + 4*kk + {0..3} of voxel (m, i)
+    constexpr int NSS = STATS ? NS : 1;
+    float s1[NSS][4], s2[NSS][4];        // batch-norm statistics of this lane's channels (STATS)
+#pragma unroll
+    for (int n = 0; n < NSS; ++n)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s1[n][k] = s2[n][k] = 0.f;
 #pragma unroll
     for (int m = 0; m < MS; ++m) {
         const int v = (wave * MS + m) * 16 + i;
@@ -343,6 +368,13 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
                 float e[4] = {r.x, r.y, r.z, r.w};
                 if (a.vec_out && co + 3 < a.Cout) {
                     if (a.bias) { e[0] += a.bias[co]; e[1] += a.bias[co + 1]; e[2] += a.bias[co + 2]; e[3] += a.bias[co + 3]; }
+                    if constexpr (STATS) {
+                        float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (a.res) rr = *reinterpret_cast<const float4*>(a.res + ov * a.Cout + co);
+                        const float vv[4] = {e[0] + rr.x, e[1] + rr.y, e[2] + rr.z, e[3] + rr.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { s1[n][k] += vv[k]; s2[n][k] += vv[k] * vv[k]; }
+                    }
                     float* p = (co < a.Cy0) ? a.y0 + ov * a.Cy0 + co : a.y1 + ov * a.Cy1 + (co - a.Cy0);
                     if (a.accum) { const float4 old = *reinterpret_cast<const float4*>(p); e[0] += old.x; e[1] += old.y; e[2] += old.z; e[3] += old.w; }
                     *reinterpret_cast<float4*>(p) = make_float4(e[0], e[1], e[2], e[3]);
@@ -358,20 +390,59 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
             }
         }
     }
+    if constexpr (STATS && !UP) if (!a.part) {
+        // lanes of one kk group hold the same channels for 16 different voxels: butterfly over i, then across waves via LDS
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    s1[n][k] += __shfl_xor(s1[n][k], off, 64);
+                    s2[n][k] += __shfl_xor(s2[n][k], off, 64);
+                }
+        constexpr int CW = NS * 16;
+        __syncthreads();                                   // every wave is done with the LDS tile
+        if (i == 0) {
+#pragma unroll
+            for (int n = 0; n < NS; ++n)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    lds[wave * 2 * CW + n * 16 + kk * 4 + k] = s1[n][k];
+                    lds[wave * 2 * CW + CW + n * 16 + kk * 4 + k] = s2[n][k];
+                }
+        }
+        __syncthreads();
+        stats_row_write<WAVES, CW>(lds, a.stats, (size_t)brick_id, co0, a.Cout, tid);
+    }
 }
 
 // y = sum_s part[s] + bias, scattered to the (possibly dual) NDHWC destination
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, size_t part_stride, int nsplit,
                                      const float* __restrict__ bias, float* y0, float* y1, int Cy0, int Cy1,
-                                     int CoutP, size_t nvox, int accum) {
+                                     int CoutP, size_t nvox, int accum, const float* __restrict__ res, float* __restrict__ stats) {
     const int Cout = Cy0 + Cy1;
     const size_t total = nvox * (size_t)Cout;
+    // statistics (stats != NULL): 256 % Cout == 0, so a thread meets ONE channel (tid % Cout) on its whole grid-stride walk
+    float t1 = 0.f, t2 = 0.f;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const size_t v = idx / Cout; const int c = (int)(idx - v * Cout);
         float s = bias ? bias[c] : 0.f;
         for (int k = 0; k < nsplit; ++k) s += part[k * part_stride + v * CoutP + c];
+        if (stats) { const float w = s + (res ? res[idx] : 0.f); t1 += w; t2 += w * w; }
         float* dst = (c < Cy0) ? y0 + v * Cy0 + c : y1 + v * Cy1 + (c - Cy0);
         *dst = accum ? *dst + s : s;
+    }
+    if (stats) {
+        __shared__ float sh[2][256];
+        sh[0][threadIdx.x] = t1; sh[1][threadIdx.x] = t2;
+        __syncthreads();
+        for (int q = threadIdx.x; q < 2 * Cout; q += 256) {
+            const int a2 = q / Cout, c = q - a2 * Cout;
+            float t = 0.f;
+            for (int k = c; k < 256; k += Cout) t += sh[a2][k];
+            stats[(size_t)blockIdx.x * 2 * Cout + (size_t)a2 * Cout + c] = t;
+        }
     }
 }
 
@@ -809,7 +880,7 @@ ConvPlan plan_conv(int ks, int stride, int up, int Cin, int Cout, int B, int Do,
     return p;
 }
 
-template <int KS, int STRIDE, int TZ, int TY, int TX, int WAVES, int MS, bool UP, int KX = KS>
+template <int KS, int STRIDE, int TZ, int TY, int TX, int WAVES, int MS, bool UP, int KX = KS, bool STATS = false>
 int launch_conv_ns(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
     using G = TileGeom<KS, STRIDE, TZ, TY, TX, KX>;
     const size_t lds = (size_t)G::LDS_FLOATS * 4;
@@ -817,7 +888,7 @@ int launch_conv_ns(const ConvArgs& a, const ConvPlan& p, hipStream_t st) {
     int e = 0;
 #define VNET_GO(NSV)                                                                              \
     {                                                                                             \
-        auto k = conv_kernel<KS, STRIDE, TZ, TY, TX, WAVES, MS, NSV, UP, KX>;                         \
+        auto k = conv_kernel<KS, STRIDE, TZ, TY, TX, WAVES, MS, NSV, UP, KX, STATS>;                  \
         static unsigned long long attr_done = 0;                                                  \
         if (int ae = ensure_lds(k, lds, attr_done)) return ae;                                    \
         hipLaunchKernelGGL(k, grid, block, lds, st, a);                                           \
@@ -918,6 +989,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
 
     const int nbrick = a.B * a.nbz * a.nby * a.nbx;
     int brick = xcd_remap(blockIdx.x, nbrick);
+    const int brick_id = brick;
     const int bx = brick % a.nbx; brick /= a.nbx;
     const int by = brick % a.nby; brick /= a.nby;
     const int bz = brick % a.nbz; const int b = brick / a.nbz;
@@ -1042,6 +1114,13 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     }
 
     // epilogue: register r of lane = cout co0 + n*32 + 8*(r/4) + 4*half + r%4 of voxel (m, q32)
+    float s1[NSB][4][4], s2[NSB][4][4];          // batch-norm statistics of this lane's channels (a.stats)
+#pragma unroll
+    for (int n = 0; n < NSB; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s1[n][g][k] = s2[n][g][k] = 0.f;
 #pragma unroll
     for (int m = 0; m < MS; ++m) {
         const int v = (wave * MS + m) * 32 + q32;
@@ -1062,6 +1141,13 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
                 if (co >= a.Cout) continue;
                 if (a.vec_out && co + 3 < a.Cout) {
                     if (a.bias) { e[0] += a.bias[co]; e[1] += a.bias[co + 1]; e[2] += a.bias[co + 2]; e[3] += a.bias[co + 3]; }
+                    if (a.stats) {
+                        float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (a.res) rr = *reinterpret_cast<const float4*>(a.res + ov * a.Cout + co);
+                        const float vv[4] = {e[0] + rr.x, e[1] + rr.y, e[2] + rr.z, e[3] + rr.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { s1[n][g][k] += vv[k]; s2[n][g][k] += vv[k] * vv[k]; }
+                    }
                     float* p = (co < a.Cy0) ? a.y0 + ov * a.Cy0 + co : a.y1 + ov * a.Cy1 + (co - a.Cy0);
                     if (a.accum) { const float4 old = *reinterpret_cast<const float4*>(p); e[0] += old.x; e[1] += old.y; e[2] += old.z; e[3] += old.w; }
                     *reinterpret_cast<float4*>(p) = make_float4(e[0], e[1], e[2], e[3]);
@@ -1075,6 +1161,30 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
                     }
                 }
             }
+    }
+    if (a.stats && !a.part) {
+        // the 32 lanes of a half hold the same channels for 32 voxels: butterfly over p32, then across waves via LDS
+        // (the main loop ends with a barrier after the last tile read, so the LDS is free here)
+        constexpr int CW = NSB * 32;
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int n = 0; n < NSB; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                    for (int off = 1; off < 32; off <<= 1) {
+                        s1[n][g][k] += __shfl_xor(s1[n][g][k], off, 64);
+                        s2[n][g][k] += __shfl_xor(s2[n][g][k], off, 64);
+                    }
+                    if (p32 == 0) {
+                        red[wave * 2 * CW + n * 32 + g * 8 + half * 4 + k] = s1[n][g][k];
+                        red[wave * 2 * CW + CW + n * 32 + g * 8 + half * 4 + k] = s2[n][g][k];
+                    }
+                }
+        __syncthreads();
+        stats_row_write<WAVES, CW>(red, a.stats, (size_t)brick_id, co0, a.Cout, tid);
     }
 }
 
@@ -1106,6 +1216,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int j = lane & 15, g = lane >> 4, half = g & 1, hi = g >> 1;
     const int vz = wave >> 1, vy0 = (wave & 1) * 4;
     unsigned char* dump = smem + G::TILE_BYTES + NFRAG * 1024 + lane * 16;
+    float* red = reinterpret_cast<float*>(smem + G::TILE_BYTES + NFRAG * 1024 + 64 * 16);      // [8 waves][2 x 16] epilogue statistics
 
     const int base0 = half * G::PLANE + ((vz * G::IY + vy0) * G::IX + j) * 16;
     const unsigned char* bZ = tile + base0 + hi * PLANEB;                // taps (dz, dz+1)
@@ -1266,6 +1377,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             int b, bz, by, bx;
             brick_origin(bi, b, bz, by, bx);
             const int oz = bz * TZ + vz, ox = bx * TX + j, co = 4 * g;
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int oy = by * TY + vy0 + m;
@@ -1273,12 +1385,28 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const size_t ov = ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
                 float e[4] = {accA[m][0], accA[m][1], accA[m][2], accA[m][3]};
                 if (a.bias) { e[0] += a.bias[co]; e[1] += a.bias[co + 1]; e[2] += a.bias[co + 2]; e[3] += a.bias[co + 3]; }
+                if (a.stats) {
+                    float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a.res) rr = *reinterpret_cast<const float4*>(a.res + ov * a.Cout + co);
+                    const float vv[4] = {e[0] + rr.x, e[1] + rr.y, e[2] + rr.z, e[3] + rr.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { s1[k] += vv[k]; s2[k] += vv[k] * vv[k]; }
+                }
                 float* p = (co < a.Cy0) ? a.y0 + ov * a.Cy0 + co : a.y1 + ov * a.Cy1 + (co - a.Cy0);
                 if (a.accum) { const float4 old = *reinterpret_cast<const float4*>(p); e[0] += old.x; e[1] += old.y; e[2] += old.z; e[3] += old.w; }
                 *reinterpret_cast<float4*>(p) = make_float4(e[0], e[1], e[2], e[3]);
             }
+            if (a.stats) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                    for (int off = 1; off < 16; off <<= 1) { s1[k] += __shfl_xor(s1[k], off, 64); s2[k] += __shfl_xor(s2[k], off, 64); }
+                    if (j == 0) { red[wave * 32 + co + k] = s1[k]; red[wave * 32 + 16 + co + k] = s2[k]; }
+                }
+            }
         }
         __syncthreads();                               // every wave is done reading the tile (and the filter chunk)
+        if (last && a.stats) stats_row_write<8, 16>(red, a.stats, (size_t)(b_lo + slot + bi * G8), 0, a.Cout, tid);
         if (more) {
             tile_commit();
             // two chunks: the other filter chunk is loaded here, synchronously, once per brick PAIR (every 4th step) -- a
@@ -1614,10 +1742,35 @@ size_t vnet_conv_ws_bytes(int ks, int kx, int stride, int up, int Cin, int Cout,
     return (size_t)p.nsplit * p.nz * B * Do * Ho * Wo * round_up(Cout, 16) * sizeof(float);
 }
 
+// rows of the epilogue-statistics partial buffer [rows][2][Cout] (0 = this launch cannot produce them: transposed conv, split
+// output, channel count that is no multiple of 4, or a split-K reduce whose channel count does not divide 256)
+int vnet_conv_stats_rows(int ks, int kx, int stride, int up, int Cin, int Cy0, int Cy1, int B, int Do, int Ho, int Wo) {
+    if (up || Cy1 != 0 || Cy0 <= 0 || (Cy0 & 3) || Cin <= 0 || B <= 0) return 0;
+    const bool is5 = (ks == 5 && stride == 1), isdown = (ks == 2 && stride == 2);
+    if (!is5 && !isdown) return 0;
+    if (kx == 0) kx = ks;
+    ConvPlan p = plan_conv(ks, stride, 0, Cin, Cy0, B, Do, Ho, Wo, Wo);
+    if (p.nsplit * p.nz > 1) {
+        if (Cy0 > 256 || 256 % Cy0) return 0;
+        const size_t total = (size_t)B * Do * Ho * Wo * Cy0;
+        return (int)min((size_t)2048, (total + 255) / 256);
+    }
+    return B * p.nbz * p.nby * p.nbx;
+}
+
+// 1: the statistics of this launch come from the split-K reduce kernel (an HBM-bound pass that already touches every output
+// element: they are free there); 0: from the MFMA kernel's own epilogue (the STATS instantiation)
+int vnet_conv_stats_from_reduce(int ks, int kx, int stride, int Cin, int Cout, int B, int Do, int Ho, int Wo) {
+    const bool is5 = (ks == 5 && stride == 1), isdown = (ks == 2 && stride == 2);
+    if ((!is5 && !isdown) || Cin <= 0 || Cout <= 0 || B <= 0) return 0;
+    ConvPlan p = plan_conv(ks, stride, 0, Cin, Cout, B, Do, Ho, Wo, Wo);
+    return p.nsplit * p.nz > 1 ? 1 : 0;
+}
+
 static int conv_fwd_impl(int ks, int kx, int stride, int up, const float* x0, int C0, const float* x1, int C1,
                          const float* wp, const float* bias, float* y0, int Cy0, float* y1, int Cy1,
                          int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
-                         void* ws, size_t ws_bytes, void* stream, int accum) {
+                         void* ws, size_t ws_bytes, void* stream, int accum, const float* res = nullptr, float* stats = nullptr) {
     if (!x0 || !wp || !y0 || C0 <= 0 || Cy0 <= 0 || B <= 0) return VNET_E_BADARG;
     if ((C1 > 0 && !x1) || (Cy1 > 0 && !y1) || C1 < 0 || Cy1 < 0) return VNET_E_BADARG;
     if (Di <= 0 || Hi <= 0 || Wi <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return VNET_E_BADARG;
@@ -1631,7 +1784,8 @@ static int conv_fwd_impl(int ks, int kx, int stride, int up, const float* x0, in
     a.nchunks = a.CQ / 4;
     a.vec_in = (C0 % 4 == 0) && (C1 % 4 == 0);
     a.vec_out = (Cy0 % 4 == 0) && (Cy1 % 4 == 0);
-    a.part = nullptr; a.part_stride = 0; a.upO = 0; a.accum = accum;
+    a.part = nullptr; a.part_stride = 0; a.upO = 0; a.accum = accum; a.res = res; a.stats = stats;
+    if (stats && vnet_conv_stats_rows(ks, kx, stride, up, C0 + C1, Cy0, Cy1, B, Do, Ho, Wo) == 0) return VNET_E_UNSUPPORTED;
     const bool is5 = (ks == 5 && stride == 1 && !up), isdown = (ks == 2 && stride == 2 && !up), isup = (ks == 2 && stride == 2 && up);
     if (!is5 && !isdown && !isup) return VNET_E_UNSUPPORTED;
     if (kx == 0) kx = ks;
@@ -1654,7 +1808,14 @@ static int conv_fwd_impl(int ks, int kx, int stride, int up, const float* x0, in
         a.part = reinterpret_cast<float*>(ws); a.part_stride = nvox * a.CoutP;
     }
     int e;
-    if (is5) {
+    if (a.stats && nslab == 1) {     // statistics in the conv epilogue: the STATS instantiations (split-K launches take theirs from the reduce)
+        if (is5) {
+            if (kx == 1) e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false, 1, true>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 8, 4, 4, false, 1, true>(a, p, st);
+            else e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false, 5, true>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 8, 4, 4, false, 5, true>(a, p, st);
+        } else {
+            e = p.small ? launch_conv_ns<2, 2, 2, 8, 8, 4, 2, false, 2, true>(a, p, st) : launch_conv_ns<2, 2, 2, 4, 16, 4, 2, false, 2, true>(a, p, st);
+        }
+    } else if (is5) {
         if (kx == 1) e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false, 1>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 8, 4, 4, false, 1>(a, p, st);
         else e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 8, 4, 4, false>(a, p, st);
     } else if (isdown) {
@@ -1668,7 +1829,7 @@ static int conv_fwd_impl(int ks, int kx, int stride, int up, const float* x0, in
         const size_t total = nvox * a.Cout;
         const int blocks = (int)min((size_t)2048, (total + 255) / 256);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, a.part_stride, nslab, bias,
-                           y0, y1, Cy0, Cy1, a.CoutP, nvox, a.accum);
+                           y0, y1, Cy0, Cy1, a.CoutP, nvox, a.accum, a.res, a.stats);
         VNET_LAUNCH_CHECK();
     }
     return VNET_OK;
@@ -1688,15 +1849,36 @@ int vnet_conv_fwd_acc(int ks, int kx, int stride, int up, const float* x0, int C
     return conv_fwd_impl(ks, kx, stride, up, x0, C0, x1, C1, wp, bias, y0, Cy0, y1, Cy1, B, Di, Hi, Wi, Do, Ho, Wo, ws, ws_bytes, stream, 1);
 }
 
+int vnet_conv_fwd_stats(int ks, int kx, int stride, const float* x0, int C0, const float* x1, int C1,
+                        const float* wp, const float* bias, float* y, int Cout,
+                        int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                        const float* res, float* stats, void* ws, size_t ws_bytes, void* stream) {
+    if (!stats) return VNET_E_BADARG;
+    return conv_fwd_impl(ks, kx, stride, 0, x0, C0, x1, C1, wp, bias, y, Cout, nullptr, 0, B, Di, Hi, Wi, Do, Ho, Wo, ws, ws_bytes, stream, 0,
+                         res, stats);
+}
+
 size_t vnet_conv_bf16_ws_bytes(int Cin, int Cout, int B, int D, int H, int W) {
     Bf16Plan p = plan_conv_bf16(Cin, Cout, B, D, H, W);
     if (p.nsplit * p.nz <= 1) return 0;
     return (size_t)p.nsplit * p.nz * B * D * H * W * round_up(Cout, 32) * sizeof(float);
 }
 
+int vnet_conv_bf16_stats_rows(int Cin, int Cy0, int Cy1, int C0, int C1, int B, int D, int H, int W) {
+    if (Cy1 != 0 || Cy0 <= 0 || (Cy0 & 3) || Cin <= 0 || B <= 0) return 0;
+    if (conv_bf16_use_c16(Cin, Cy0, C0, C1, Cy0, 0, B, D, H, W)) return B * ceil_div(D, 4) * ceil_div(H, 8) * ceil_div(W, 16);
+    Bf16Plan p = plan_conv_bf16(Cin, Cy0, B, D, H, W);
+    if (p.nsplit * p.nz > 1) {
+        if (Cy0 > 256 || 256 % Cy0) return 0;
+        const size_t total = (size_t)B * D * H * W * Cy0;
+        return (int)min((size_t)2048, (total + 255) / 256);
+    }
+    return B * p.nbz * p.nby * p.nbx;
+}
+
 static int conv_fwd_bf16_impl(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
                               float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
-                              void* ws, size_t ws_bytes, void* stream, int accum) {
+                              void* ws, size_t ws_bytes, void* stream, int accum, const float* res = nullptr, float* stats = nullptr) {
     if (!x0 || !wp || !y0 || C0 <= 0 || Cy0 <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return VNET_E_BADARG;
     if ((C1 > 0 && !x1) || (Cy1 > 0 && !y1) || C1 < 0 || Cy1 < 0) return VNET_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -1709,7 +1891,8 @@ static int conv_fwd_bf16_impl(const float* x0, int C0, const float* x1, int C1, 
     a.CoutP = round_up(a.Cout, 32);
     a.vec_in = (C0 % 4 == 0) && (C1 % 4 == 0);
     a.vec_out = (Cy0 % 4 == 0) && (Cy1 % 4 == 0);
-    a.pad = 2; a.padx = 2; a.accum = accum;
+    a.pad = 2; a.padx = 2; a.accum = accum; a.res = res; a.stats = stats;
+    if (stats && vnet_conv_bf16_stats_rows(a.Cin, Cy0, Cy1, C0, C1, B, D, H, W) == 0) return VNET_E_UNSUPPORTED;
     Bf16Plan p = plan_conv_bf16(a.Cin, a.Cout, B, D, H, W);
     a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.cps = p.cps; a.nz = p.nz;
     const int nslab = p.nsplit * p.nz;
@@ -1724,7 +1907,7 @@ static int conv_fwd_bf16_impl(const float* x0, int C0, const float* x1, int C1, 
         using GC = Bf16Geom<4, 8, 16>;
         a.nbz = ceil_div(D, 4); a.nby = ceil_div(H, 8); a.nbx = ceil_div(W, 16);
         auto k = conv5_bf16_c16_kernel<4, 8, 16>;
-        const size_t lds = (size_t)GC::TILE_BYTES + 65 * 1024 + 64 * 16;
+        const size_t lds = (size_t)GC::TILE_BYTES + 65 * 1024 + 64 * 16 + 8 * 32 * 4;
         static unsigned long long attr_done = 0;
         if (int ae = ensure_lds(k, lds, attr_done)) return ae;
         hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, st, a);
@@ -1738,7 +1921,7 @@ static int conv_fwd_bf16_impl(const float* x0, int C0, const float* x1, int C1, 
         const size_t total = nvox * a.Cout;
         const int blocks = (int)min((size_t)2048, (total + 255) / 256);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, a.part_stride, nslab, bias,
-                           y0, y1, Cy0, Cy1, a.CoutP, nvox, a.accum);
+                           y0, y1, Cy0, Cy1, a.CoutP, nvox, a.accum, a.res, a.stats);
         VNET_LAUNCH_CHECK();
     }
     return VNET_OK;
@@ -1753,6 +1936,12 @@ int vnet_conv_fwd_bf16_acc(const float* x0, int C0, const float* x1, int C1, con
                            float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
                            void* ws, size_t ws_bytes, void* stream) {
     return conv_fwd_bf16_impl(x0, C0, x1, C1, wp, bias, y0, Cy0, y1, Cy1, B, D, H, W, ws, ws_bytes, stream, 1);
+}
+int vnet_conv_fwd_bf16_stats(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
+                             float* y, int Cout, int B, int D, int H, int W,
+                             const float* res, float* stats, void* ws, size_t ws_bytes, void* stream) {
+    if (!stats) return VNET_E_BADARG;
+    return conv_fwd_bf16_impl(x0, C0, x1, C1, wp, bias, y, Cout, nullptr, 0, B, D, H, W, ws, ws_bytes, stream, 0, res, stats);
 }
 
 }  // extern "C"

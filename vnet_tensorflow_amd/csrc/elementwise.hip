@@ -979,6 +979,15 @@ int vnet_bn_stats(const float* x, const float* r, int bcast, int64_t M, int C, f
     return VNET_OK;
 }
 
+int vnet_bn_finalize_partial(const float* partial, int rows, int C, double M_total, float eps, float momentum,
+                             float* mean, float* invstd, float* moving_mean, float* moving_var, void* stream) {
+    if (!partial || !mean || !invstd || rows <= 0 || C <= 0 || C > MAXC || M_total <= 0.0) return VNET_E_BADARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, rows, C, C, M_total, eps, momentum,
+                       mean, invstd, moving_mean, moving_var);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
 int vnet_bn_moments(const float* x, const float* r, int bcast, int64_t M, int C, double* sums,
                     void* ws, size_t ws_bytes, void* stream) {
     if (!x || !sums || M <= 0 || C <= 0 || C > MAXC) return VNET_E_BADARG;

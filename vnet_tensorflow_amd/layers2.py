@@ -54,7 +54,7 @@ def _check_filter(filter, rank):
     return k[0]
 
 
-def convolution(x, filter, padding='SAME', strides=None, dilation_rate=None, initializer="XAVIER"):
+def convolution(x, filter, padding='SAME', strides=None, dilation_rate=None, initializer="XAVIER", bn_stats=False, bn_residual=None):
     """tf.nn.convolution(x, w, padding, strides, dilation_rate) + b with variables 'weights'/'biases'."""
     if padding != 'SAME':
         raise ValueError("only SAME padding is used by the reference networks")
@@ -70,16 +70,17 @@ def convolution(x, filter, padding='SAME', strides=None, dilation_rate=None, ini
         return ops.head_conv(x, w, b)
     if not ((k == 5 and s == 1) or (k == 2 and s == 2)):
         raise NotImplementedError("kernel %d stride %d is not instantiated (V-Net uses 5/1, 2/2, 1/1)" % (k, s))
-    return ops.conv(x, w, b, k, s)
+    # bn_stats / bn_residual (extension): the caller normalises this output (+ residual) next -- see ops.conv
+    return ops.conv(x, w, b, k, s, bn_stats=bn_stats, bn_residual=bn_residual)
 
 
-def convolution_concat(x, skip, filter):
+def convolution_concat(x, skip, filter, bn_stats=False):
     """convolution(tf.concat((x, skip), -1), filter) without materialising the concat (networks.py:325)."""
     filter = list(filter)
     w = get_variable(name='weights', initializer=lambda: xavier_initializer_convolution(shape=filter))
     b = get_variable(name='biases', initializer=lambda: constant_initializer(0, shape=filter[-1]))
     k = _check_filter(filter, get_spatial_rank(x))
-    return ops.conv(x, w, b, k, 1, x1=skip)
+    return ops.conv(x, w, b, k, 1, x1=skip, bn_stats=bn_stats)
 
 
 def deconvolution(x, filter, output_shape, strides, padding='SAME'):
@@ -97,12 +98,12 @@ def deconvolution(x, filter, output_shape, strides, padding='SAME'):
     return ops.conv_transpose2(x, w, b, out_spatial)
 
 
-def down_convolution(x, factor, kernel_size):
+def down_convolution(x, factor, kernel_size, bn_stats=False):
     num_channels = get_num_channels(x)
     spatial_rank = get_spatial_rank(x)
     strides = spatial_rank * [factor]
     filter = list(kernel_size) + [num_channels, num_channels * factor]
-    return convolution(x, filter, strides=strides)
+    return convolution(x, filter, strides=strides, bn_stats=bn_stats)
 
 
 def up_convolution(x, output_shape, factor, kernel_size):
@@ -131,7 +132,7 @@ def leaky_relu(x):
     return ops.activation(x, "lrelu")
 
 
-def convolution_tiled(tiled, filter):
+def convolution_tiled(tiled, filter, bn_stats=False, bn_residual=None):
     """convolution(x, filter) where x = batch_normalization(tf.tile(img)) of a 1-channel image (reference
     networks.py:254-259 followed by networks.py:316): same variables ('weights', 'biases'), same result up to fp32
     summation order, 5x fewer matrix instructions forward / in the filter gradient and no backward-data pass
@@ -140,7 +141,7 @@ def convolution_tiled(tiled, filter):
     w = get_variable(name='weights', initializer=lambda: xavier_initializer_convolution(shape=filter))
     b = get_variable(name='biases', initializer=lambda: constant_initializer(0, shape=filter[-1]))
     img, gamma, beta, mean, invstd = tiled
-    return ops.input_conv(img, gamma, beta, mean, invstd, w, b)
+    return ops.input_conv(img, gamma, beta, mean, invstd, w, b, bn_stats=bn_stats, bn_residual=bn_residual)
 
 
 def batch_normalization(x, activation=None, residual=None, tile=False, channels=None, dead=False,

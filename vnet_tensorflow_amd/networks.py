@@ -41,6 +41,7 @@ class VNet(object):
         self.activation_fn = activation_fn
         self.fuse_input_block = True       # single-modality input: skip the 16x redundant work of the tiled conv
         self.fuse_bn_chains = True         # decoder BN->BN->add->BN chains in closed form (ops.bn_chain)
+        self.fuse_bn_stats = True          # batch-norm statistics from the producing convolution's epilogue (ops.conv bn_stats)
         self.fuse_grad_accumulation = True # tensors with two consumers: second gradient accumulated by its producer (ops.fork)
         self.fuse_zero_bias_grad = True    # conv biases feed batch-norms: their gradient is identically 0 (ops.zero_bias_gradients)
         self.variables = VariableStore(device)
@@ -90,7 +91,7 @@ class VNet(object):
                     if self.num_channels > 16 or not self.fuse_input_block:
                         tiled = None
                 else:
-                    x = L.convolution(x, [5, 5, 5, input_channels, self.num_channels])
+                    x = L.convolution(x, [5, 5, 5, input_channels, self.num_channels], bn_stats=self.fuse_bn_stats)
                     x = L.batch_normalization(x, activation=act)
 
             features = list()
@@ -105,7 +106,7 @@ class VNet(object):
                     else:
                         features.append(x)
                     with store.variable_scope('down_convolution'):
-                        x = L.down_convolution(x, factor=2, kernel_size=[2, 2, 2])
+                        x = L.down_convolution(x, factor=2, kernel_size=[2, 2, 2], bn_stats=self.fuse_bn_stats)
                         x = L.batch_normalization(x, activation=act)
 
             with store.variable_scope('vnet/bottom_level'):
@@ -135,11 +136,11 @@ class VNet(object):
             x, layer_input = ops.fork(layer_input)
         for i in range(num_convolutions):
             with store.variable_scope('conv_' + str(i + 1)):
-                if i == 0 and tiled is not None:
-                    x = L.convolution_tiled(tiled, [5, 5, 5, n_channels, n_channels])
-                else:
-                    x = L.convolution(x, [5, 5, 5, n_channels, n_channels])
                 res = layer_input if i == num_convolutions - 1 else None          # x = x + layer_input
+                if i == 0 and tiled is not None:
+                    x = L.convolution_tiled(tiled, [5, 5, 5, n_channels, n_channels], bn_stats=self.fuse_bn_stats, bn_residual=res)
+                else:
+                    x = L.convolution(x, [5, 5, 5, n_channels, n_channels], bn_stats=self.fuse_bn_stats, bn_residual=res)
                 x = L.batch_normalization(x, activation=activation_fn, residual=res)
                 x = ops.dropout(x, dropout_rate)
         return x
@@ -152,7 +153,7 @@ class VNet(object):
         n_channels = L.get_num_channels(layer_input)
         if num_convolutions == 1:
             with store.variable_scope('conv_' + str(1)):
-                x = L.convolution_concat(layer_input, fine_grained_features, [5, 5, 5, n_channels * 2, n_channels])
+                x = L.convolution_concat(layer_input, fine_grained_features, [5, 5, 5, n_channels * 2, n_channels], bn_stats=self.fuse_bn_stats)
                 if self.fuse_bn_chains:
                     # x = BN(x); r = BN(x) (networks.py:335); x = act(BN(x + r)) -- one fused normalisation of the conv output
                     x = L.batch_normalization_chain(x, 0, activation_fn)
@@ -164,13 +165,13 @@ class VNet(object):
             return x
 
         with store.variable_scope('conv_' + str(1)):
-            x = L.convolution_concat(layer_input, fine_grained_features, [5, 5, 5, n_channels * 2, n_channels])
+            x = L.convolution_concat(layer_input, fine_grained_features, [5, 5, 5, n_channels * 2, n_channels], bn_stats=self.fuse_bn_stats)
             x = L.batch_normalization(x, activation=activation_fn)
             x = ops.dropout(x, dropout_rate)
 
         for i in range(1, num_convolutions):
             with store.variable_scope('conv_' + str(i + 1)):
-                x = L.convolution(x, [5, 5, 5, n_channels, n_channels])
+                x = L.convolution(x, [5, 5, 5, n_channels, n_channels], bn_stats=self.fuse_bn_stats)
                 last = (i == num_convolutions - 1)
                 # networks.py:358 builds this BN for every i; its output is used only by the last conv
                 if last and self.fuse_bn_chains:

@@ -314,7 +314,7 @@ class _Timed(object):
 
 
 # ---- convolution family ----------------------------------------------------------------------------
-def _conv_call(ks, stride, up, x0, x1, wp, bias, y0, y1, dims_in, dims_out, kx=0, accum=False):
+def _conv_call(ks, stride, up, x0, x1, wp, bias, y0, y1, dims_in, dims_out, kx=0, accum=False, stats=None, res=None):
     L = _lib.lib()
     B = x0.shape[0]
     C0, C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
@@ -328,13 +328,17 @@ def _conv_call(ks, stride, up, x0, x1, wp, bias, y0, y1, dims_in, dims_out, kx=0
     nbytes = 4.0 * (nin * (C0 + C1) + nout * (Cy0 + Cy1) + taps * (C0 + C1) * (Cy0 + Cy1) + (Cy0 + Cy1))
     tag = "conv k%d%s s%d%s %d^3x%d %d->%d" % (ks, "x%d" % kx if kx else "", stride, " up" if up else "", dims_out[2], B, C0 + C1, Cy0 + Cy1)
     with _Timed(tag, flops, nbytes):
+        if stats is not None:        # batch-norm statistics of y (+ res) from the epilogue
+            check(L.vnet_conv_fwd_stats(ks, kx, stride, _ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias), _ptr(y0), Cy0,
+                                        B, *dims_in, *dims_out, _ptr(res), _ptr(stats), _ptr(ws), nb, _stream()), "vnet_conv_fwd_stats")
+            return
         fn = L.vnet_conv_fwd_acc if accum else L.vnet_conv_fwd
         check(fn(ks, kx, stride, up, _ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias),
                  _ptr(y0), Cy0, _ptr(y1), Cy1, B, *dims_in, *dims_out,
                  _ptr(ws), nb, _stream()), "vnet_conv_fwd")
 
 
-def _conv_bf16_call(x0, x1, wp, bias, y0, y1, dims, accum=False):
+def _conv_bf16_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res=None):
     """5^3 stride-1 conv with bf16 operands / fp32 accumulation (vnet_conv_fwd_bf16)."""
     L = _lib.lib()
     B = x0.shape[0]
@@ -347,6 +351,10 @@ def _conv_bf16_call(x0, x1, wp, bias, y0, y1, dims, accum=False):
     nbytes = 4.0 * nvox * (C0 + C1 + Cy0 + Cy1) + 2.0 * 125 * (C0 + C1) * (Cy0 + Cy1)
     tag = "conv-bf16 k5 s1 %d^3x%d %d->%d" % (dims[2], B, C0 + C1, Cy0 + Cy1)
     with _Timed(tag, flops, nbytes):
+        if stats is not None:
+            check(L.vnet_conv_fwd_bf16_stats(_ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias), _ptr(y0), Cy0, B, *dims,
+                                             _ptr(res), _ptr(stats), _ptr(ws), nb, _stream()), "vnet_conv_fwd_bf16_stats")
+            return
         fn = L.vnet_conv_fwd_bf16_acc if accum else L.vnet_conv_fwd_bf16
         check(fn(_ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias), _ptr(y0), Cy0, _ptr(y1), Cy1,
                  B, *dims, _ptr(ws), nb, _stream()), "vnet_conv_fwd_bf16")
@@ -455,7 +463,17 @@ def _slot_target(slot, dy, shape):
 # in exact arithmetic (the fp64 oracle gets ~1e-12).  Inside this context the convolutions take the closed form: the bias
 # gradient is left at exactly 0 in the flat gradient buffer and the 29 column-sum + 29 finalize launches per step are not
 # made.  Stand-alone layers2.convolution (outside the networks) keeps the generic column sum.
-_FUSE = {"zero_bias_grad": False}
+import os as _os
+_FUSE = {"zero_bias_grad": False, "bn_stats": _os.environ.get("VNET_BN_STATS", "1") != "0",
+         "bn_stats_fp32_direct": _os.environ.get("VNET_BN_STATS_FP32", "1") == "1"}     # (environment: A/B measurements)
+
+
+def set_epilogue_bn_stats(on, fp32_direct=None):
+    """Switch for the batch-norm statistics in the convolution epilogues (on by default; off = separate statistics pass).
+    fp32_direct: also in the epilogue of the non-split fp32 MFMA kernels (on by default; worth 0.07 ms per 128^3 step)."""
+    _FUSE["bn_stats"] = bool(on)
+    if fp32_direct is not None:
+        _FUSE["bn_stats_fp32_direct"] = bool(fp32_direct)
 
 
 @contextlib.contextmanager
@@ -472,7 +490,7 @@ class _ConvFn(torch.autograd.Function):
     """conv (ks=5,s=1 | ks=2,s=2) or 2^3 transposed conv (up) + bias, two-source input."""
 
     @staticmethod
-    def forward(ctx, x0, x1, w, b, ks, stride, up, out_spatial):
+    def forward(ctx, x0, x1, w, b, ks, stride, up, out_spatial, stats=None, res=None):
         slot0, slot1 = getattr(x0, "_vnet_slot", None), getattr(x1, "_vnet_slot", None)
         x0 = x0.contiguous()
         x1 = x1.contiguous() if x1 is not None else None
@@ -490,12 +508,14 @@ class _ConvFn(torch.autograd.Function):
             raise VnetHipError("conv: filter expects %d input channels, got %d" % (I, C0 + C1))
         y = torch.empty((B,) + dims_out + (O,), dtype=torch.float32, device=x0.device)
         bf16 = (not up) and ks == 5 and stride == 1 and _COMPUTE["dtype"] == "bf16"
+        if res is not None:
+            res = res.contiguous()
         if bf16:
-            _conv_bf16_call(x0, x1, packed_weights(w, PACK_FWD_BF16, 125, I, O), b, y, None, dims_out)
+            _conv_bf16_call(x0, x1, packed_weights(w, PACK_FWD_BF16, 125, I, O), b, y, None, dims_out, stats=stats, res=res)
         else:
             if wp is None:
                 wp = packed_weights(w, PACK_FWD, ks ** 3, I, O)
-            _conv_call(ks, stride, 1 if up else 0, x0, x1, wp, b, y, None, (Di, Hi, Wi), dims_out)
+            _conv_call(ks, stride, 1 if up else 0, x0, x1, wp, b, y, None, (Di, Hi, Wi), dims_out, stats=stats, res=res)
         ctx.save_for_backward(x0, x1, w)
         ctx.params = (w, b)
         ctx.cfg = (ks, stride, up, (Di, Hi, Wi), dims_out, C0, C1, I, O)
@@ -589,7 +609,7 @@ class _ConvFn(torch.autograd.Function):
             if slot1 is not None and slot1.first is None:
                 slot1.first = dx1
         gb = _grad_ret(db, sb) if (db is not None or bias_zero) else None
-        return r0, r1, _grad_ret(dw, sw), gb, None, None, None, None
+        return r0, r1, _grad_ret(dw, sw), gb, None, None, None, None, None, None
 
 
 def _meta(*ts):
@@ -602,9 +622,11 @@ class _InputConvFn(torch.autograd.Function):
     the 2-channel filter gradient G -- dw, and the conv-path parts of the input BN's dgamma/dbeta follow from it."""
 
     @staticmethod
-    def forward(ctx, img, gamma, beta, mean, invstd, w, b):
+    def forward(ctx, img, gamma, beta, mean, invstd, w, b, stats=None, res=None):
         L = _lib.lib()
         img = img.contiguous()
+        if res is not None:
+            res = res.contiguous()
         B, D, H, W, _ = img.shape
         C, O = w.shape[-2], w.shape[-1]
         dev = img.device
@@ -616,7 +638,7 @@ class _InputConvFn(torch.autograd.Function):
         wp = torch.empty(L.vnet_packed_weight_floats(PACK_FWD, 25, 16, O), dtype=torch.float32, device=dev)
         check(L.vnet_pack_weights(PACK_FWD, _ptr(wv), _ptr(wp), 25, 16, O, _stream()), "vnet_pack_weights")
         y = torch.empty((B, D, H, W, O), dtype=torch.float32, device=dev)
-        _conv_call(5, 1, 0, xv, None, wp, b, y, None, (D, H, W), (D, H, W), kx=1)
+        _conv_call(5, 1, 0, xv, None, wp, b, y, None, (D, H, W), (D, H, W), kx=1, stats=stats, res=res)
         ctx.save_for_backward(xv, gamma, beta, mean, invstd, w)
         ctx.params = (w, b)
         ctx.bias_zero = _FUSE["zero_bias_grad"]
@@ -643,26 +665,75 @@ class _InputConvFn(torch.autograd.Function):
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         check(L.vnet_input_conv_grads(_ptr(G), _ptr(w), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(dw),
                                       _ptr(dgamma), _ptr(dbeta), C, O, 0, _stream()), "vnet_input_conv_grads")
-        return None, dgamma, dbeta, None, None, _grad_ret(dw, sw), _grad_ret(db, sb)
+        return None, dgamma, dbeta, None, None, _grad_ret(dw, sw), _grad_ret(db, sb), None, None
 
 
-def input_conv(img, gamma, beta, mean, invstd, w, b):
+def input_conv(img, gamma, beta, mean, invstd, w, b, bn_stats=False, bn_residual=None):
     """convolution(BN(tf.tile(img)), [5,5,5,C,C]) for a 1-channel `img` (networks.py:254-259 + 316)."""
     if _meta(img):
         return torch.empty(img.shape[:-1] + (w.shape[-1],), device="meta")
     _need_gpu(img, "input_conv")
-    return _InputConvFn.apply(img, gamma, beta, mean, invstd, w, b)
+    stats = None
+    if bn_stats and _FUSE["bn_stats"] and _FUSE["bn_stats_fp32_direct"] and _SYNC_BN is None:
+        B, D, H, W, _ = img.shape
+        rows = _lib.lib().vnet_conv_stats_rows(5, 1, 1, 0, 16, w.shape[-1], 0, B, D, H, W)
+        if rows > 0:
+            stats = torch.empty((rows, 2 * w.shape[-1]), dtype=torch.float32, device=img.device)
+    if stats is None:
+        return _InputConvFn.apply(img, gamma, beta, mean, invstd, w, b)
+    y = _InputConvFn.apply(img, gamma, beta, mean, invstd, w, b, stats, bn_residual)
+    y._vnet_stats = _EpilogueStats(stats, stats.shape[0], bn_residual)
+    return y
 
 
-def conv(x0, w, b, ks, stride=1, x1=None):
-    """tf.nn.convolution(concat(x0,x1), w, 'SAME', strides) + b (reference layers2.py:63)."""
+class _EpilogueStats(object):
+    """Partial batch-norm sums a convolution wrote in its epilogue for its output y: rows x [sum(C) | sum of squares(C)] of
+    v = y (+ residual).  Attached to y as `_vnet_stats`; the batch-norm that normalises (y + residual) runs only its finalize."""
+    __slots__ = ("partial", "rows", "residual")
+
+    def __init__(self, partial, rows, residual):
+        self.partial, self.rows, self.residual = partial, rows, residual
+
+
+def _epilogue_stats_buffer(bf16, ks, kx, stride, x0, x1, O, dims_out):
+    if _SYNC_BN is not None:                  # cross-replica statistics need the raw moments of the whole tensor: generic path
+        return None
+    L = _lib.lib()
+    B, C0, C1 = x0.shape[0], x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
+    if bf16:
+        rows = L.vnet_conv_bf16_stats_rows(C0 + C1, O, 0, C0, C1, B, *dims_out)
+    else:
+        # fp32 MFMA kernels: measured (profiles/r02_epilogue_stats.txt) the STATS instantiations lose in their main loop most of
+        # what the statistics pass costs (+1..3 % per launch, residual re-read on the input conv): the fused form is worth
+        # 0.07 ms of a 25.7 ms step; VNET_BN_STATS_FP32=0 keeps it to the split-K launches (statistics from the reduce kernel)
+        if not _FUSE["bn_stats_fp32_direct"] and not L.vnet_conv_stats_from_reduce(ks, kx, stride, C0 + C1, O, B, *dims_out):
+            return None
+        rows = L.vnet_conv_stats_rows(ks, kx, stride, 0, C0 + C1, O, 0, B, *dims_out)
+    if rows <= 0:
+        return None
+    return torch.empty((rows, 2 * O), dtype=torch.float32, device=x0.device)
+
+
+def conv(x0, w, b, ks, stride=1, x1=None, bn_stats=False, bn_residual=None):
+    """tf.nn.convolution(concat(x0,x1), w, 'SAME', strides) + b (reference layers2.py:63).
+    bn_stats: the output feeds tf.layers.batch_normalization(y [+ bn_residual]) -- the convolution's epilogue also produces
+    that batch-norm's partial sums (include/vnet_hip.h: vnet_conv_fwd_stats), so its statistics pass over y is not needed."""
     if x0.dim() != 5:
         raise NotImplementedError("only the 3-D (NDHWC) path is built; 2-D is out of scope (SURVEY section 2 row 11)")
     if _meta(x0):
         B, D, H, W, _ = x0.shape
         return torch.empty((B, _same_out(D, stride), _same_out(H, stride), _same_out(W, stride), w.shape[-1]), device="meta")
     _need_gpu(x0, "conv")
-    return _ConvFn.apply(x0, x1, w, b, ks, stride, False, None)
+    stats = None
+    if bn_stats and _FUSE["bn_stats"]:
+        dims_out = tuple(_same_out(int(v), stride) for v in x0.shape[1:4])
+        bf16 = ks == 5 and stride == 1 and _COMPUTE["dtype"] == "bf16"
+        stats = _epilogue_stats_buffer(bf16, ks, 0, stride, x0, x1, w.shape[-1], dims_out)
+    if stats is None:
+        return _ConvFn.apply(x0, x1, w, b, ks, stride, False, None)
+    y = _ConvFn.apply(x0, x1, w, b, ks, stride, False, None, stats, bn_residual)
+    y._vnet_stats = _EpilogueStats(stats, stats.shape[0], bn_residual)
+    return y
 
 
 def conv_transpose2(x, w, b, out_spatial):
@@ -698,8 +769,13 @@ def set_sync_batch_norm(group=None, enabled=True):
     _SYNC_BN = ((lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)), world) if world > 1 else None
 
 
-def _bn_statistics(L, x, r, bcast, M, C, mean, invstd, mm, mv, ws, nb):
-    """mean/invstd (+ moving-average update) of s = x (+ r); returns the row count the statistics cover."""
+def _bn_statistics(L, x, r, bcast, M, C, mean, invstd, mm, mv, ws, nb, pre=None, r_orig=None):
+    """mean/invstd (+ moving-average update) of s = x (+ r); returns the row count the statistics cover.
+    pre: _EpilogueStats the producing convolution attached to x (used when it covers exactly x + r)."""
+    if (_SYNC_BN is None and pre is not None and not bcast and pre.residual is r_orig and pre.partial.shape[1] == 2 * C):
+        check(L.vnet_bn_finalize_partial(_ptr(pre.partial), pre.rows, C, float(M), BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(invstd),
+                                         _ptr(mm), _ptr(mv), _stream()), "vnet_bn_finalize_partial")
+        return float(M)
     if _SYNC_BN is None:
         check(L.vnet_bn_stats(_ptr(x), _ptr(r), int(bcast), M, C, BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(invstd),
                               _ptr(mm), _ptr(mv), _ptr(ws), nb, _stream()), "vnet_bn_stats")
@@ -718,6 +794,7 @@ class _BnActFn(torch.autograd.Function):
     def forward(ctx, x, r, gamma, beta, alpha, act, bcast, mm, mv):
         L = _lib.lib()
         ctx.slot_r = getattr(r, "_vnet_slot", None)
+        pre, r_orig = getattr(x, "_vnet_stats", None), r
         x = x.contiguous()
         r = r.contiguous() if r is not None else None
         C = gamma.numel()
@@ -727,7 +804,7 @@ class _BnActFn(torch.autograd.Function):
         invstd = torch.empty(C, dtype=torch.float32, device=dev)
         nb = L.vnet_bn_ws_bytes(C)
         ws = workspace(nb, dev)
-        ctx.m_total = _bn_statistics(L, x, r, bcast, M, C, mean, invstd, mm, mv, ws, nb)
+        ctx.m_total = _bn_statistics(L, x, r, bcast, M, C, mean, invstd, mm, mv, ws, nb, pre, r_orig)
         ctx.sync = _SYNC_BN
         y = torch.empty(x.shape[:-1] + (C,), dtype=torch.float32, device=dev)
         check(L.vnet_bn_act_fwd(_ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
@@ -786,6 +863,7 @@ class _BnChainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, kind, act, alpha, g1, b1, g2, b2, g3, b3, bufs):
         L = _lib.lib()
+        pre = getattr(x, "_vnet_stats", None)
         x = x.contiguous()
         C = g1.numel()
         M = x.numel() // C
@@ -795,7 +873,7 @@ class _BnChainFn(torch.autograd.Function):
         invstd = torch.empty(C, dtype=torch.float32, device=dev)
         nb = L.vnet_bn_ws_bytes(C)
         ws = workspace(nb, dev)
-        ctx.m_total = _bn_statistics(L, x, None, False, M, C, mean, invstd, mm1, mv1, ws, nb)
+        ctx.m_total = _bn_statistics(L, x, None, False, M, C, mean, invstd, mm1, mv1, ws, nb, pre, None)
         ctx.sync = _SYNC_BN
         ceff = torch.empty(C, dtype=torch.float32, device=dev)
         deff = torch.empty(C, dtype=torch.float32, device=dev)
@@ -892,13 +970,14 @@ def bn_update_only(x, C, moving_mean, moving_var):
     if _meta(x):
         return
     L = _lib.lib()
+    pre = getattr(x, "_vnet_stats", None)
     x = x.contiguous()
     M = x.numel() // C
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     invstd = torch.empty(C, dtype=torch.float32, device=x.device)
     nb = L.vnet_bn_ws_bytes(C)
     ws = workspace(nb, x.device)
-    _bn_statistics(L, x, None, False, M, C, mean, invstd, moving_mean, moving_var, ws, nb)
+    _bn_statistics(L, x, None, False, M, C, mean, invstd, moving_mean, moving_var, ws, nb, pre, None)
 
 
 # ---- stand-alone activation (API parity with layers2.prelu; the networks use the fused bn_act) ------------
