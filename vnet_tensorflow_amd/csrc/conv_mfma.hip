@@ -163,6 +163,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, kk = lane >> 4;
+    // (static priority for the second half of the waves, which helps the 8-wave filter-gradient kernel, measured +0.27 ms
+    // per step here: two 4-wave workgroups share a CU and the priority then favours one workgroup's waves over the other's)
 
     const int nbrick = a.B * a.nbz * a.nby * a.nbx;
     int brick = xcd_remap(blockIdx.x, nbrick);
@@ -475,6 +477,9 @@ __global__ void __launch_bounds__(512) wgrad_kernel(WgradArgs a) {
     const int tid = threadIdx.x;
     // 8 waves = 2 per SIMD; wave w owns TW taps for the workgroup's NS*16 cout x 16 cin
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // static priority for the second-dispatched half of the workgroup (it loses the issue arbitration on every segment
+    // otherwise; MI355X_MICROARCH.md "two waves per SIMD" item 4): -0.04 ms per step, measured in an interleaved A/B
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int i = lane & 15, kk = lane >> 4;
     const int split = blockIdx.x;
     const int chunk = blockIdx.y / a.ncob, cob = blockIdx.y - chunk * a.ncob;
