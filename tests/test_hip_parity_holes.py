@@ -261,3 +261,28 @@ def test_batch_norm_statistics_from_the_conv_epilogue(dev, mode, ks, stride, sha
     check_close("normalised output", zf, outs[False][1].cpu().numpy(), 2e-6)
     check_close("moving mean", mm, (0.01 * mu).cpu().numpy(), 1e-5, atol=1e-7)
     check_close("moving variance", mv, (0.99 + 0.01 * var).cpu().numpy(), 1e-6)
+
+
+@pytest.mark.parametrize("taps,I,O", [(125, 16, 16), (125, 32, 16), (125, 4, 16), (125, 24, 40), (8, 16, 32), (125, 6, 10)])
+def test_batched_filter_repack_equals_single_pack(dev, taps, I, O):
+    """The one-launch repack of every registered filter (after each optimiser step) must produce, bit for bit, the images
+    the single-filter packer produces -- all five layouts (fp32 forward / backward-data / transposed, bf16 forward / backward)."""
+    from vnet_tensorflow_amd import ops
+    ks = 5 if taps == 125 else 2
+    gen = torch.Generator().manual_seed(taps + I + O)
+    w = torch.nn.Parameter(torch.randn(ks, ks, ks, I, O, generator=gen).to(dev))
+    modes = [ops.PACK_FWD, ops.PACK_BWD] + ([ops.PACK_FWD_BF16, ops.PACK_BWD_BF16] if taps == 125 else [])
+    ops.clear_pack_registry()
+    try:
+        single = {m: ops.packed_weights(w, m, taps, I, O).clone() for m in modes}          # registers (w, mode) and packs one by one
+        for m in modes:
+            w._vnet_packed[(m, taps, I, O)][1].fill_(float("nan"))                             # wipe, then refresh all in one launch
+        with torch.no_grad():
+            w.mul_(1.0)
+        ops.invalidate_packed()
+        ops.repack_registered()
+        for m in modes:
+            got = w._vnet_packed[(m, taps, I, O)][1]
+            assert torch.equal(got.view(torch.int32), single[m].view(torch.int32)), (m, taps, I, O)
+    finally:
+        ops.clear_pack_registry()
