@@ -996,7 +996,7 @@ __device__ __forceinline__ void bf16_tile_commit(unsigned char* tile, unsigned c
     }
 }
 
-template <int TZ, int TY, int TX, int NSB, int WAVES>
+template <int TZ, int TY, int TX, int NSB, int WAVES, bool STATS = false>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) conv5_bf16_kernel(ConvArgs a) {
     using G = Bf16Geom<TZ, TY, TX>;
     constexpr int MS = 2, NT = WAVES * 64;
@@ -1149,9 +1149,10 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     }
 
     // epilogue: register r of lane = cout co0 + n*32 + 8*(r/4) + 4*half + r%4 of voxel (m, q32)
-    float s1[NSB][4][4], s2[NSB][4][4];          // batch-norm statistics of this lane's channels (a.stats)
+    constexpr int NSS = STATS ? NSB : 1;
+    float s1[NSS][4][4], s2[NSS][4][4];          // batch-norm statistics of this lane's channels (STATS)
 #pragma unroll
-    for (int n = 0; n < NSB; ++n)
+    for (int n = 0; n < NSS; ++n)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -1176,7 +1177,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
                 if (co >= a.Cout) continue;
                 if (a.vec_out && co + 3 < a.Cout) {
                     if (a.bias) { e[0] += a.bias[co]; e[1] += a.bias[co + 1]; e[2] += a.bias[co + 2]; e[3] += a.bias[co + 3]; }
-                    if (a.stats) {
+                    if constexpr (STATS) {
                         float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (a.res) rr = *reinterpret_cast<const float4*>(a.res + ov * a.Cout + co);
                         const float vv[4] = {e[0] + rr.x, e[1] + rr.y, e[2] + rr.z, e[3] + rr.w};
@@ -1197,7 +1198,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
                 }
             }
     }
-    if (a.stats && !a.part) {
+    if constexpr (STATS) if (!a.part) {
         // the 32 lanes of a half hold the same channels for 32 voxels: butterfly over p32, then across waves via LDS
         // (the main loop ends with a barrier after the last tile read, so the LDS is free here)
         constexpr int CW = NSB * 32;
@@ -1237,7 +1238,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
 //   * persistent workgroups (one per CU) walk their bricks; the next tile (and filter chunk) is prefetched global ->
 //     registers during the MFMAs and committed between two barriers.
 // ------------------------------------------------------------------------------------------
-template <int TZ, int TY, int TX>
+template <int TZ, int TY, int TX, bool STATS = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv5_bf16_c16_kernel(ConvArgs a) {
     using G = Bf16Geom<TZ, TY, TX>;
     static_assert(TZ == 4 && TY == 8 && TX == 16, "8 waves x 4 rows of 16 voxels");
@@ -1390,6 +1391,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                                                        // group's MFMAs (the allocator then runs out of registers and spills)
             }
         if (more) tile_pack();          // the prefetched tile has long arrived: convert now, 32 fewer live registers from here
+                                        // (packing after the first dz pair and letting the second pair's reads hoist: measured 2 % slower)
         // ---- dz = 4: dy pairs (0,1), (2,3) and the single tap dy = 4 ----
 #pragma unroll
         for (int dx = 0; dx < 5; ++dx) {
@@ -1420,7 +1422,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const size_t ov = ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
                 float e[4] = {accA[m][0], accA[m][1], accA[m][2], accA[m][3]};
                 if (a.bias) { e[0] += a.bias[co]; e[1] += a.bias[co + 1]; e[2] += a.bias[co + 2]; e[3] += a.bias[co + 3]; }
-                if (a.stats) {
+                if constexpr (STATS) {
                     float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (a.res) rr = *reinterpret_cast<const float4*>(a.res + ov * a.Cout + co);
                     const float vv[4] = {e[0] + rr.x, e[1] + rr.y, e[2] + rr.z, e[3] + rr.w};
@@ -1431,7 +1433,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 if (a.accum) { const float4 old = *reinterpret_cast<const float4*>(p); e[0] += old.x; e[1] += old.y; e[2] += old.z; e[3] += old.w; }
                 *reinterpret_cast<float4*>(p) = make_float4(e[0], e[1], e[2], e[3]);
             }
-            if (a.stats) {
+            if constexpr (STATS) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
 #pragma unroll
@@ -1441,7 +1443,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         }
         __syncthreads();                               // every wave is done reading the tile (and the filter chunk)
-        if (last && a.stats) stats_row_write<8, 16>(red, a.stats, (size_t)(b_lo + slot + bi * G8), 0, a.Cout, tid);
+        if constexpr (STATS) if (last) stats_row_write<8, 16>(red, a.stats, (size_t)(b_lo + slot + bi * G8), 0, a.Cout, tid);
         if (more) {
             tile_commit();
             // two chunks: the other filter chunk is loaded here, synchronously, once per brick PAIR (every 4th step) -- a
@@ -1701,13 +1703,13 @@ bool conv_bf16_use_c16(int Cin, int Cout, int C0, int C1, int Cy0, int Cy1, int 
     return (long)B * ceil_div(D, 4) * ceil_div(H, 8) * ceil_div(W, 16) >= 256;
 }
 
-template <int TZ, int TY, int TX, int WAVES>
+template <int TZ, int TY, int TX, int WAVES, bool STATS = false>
 int launch_conv_bf16(const ConvArgs& a, const Bf16Plan& p, hipStream_t st) {
     using G = Bf16Geom<TZ, TY, TX>;
     dim3 grid(a.B * p.nbz * p.nby * p.nbx, p.ncobg, p.nsplit * p.nz), block(WAVES * 64);
 #define VNET_GO(NSBV)                                                                             \
     {                                                                                             \
-        auto k = conv5_bf16_kernel<TZ, TY, TX, NSBV, WAVES>;                                      \
+        auto k = conv5_bf16_kernel<TZ, TY, TX, NSBV, WAVES, STATS>;                               \
         const size_t lds = (size_t)G::TILE_BYTES + (size_t)25 * NSBV * 1024 + 16 + 64 * 16;       \
         static unsigned long long attr_done = 0;                                                  \
         if (int ae = ensure_lds(k, lds, attr_done)) return ae;                                    \
@@ -1941,16 +1943,26 @@ static int conv_fwd_bf16_impl(const float* x0, int C0, const float* x1, int C1, 
         // 16 output channels at a size with enough bricks for one persistent workgroup per CU: no padding to 32 cout
         using GC = Bf16Geom<4, 8, 16>;
         a.nbz = ceil_div(D, 4); a.nby = ceil_div(H, 8); a.nbx = ceil_div(W, 16);
-        auto k = conv5_bf16_c16_kernel<4, 8, 16>;
         const size_t lds = (size_t)GC::TILE_BYTES + 65 * 1024 + 64 * 16 + 8 * 32 * 4;
-        static unsigned long long attr_done = 0;
-        if (int ae = ensure_lds(k, lds, attr_done)) return ae;
-        hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, st, a);
+        if (a.stats) {
+            auto k = conv5_bf16_c16_kernel<4, 8, 16, true>;
+            static unsigned long long attr_done = 0;
+            if (int ae = ensure_lds(k, lds, attr_done)) return ae;
+            hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, st, a);
+        } else {
+            auto k = conv5_bf16_c16_kernel<4, 8, 16, false>;
+            static unsigned long long attr_done = 0;
+            if (int ae = ensure_lds(k, lds, attr_done)) return ae;
+            hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, st, a);
+        }
         VNET_LAUNCH_CHECK();
         return VNET_OK;
     }
-    const int e = p.small ? launch_conv_bf16<8, 8, 8, 8>(a, p, st)
-                : p.half  ? launch_conv_bf16<4, 8, 8, 4>(a, p, st) : launch_conv_bf16<4, 8, 16, 8>(a, p, st);
+    const int e = (a.stats && nslab == 1)
+                ? (p.small ? launch_conv_bf16<8, 8, 8, 8, true>(a, p, st)
+                   : p.half ? launch_conv_bf16<4, 8, 8, 4, true>(a, p, st) : launch_conv_bf16<4, 8, 16, 8, true>(a, p, st))
+                : (p.small ? launch_conv_bf16<8, 8, 8, 8>(a, p, st)
+                   : p.half ? launch_conv_bf16<4, 8, 8, 4>(a, p, st) : launch_conv_bf16<4, 8, 16, 8>(a, p, st));
     if (e) return e;
     if (nslab > 1) {
         const size_t total = nvox * a.Cout;
