@@ -136,3 +136,19 @@ preprocess:
     bad.write_text("preprocess:\n  train:\n    3D:\n      - name: Resample\n        variables: {voxel_size: [1, 1, 1]}\n")
     with pytest.raises(NotImplementedError):
         T.build_pipeline(str(bad), "train")
+
+
+def test_largest_component_and_volume_threshold():
+    """model.py:117-167 post-processing of the predicted label map."""
+    from vnet_tensorflow_amd.model import ExtractLargestConnectedComponents, volume_threshold
+    lab = np.zeros((12, 12, 12), dtype=np.int64)
+    lab[1:3, 1:3, 1:3] = 2            # 8 voxels
+    lab[5:9, 5:9, 5:9] = 1            # 64 voxels
+    lab[8, 8, 9] = 3                  # face-connected to the big block: 65 voxels, one component across label values
+    lab[11, 0, 0] = 1                 # 1 voxel
+    lcc = ExtractLargestConnectedComponents(lab)
+    assert lcc.dtype == np.uint8 and lcc.sum() == 65 and lcc[6, 6, 6] == 1 and lcc[1, 1, 1] == 0
+    vt = volume_threshold(lab, 7.5)
+    assert vt.sum() == 65 + 8 and vt[11, 0, 0] == 0
+    assert volume_threshold(lab, 7.5, spacing=(0.5, 0.5, 0.5)).sum() == 65           # physical size: 8 voxels = 1.0 < 7.5
+    assert ExtractLargestConnectedComponents(np.zeros((4, 4, 4))).sum() == 0

@@ -70,6 +70,31 @@ def dice_coe(output, target, loss_type='jaccard', axis=(1, 2, 3), weights=[], sm
     return _DiceCoeFn.apply(output, target.to(torch.float32), loss_type == 'jaccard', wt, float(smooth))
 
 
+def volume_threshold(label, volume, spacing=(1.0, 1.0, 1.0)):
+    """reference model.py:117-140: keep (as 1) every face-connected component of the non-zero label whose PHYSICAL size
+    (voxels x voxel volume) exceeds `volume`; the result is a uint8 0/1 map."""
+    from scipy import ndimage
+    cc, n = ndimage.label(np.asarray(label) != 0)
+    if n == 0:
+        return np.zeros(np.shape(label), dtype=np.uint8)
+    sizes = np.bincount(cc.ravel(), minlength=n + 1).astype(np.float64) * float(np.prod(spacing))
+    keep = sizes > volume
+    keep[0] = False
+    return keep[cc].astype(np.uint8)
+
+
+def ExtractLargestConnectedComponents(label, spacing=(1.0, 1.0, 1.0)):
+    """reference model.py:142-167: 1 on the largest face-connected component of the (uint8-cast) non-zero label, 0 elsewhere
+    (first one wins a tie, like the reference's strict `>` scan in label order)."""
+    from scipy import ndimage
+    cc, n = ndimage.label(np.asarray(label).astype(np.uint8) != 0)
+    if n == 0:
+        return np.zeros(np.shape(label), dtype=np.uint8)
+    sizes = np.bincount(cc.ravel(), minlength=n + 1)
+    sizes[0] = 0
+    return (cc == int(np.argmax(sizes))).astype(np.uint8)
+
+
 def prepare_batch(image_ijk_patch_indices_dict):
     """reference model.py:94-115"""
     images, ijk = image_ijk_patch_indices_dict['images'], image_ijk_patch_indices_dict['indexes']
@@ -723,7 +748,20 @@ class image2label(object):
             if not os.path.isdir(cdir):
                 continue
             chans = [np.asarray(vdata.load_volume(os.path.join(cdir, f)), dtype=np.float32) for f in self.evaluate_image_filenames]
-            label, softmax = self.evaluate_single_3D(np.stack(chans, axis=-1))
+            image = np.stack(chans, axis=-1)
+            if self.evaluate_pipeline:
+                # EvaluationSetting.Pipeline: the 'evaluate' transform list of the reference's YAML (model.py:1142-1167);
+                # intensity transforms and Padding are restated on arrays, physical-grid resampling is refused
+                from . import transforms as vtf
+                tf = vtf.build_pipeline(self.evaluate_pipeline, "evaluate")
+                image, _ = vtf.apply_pipeline(tf, image, np.zeros(image.shape[:3], dtype=np.int32), np.random.default_rng(0))
+            label, softmax = self.evaluate_single_3D(image)
+            label = label[tuple(slice(0, n) for n in chans[0].shape)]
+            softmax = softmax[(slice(None),) + tuple(slice(0, n) for n in chans[0].shape)]
+            if self.evaluate_lcc:                                     # model.py:1218-1219
+                label = ExtractLargestConnectedComponents(label)
+            if self.evaluate_volume_threshold and self.evaluate_volume_threshold > 0:      # model.py:1222-1223
+                label = volume_threshold(label, self.evaluate_volume_threshold)
             out = os.path.join(cdir, self.evaluate_label_filename)
             if out.endswith(".npy"):
                 np.save(out, label.astype(np.int16))
