@@ -372,11 +372,16 @@ class image2label(object):
 
     # -- one training step (reference model.py:743-748: ONE sess.run per step) ------------------------------------
     def _compute_gradients(self, images, labels, dropout):
-        """zero the flat gradient buffer, forward, loss, backward, join the parameter-gradient stream."""
-        self.flat.zero_grad()
+        """forward, loss, backward (gradients written into the flat buffer), join the parameter-gradient stream."""
+        if getattr(self.network, "fuse_zero_bias_grad", False):
+            self.flat.begin_step()            # nothing to clear: see FlatParams.begin_step
+        else:
+            self.flat.zero_grad()
         ops.begin_dropout_pass()
         _, loss, _, _ = self.forward(images, labels, dropout)
-        loss.backward()
+        if getattr(self, "_one", None) is None:
+            self._one = torch.ones((), dtype=torch.float32, device=self.device)     # autograd would fill a fresh one every step
+        loss.backward(self._one)
         ops.join_param_grad_stream()          # filter / bias gradients were enqueued on their own stream
         return loss
 

@@ -641,6 +641,7 @@ class _InputConvFn(torch.autograd.Function):
         _conv_call(5, 1, 0, xv, None, wp, b, y, None, (D, H, W), (D, H, W), kx=1, stats=stats, res=res)
         ctx.save_for_backward(xv, gamma, beta, mean, invstd, w)
         ctx.params = (w, b)
+        ctx.gb = (gamma, beta)
         ctx.bias_zero = _FUSE["zero_bias_grad"]
         return y
 
@@ -661,6 +662,29 @@ class _InputConvFn(torch.autograd.Function):
         G = torch.empty((25, 16, O), dtype=torch.float32, device=dev)
         _wgrad_call(5, 1, xv, None, dy, G, (D, H, W), (D, H, W), kx=1)
         dw, sw = _grad_out(wref)
+        gpar, bpar = ctx.gb
+        gs, bs = getattr(gpar, "_vnet_sink", None), getattr(bpar, "_vnet_sink", None)
+        if (sw is not None and gs is not None and bs is not None and not gs.written and not bs.written
+                and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]):
+            # gamma / beta of the input batch-norm get two contributions: this one (through the folded filter) and the
+            # batch-norm's own.  The batch-norm's backward runs later in this pass and WRITES its part into the flat buffer;
+            # this kernel is deferred until then and ADDS its part (accumulate = 1) -- no autodiff add kernels, one launch.
+            def deferred(accumulate, L=L, G=G, w=w, gamma=gamma, beta=beta, mean=mean, invstd=invstd, dw=dw, sw=sw, gs=gs, bs=bs):
+                check(L.vnet_input_conv_grads(_ptr(G), _ptr(w), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(dw),
+                                              _ptr(gs.view), _ptr(bs.view), C, O, int(accumulate), _stream()), "vnet_input_conv_grads")
+                _grad_ret(dw, sw)
+                if not accumulate:          # the batch-norm's backward never came: these sinks are complete now
+                    _grad_ret(gs.view, gs)
+                    _grad_ret(bs.view, bs)
+            gpar._vnet_deferred = deferred
+
+            def flush(gpar=gpar):
+                th = getattr(gpar, "_vnet_deferred", None)
+                if th is not None:
+                    del gpar._vnet_deferred
+                    th(0)
+            torch.autograd.Variable._execution_engine.queue_callback(flush)
+            return None, None, None, None, None, None, _grad_ret(db, sb), None, None
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         check(L.vnet_input_conv_grads(_ptr(G), _ptr(w), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(dw),
@@ -847,6 +871,10 @@ class _BnActFn(torch.autograd.Function):
                 check(L.vnet_bn_act_bwd_apply(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd),
                                               _ptr(gamma), _ptr(beta), act, _ptr(alpha), _ptr(tot), _ptr(tot[C:]),
                                               ctx.m_total, None, _ptr(ds), _stream()), "vnet_bn_act_bwd_apply")
+        th = getattr(gref, "_vnet_deferred", None)
+        if th is not None and sg is not None and sbt is not None:
+            del gref._vnet_deferred
+            th(1)                                          # the fused input conv adds its share of dgamma / dbeta (see _InputConvFn)
         dx = ds
         if bcast and ds is not None:
             dx = colsum_rows(ds)
