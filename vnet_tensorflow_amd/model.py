@@ -569,6 +569,8 @@ class image2label(object):
         ck = torch.load(path, map_location="cpu", weights_only=True)      # tensors, ints and a list of names only
         self.network.load_state_dict(ck["variables"])
         ops.invalidate_packed()
+        if self.device is not None and self.device.type == "cuda":
+            ops.repack_registered()      # a captured step graph reads the packed filters without checking their tags
         self.global_step, self.start_epoch = int(ck["global_step"]), int(ck["start_epoch"])
         if with_optimizer and getattr(self, "optimizer", None) is not None and ck.get("optimizer"):
             if list(ck.get("opt_names", [])) != list(self.flat.names):
