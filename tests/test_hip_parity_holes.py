@@ -286,3 +286,42 @@ def test_batched_filter_repack_equals_single_pack(dev, taps, I, O):
             assert torch.equal(got.view(torch.int32), single[m].view(torch.int32)), (m, taps, I, O)
     finally:
         ops.clear_pack_registry()
+
+
+@pytest.mark.parametrize("shape,C0,C1,Cout", [((1, 30, 50, 70), 12, 8, 12), ((2, 33, 40, 49), 4, 0, 16), ((1, 37, 49, 65), 16, 16, 8)])
+def test_bf16_16cout_kernel_ragged(dev, shape, C0, C1, Cout):
+    """conv5_bf16_c16_kernel (persistent workgroups, 4x8x16 bricks, two-chunk pairing) on volumes that are no multiple of the
+    brick, two-source inputs whose channel counts are no multiple of 16, fewer than 16 output channels, odd brick counts per
+    workgroup: forward against the rounded-operand oracle (2e-6), the accumulating form (y += conv) and the epilogue
+    statistics."""
+    from vnet_tensorflow_amd import ops, _lib
+    B, D, H, W = shape
+    assert _lib.lib().vnet_conv_bf16_stats_rows(C0 + C1, Cout, 0, C0, C1, B, D, H, W) == B * -(-D // 4) * -(-H // 8) * -(-W // 16)
+    gen = torch.Generator().manual_seed(D * H + W)
+    x0 = torch.randn(B, D, H, W, C0, generator=gen)
+    x1 = torch.randn(B, D, H, W, C1, generator=gen) if C1 else None
+    w = torch.randn(5, 5, 5, C0 + C1, Cout, generator=gen) * 0.05
+    b = torch.randn(Cout, generator=gen)
+    xcat = x0.numpy() if x1 is None else np.concatenate((x0.numpy(), x1.numpy()), -1)
+    ref = O.conv_nd_fwd(O.round_bf16(xcat.astype(np.float64)), O.round_bf16(w.numpy().astype(np.float64)), 1) + b.numpy().astype(np.float64)
+    ops.set_compute_dtype("bf16")
+    try:
+        with torch.no_grad():
+            tx0, tx1 = x0.to(dev), (x1.to(dev) if C1 else None)
+            tw, tb = torch.nn.Parameter(w.to(dev)), b.to(dev)
+            y = ops.conv(tx0, tw, tb, 5, 1, x1=tx1, bn_stats=True)
+            check_close("c16 forward", y, ref, 2e-6)
+            st = y._vnet_stats
+            tot = st.partial.double().sum(0).cpu().numpy()
+            yd = y.double().reshape(-1, Cout)
+            check_close("epilogue sums", tot[:Cout], yd.sum(0).cpu().numpy(), 1e-5, atol=1e-2)
+            check_close("epilogue sums of squares", tot[Cout:], (yd * yd).sum(0).cpu().numpy(), 1e-5)
+            # accumulating form through the C ABI directly
+            L = _lib.lib()
+            acc = torch.full_like(y, 0.5)
+            wp = ops.packed_weights(tw, ops.PACK_FWD_BF16, 125, C0 + C1, Cout)
+            _lib.check(L.vnet_conv_fwd_bf16_acc(tx0.data_ptr(), C0, tx1.data_ptr() if C1 else None, C1, wp.data_ptr(), None,
+                                                acc.data_ptr(), Cout, None, 0, B, D, H, W, None, 0, ops._stream()), "acc")
+            check_close("c16 accumulate", acc, ref - b.numpy().astype(np.float64) + 0.5, 2e-6)
+    finally:
+        ops.set_compute_dtype("fp32")
