@@ -150,7 +150,8 @@ def _dp_worker(rank, world, port, out, mode):
     """One rank, process group "nccl" (= RCCL) on cuda:0, the data-parallel collective path forced on."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                       VNET_DP_FORCE="1", VNET_DP_BUCKET_BYTES=str(16 << 10))
-    os.environ["VNET_STEP_GRAPH"] = "0" if mode == "eager" else "1"
+    os.environ["VNET_STEP_GRAPH"] = "0" if mode.startswith("eager") else "1"
+    os.environ["VNET_DP_TWO_PASS"] = "0" if mode.endswith("1p") else "1"
     import torch.distributed as dist
     from vnet_tensorflow_amd.model import image2label
     from oracle.vnet_oracle import synthetic_batch
@@ -167,20 +168,36 @@ def _dp_worker(rank, world, port, out, mode):
     x, l = torch.from_numpy(x).to(dev), torch.from_numpy(l).to(dev)
     losses = [float(m.train_step(x, l)) for _ in range(5)]
     torch.cuda.synchronize()
-    assert m._graph_mode() == {"eager": "off", "segmented": "segmented"}[mode]
-    if mode != "eager":
-        assert m._graphs is not None and len(m._graphs) == 2
+    assert m._graph_mode() == ("off" if mode.startswith("eager") else "segmented")
+    assert m._two_pass == (not mode.endswith("1p"))
+    if not mode.startswith("eager"):
+        # gradients graph 1 (forward + decoder / bottom backward), [gradients graph 2 (encoder backward)], optimiser graph
+        assert m._graphs is not None and len(m._graphs) == (2 if mode.endswith("1p") else 3)
+        if not mode.endswith("1p"):
+            # the first pass's buckets end exactly where the bottom level's gradients end
+            names = m.flat.names
+            k = m.sync.phase1_last
+            assert all(not n.startswith(("vnet/encoder", "vnet/input_layer")) for n in names[:k + 1])
+            assert all(n.startswith(("vnet/encoder", "vnet/input_layer")) for n in names[k + 1:])
+            assert any(last == k + 1 for _, _, _, last in m.sync.buckets)
     torch.save({"losses": losses, "data": m.flat.data.cpu()}, os.path.join(out, "dp_%s.pt" % mode))
     dist.destroy_process_group()
 
 
 def test_data_parallel_segmented_graph_rccl_group_of_one(tmp_path, dev):
-    """Data-parallel step with RCCL in the loop (group of one rank: all a 1-GPU box can host): gradients graph -> eager
-    bucket all-reduces on the communication stream -> optimiser graph.  No collective is captured (a captured RCCL
-    all-reduce trips ProcessGroupNCCL's watchdog: hipErrorCapturedEvent).  Must reproduce the eager step bit for bit."""
-    mode = "segmented"
-    for md in ("eager", mode):
+    """Data-parallel step with RCCL in the loop (group of one rank: all a 1-GPU box can host).
+    eager      : kernel-by-kernel enqueue, bucket all-reduces launched from the gradient hooks (overlapping backward);
+    segmented  : gradients graph 1 (forward, decoder + bottom-level backward) -> all-reduce of those buckets, asynchronous
+                 -> gradients graph 2 (encoder backward) -> remaining buckets -> optimiser graph;
+    *1p        : the same with a single backward pass (VNET_DP_TWO_PASS=0: gradients graph -> all buckets -> optimiser).
+    No collective is captured (a captured RCCL all-reduce trips ProcessGroupNCCL's watchdog: hipErrorCapturedEvent).
+    All four must produce the same losses and parameters bit for bit (the cut adds the two gradients of a skip tensor with
+    an add kernel instead of in the backward-data epilogue: the same two fp32 numbers)."""
+    modes = ("eager", "eager1p", "segmented", "segmented1p")
+    for md in modes:
         mp.spawn(_dp_worker, args=(1, _free_port(), str(tmp_path), md), nprocs=1, join=True)
-    a, b = torch.load(tmp_path / "dp_eager.pt"), torch.load(tmp_path / ("dp_%s.pt" % mode))
-    assert a["losses"] == b["losses"]
-    assert torch.equal(a["data"], b["data"])
+    a = torch.load(tmp_path / "dp_eager.pt")
+    for md in modes[1:]:
+        b = torch.load(tmp_path / ("dp_%s.pt" % md))
+        assert a["losses"] == b["losses"], md
+        assert torch.equal(a["data"], b["data"]), md

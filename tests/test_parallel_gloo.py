@@ -240,3 +240,36 @@ def test_step_mode_autotune_single_candidate_is_free():
     assert t.choice == "segmented" and t.mode() == "segmented"
     t.before(); t.after()
     assert t.times == []
+
+
+# ---- two-pass exchange: prefix buckets first (asynchronously), the rest after the second backward pass ---------------------
+def _two_pass_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from vnet_tensorflow_amd import optim, parallel
+    parallel.init_from_env("gloo")
+    params = _chain_model(5 + rank)
+    flat = optim.FlatParams(params)          # gradient-production order: e, d, c, b, a
+    parallel.broadcast_parameters(flat.data)
+    sync = parallel.BucketedGradAllReduce(flat, bucket_bytes=256, phase1_last=1)      # pass 1 ends with d
+    assert any(last == 2 for _, _, _, last in sync.buckets)
+    sync.hold_all = True                      # segmented-graph mode: hooks only count
+    x = torch.randn(4, 6, generator=torch.Generator().manual_seed(rank))
+    flat.zero_grad()
+    _chain_loss(params, x).backward()
+    local = flat.grad.clone()
+    sync.reduce_prefix()
+    launched_prefix = list(sync._launched)
+    sync.reduce_rest()
+    torch.save({"local": local, "reduced": flat.grad.clone(), "prefix": launched_prefix,
+                "buckets": [(f, l) for _, _, f, l in sync.buckets]}, os.path.join(out, "p%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_prefix_then_rest_reduction(tmp_path):
+    mp.spawn(_two_pass_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(tmp_path / ("p%d.pt" % k)) for k in range(2)]
+    assert torch.allclose(r[0]["reduced"], r[0]["local"] + r[1]["local"], atol=1e-6)
+    assert torch.equal(r[0]["reduced"], r[1]["reduced"])
+    for (first, last), went in zip(r[0]["buckets"], r[0]["prefix"]):
+        assert went == (last <= 2), (first, last, went)          # exactly the buckets of pass 1 (variables e, d) left early
+    assert any(r[0]["prefix"]) and not all(r[0]["prefix"])

@@ -347,6 +347,7 @@ class image2label(object):
         self.flat = optim.FlatParams(self.network.named_parameters())
         self.optimizer = optim.make_optimizer(self.optimizer_name, self.flat, self.momentum)
         self.sync = None
+        self._two_pass = False
         pg = os.environ.get("VNET_PARAM_GRAD_STREAM")
         ops.set_param_grad_stream(self.device.type == "cuda" and (getattr(self, "param_grad_stream", True) if pg is None else pg == "1"))
         self._pg_env = pg
@@ -359,8 +360,17 @@ class image2label(object):
             # (bf16 mode: the backward pass that is left after encoder level 3 is shorter than the all-reduce -> launch when ready)
             default_hold = 0.99 if ops.get_compute_dtype() == "fp32" else 0.0
             hold = float(os.environ.get("VNET_DP_HOLD", getattr(self, "allreduce_hold_fraction", default_hold)))
+            # two-pass backward (pass 1: output layer, decoder, bottom level = 81 % of the gradient bytes; pass 2: encoder):
+            # the replayed step is then gradients graph 1 -> all-reduce of pass 1's buckets (asynchronous) -> gradients graph 2
+            # -> the remaining buckets -> optimiser graph, i.e. the collective travels under the encoder's backward kernels
+            names = self.flat.names
+            enc = ("vnet/encoder", "vnet/input_layer")
+            head = [i for i, n in enumerate(names) if not n.startswith(enc)]
+            self._two_pass = (os.environ.get("VNET_DP_TWO_PASS", "1") != "0" and hasattr(self.network, "cut_backward") and bool(head)
+                              and len(head) < len(names) and head == list(range(len(head))))
             self.sync = parallel.BucketedGradAllReduce(self.flat, hold_fraction=hold, force=force,
-                                                       bucket_bytes=int(os.environ.get("VNET_DP_BUCKET_BYTES", 32 << 20)))
+                                                       bucket_bytes=int(os.environ.get("VNET_DP_BUCKET_BYTES", 32 << 20)),
+                                                       phase1_last=(head[-1] if self._two_pass else None))
             if getattr(self, "sync_batch_norm", False):
                 # single-device BatchSize = world x per-rank batch semantics of the reference (networks.py:319);
                 # the default (per-replica statistics) equals the reference run on each rank's batch alone
@@ -371,8 +381,11 @@ class image2label(object):
             ops.set_param_grad_stream(False)
 
     # -- one training step (reference model.py:743-748: ONE sess.run per step) ------------------------------------
-    def _compute_gradients(self, images, labels, dropout):
-        """forward, loss, backward (gradients written into the flat buffer), join the parameter-gradient stream."""
+    def _compute_gradients(self, images, labels, dropout, split=False):
+        """forward, loss, backward (gradients written into the flat buffer), join the parameter-gradient stream.
+        split: stop the backward pass at the network's cut (encoder | bottom level + decoder); _backward_rest() continues."""
+        if hasattr(self.network, "cut_backward"):
+            self.network.cut_backward = bool(split)
         if getattr(self.network, "fuse_zero_bias_grad", False):
             self.flat.begin_step()            # nothing to clear: see FlatParams.begin_step
         else:
@@ -385,6 +398,14 @@ class image2label(object):
         ops.join_param_grad_stream()          # filter / bias gradients were enqueued on their own stream
         return loss
 
+    def _backward_rest(self):
+        """Second backward pass of a split step: from the cut tensors through the encoder."""
+        cuts = [(o, l.grad) for o, l in self.network.backward_cuts if l.grad is not None]
+        self.network.backward_cuts = []
+        if cuts:
+            torch.autograd.backward([o for o, _ in cuts], [g for _, g in cuts])
+        ops.join_param_grad_stream()
+
     def _train_step_eager(self, images, labels, dropout):
         lr = optim.exponential_decay(self.initial_learning_rate, self.global_step, self.decay_steps, self.decay_factor)
         if self.sync is not None:
@@ -395,9 +416,13 @@ class image2label(object):
             st = ops.step_state(self.device)
             ops.set_step_state(st, lr, lr, self.global_step)
             with ops.use_step_state(st):
-                loss = self._compute_gradients(images, labels, dropout)
+                loss = self._compute_gradients(images, labels, dropout, split=self._two_pass)
+                if self._two_pass:
+                    self._backward_rest()
         else:
-            loss = self._compute_gradients(images, labels, dropout)
+            loss = self._compute_gradients(images, labels, dropout, split=self._two_pass)
+            if self._two_pass:
+                self._backward_rest()
         if self.sync is not None:
             self.sync.finish()
         self.optimizer.apply(lr)
@@ -445,7 +470,11 @@ class image2label(object):
 
         def grads():
             with ops.use_step_state(st):
-                return self._compute_gradients(self._g_images, self._g_labels, dropout)
+                return self._compute_gradients(self._g_images, self._g_labels, dropout, split=self._two_pass)
+
+        def grads_rest():
+            with ops.use_step_state(st):
+                self._backward_rest()
 
         def update():
             self.optimizer.launch(0.0, state=st)
@@ -458,13 +487,13 @@ class image2label(object):
         ops.set_param_grad_stream(False)
         ops.settle_pack_registry()
         try:
-            loss = self._capture_mode(mode, grads, update)
+            loss = self._capture_mode(mode, grads, update, grads_rest)
         finally:
             ops.set_param_grad_stream(pg_on)
         self._g_loss = loss.detach()
         self._g_mode = mode
 
-    def _capture_mode(self, mode, grads, update):
+    def _capture_mode(self, mode, grads, update, grads_rest=None):
         if mode == "whole":
             def whole():
                 loss = grads()
@@ -475,8 +504,11 @@ class image2label(object):
         else:
             # (sync.hold_all is set by train_step: hooks only count, reduce_all() launches every bucket after the graph)
             ga, loss = self._capture(grads)
+            gr = None
+            if self._two_pass:
+                gr, _ = self._capture(grads_rest, pool=ga.pool())
             gb, _ = self._capture(update, pool=ga.pool())
-            self._graphs = [ga, gb]
+            self._graphs = [ga, gb] if gr is None else [ga, gr, gb]
         return loss
 
     def train_step(self, images, labels, dropout=None):
@@ -541,8 +573,13 @@ class image2label(object):
         ops.set_step_state(self._step_state, lr, self.optimizer.schedule(lr), self.global_step)
         self._graphs[0].replay()
         if mode == "segmented":
-            self.sync.reduce_all()               # every bucket: RCCL all-reduce on the communication stream, then wait
-            self._graphs[1].replay()
+            if len(self._graphs) == 3:
+                self.sync.reduce_prefix()        # pass 1's buckets (decoder, bottom level) start their all-reduce ...
+                self._graphs[1].replay()         # ... while the encoder's backward runs
+                self.sync.reduce_rest()          # the rest, then wait for all of them
+            else:
+                self.sync.reduce_all()           # every bucket: RCCL all-reduce on the communication stream, then wait
+            self._graphs[-1].replay()
         self.global_step += 1
         return self._g_loss
 

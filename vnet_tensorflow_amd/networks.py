@@ -41,6 +41,8 @@ class VNet(object):
         self.activation_fn = activation_fn
         self.fuse_input_block = True       # single-modality input: skip the 16x redundant work of the tiled conv
         self.fuse_bn_chains = True         # decoder BN->BN->add->BN chains in closed form (ops.bn_chain)
+        self.cut_backward = False          # data-parallel step graphs: cut the autograd graph between encoder and bottom level / skips
+        self.backward_cuts = []
         self.fuse_bn_stats = True          # batch-norm statistics from the producing convolution's epilogue (ops.conv bn_stats)
         self.fuse_grad_accumulation = True # tensors with two consumers: second gradient accumulated by its producer (ops.fork)
         self.fuse_zero_bias_grad = True    # conv biases feed batch-norms: their gradient is identically 0 (ops.zero_bias_gradients)
@@ -95,11 +97,13 @@ class VNet(object):
                     x = L.batch_normalization(x, activation=act)
 
             features = list()
+            cutting = self.cut_backward and x.device.type != "meta" and torch.is_grad_enabled()
+            self.backward_cuts = []
             for l in range(self.num_levels):
                 with store.variable_scope('vnet/encoder/level_' + str(l + 1)):
                     x = self.convolution_block(x, self.num_convolutions[l], dropout_rate, act,
                                                tiled=tiled if l == 0 else None)
-                    if self.fuse_grad_accumulation:
+                    if self.fuse_grad_accumulation and not cutting:
                         # skip connection: decoder concat + down convolution consume x (ops.fork)
                         skip, x = ops.fork(x)
                         features.append(skip)
@@ -109,6 +113,10 @@ class VNet(object):
                         x = L.down_convolution(x, factor=2, kernel_size=[2, 2, 2], bn_stats=self.fuse_bn_stats)
                         x = L.batch_normalization(x, activation=act)
 
+            if cutting:
+                # everything the decoder and the bottom level take from the encoder becomes a leaf: backward pass 1 ends here
+                features = [ops.cut(f, self.backward_cuts) for f in features]
+                x = ops.cut(x, self.backward_cuts)
             with store.variable_scope('vnet/bottom_level'):
                 x = self.convolution_block(x, self.bottom_convolutions, dropout_rate, act)
 

@@ -43,7 +43,7 @@ def broadcast_parameters(flat_data, src=0, group=None):
 class BucketedGradAllReduce(object):
     """All-reduces `flat.grad` bucket by bucket as soon as every variable of a bucket has its gradient."""
 
-    def __init__(self, flat, bucket_bytes=32 << 20, group=None, overlap=True, force=False, hold_fraction=0.0):
+    def __init__(self, flat, bucket_bytes=32 << 20, group=None, overlap=True, force=False, hold_fraction=0.0, phase1_last=None):
         """`force`: run the collective path even in a group of one (lets a 1-GPU box exercise RCCL itself).
         `hold_fraction`: ready buckets are held back until this fraction of the gradient bytes is ready, then all of
         them go out back to back (0 = every bucket as soon as it is ready).  V-Net produces 98 % of its gradient bytes
@@ -58,6 +58,11 @@ class BucketedGradAllReduce(object):
         # on where the size-driven cuts happen to fall (without it the 0.99 threshold of the V-Net layout is only crossed
         # by the LAST bucket and nothing overlaps backward)
         cut = [flat.first_index_reaching(self.hold_fraction)] if 0.0 < self.hold_fraction < 1.0 else []
+        # phase1_last: index (gradient-production order) of the last variable whose gradient the FIRST backward pass writes
+        # (output layer, decoder, bottom level); a bucket ends there, so reduce_prefix() can send exactly those buckets
+        self.phase1_last = phase1_last
+        if phase1_last is not None:
+            cut = cut + [int(phase1_last)]
         self.buckets = flat.buckets(bucket_bytes, cut_after=cut)
         self.hold_all = False            # graph mode "segmented": hooks only count, reduce_all() launches everything
         self.launch_log = []             # (bucket index, gradient events seen so far) per launch of the current step
@@ -100,6 +105,30 @@ class BucketedGradAllReduce(object):
         self._ready_bytes = 0
         self._held = []
         self.launch_log = []
+
+    def reduce_prefix(self):
+        """Two-pass backward (model.train_step, segmented graphs): all-reduce the buckets the first pass completed, on the
+        communication stream, WITHOUT waiting -- the second pass (encoder backward) runs meanwhile."""
+        if not self.active:
+            return
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+        self.launch_log = []
+        for bi, (_, _, _, last) in enumerate(self.buckets):
+            if self.phase1_last is not None and last <= self.phase1_last + 1:
+                self._launch(bi)
+
+    def reduce_rest(self):
+        """The remaining buckets, then make the current stream wait for every all-reduce of this step."""
+        if not self.active:
+            return
+        for bi in range(len(self.buckets)):
+            self._launch(bi)                 # (skips the ones reduce_prefix launched)
+        for h in self._handles:
+            h.wait()
+        if self.overlap:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._handles = []
 
     def reduce_all(self):
         """All-reduce every bucket now (the gradients are complete on the current stream) and make the current stream
