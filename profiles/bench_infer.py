@@ -15,20 +15,29 @@ from vnet_tensorflow_amd import model as M
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-class A:
-    pass
-
-
-args = A(); args.channels = 1; args.classes = 2; args.batch = 2; args.patch = 128; args.compute = "fp32"
+import time
 dev = torch.device("cuda", 0)
 np.random.seed(42)
-m = M.image2label(None, bench.config(args), device=dev, verbose=False)
+cfg = bench.config(128, 2, 1, 2, "fp32")
+cfg["EvaluationSetting"] = {"Stride": [64, 64, 64], "BatchSize": 2, "ProbabilityOutput": False}
+m = M.image2label(None, cfg, device=dev, verbose=False)
 m.read_config(); m.build_model_graph()
 with tempfile.TemporaryDirectory() as tmp:
     w, v = os.path.join(tmp, "net.vnetw"), os.path.join(tmp, "vol.npy")
     M.export_weights(m.network, w)
     rng = np.random.default_rng(0)
-    np.save(v, np.clip(127.5 + 40 * rng.standard_normal((256, 256, 256, 1)), 0, 255).astype(np.float32))
+    vol = np.clip(127.5 + 40 * rng.standard_normal((256, 256, 256, 1)), 0, 255).astype(np.float32)
+    np.save(v, vol)
+    # the Python evaluate path (image2label.evaluate_single_3D): 27 patches + the duplicated last batch = 14 batches of 2
+    from vnet_tensorflow_amd import ops
+    for compute in ("fp32", "bf16"):
+        ops.set_compute_dtype(compute)
+        m.evaluate_single_3D(vol[:192, :192, :192])               # warm-up
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        m.evaluate_single_3D(vol)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print("python evaluate_single_3D %s: %.3f s = %.1f patches/s (crop + H2D + forward + accumulate + argmax + D2H)" % (compute, dt, 28 / dt))
+    ops.set_compute_dtype("fp32")
     del m
     torch.cuda.empty_cache()
     for compute in ("fp32", "bf16"):

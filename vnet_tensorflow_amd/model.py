@@ -734,6 +734,14 @@ class image2label(object):
             self._print("{}: Saving checkpoint of epoch {} at {}...".format(_now(), epoch + 1, self.ckpt_dir))
             self.save_checkpoint()
 
+    def _infer(self, batch):
+        """softmax of one evaluation batch (model.py:914-917: dropout 0, batch statistics of THIS batch).  Enqueued kernel by
+        kernel: a replayed hipGraph of the forward pass was built and measured 5-8 % SLOWER end to end here
+        (profiles/bench_infer.py: 66.7 vs 70.3 patches/s fp32, 109 vs 118 bf16) -- the eager enqueue already runs ahead of
+        the GPU while the next batch is cropped and copied on other threads / streams."""
+        with torch.no_grad():
+            return self.forward(batch, None, 0.0)[2]
+
     # -- reference model.py:817-977 (array in / arrays out; SimpleITK resampling not carried) -----------------
     def evaluate_single_3D(self, images_np):
         """images_np float32 [X,Y,Z,Cin] -> (label int64 [X,Y,Z], softmax float32 [K,X,Y,Z]).
@@ -766,18 +774,27 @@ class image2label(object):
         K = self.output_channel_num
         vol = torch.zeros(dims + (K,), dtype=torch.float32, device=self.device)
         cnt = torch.zeros(dims, dtype=torch.float32, device=self.device)
-        for bd in batches:
-            batch = torch.from_numpy(prepare_batch(bd)).to(self.device)
-            with torch.no_grad():
-                _, _, sm, _ = self.forward(batch, None, 0.0)
-            for j, idx in enumerate(bd['indexes']):
-                ops.accumulate_patch(sm[j], vol, cnt, (idx[0], idx[2], idx[4]))
-        vol_np, cnt_np = vol.cpu().numpy(), cnt.cpu().numpy()
-        label_np = np.argmax(vol_np, axis=-1)
-        softmax_np = np.moveaxis(vol_np, -1, 0)
-        if self.evaluate_probability_output:
-            softmax_np = softmax_np / np.float32(cnt_np)
+        # patches are cropped on worker threads into pinned memory and copied to the device on the copy stream while the
+        # previous batch is in the network (the same feeder as the training loop)
+        def crop(bd):
+            t = torch.from_numpy(prepare_batch(bd))
+            return (t.pin_memory() if self.device.type == "cuda" else t), torch.zeros(1, dtype=torch.int32)
+
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=int(os.environ.get("VNET_LOADER_THREADS", "3"))) as pool:
+            feeder = _DeviceFeeder(self.device, pool.map(crop, batches))
+            for bd, (batch, _) in zip(batches, feeder):
+                sm = self._infer(batch)
+                for j, idx in enumerate(bd['indexes']):
+                    ops.accumulate_patch(sm[j], vol, cnt, (idx[0], idx[2], idx[4]))
+                feeder.step_done()
+        # argmax of the summed softmax (model.py:934) on the device: only the label map crosses PCIe unless probabilities are wanted
+        label_np = torch.argmax(vol, dim=-1).to(torch.int16 if K < 32768 else torch.int64).cpu().numpy().astype(np.int64)
         sl = tuple(slice(0, s) for s in orig)
+        if not self.evaluate_probability_output:
+            return label_np[sl], None
+        vol_np, cnt_np = vol.cpu().numpy(), cnt.cpu().numpy()
+        softmax_np = np.moveaxis(vol_np, -1, 0) / np.float32(cnt_np)          # model.py:935-937
         return label_np[sl], softmax_np[(slice(None),) + sl]
 
     # -- reference model.py:1131-1242 ------------------------------------------------------------------------------
@@ -801,7 +818,8 @@ class image2label(object):
                 image, _ = vtf.apply_pipeline(tf, image, np.zeros(image.shape[:3], dtype=np.int32), np.random.default_rng(0))
             label, softmax = self.evaluate_single_3D(image)
             label = label[tuple(slice(0, n) for n in chans[0].shape)]
-            softmax = softmax[(slice(None),) + tuple(slice(0, n) for n in chans[0].shape)]
+            if softmax is not None:
+                softmax = softmax[(slice(None),) + tuple(slice(0, n) for n in chans[0].shape)]
             if self.evaluate_lcc:                                     # model.py:1218-1219
                 label = ExtractLargestConnectedComponents(label)
             if self.evaluate_volume_threshold and self.evaluate_volume_threshold > 0:      # model.py:1222-1223
