@@ -130,6 +130,18 @@ int vnet_conv_fwd_bf16_stats(const float* x0, int C0, const float* x1, int C1, c
                              float* y, int Cout, int B, int D, int H, int W,
                              const float* res, float* stats, void* ws, size_t ws_bytes, void* stream);   /* see vnet_conv_fwd_stats */
 
+/* bf16 SHADOWS (round 2).  In bf16 mode every convolution input is produced by a batch-norm / dropout kernel (forward) or
+ * a batch-norm backward kernel (dy); the *_x16 producers below write, next to the fp32 tensor, its bf16 image (RNE -- the very
+ * rounding the kernels above apply while staging), and these entry points stage THAT: half the bytes through L2, no
+ * conversion, bit-identical results.  x0h/x1h/dyh: 16-byte aligned, 2-byte elements, same NDHWC indexing; channel counts
+ * multiples of 8 (VNET_E_UNSUPPORTED otherwise -- use the fp32-source entry points).  accum/res/stats as in
+ * vnet_conv_fwd_bf16_acc / _stats (stats requires Cy1 == 0). */
+int vnet_conv_fwd_bf16_x16(const void* x0h, int C0, const void* x1h, int C1, const void* wp, const float* bias,
+                           float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
+                           int accum, const float* res, float* stats, void* ws, size_t ws_bytes, void* stream);
+int vnet_conv_wgrad_bf16_x16(const void* x0h, int C0, const void* x1h, int C1, const void* dyh, int Cout, float* dw,
+                             int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream);
+
 /* filter gradient of the same convolution with x and dy rounded to bf16, fp32 accumulation
  * (v_mfma_f32_16x16x32_bf16 fed by LDS transpose reads); dw is fp32 in TF layout [125][Cin][Cout]. */
 size_t vnet_wgrad_bf16_ws_bytes(int Cin, int Cout, int B, int D, int H, int W);
@@ -185,6 +197,9 @@ int vnet_bn_stats(const float* x, const float* r, int bcast, int64_t M, int C, f
 int vnet_bn_act_fwd(const float* x, const float* r, int bcast, int64_t M, int C,
                     const float* mean, const float* invstd, const float* gamma, const float* beta,
                     int act, const float* alpha, float* y, void* stream);
+int vnet_bn_act_fwd_x16(const float* x, const float* r, int bcast, int64_t M, int C,
+                        const float* mean, const float* invstd, const float* gamma, const float* beta,
+                        int act, const float* alpha, float* y, void* yh /* NULL or bf16 shadow of y, C % 4 == 0 */, void* stream);
 /* backward: pass 1 reduces dgamma,dbeta,dalpha; pass 2 writes ds (gradient w.r.t. s = x + r;
  * the same tensor is the gradient of both x and r).  bcast=1: ds has C channels (caller sums). */
 int vnet_bn_act_bwd(const float* dy, const float* x, const float* r, int bcast, int64_t M, int C,
@@ -218,6 +233,10 @@ int vnet_bn_act_bwd_apply(const float* dy, const float* x, const float* r, int b
                           int act, const float* alpha, const float* sum_dz, const float* sum_dz_xhat, double M_total,
                           const float* xhat_coef /* NULL, or [C]: ds += xhat * xhat_coef (batch-norm chains) */,
                           float* ds, void* stream);
+int vnet_bn_act_bwd_apply_x16(const float* dy, const float* x, const float* r, int bcast, int64_t M, int C,
+                              const float* mean, const float* invstd, const float* gamma, const float* beta,
+                              int act, const float* alpha, const float* sum_dz, const float* sum_dz_xhat, double M_total,
+                              const float* xhat_coef, float* ds, void* dsh /* NULL or bf16 shadow of ds */, void* stream);
 
 /* Batch-norm CHAINS of the decoder, evaluated in closed form on ONE tensor x (the convolution output):
  *   kind 0 (networks.py:333-337, block with one convolution): y1 = BN1(x); y2 = BN2(y1); out = act(BN3(y1 + y2))
@@ -301,6 +320,8 @@ int vnet_momentum_apply_dev(float* p, const float* g, float* acc, int64_t n, con
                             int nesterov, float gscale, void* stream);
 int vnet_dropout_fwd_dev(const float* x, float* y, uint8_t* mask, int64_t n, float rate, uint64_t seed,
                          const void* state, void* stream);
+int vnet_dropout_fwd_x16(const float* x, float* y, void* yh /* NULL or bf16 shadow of y */, uint8_t* mask, int64_t n, float rate,
+                         uint64_t seed, const void* state /* NULL: host step */, void* stream);
 
 /* ---- hard metrics (model.py:588-626): K x K confusion matrix cm[label][prediction] as float64 counts;
  * accuracy, per-class tp/tn/fp/fn, sensitivity, specificity and hard Dice 2tp/(2tp+fp+fn) follow on the host. */

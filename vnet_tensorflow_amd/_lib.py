@@ -38,6 +38,8 @@ SIGNATURES = {
     "vnet_conv_fwd_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "vnet_wgrad_bf16_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "vnet_conv_wgrad_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "vnet_conv_wgrad_bf16_x16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "vnet_conv_fwd_bf16_x16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "vnet_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "vnet_conv_wgrad": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp,
                              _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
@@ -55,9 +57,11 @@ SIGNATURES = {
     "vnet_bn_finalize": (_i, [_vp, _d, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "vnet_bn_act_bwd_reduce": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vnet_bn_act_bwd_apply": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp, _vp]),
+    "vnet_bn_act_bwd_apply_x16": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp, _vp, _vp]),
     "vnet_bn_chain_coef_fwd": (_i, [_i, _i, _f, _f] + [_vp] * 14 + [_vp]),
     "vnet_bn_chain_coef_bwd": (_i, [_i, _i, _f, _d] + [_vp] * 15 + [_vp]),
     "vnet_bn_act_fwd": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "vnet_bn_act_fwd_x16": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "vnet_bn_act_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp,
                              _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vnet_act_fwd": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp]),
@@ -77,6 +81,7 @@ SIGNATURES = {
     "vnet_sgd_apply_dev": (_i, [_vp, _vp, _i64, _vp, _f, _vp]),
     "vnet_momentum_apply_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _f, _i, _f, _vp]),
     "vnet_dropout_fwd_dev": (_i, [_vp, _vp, _vp, _i64, _f, _u64, _vp, _vp]),
+    "vnet_dropout_fwd_x16": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _u64, _vp, _vp]),
     "vnet_confusion_ws_bytes": (_sz, [_i]),
     "vnet_confusion_matrix": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
     "vnet_auc_ws_bytes": (_sz, [_i]),

@@ -6,6 +6,13 @@
 #include "../../include/vnet_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// two fp32 -> packed bf16 pair, round-to-nearest-even (the rounding of every bf16 operand in this library)
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
 
 #define VNET_LAUNCH_CHECK()                                  \
     do {                                                     \

@@ -680,12 +680,6 @@ void launch_wgrad_reduce(const float* part, int nsplit, int T3, int CinP, int Co
     else hipLaunchKernelGGL(wgrad_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, part, nsplit, T3, CinP, CoutP, Cin, Cout, dw);
 }
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
 
 // bf16 filter image: [cin chunk of 16][tap][cout block of 32][cin half][32 cout][8 cin]
 __device__ __forceinline__ void pack_bf16_elem(int mode, const float* __restrict__ w, unsigned short* __restrict__ wp,
@@ -959,6 +953,46 @@ struct Bf16Geom {
     static constexpr int TILE_BYTES = 2 * PLANE;
 };
 
+// bf16-source twin of XTile (round 2: activations that carry a bf16 shadow, see vnet_conv_fwd_bf16_x16): a thread owns one
+// (x, cin half) column = 8 channels = ONE 16-byte unit per row, loaded as it will sit in LDS -- half the bytes through L2,
+// half the load/store instructions and no conversion.  Channel counts must be multiples of 8.
+template <int IZ, int IY, int IX, int NT>
+struct XTileH {
+    static constexpr int COLS = IX * 2;
+    static constexpr int RPI = NT / COLS;
+    static constexpr int ROWS = IZ * IY;
+    static constexpr int PER = (ROWS + RPI - 1) / RPI;
+    static_assert(RPI >= 1, "tile row wider than the workgroup");
+    template <int K0, int KN>
+    __device__ static __forceinline__ void issue_part(u32x4 (&v)[KN], const unsigned short* __restrict__ x0, const unsigned short* __restrict__ x1,
+                                                      int C0, int C1, int chunk, int b, int gz0, int gy0, int gx0,
+                                                      int Di, int Hi, int Wi, int tid) {
+        const int r0 = tid / COLS, col = tid - r0 * COLS;
+        const int ix = col >> 1, hf = col & 1;
+        const int c = chunk * 16 + hf * 8;
+        const int gx = gx0 + ix;
+        const bool colok = r0 < RPI && (unsigned)gx < (unsigned)Wi && c < C0 + C1;
+        const bool first = c < C0 || !colok;
+        const int Cs = first ? C0 : C1;
+        const int rowstride = Wi * Cs, planestride = Hi * rowstride;
+        const unsigned short* bp = (first ? x0 + (colok ? c : 0) : x1 + (c - C0)) + (size_t)b * Di * planestride + (colok ? gx * Cs : 0);
+        constexpr int DIZ = RPI / IY, DIY = RPI % IY;
+        int row = r0 + K0 * RPI;
+        int iz = row / IY, iy = row - iz * IY;
+#pragma unroll
+        for (int k = 0; k < KN; ++k) {
+            const int gz = gz0 + iz, gy = gy0 + iy;
+            const bool ok = colok && row < ROWS && (unsigned)gz < (unsigned)Di && (unsigned)gy < (unsigned)Hi;
+            const int off = ok ? gz * planestride + gy * rowstride : 0;
+            const u32x4 t = *reinterpret_cast<const u32x4*>(bp + off);
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            v[k] = ok ? t : z;
+            row += RPI; iy += DIY; iz += DIZ;
+            if (iy >= IY) { iy -= IY; ++iz; }
+        }
+    }
+};
+
 // filter-plane prefetch: WPER 16-byte units per thread, global -> registers (issue) -> LDS (commit)
 template <int NSB, int WPER, int NT>
 __device__ __forceinline__ void bf16_w_issue(u32x4 (&wreg)[WPER], const u32x4* __restrict__ src, int ncob, int tid) {
@@ -996,7 +1030,20 @@ __device__ __forceinline__ void bf16_tile_commit(unsigned char* tile, unsigned c
     }
 }
 
-template <int TZ, int TY, int TX, int NSB, int WAVES, bool STATS = false>
+template <typename G, typename XH, int K0, int KN>
+__device__ __forceinline__ void bf16_tile_commit_h(unsigned char* tile, unsigned char* dump, const u32x4 (&v)[KN], int tid) {
+    const int r0 = tid / XH::COLS, col = tid - r0 * XH::COLS;
+    unsigned char* base = tile + (col & 1) * G::PLANE + (col >> 1) * 16;
+#pragma unroll
+    for (int k = 0; k < KN; ++k) {
+        const int row = r0 + (K0 + k) * XH::RPI;
+        const bool ok = r0 < XH::RPI && row < XH::ROWS;
+        *reinterpret_cast<u32x4*>(ok ? base + row * (G::IX * 16) : dump) = v[k];
+    }
+}
+
+// H: x0 / x1 point at bf16 shadows of the activations (same NDHWC indexing, 2-byte elements)
+template <int TZ, int TY, int TX, int NSB, int WAVES, bool STATS = false, bool H = false>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) conv5_bf16_kernel(ConvArgs a) {
     using G = Bf16Geom<TZ, TY, TX>;
     constexpr int MS = 2, NT = WAVES * 64;
@@ -1061,7 +1108,14 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     unsigned char* dump = smem + G::TILE_BYTES + WUNITS * 16 + (tid & 63) * 16;       // per-lane slot for masked-off stores
     auto wsrc = [&](int chunk, int dz) { return wg + ((size_t)(chunk * 125 + dz * 25) * ncob + cob0) * 64; };
     auto stage_tile = [&](int chunk) {
-        if (a.vec_in) {
+        if constexpr (H) {
+            using XH = XTileH<G::IZ, G::IY, G::IX, NT>;
+            u32x4 v[XH::PER];
+            XH::template issue_part<0, XH::PER>(v, reinterpret_cast<const unsigned short*>(a.x0), reinterpret_cast<const unsigned short*>(a.x1),
+                                                a.C0, a.C1, chunk, b, gz0, gy0, gx0, a.Di, a.Hi, a.Wi, tid);
+            __builtin_amdgcn_sched_barrier(0);
+            bf16_tile_commit_h<G, XH, 0, XH::PER>(tile, dump, v, tid);
+        } else if (a.vec_in) {
             constexpr int H0 = XT::PER / 2, H1 = XT::PER - H0;       // two batches: half the staging registers
             {
                 float4 v[H0];
@@ -1238,7 +1292,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
 //   * persistent workgroups (one per CU) walk their bricks; the next tile (and filter chunk) is prefetched global ->
 //     registers during the MFMAs and committed between two barriers.
 // ------------------------------------------------------------------------------------------
-template <int TZ, int TY, int TX, bool STATS = false>
+template <int TZ, int TY, int TX, bool STATS = false, bool H = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv5_bf16_c16_kernel(ConvArgs a) {
     using G = Bf16Geom<TZ, TY, TX>;
     static_assert(TZ == 4 && TY == 8 && TX == 16, "8 waves x 4 rows of 16 voxels");
@@ -1319,27 +1373,39 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         const bool second = (r == 1 || r == 2);
         bi = 2 * q + (second ? 1 : 0); ch = r < 2 ? cf : 1 - cf; first = r < 2; last = r >= 2; swap = (r == 1 || r == 3);
     };
-    float4 v[XT::PER];
-    uint2 pk[XT::PER];
+    using XH = XTileH<G::IZ, G::IY, G::IX, NT>;
+    float4 v[H ? 1 : XT::PER];
+    uint2 pk[H ? 1 : XT::PER];
+    u32x4 hv[H ? XH::PER : 1];           // H: the prefetched tile as it will sit in LDS
     auto tile_issue = [&](int bi, int ch) {
         int b, bz, by, bx;
         brick_origin(bi, b, bz, by, bx);
-        XT::template issue_part<0, XT::PER>(v, a.x0, a.x1, a.C0, a.C1, ch, b, bz * TZ - 2, by * TY - 2, bx * TX - 2,
-                                            a.Di, a.Hi, a.Wi, tid);
+        if constexpr (H)
+            XH::template issue_part<0, XH::PER>(hv, reinterpret_cast<const unsigned short*>(a.x0), reinterpret_cast<const unsigned short*>(a.x1),
+                                                a.C0, a.C1, ch, b, bz * TZ - 2, by * TY - 2, bx * TX - 2, a.Di, a.Hi, a.Wi, tid);
+        else
+            XT::template issue_part<0, XT::PER>(v, a.x0, a.x1, a.C0, a.C1, ch, b, bz * TZ - 2, by * TY - 2, bx * TX - 2,
+                                                a.Di, a.Hi, a.Wi, tid);
     };
     auto tile_pack = [&]() {            // fp32 -> bf16 (RNE) in registers; halves the registers the prefetch holds
+        if constexpr (!H) {
 #pragma unroll
-        for (int k = 0; k < XT::PER; ++k) pk[k] = make_uint2(pk_bf16(v[k].x, v[k].y), pk_bf16(v[k].z, v[k].w));
+            for (int k = 0; k < XT::PER; ++k) pk[k] = make_uint2(pk_bf16(v[k].x, v[k].y), pk_bf16(v[k].z, v[k].w));
+        }
     };
     auto tile_commit = [&]() {
-        const int r0 = tid / XT::COLS, col = tid - r0 * XT::COLS;
-        const int ix = col >> 2, cq = col & 3;
-        unsigned char* base = tile + (cq >> 1) * G::PLANE + ix * 16 + (cq & 1) * 8;
+        if constexpr (H) {
+            bf16_tile_commit_h<G, XH, 0, XH::PER>(tile, dump, hv, tid);
+        } else {
+            const int r0 = tid / XT::COLS, col = tid - r0 * XT::COLS;
+            const int ix = col >> 2, cq = col & 3;
+            unsigned char* base = tile + (cq >> 1) * G::PLANE + ix * 16 + (cq & 1) * 8;
 #pragma unroll
-        for (int k = 0; k < XT::PER; ++k) {
-            const int row = r0 + k * XT::RPI;
-            const bool ok = r0 < XT::RPI && row < XT::ROWS;
-            *reinterpret_cast<uint2*>(ok ? base + row * (G::IX * 16) : dump) = pk[k];
+            for (int k = 0; k < XT::PER; ++k) {
+                const int row = r0 + k * XT::RPI;
+                const bool ok = r0 < XT::RPI && row < XT::ROWS;
+                *reinterpret_cast<uint2*>(ok ? base + row * (G::IX * 16) : dump) = pk[k];
+            }
         }
     };
 
@@ -1388,7 +1454,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     for (int m = 0; m < 4; ++m)
                         accA[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[dy], R[m + dy], accA[m], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);     // keep the next group's 13 fragment reads from being hoisted above this
-                                                       // group's MFMAs (the allocator then runs out of registers and spills)
+                                                       // group's MFMAs (the allocator then runs out of registers and spills).
+                                                       // With the bf16-source tile (H: 206 VGPRs) an explicit ping-pong of the
+                                                       // 13 fragment registers fits (250 VGPRs, no spill) -- measured no faster
+                                                       // (0.155-0.172 vs 0.157-0.167 ms at 128^3 16->16): two waves per SIMD
+                                                       // already cover the read latency
             }
         if (more) tile_pack();          // the prefetched tile has long arrived: convert now, 32 fewer live registers from here
                                         // (packing after the first dz pair and letting the second pair's reads hoist: measured 2 % slower)
@@ -1487,10 +1557,12 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p, int off) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TZ, int TY, int TX, int NS, int TW>
+template <int TZ, int TY, int TX, int NS, int TW, bool H = false>
 __global__ void __launch_bounds__(512) wgrad5_bf16_kernel(WgradArgs a) {
     using G = TileGeom<5, 1, TZ, TY, TX, 5>;
     using XT = XTile<G::IZ, G::IY, G::IX, 512>;
+    using XH = XTileH<G::IZ, G::IY, G::IX, 512>;
+    constexpr int NQH = TZ * TY * TX * NS * 2, PERH = (NQH + 511) / 512;     // H: 16-byte units (voxel, cout block, half) of the dy brick
     constexpr int NV = TZ * TY * TX, T3 = 125;
     constexpr int TXP = TX + 4;                                  // dy row pitch (voxels): same bank argument as the x tile
     constexpr int XBYTES = G::NVOX_IN * 32;
@@ -1527,9 +1599,11 @@ __global__ void __launch_bounds__(512) wgrad5_bf16_kernel(WgradArgs a) {
 #pragma unroll
         for (int n = 0; n < NS; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const bool pre = a.vec_in && a.vec_dy;
-    float4 px[XT::PER];
-    float4 pd[PERD];
+    const bool pre = H || (a.vec_in && a.vec_dy);
+    float4 px[H ? 1 : XT::PER];
+    float4 pd[H ? 1 : PERD];
+    u32x4 hx[H ? XH::PER : 1];
+    u32x4 hd[H ? PERH : 1];
 
     auto brick_coords = [&](int brick, int& b, int& bz, int& by, int& bx) {
         bx = brick % a.nbx; brick /= a.nbx;
@@ -1539,18 +1613,37 @@ __global__ void __launch_bounds__(512) wgrad5_bf16_kernel(WgradArgs a) {
     auto issue = [&](int brick) {
         int b, bz, by, bx;
         brick_coords(brick, b, bz, by, bx);
-        XT::issue(px, a.x0, a.x1, a.C0, a.C1, chunk, b, bz * TZ - 2, by * TY - 2, bx * TX - 2, a.Di, a.Hi, a.Wi, tid);
+        if constexpr (H) {
+            XH::template issue_part<0, XH::PER>(hx, reinterpret_cast<const unsigned short*>(a.x0), reinterpret_cast<const unsigned short*>(a.x1),
+                                                a.C0, a.C1, chunk, b, bz * TZ - 2, by * TY - 2, bx * TX - 2, a.Di, a.Hi, a.Wi, tid);
+            const unsigned short* dyh = reinterpret_cast<const unsigned short*>(a.dy);
 #pragma unroll
-        for (int k = 0; k < PERD; ++k) {
-            const int q = tid + k * 512;
-            const int v = q / (NS * 4), cq = q - v * (NS * 4);
-            const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
-            const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
-            const int c = co0 + cq * 4;
-            const bool ok = q < NQD && oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout;
-            const size_t ov = ok ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
-            const float4 t = *reinterpret_cast<const float4*>(a.dy + ov * a.Cout + (ok ? c : 0));
-            pd[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < PERH; ++k) {
+                const int q = tid + k * 512;
+                const int v = q / (NS * 2), cu = q - v * (NS * 2);
+                const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+                const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
+                const int c = co0 + cu * 8;
+                const bool ok = q < NQH && oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout;
+                const size_t ov = ok ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
+                const u32x4 t = *reinterpret_cast<const u32x4*>(dyh + ov * a.Cout + (ok ? c : 0));
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                hd[k] = ok ? t : z;
+            }
+        } else {
+            XT::issue(px, a.x0, a.x1, a.C0, a.C1, chunk, b, bz * TZ - 2, by * TY - 2, bx * TX - 2, a.Di, a.Hi, a.Wi, tid);
+#pragma unroll
+            for (int k = 0; k < PERD; ++k) {
+                const int q = tid + k * 512;
+                const int v = q / (NS * 4), cq = q - v * (NS * 4);
+                const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+                const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
+                const int c = co0 + cq * 4;
+                const bool ok = q < NQD && oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout;
+                const size_t ov = ok ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
+                const float4 t = *reinterpret_cast<const float4*>(a.dy + ov * a.Cout + (ok ? c : 0));
+                pd[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
     auto dy_addr = [&](int q) -> unsigned char* {
@@ -1562,7 +1655,22 @@ __global__ void __launch_bounds__(512) wgrad5_bf16_kernel(WgradArgs a) {
     if (pre && split < a.nbrick) issue(split);
     for (int brick = split; brick < a.nbrick; brick += a.nsplit) {
         __syncthreads();
-        if (pre) {
+        if constexpr (H) {
+            const int r0 = tid / XH::COLS, col = tid - r0 * XH::COLS;
+#pragma unroll
+            for (int k = 0; k < XH::PER; ++k) {
+                const int row = r0 + k * XH::RPI;
+                if (r0 < XH::RPI && row < XH::ROWS)
+                    *reinterpret_cast<u32x4*>(xt + (row * G::IX + (col >> 1)) * 32 + (col & 1) * 16) = hx[k];
+            }
+#pragma unroll
+            for (int k = 0; k < PERH; ++k) {
+                const int q = tid + k * 512;
+                const int v = q / (NS * 2), cu = q - v * (NS * 2);
+                const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+                if (q < NQH) *reinterpret_cast<u32x4*>(dyt + (cu >> 1) * DYPLANE + (((vz * TY + vy) * TXP + vx) * 32) + (cu & 1) * 16) = hd[k];
+            }
+        } else if (pre) {
             const int r0 = tid / XT::COLS, col = tid - r0 * XT::COLS;
 #pragma unroll
             for (int k = 0; k < XT::PER; ++k) {
@@ -1662,11 +1770,11 @@ __global__ void __launch_bounds__(512) wgrad5_bf16_kernel(WgradArgs a) {
     }
 }
 
-template <int TZ, int TY, int TX, int NS, int TW>
+template <int TZ, int TY, int TX, int NS, int TW, bool H = false>
 int launch_wgrad_bf16(const WgradArgs& a, int nsplit, int ncob, int ntg, hipStream_t st) {
     using G = TileGeom<5, 1, TZ, TY, TX, 5>;
     const size_t lds = (size_t)G::NVOX_IN * 32 + (size_t)NS * TZ * TY * (TX + 4) * 32;
-    auto k = wgrad5_bf16_kernel<TZ, TY, TX, NS, TW>;
+    auto k = wgrad5_bf16_kernel<TZ, TY, TX, NS, TW, H>;
     static unsigned long long attr_done = 0;
     if (int ae = ensure_lds(k, lds, attr_done)) return ae;
     dim3 grid(nsplit, (a.CinP / 16) * ncob, ntg);
@@ -1703,13 +1811,13 @@ bool conv_bf16_use_c16(int Cin, int Cout, int C0, int C1, int Cy0, int Cy1, int 
     return (long)B * ceil_div(D, 4) * ceil_div(H, 8) * ceil_div(W, 16) >= 256;
 }
 
-template <int TZ, int TY, int TX, int WAVES, bool STATS = false>
+template <int TZ, int TY, int TX, int WAVES, bool STATS = false, bool H = false>
 int launch_conv_bf16(const ConvArgs& a, const Bf16Plan& p, hipStream_t st) {
     using G = Bf16Geom<TZ, TY, TX>;
     dim3 grid(a.B * p.nbz * p.nby * p.nbx, p.ncobg, p.nsplit * p.nz), block(WAVES * 64);
 #define VNET_GO(NSBV)                                                                             \
     {                                                                                             \
-        auto k = conv5_bf16_kernel<TZ, TY, TX, NSBV, WAVES, STATS>;                               \
+        auto k = conv5_bf16_kernel<TZ, TY, TX, NSBV, WAVES, STATS, H>;                            \
         const size_t lds = (size_t)G::TILE_BYTES + (size_t)25 * NSBV * 1024 + 16 + 64 * 16;       \
         static unsigned long long attr_done = 0;                                                  \
         if (int ae = ensure_lds(k, lds, attr_done)) return ae;                                    \
@@ -1913,11 +2021,44 @@ int vnet_conv_bf16_stats_rows(int Cin, int Cy0, int Cy1, int C0, int C1, int B, 
     return B * p.nbz * p.nby * p.nbx;
 }
 
+extern "C++" {
+template <bool HS>
+static int conv_fwd_bf16_go(ConvArgs& a, const Bf16Plan& p, int nslab, int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W, hipStream_t st) {
+    if (conv_bf16_use_c16(a.Cin, a.Cout, C0, C1, Cy0, Cy1, B, D, H, W)) {
+        // 16 output channels at a size with enough bricks for one persistent workgroup per CU: no padding to 32 cout
+        using GC = Bf16Geom<4, 8, 16>;
+        a.nbz = ceil_div(D, 4); a.nby = ceil_div(H, 8); a.nbx = ceil_div(W, 16);
+        const size_t lds = (size_t)GC::TILE_BYTES + 65 * 1024 + 64 * 16 + 8 * 32 * 4;
+        if (a.stats) {
+            auto k = conv5_bf16_c16_kernel<4, 8, 16, true, HS>;
+            static unsigned long long attr_done = 0;
+            if (int ae = ensure_lds(k, lds, attr_done)) return ae;
+            hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, st, a);
+        } else {
+            auto k = conv5_bf16_c16_kernel<4, 8, 16, false, HS>;
+            static unsigned long long attr_done = 0;
+            if (int ae = ensure_lds(k, lds, attr_done)) return ae;
+            hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, st, a);
+        }
+        VNET_LAUNCH_CHECK();
+        return -1;            // done, no reduce
+    }
+    return (a.stats && nslab == 1)
+         ? (p.small ? launch_conv_bf16<8, 8, 8, 8, true, HS>(a, p, st)
+            : p.half ? launch_conv_bf16<4, 8, 8, 4, true, HS>(a, p, st) : launch_conv_bf16<4, 8, 16, 8, true, HS>(a, p, st))
+         : (p.small ? launch_conv_bf16<8, 8, 8, 8, false, HS>(a, p, st)
+            : p.half ? launch_conv_bf16<4, 8, 8, 4, false, HS>(a, p, st) : launch_conv_bf16<4, 8, 16, 8, false, HS>(a, p, st));
+}
+}  // extern "C++"
+
+// src16: x0 / x1 are bf16 shadows (2-byte elements, same NDHWC indexing) written by the producing kernels
 static int conv_fwd_bf16_impl(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
                               float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
-                              void* ws, size_t ws_bytes, void* stream, int accum, const float* res = nullptr, float* stats = nullptr) {
+                              void* ws, size_t ws_bytes, void* stream, int accum, const float* res = nullptr, float* stats = nullptr,
+                              bool src16 = false) {
     if (!x0 || !wp || !y0 || C0 <= 0 || Cy0 <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return VNET_E_BADARG;
     if ((C1 > 0 && !x1) || (Cy1 > 0 && !y1) || C1 < 0 || Cy1 < 0) return VNET_E_BADARG;
+    if (src16 && ((C0 & 7) || (C1 & 7) || ((reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(x1)) & 15))) return VNET_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     ConvArgs a{};
     a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1;
@@ -1939,30 +2080,9 @@ static int conv_fwd_bf16_impl(const float* x0, int C0, const float* x1, int C1, 
         if (!ws || ws_bytes < need) return VNET_E_WORKSPACE;
         a.part = reinterpret_cast<float*>(ws); a.part_stride = nvox * a.CoutP;
     }
-    if (conv_bf16_use_c16(a.Cin, a.Cout, C0, C1, Cy0, Cy1, B, D, H, W)) {
-        // 16 output channels at a size with enough bricks for one persistent workgroup per CU: no padding to 32 cout
-        using GC = Bf16Geom<4, 8, 16>;
-        a.nbz = ceil_div(D, 4); a.nby = ceil_div(H, 8); a.nbx = ceil_div(W, 16);
-        const size_t lds = (size_t)GC::TILE_BYTES + 65 * 1024 + 64 * 16 + 8 * 32 * 4;
-        if (a.stats) {
-            auto k = conv5_bf16_c16_kernel<4, 8, 16, true>;
-            static unsigned long long attr_done = 0;
-            if (int ae = ensure_lds(k, lds, attr_done)) return ae;
-            hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, st, a);
-        } else {
-            auto k = conv5_bf16_c16_kernel<4, 8, 16, false>;
-            static unsigned long long attr_done = 0;
-            if (int ae = ensure_lds(k, lds, attr_done)) return ae;
-            hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, st, a);
-        }
-        VNET_LAUNCH_CHECK();
-        return VNET_OK;
-    }
-    const int e = (a.stats && nslab == 1)
-                ? (p.small ? launch_conv_bf16<8, 8, 8, 8, true>(a, p, st)
-                   : p.half ? launch_conv_bf16<4, 8, 8, 4, true>(a, p, st) : launch_conv_bf16<4, 8, 16, 8, true>(a, p, st))
-                : (p.small ? launch_conv_bf16<8, 8, 8, 8>(a, p, st)
-                   : p.half ? launch_conv_bf16<4, 8, 8, 4>(a, p, st) : launch_conv_bf16<4, 8, 16, 8>(a, p, st));
+    const int e = src16 ? conv_fwd_bf16_go<true>(a, p, nslab, C0, C1, Cy0, Cy1, B, D, H, W, st)
+                        : conv_fwd_bf16_go<false>(a, p, nslab, C0, C1, Cy0, Cy1, B, D, H, W, st);
+    if (e == -1) return VNET_OK;
     if (e) return e;
     if (nslab > 1) {
         const size_t total = nvox * a.Cout;
@@ -1989,6 +2109,13 @@ int vnet_conv_fwd_bf16_stats(const float* x0, int C0, const float* x1, int C1, c
                              const float* res, float* stats, void* ws, size_t ws_bytes, void* stream) {
     if (!stats) return VNET_E_BADARG;
     return conv_fwd_bf16_impl(x0, C0, x1, C1, wp, bias, y, Cout, nullptr, 0, B, D, H, W, ws, ws_bytes, stream, 0, res, stats);
+}
+int vnet_conv_fwd_bf16_x16(const void* x0h, int C0, const void* x1h, int C1, const void* wp, const float* bias,
+                           float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
+                           int accum, const float* res, float* stats, void* ws, size_t ws_bytes, void* stream) {
+    if (stats && Cy1 > 0) return VNET_E_BADARG;
+    return conv_fwd_bf16_impl(reinterpret_cast<const float*>(x0h), C0, reinterpret_cast<const float*>(x1h), C1, wp, bias,
+                              y0, Cy0, y1, Cy1, B, D, H, W, ws, ws_bytes, stream, accum ? 1 : 0, res, stats, true);
 }
 
 }  // extern "C"
@@ -2102,10 +2229,12 @@ size_t vnet_wgrad_bf16_ws_bytes(int Cin, int Cout, int B, int D, int H, int W) {
     return (size_t)p.nsplit * 125 * round_up(Cin, 16) * round_up(Cout, 16) * sizeof(float);
 }
 
-int vnet_conv_wgrad_bf16(const float* x0, int C0, const float* x1, int C1, const float* dy, int Cout, float* dw,
-                         int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+static int conv_wgrad_bf16_impl(const float* x0, int C0, const float* x1, int C1, const float* dy, int Cout, float* dw,
+                                int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream, bool src16) {
     if (!x0 || !dy || !dw || C0 <= 0 || Cout <= 0 || B <= 0 || C1 < 0 || (C1 > 0 && !x1)) return VNET_E_BADARG;
     if (D <= 0 || H <= 0 || W <= 0) return VNET_E_BADARG;
+    if (src16 && ((C0 & 7) || (C1 & 7) || (Cout & 7) ||
+                  ((reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(dy)) & 15))) return VNET_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     WgradArgs a{};
     a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.dy = dy; a.Cout = Cout;
@@ -2120,7 +2249,15 @@ int vnet_conv_wgrad_bf16(const float* x0, int C0, const float* x1, int C1, const
     if (!direct && (!ws || ws_bytes < need)) return VNET_E_WORKSPACE;
     a.part = direct ? dw : reinterpret_cast<float*>(ws);
     int e;
-    if (p.small) {
+    if (src16) {
+        if (p.small) {
+            e = p.ns == 2 ? launch_wgrad_bf16<4, 8, 8, 2, 8, true>(a, p.nsplit, p.ncob, p.ntg, st)
+                          : launch_wgrad_bf16<4, 8, 8, 1, 16, true>(a, p.nsplit, p.ncob, p.ntg, st);
+        } else {
+            e = p.ns == 2 ? launch_wgrad_bf16<4, 4, 16, 2, 8, true>(a, p.nsplit, p.ncob, p.ntg, st)
+                          : launch_wgrad_bf16<4, 4, 16, 1, 16, true>(a, p.nsplit, p.ncob, p.ntg, st);
+        }
+    } else if (p.small) {
         e = p.ns == 2 ? launch_wgrad_bf16<4, 8, 8, 2, 8>(a, p.nsplit, p.ncob, p.ntg, st)
                       : launch_wgrad_bf16<4, 8, 8, 1, 16>(a, p.nsplit, p.ncob, p.ntg, st);
     } else {
@@ -2132,6 +2269,16 @@ int vnet_conv_wgrad_bf16(const float* x0, int C0, const float* x1, int C1, const
     launch_wgrad_reduce(a.part, p.nsplit, 125, a.CinP, a.CoutP, a.Cin, Cout, dw, st);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
+}
+
+int vnet_conv_wgrad_bf16(const float* x0, int C0, const float* x1, int C1, const float* dy, int Cout, float* dw,
+                         int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    return conv_wgrad_bf16_impl(x0, C0, x1, C1, dy, Cout, dw, B, D, H, W, ws, ws_bytes, stream, false);
+}
+int vnet_conv_wgrad_bf16_x16(const void* x0h, int C0, const void* x1h, int C1, const void* dyh, int Cout, float* dw,
+                             int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    return conv_wgrad_bf16_impl(reinterpret_cast<const float*>(x0h), C0, reinterpret_cast<const float*>(x1h), C1,
+                                reinterpret_cast<const float*>(dyh), Cout, dw, B, D, H, W, ws, ws_bytes, stream, true);
 }
 
 }  // extern "C"

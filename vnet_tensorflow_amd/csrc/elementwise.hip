@@ -313,6 +313,7 @@ struct BnP {
     float* out; float* partial;
     size_t M; int C; int bcast; int act; float invM; int identity;
     const float* extra;      // optional per-channel coefficient of xhat added to ds (batch-norm chains: variance-dependent scale)
+    unsigned short* outh;    // optional bf16 shadow of `out` (RNE), what the bf16-operand convolutions stage instead of the fp32 tensor
 };
 
 __device__ __forceinline__ void bn_load_coef(const BnP& p, float* sc, float* sf, float* al) {
@@ -345,6 +346,7 @@ __global__ void __launch_bounds__(EW_BLOCK) bn_act_fwd_kernel(BnP p) {
             o.z = act_fwd(v.z * sc[c + 2] + sf[c + 2], p.act, al[c + 2]);
             o.w = act_fwd(v.w * sc[c + 3] + sf[c + 3], p.act, al[c + 3]);
             reinterpret_cast<float4*>(p.out)[idx] = o;
+            if (p.outh) reinterpret_cast<uint2*>(p.outh)[idx] = make_uint2(pk_bf16(o.x, o.y), pk_bf16(o.z, o.w));
         }
     } else {
         const size_t n = p.M * p.C;
@@ -477,6 +479,7 @@ __global__ void __launch_bounds__(EW_BLOCK) bn_act_bwd_apply_kernel(BnP p) {
                 o[k] = sc[c + k] * (dz - k1[c + k] - xh * k2[c + k]) + xh * ex[c + k];
             }
             reinterpret_cast<float4*>(p.out)[idx] = make_float4(o[0], o[1], o[2], o[3]);
+            if (p.outh) reinterpret_cast<uint2*>(p.outh)[idx] = make_uint2(pk_bf16(o[0], o[1]), pk_bf16(o[2], o[3]));
         }
     } else {
         const size_t n = p.M * p.C;
@@ -836,13 +839,15 @@ struct StepState { float lr, lr_t; uint32_t pad0, pad1; uint64_t step; uint64_t 
 __global__ void step_state_kernel(StepState* s, float lr, float lr_t, uint64_t step) { s->lr = lr; s->lr_t = lr_t; s->step = step; }
 
 __global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ mask,
-                                   size_t n, float rate, uint64_t seed, const StepState* __restrict__ st) {
+                                   size_t n, float rate, uint64_t seed, const StepState* __restrict__ st, __bf16* __restrict__ yh) {
     const float sc = 1.f / (1.f - rate);
     if (st) seed += st->step * 0xD1342543DE82EF95ULL;          // a fresh mask per replayed step
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float u = (mix32(seed * 0x9E3779B97F4A7C15ULL + i) >> 8) * (1.f / 16777216.f);
         const uint8_t keep = u >= rate;
-        mask[i] = keep; y[i] = keep ? x[i] * sc : 0.f;
+        const float o = keep ? x[i] * sc : 0.f;
+        mask[i] = keep; y[i] = o;
+        if (yh) yh[i] = (__bf16)o;                              // RNE, like pk_bf16
     }
 }
 __global__ void dropout_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask, float* __restrict__ dx, size_t n, float rate) {
@@ -1014,11 +1019,18 @@ int vnet_bn_finalize(const double* sums, double M_total, int C, float eps, float
 int vnet_bn_act_fwd(const float* x, const float* r, int bcast, int64_t M, int C,
                     const float* mean, const float* invstd, const float* gamma, const float* beta,
                     int act, const float* alpha, float* y, void* stream) {
+    return vnet_bn_act_fwd_x16(x, r, bcast, M, C, mean, invstd, gamma, beta, act, alpha, y, nullptr, stream);
+}
+
+int vnet_bn_act_fwd_x16(const float* x, const float* r, int bcast, int64_t M, int C,
+                        const float* mean, const float* invstd, const float* gamma, const float* beta,
+                        int act, const float* alpha, float* y, void* yh, void* stream) {
+    if (yh && (C % 4 != 0 || (reinterpret_cast<uintptr_t>(yh) & 7))) return VNET_E_UNSUPPORTED;
     if (!x || !mean || !invstd || !gamma || !beta || !y || M <= 0 || C <= 0 || C > MAXC) return VNET_E_BADARG;
     if (act == VNET_ACT_PRELU && !alpha) return VNET_E_BADARG;
     if (act < 0 || act > 3) return VNET_E_UNSUPPORTED;
     BnP p{}; p.x = x; p.r = r; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.alpha = alpha;
-    p.out = y; p.M = (size_t)M; p.C = C; p.bcast = bcast; p.act = act;
+    p.out = y; p.outh = reinterpret_cast<unsigned short*>(yh); p.M = (size_t)M; p.C = C; p.bcast = bcast; p.act = act;
     hipStream_t st = (hipStream_t)stream;
     if (C % 4 == 0) hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(ew_blocks((size_t)M * C / 4 / 4 + 1) ), dim3(EW_BLOCK), 0, st, p);
     else hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(ew_blocks((size_t)M * C / 4 + 1)), dim3(EW_BLOCK), 0, st, p);
@@ -1059,6 +1071,15 @@ int vnet_bn_act_bwd_apply(const float* dy, const float* x, const float* r, int b
                           const float* mean, const float* invstd, const float* gamma, const float* beta,
                           int act, const float* alpha, const float* sum_dz, const float* sum_dz_xhat, double M_total,
                           const float* xhat_coef, float* ds, void* stream) {
+    return vnet_bn_act_bwd_apply_x16(dy, x, r, bcast, M, C, mean, invstd, gamma, beta, act, alpha, sum_dz, sum_dz_xhat, M_total,
+                                     xhat_coef, ds, nullptr, stream);
+}
+
+int vnet_bn_act_bwd_apply_x16(const float* dy, const float* x, const float* r, int bcast, int64_t M, int C,
+                              const float* mean, const float* invstd, const float* gamma, const float* beta,
+                              int act, const float* alpha, const float* sum_dz, const float* sum_dz_xhat, double M_total,
+                              const float* xhat_coef, float* ds, void* dsh, void* stream) {
+    if (dsh && (C % 4 != 0 || (reinterpret_cast<uintptr_t>(dsh) & 7))) return VNET_E_UNSUPPORTED;
     if (!dy || !x || !mean || !invstd || !gamma || !beta || !sum_dz || !sum_dz_xhat || !ds || M <= 0 || M_total <= 0.0 || C <= 0 || C > MAXC)
         return VNET_E_BADARG;
     if (act == VNET_ACT_PRELU && !alpha) return VNET_E_BADARG;
@@ -1066,7 +1087,7 @@ int vnet_bn_act_bwd_apply(const float* dy, const float* x, const float* r, int b
     BnP p{}; bn_bwd_fill(p, dy, x, r, bcast, M, C, mean, invstd, gamma, beta, act, alpha);
     p.invM = (float)(1.0 / M_total);
     p.extra = xhat_coef;
-    p.out = ds; p.dgamma = sum_dz_xhat; p.dbeta = sum_dz;
+    p.out = ds; p.outh = reinterpret_cast<unsigned short*>(dsh); p.dgamma = sum_dz_xhat; p.dbeta = sum_dz;
     if (C % 4 == 0) hipLaunchKernelGGL(bn_act_bwd_apply_kernel<true>, dim3(ew_blocks((size_t)M * C / 4 / 4 + 1)), dim3(EW_BLOCK), 0, st, p);
     else hipLaunchKernelGGL(bn_act_bwd_apply_kernel<false>, dim3(ew_blocks((size_t)M * C / 4 + 1)), dim3(EW_BLOCK), 0, st, p);
     VNET_LAUNCH_CHECK();
@@ -1278,12 +1299,15 @@ int vnet_step_state_set(void* state, float lr, float lr_t, uint64_t step, void* 
     return VNET_OK;
 }
 
-int vnet_dropout_fwd_dev(const float* x, float* y, uint8_t* mask, int64_t n, float rate, uint64_t seed, const void* state, void* stream) {
+int vnet_dropout_fwd_x16(const float* x, float* y, void* yh, uint8_t* mask, int64_t n, float rate, uint64_t seed, const void* state, void* stream) {
     if (!x || !y || !mask || n <= 0 || rate < 0.f || rate >= 1.f) return VNET_E_BADARG;
     hipLaunchKernelGGL(dropout_fwd_kernel, dim3(ew_blocks((size_t)n / 4 + 1)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, y, mask, (size_t)n, rate, seed,
-                       (const StepState*)state);
+                       (const StepState*)state, reinterpret_cast<__bf16*>(yh));
     VNET_LAUNCH_CHECK();
     return VNET_OK;
+}
+int vnet_dropout_fwd_dev(const float* x, float* y, uint8_t* mask, int64_t n, float rate, uint64_t seed, const void* state, void* stream) {
+    return vnet_dropout_fwd_x16(x, y, nullptr, mask, n, rate, seed, state, stream);
 }
 int vnet_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float rate, uint64_t seed, void* stream) {
     return vnet_dropout_fwd_dev(x, y, mask, n, rate, seed, nullptr, stream);

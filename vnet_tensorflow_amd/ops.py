@@ -314,6 +314,47 @@ class _Timed(object):
 
 
 # ---- convolution family ----------------------------------------------------------------------------
+# ---- bf16 shadows (bf16 compute mode) ---------------------------------------------------------------------------------
+# Every input of a bf16-operand 5^3 convolution is written by a batch-norm / dropout kernel (forward) or a batch-norm backward
+# kernel (dy).  Those producers write, behind the fp32 tensor IN THE SAME ALLOCATION, its bf16 image (round-to-nearest-even,
+# the rounding the convolution kernels apply while staging), and the convolutions stage that image instead: half the bytes
+# through L2, no conversion, bit-identical results (include/vnet_hip.h: *_x16).  A tensor carries a shadow iff its storage is
+# exactly 6 bytes per element -- only _alloc_shadowed() makes those, and only next to the call that fills the shadow.
+def _want_shadow(C):
+    return _COMPUTE["dtype"] == "bf16" and _FUSE["bf16_shadow"] and C % 8 == 0
+
+
+def _alloc_shadowed(shape, device):
+    """(fp32 tensor of `shape`, address of the bf16 shadow behind its data)."""
+    n = 1
+    for v in shape:
+        n *= int(v)
+    st = torch.UntypedStorage(n * 6, device=device)
+    y = torch.empty(0, dtype=torch.float32, device=device).set_(st, 0, tuple(int(v) for v in shape))
+    return y, y.data_ptr() + n * 4
+
+
+def with_shadow(t):
+    """Copy of `t` in a shadowed allocation, the shadow filled by torch's own round-to-nearest-even conversion (tests,
+    micro-benchmarks: stands in for a producer kernel)."""
+    y, _ = _alloc_shadowed(t.shape, t.device)
+    y.copy_(t)
+    n = t.numel()
+    sh = torch.empty(0, dtype=torch.bfloat16, device=t.device).set_(y.untyped_storage(), 2 * n, (n,))
+    sh.copy_(t.reshape(-1).to(torch.bfloat16))
+    return y
+
+
+def _shadow_ptr(x):
+    """Address of the bf16 shadow a producer wrote behind x, or None."""
+    if x is None or not _FUSE["bf16_shadow"] or x.dtype != torch.float32 or x.storage_offset() != 0 or not x.is_contiguous():
+        return None
+    n = x.numel()
+    if n == 0 or x.untyped_storage().nbytes() != n * 6:
+        return None
+    return x.data_ptr() + n * 4
+
+
 def _conv_call(ks, stride, up, x0, x1, wp, bias, y0, y1, dims_in, dims_out, kx=0, accum=False, stats=None, res=None):
     L = _lib.lib()
     B = x0.shape[0]
@@ -350,7 +391,12 @@ def _conv_bf16_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res
     flops = 2.0 * nvox * 125 * (C0 + C1) * (Cy0 + Cy1)
     nbytes = 4.0 * nvox * (C0 + C1 + Cy0 + Cy1) + 2.0 * 125 * (C0 + C1) * (Cy0 + Cy1)
     tag = "conv-bf16 k5 s1 %d^3x%d %d->%d" % (dims[2], B, C0 + C1, Cy0 + Cy1)
+    h0, h1 = _shadow_ptr(x0), _shadow_ptr(x1)
     with _Timed(tag, flops, nbytes):
+        if h0 is not None and (x1 is None or h1 is not None) and C0 % 8 == 0 and C1 % 8 == 0:
+            check(L.vnet_conv_fwd_bf16_x16(h0, C0, h1, C1, _ptr(wp), _ptr(bias), _ptr(y0), Cy0, _ptr(y1), Cy1, B, *dims,
+                                           int(bool(accum)), _ptr(res), _ptr(stats), _ptr(ws), nb, _stream()), "vnet_conv_fwd_bf16_x16")
+            return
         if stats is not None:
             check(L.vnet_conv_fwd_bf16_stats(_ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias), _ptr(y0), Cy0, B, *dims,
                                              _ptr(res), _ptr(stats), _ptr(ws), nb, _stream()), "vnet_conv_fwd_bf16_stats")
@@ -372,7 +418,12 @@ def _wgrad_bf16_call(x0, x1, dy, dw, dims):
     flops = 2.0 * nvox * 125 * (C0 + C1) * Co
     nbytes = 4.0 * (nvox * (C0 + C1 + Co) + 125 * (C0 + C1) * Co)
     tag = _wgrad_tag(True, 5, 0, 1, dims[2], B, C0 + C1, Co)
+    h0, h1, hd = _shadow_ptr(x0), _shadow_ptr(x1), _shadow_ptr(dy)
     with _Timed(tag, flops, nbytes):
+        if h0 is not None and hd is not None and (x1 is None or h1 is not None) and C0 % 8 == 0 and C1 % 8 == 0 and Co % 8 == 0:
+            check(L.vnet_conv_wgrad_bf16_x16(h0, C0, h1, C1, hd, Co, _ptr(dw), B, *dims, _ptr(ws), nb, _stream()),
+                  "vnet_conv_wgrad_bf16_x16")
+            return
         check(L.vnet_conv_wgrad_bf16(_ptr(x0), C0, _ptr(x1), C1, _ptr(dy), Co, _ptr(dw), B, *dims,
                                      _ptr(ws), nb, _stream()), "vnet_conv_wgrad_bf16")
 
@@ -480,6 +531,7 @@ def _slot_target(slot, dy, shape):
 # made.  Stand-alone layers2.convolution (outside the networks) keeps the generic column sum.
 import os as _os
 _FUSE = {"zero_bias_grad": False, "bn_stats": _os.environ.get("VNET_BN_STATS", "1") != "0",
+         "bf16_shadow": _os.environ.get("VNET_BF16_SHADOW", "1") != "0",
          "bn_stats_fp32_direct": _os.environ.get("VNET_BN_STATS_FP32", "1") == "1"}     # (environment: A/B measurements)
 
 
@@ -489,6 +541,12 @@ def set_epilogue_bn_stats(on, fp32_direct=None):
     _FUSE["bn_stats"] = bool(on)
     if fp32_direct is not None:
         _FUSE["bn_stats_fp32_direct"] = bool(fp32_direct)
+
+
+def set_bf16_shadows(on):
+    """Switch for the bf16 shadows of the activations in bf16 compute mode (on by default; off = the convolutions convert the
+    fp32 tensors while staging; results are bit-identical either way)."""
+    _FUSE["bf16_shadow"] = bool(on)
 
 
 @contextlib.contextmanager
@@ -768,10 +826,16 @@ def conv(x0, w, b, ks, stride=1, x1=None, bn_stats=False, bn_residual=None):
         dims_out = tuple(_same_out(int(v), stride) for v in x0.shape[1:4])
         bf16 = ks == 5 and stride == 1 and _COMPUTE["dtype"] == "bf16"
         stats = _epilogue_stats_buffer(bf16, ks, 0, stride, x0, x1, w.shape[-1], dims_out)
+    dy16 = ks == 5 and stride == 1 and _want_shadow(int(w.shape[-1]))
     if stats is None:
-        return _ConvFn.apply(x0, x1, w, b, ks, stride, False, None)
+        y = _ConvFn.apply(x0, x1, w, b, ks, stride, False, None)
+        if dy16:
+            y._vnet_dy16 = True            # the batch-norm behind y writes a bf16 shadow of ds (= this convolution's dy)
+        return y
     y = _ConvFn.apply(x0, x1, w, b, ks, stride, False, None, stats, bn_residual)
     y._vnet_stats = _EpilogueStats(stats, stats.shape[0], bn_residual)
+    if dy16:
+        y._vnet_dy16 = True
     return y
 
 
@@ -834,6 +898,7 @@ class _BnActFn(torch.autograd.Function):
         L = _lib.lib()
         ctx.slot_r = getattr(r, "_vnet_slot", None)
         pre, r_orig = getattr(x, "_vnet_stats", None), r
+        ctx.dy16 = bool(getattr(x, "_vnet_dy16", False))
         x = x.contiguous()
         r = r.contiguous() if r is not None else None
         C = gamma.numel()
@@ -845,9 +910,12 @@ class _BnActFn(torch.autograd.Function):
         ws = workspace(nb, dev)
         ctx.m_total = _bn_statistics(L, x, r, bcast, M, C, mean, invstd, mm, mv, ws, nb, pre, r_orig)
         ctx.sync = _SYNC_BN
-        y = torch.empty(x.shape[:-1] + (C,), dtype=torch.float32, device=dev)
-        check(L.vnet_bn_act_fwd(_ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
-                                act, _ptr(alpha), _ptr(y), _stream()), "vnet_bn_act_fwd")
+        if _want_shadow(C):
+            y, yh = _alloc_shadowed(x.shape[:-1] + (C,), dev)
+        else:
+            y, yh = torch.empty(x.shape[:-1] + (C,), dtype=torch.float32, device=dev), None
+        check(L.vnet_bn_act_fwd_x16(_ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
+                                    act, _ptr(alpha), _ptr(y), yh, _stream()), "vnet_bn_act_fwd")
         ctx.save_for_backward(x, r, gamma, beta, alpha, mean, invstd)
         ctx.params = (gamma, beta, alpha)
         ctx.cfg = (act, bcast, M, C)
@@ -867,10 +935,21 @@ class _BnActFn(torch.autograd.Function):
         dbeta, sbt = _grad_out(bref)
         dalpha, sa = _grad_out(aref) if alpha is not None else (None, None)
         need_ds = ctx.needs_input_grad[0] or (r is not None and ctx.needs_input_grad[1])
-        ds = torch.empty_like(dy) if need_ds else None
+        dsh = None
+        if need_ds and ctx.dy16 and not bcast and _want_shadow(C):
+            ds, dsh = _alloc_shadowed(dy.shape, dev)
+        else:
+            ds = torch.empty(dy.shape, dtype=torch.float32, device=dev) if need_ds else None
         nb = L.vnet_bn_ws_bytes(C)
         ws = workspace(nb, dev)
-        if ctx.sync is None:
+        if ctx.sync is None and dsh is not None:
+            check(L.vnet_bn_act_bwd_reduce(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd),
+                                           _ptr(gamma), _ptr(beta), act, _ptr(alpha), _ptr(dgamma), _ptr(dbeta),
+                                           _ptr(dalpha), _ptr(ws), nb, _stream()), "vnet_bn_act_bwd_reduce")
+            check(L.vnet_bn_act_bwd_apply_x16(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd),
+                                              _ptr(gamma), _ptr(beta), act, _ptr(alpha), _ptr(dbeta), _ptr(dgamma),
+                                              float(M), None, _ptr(ds), dsh, _stream()), "vnet_bn_act_bwd_apply")
+        elif ctx.sync is None:
             check(L.vnet_bn_act_bwd(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd), _ptr(gamma),
                                     _ptr(beta), act, _ptr(alpha), _ptr(dgamma), _ptr(dbeta), _ptr(dalpha), _ptr(ds),
                                     _ptr(ws), nb, _stream()), "vnet_bn_act_bwd")
@@ -883,9 +962,9 @@ class _BnActFn(torch.autograd.Function):
             if ds is not None:
                 tot = torch.cat([dbeta.reshape(-1), dgamma.reshape(-1)])
                 ctx.sync[0](tot)
-                check(L.vnet_bn_act_bwd_apply(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd),
-                                              _ptr(gamma), _ptr(beta), act, _ptr(alpha), _ptr(tot), _ptr(tot[C:]),
-                                              ctx.m_total, None, _ptr(ds), _stream()), "vnet_bn_act_bwd_apply")
+                check(L.vnet_bn_act_bwd_apply_x16(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd),
+                                                  _ptr(gamma), _ptr(beta), act, _ptr(alpha), _ptr(tot), _ptr(tot[C:]),
+                                                  ctx.m_total, None, _ptr(ds), dsh, _stream()), "vnet_bn_act_bwd_apply")
         th = getattr(gref, "_vnet_deferred", None)
         if th is not None and sg is not None and sbt is not None:
             del gref._vnet_deferred
@@ -907,6 +986,7 @@ class _BnChainFn(torch.autograd.Function):
     def forward(ctx, x, kind, act, alpha, g1, b1, g2, b2, g3, b3, bufs):
         L = _lib.lib()
         pre = getattr(x, "_vnet_stats", None)
+        ctx.dy16 = bool(getattr(x, "_vnet_dy16", False))
         x = x.contiguous()
         C = g1.numel()
         M = x.numel() // C
@@ -923,9 +1003,12 @@ class _BnChainFn(torch.autograd.Function):
         check(L.vnet_bn_chain_coef_fwd(kind, C, BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(invstd), _ptr(g1), _ptr(b1), _ptr(g2), _ptr(b2),
                                        _ptr(g3), _ptr(b3), _ptr(ceff), _ptr(deff), _ptr(mm2), _ptr(mv2), _ptr(mm3), _ptr(mv3),
                                        _stream()), "vnet_bn_chain_coef_fwd")
-        y = torch.empty_like(x)
-        check(L.vnet_bn_act_fwd(_ptr(x), None, 0, M, C, _ptr(mean), _ptr(invstd), _ptr(ceff), _ptr(deff),
-                                act, _ptr(alpha), _ptr(y), _stream()), "vnet_bn_act_fwd")
+        if _want_shadow(C):
+            y, yh = _alloc_shadowed(x.shape, dev)
+        else:
+            y, yh = torch.empty(x.shape, dtype=torch.float32, device=dev), None
+        check(L.vnet_bn_act_fwd_x16(_ptr(x), None, 0, M, C, _ptr(mean), _ptr(invstd), _ptr(ceff), _ptr(deff),
+                                    act, _ptr(alpha), _ptr(y), yh, _stream()), "vnet_bn_act_fwd")
         ctx.save_for_backward(x, alpha, g1, g2, g3, mean, invstd, ceff, deff)
         ctx.params = (alpha, g1, b1, g2, b2, g3, b3)
         ctx.cfg = (kind, act, M, C)
@@ -962,10 +1045,13 @@ class _BnChainFn(torch.autograd.Function):
                                        _ptr(extra), _stream()), "vnet_bn_chain_coef_bwd")
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(dy)
-            check(L.vnet_bn_act_bwd_apply(_ptr(dy), _ptr(x), None, 0, M, C, _ptr(mean), _ptr(invstd), _ptr(ceff), _ptr(deff),
-                                          act, _ptr(alpha), _ptr(dDg), _ptr(dCg), ctx.m_total, _ptr(extra), _ptr(dx), _stream()),
-                  "vnet_bn_act_bwd_apply")
+            if ctx.dy16 and _want_shadow(C):
+                dx, dxh = _alloc_shadowed(dy.shape, dev)
+            else:
+                dx, dxh = torch.empty(dy.shape, dtype=torch.float32, device=dev), None
+            check(L.vnet_bn_act_bwd_apply_x16(_ptr(dy), _ptr(x), None, 0, M, C, _ptr(mean), _ptr(invstd), _ptr(ceff), _ptr(deff),
+                                              act, _ptr(alpha), _ptr(dDg), _ptr(dCg), ctx.m_total, _ptr(extra), _ptr(dx), dxh,
+                                              _stream()), "vnet_bn_act_bwd_apply")
         g3ret = _grad_ret(dg3, s3) if g3r is not None else None
         b3ret = _grad_ret(db3, t3) if b3r is not None else None
         return (dx, None, None, _grad_ret(dalpha, sa) if alpha is not None else None, _grad_ret(dg1, s1), _grad_ret(db1, t1),
@@ -1201,13 +1287,13 @@ class _DropoutFn(torch.autograd.Function):
     def forward(ctx, x, rate, seed):
         L = _lib.lib()
         x = x.contiguous()
-        y = torch.empty_like(x)
+        if x.dim() == 5 and _want_shadow(int(x.shape[-1])):
+            y, yh = _alloc_shadowed(x.shape, x.device)
+        else:
+            y, yh = torch.empty(x.shape, dtype=torch.float32, device=x.device), None
         mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
         st = _STEP_STATE["active"]
-        if st is not None:
-            check(L.vnet_dropout_fwd_dev(_ptr(x), _ptr(y), _ptr(mask), x.numel(), rate, seed, _ptr(st), _stream()), "vnet_dropout_fwd_dev")
-        else:
-            check(L.vnet_dropout_fwd(_ptr(x), _ptr(y), _ptr(mask), x.numel(), rate, seed, _stream()), "vnet_dropout_fwd")
+        check(L.vnet_dropout_fwd_x16(_ptr(x), _ptr(y), yh, _ptr(mask), x.numel(), rate, seed, _ptr(st), _stream()), "vnet_dropout_fwd")
         ctx.save_for_backward(mask)
         ctx.rate = rate
         return y
