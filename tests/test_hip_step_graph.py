@@ -201,3 +201,30 @@ def test_data_parallel_segmented_graph_rccl_group_of_one(tmp_path, dev):
         b = torch.load(tmp_path / ("dp_%s.pt" % md))
         assert a["losses"] == b["losses"], md
         assert torch.equal(a["data"], b["data"]), md
+
+
+def test_refused_capture_falls_back_to_eager_steps(dev, monkeypatch):
+    """A capture the runtime refuses (RuntimeError from torch.cuda.graph) must not end the job: the step keeps running
+    eagerly -- same math (the bit-identity tests above) -- and never retries the capture."""
+    from vnet_tensorflow_amd import ops
+    from vnet_tensorflow_amd.model import image2label
+    from oracle.vnet_oracle import synthetic_batch
+    monkeypatch.setenv("VNET_STEP_GRAPH", "1")
+    np.random.seed(7)
+    m = image2label(None, _cfg(), device=dev, verbose=False)
+    m.read_config()
+    m.build_model_graph()
+    m._setup_training()
+    calls = []
+
+    def refuse(*a, **k):
+        calls.append(1)
+        raise RuntimeError("hipErrorStreamCaptureUnsupported (simulated)")
+    monkeypatch.setattr(m, "_build_step_graph", refuse)
+    x, l = synthetic_batch(2, 16, 1, 2, seed=40)
+    x, l = torch.from_numpy(x).to(dev), torch.from_numpy(l).to(dev)
+    losses = [float(m.train_step(x, l)) for _ in range(6)]
+    assert len(calls) == 1 and m.step_mode() == "off" and m.global_step == 6
+    ref, _, _, _ = _run(dev, False, 6, monkeypatch)
+    # same seed, same first batch repeated vs alternating batches: only the first step is comparable
+    assert losses[0] == ref[0] and all(np.isfinite(losses)) and losses[-1] < losses[0]

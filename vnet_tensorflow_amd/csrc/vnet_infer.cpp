@@ -143,7 +143,7 @@ static std::map<std::string, Var> load_weights(const std::string& path) {
 }
 
 // ---- the network (forward only), wired on the C ABI ----------------------------------------------------------------
-struct Tensor { float* p; int B, D, H, W, C; size_t numel() const { return (size_t)B * D * H * W * C; } int64_t rows() const { return (int64_t)B * D * H * W; } };
+struct Tensor { float* p; void* h /* bf16 shadow behind the fp32 data (bf16 mode, vnet_hip.h *_x16) or null */; int B, D, H, W, C; size_t numel() const { return (size_t)B * D * H * W * C; } int64_t rows() const { return (int64_t)B * D * H * W; } };
 
 struct Config {
     int classes = 2, channels = 16, levels = 4, bottom = 3, batch = 1;
@@ -210,11 +210,13 @@ private:
         if (it == vars_.end()) { std::fprintf(stderr, "weights blob has no variable %s\n", name.c_str()); std::exit(1); }
         return it->second;
     }
-    Tensor alloc(int B, int D, int H, int W, int C) {
-        Tensor t{nullptr, B, D, H, W, C};
-        size_t bytes = (t.numel() * 4 + 255) / 256 * 256;
+    Tensor alloc(int B, int D, int H, int W, int C, bool shadow = false) {
+        Tensor t{nullptr, nullptr, B, D, H, W, C};
+        shadow = shadow && cfg.bf16 && C % 8 == 0;
+        size_t bytes = (t.numel() * (shadow ? 6 : 4) + 255) / 256 * 256;
         if (top_ + bytes > arena_bytes_) { std::fprintf(stderr, "activation arena too small\n"); std::exit(1); }
         t.p = (float*)(arena_ + top_); top_ += bytes;
+        if (shadow) t.h = (char*)t.p + t.numel() * 4;
         return t;
     }
     float* pack(const std::string& wname, int mode, int taps, int I, int O) {
@@ -232,11 +234,11 @@ private:
         const std::string name = sc + "/batch_normalization" + (n ? "_" + std::to_string(n) : "");
         Var& g = var(name + "/gamma"); Var& b = var(name + "/beta");
         const int C = (int)g.n;
-        Tensor y = alloc(x.B, x.D, x.H, x.W, C);
+        Tensor y = alloc(x.B, x.D, x.H, x.W, C, true);
         float* mean = stat_; float* invstd = stat_ + 1024;
         ABI_OK(vnet_bn_stats(x.p, res ? res->p : nullptr, tile ? 1 : 0, x.rows(), C, 1e-3f, 0.99f, mean, invstd, nullptr, nullptr, ws_, ws_bytes_, st_));
         const float* alpha = act == VNET_ACT_PRELU ? var(sc + "/alpha").dev : nullptr;
-        ABI_OK(vnet_bn_act_fwd(x.p, res ? res->p : nullptr, tile ? 1 : 0, x.rows(), C, mean, invstd, g.dev, b.dev, act, alpha, y.p, st_));
+        ABI_OK(vnet_bn_act_fwd_x16(x.p, res ? res->p : nullptr, tile ? 1 : 0, x.rows(), C, mean, invstd, g.dev, b.dev, act, alpha, y.p, y.h, st_));
         return y;
     }
     // the decoder's batch-norm chains in closed form (include/vnet_hip.h, vnet_bn_chain_coef_fwd): one fused normalisation of x
@@ -252,12 +254,12 @@ private:
             Var& g = var(name + "/gamma"); Var& b = var(name + "/beta");
             gp[k] = g.dev; bp[k] = b.dev; C = (int)g.n;
         }
-        Tensor y = alloc(x.B, x.D, x.H, x.W, C);
+        Tensor y = alloc(x.B, x.D, x.H, x.W, C, true);
         float* mean = stat_; float* invstd = stat_ + 1024; float* ceff = stat_ + 2048; float* deff = stat_ + 3072;
         ABI_OK(vnet_bn_stats(x.p, nullptr, 0, x.rows(), C, 1e-3f, 0.99f, mean, invstd, nullptr, nullptr, ws_, ws_bytes_, st_));
         ABI_OK(vnet_bn_chain_coef_fwd(kind, C, 1e-3f, 0.99f, mean, invstd, gp[0], bp[0], gp[1], bp[1], gp[2], bp[2], ceff, deff,
                                       nullptr, nullptr, nullptr, nullptr, st_));
-        ABI_OK(vnet_bn_act_fwd(x.p, nullptr, 0, x.rows(), C, mean, invstd, ceff, deff, VNET_ACT_PRELU, var(sc + "/alpha").dev, y.p, st_));
+        ABI_OK(vnet_bn_act_fwd_x16(x.p, nullptr, 0, x.rows(), C, mean, invstd, ceff, deff, VNET_ACT_PRELU, var(sc + "/alpha").dev, y.p, y.h, st_));
         return y;
     }
     Tensor conv(const Tensor& x0, const Tensor* x1, int ks, int stride, int Cout) {
@@ -268,8 +270,12 @@ private:
         if (cfg.bf16 && ks == 5 && stride == 1) {
             float* wpb = pack(sc + "/weights", VNET_PACK_FWD_BF16, 125, Cin, Cout);
             if (vnet_conv_bf16_ws_bytes(Cin, Cout, x0.B, Do, Ho, Wo) > ws_bytes_) { std::fprintf(stderr, "workspace too small\n"); std::exit(1); }
-            ABI_OK(vnet_conv_fwd_bf16(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, wpb, var(sc + "/biases").dev,
-                                      y.p, Cout, nullptr, 0, x0.B, x0.D, x0.H, x0.W, ws_, ws_bytes_, st_));
+            if (x0.h && (!x1 || x1->h))         // every source carries its bf16 image: stage that (half the bytes, no conversion)
+                ABI_OK(vnet_conv_fwd_bf16_x16(x0.h, x0.C, x1 ? x1->h : nullptr, x1 ? x1->C : 0, wpb, var(sc + "/biases").dev,
+                                              y.p, Cout, nullptr, 0, x0.B, x0.D, x0.H, x0.W, 0, nullptr, nullptr, ws_, ws_bytes_, st_));
+            else
+                ABI_OK(vnet_conv_fwd_bf16(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, wpb, var(sc + "/biases").dev,
+                                          y.p, Cout, nullptr, 0, x0.B, x0.D, x0.H, x0.W, ws_, ws_bytes_, st_));
             return y;
         }
         float* wp = pack(sc + "/weights", VNET_PACK_FWD, ks * ks * ks, Cin, Cout);
@@ -383,7 +389,7 @@ int main(int argc, char** argv) {
     auto vars = load_weights(cfg.weights);
     VNetForward net(cfg, vars, compute);
     const size_t patch_vox = (size_t)P0 * P1 * P2;
-    net.set_arena((size_t)cfg.batch * patch_vox * 4 * (size_t)(cfg.channels * 14 + 64) + ((size_t)64 << 20));
+    net.set_arena((size_t)cfg.batch * patch_vox * (cfg.bf16 ? 6 : 4) * (size_t)(cfg.channels * 14 + 64) + ((size_t)64 << 20));
 
     // patch enumeration, model.py:866-903 (last patch clamped to the border; the last batch is appended twice)
     int num[3]; const int dims[3] = {X, Y, Z};
@@ -443,7 +449,7 @@ int main(int argc, char** argv) {
         if (bi + 1 < batches.size())
             next = std::async(std::launch::async, [&, bi] { HIP_OK(hipEventSynchronize(consumed[(bi + 1) & 1])); crop(bi + 1, (int)((bi + 1) & 1)); });
         HIP_OK(hipStreamWaitEvent(compute, copied[slot], 0));
-        Tensor in{d_in[slot], (int)batches[bi].size(), P0, P1, P2, Cin};
+        Tensor in{d_in[slot], nullptr, (int)batches[bi].size(), P0, P1, P2, Cin};
         Tensor sm = net.forward(in);
         for (size_t p = 0; p < batches[bi].size(); ++p)
             ABI_OK(vnet_accumulate_patch(sm.p + p * patch_vox * K, d_vol, d_cnt, K, P0, P1, P2, batches[bi][p][0], batches[bi][p][1],

@@ -438,8 +438,8 @@ class image2label(object):
         ProcessGroupNCCL watchdog thread queries the work's events, and an event last recorded in a capturing stream makes
         that query fail with hipErrorCapturedEvent and terminate the process (seen with a captured RCCL all-reduce in a
         group of one).  TrainingSetting.StepGraph / VNET_STEP_GRAPH = 0|1 switches the feature (default on)."""
-        if getattr(self, "force_eager", False):      # e.g. bench.py's per-launch timing pass (events cannot be timed in a graph)
-            return "off"
+        if getattr(self, "force_eager", False) or getattr(self, "_graph_failed", False):
+            return "off"                       # bench.py's per-launch timing pass (events cannot be timed in a graph) / failed capture
         want = os.environ.get("VNET_STEP_GRAPH")
         want = getattr(self, "step_graph", True) if want is None else want not in ("0", "off", "false")
         if not want or self.device.type != "cuda":
@@ -532,6 +532,15 @@ class image2label(object):
             tuner.after()
         return loss
 
+    def _all_ranks_agree(self, ok):
+        """True iff `ok` on every rank (data parallel: all ranks must enqueue their steps the same way)."""
+        if self.world <= 1 or not torch.distributed.is_initialized():
+            return bool(ok)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                            device=self.device if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        return bool(int(flag.item()))
+
     def step_mode(self):
         """How train_step currently enqueues the step: 'off' (eager) | 'whole' | 'segmented'."""
         t = getattr(self, "_tuner", None)
@@ -566,7 +575,18 @@ class image2label(object):
         lr = optim.exponential_decay(self.initial_learning_rate, self.global_step, self.decay_steps, self.decay_factor)
         if self._graphs is None:
             torch.cuda.current_stream(self.device).synchronize()
-            self._build_step_graph(mode, images, labels, dropout)
+            err = None
+            try:
+                self._build_step_graph(mode, images, labels, dropout)
+            except VnetHipError:
+                raise
+            except RuntimeError as e:       # a capture the runtime refuses must not end the job: the eager step is the same math
+                err = e
+            if not self._all_ranks_agree(err is None):
+                self._graphs, self._graph_failed = None, True
+                self._print("{}: step graph capture failed ({}); continuing with eager steps".format(
+                    _now(), str(err).splitlines()[0] if err is not None else "on another rank"))
+                return self._train_step_eager(images, labels, dropout)
         else:
             self._g_images.copy_(images, non_blocking=True)
             self._g_labels.copy_(labels, non_blocking=True)
