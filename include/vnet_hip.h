@@ -134,11 +134,14 @@ int vnet_conv_fwd_bf16_stats(const float* x0, int C0, const float* x1, int C1, c
  * a batch-norm backward kernel (dy); the *_x16 producers below write, next to the fp32 tensor, its bf16 image (RNE -- the very
  * rounding the kernels above apply while staging), and these entry points stage THAT: half the bytes through L2, no
  * conversion, bit-identical results.  x0h/x1h/dyh: 16-byte aligned, 2-byte elements, same NDHWC indexing; channel counts
- * multiples of 8 (VNET_E_UNSUPPORTED otherwise -- use the fp32-source entry points).  accum/res/stats as in
- * vnet_conv_fwd_bf16_acc / _stats (stats requires Cy1 == 0). */
+ * multiples of 8 (VNET_E_UNSUPPORTED otherwise -- use the fp32-source entry points).  res/stats as in
+ * vnet_conv_fwd_bf16_stats (stats requires Cy1 == 0).  acc: NULL, or a tensor added to the result -- acc == y0 is
+ * vnet_conv_fwd_bf16_acc (y0 += conv); any other tensor of y0's shape (Cy1 == 0) gives y0 = conv + acc out of place, which is
+ * what backward-data needs when the other gradient of a forked tensor IS this convolution's input dy (a one-convolution
+ * residual block, networks.py:314-318). */
 int vnet_conv_fwd_bf16_x16(const void* x0h, int C0, const void* x1h, int C1, const void* wp, const float* bias,
                            float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
-                           int accum, const float* res, float* stats, void* ws, size_t ws_bytes, void* stream);
+                           const float* acc, const float* res, float* stats, void* ws, size_t ws_bytes, void* stream);
 int vnet_conv_wgrad_bf16_x16(const void* x0h, int C0, const void* x1h, int C1, const void* dyh, int Cout, float* dw,
                              int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream);
 

@@ -210,8 +210,9 @@ def test_gradient_accumulation_in_the_producing_kernel(dev, compute):
         ops.set_compute_dtype("fp32")
     for n in grads[True][0]:
         assert np.array_equal(grads[True][0][n], grads[False][0][n]), n
-    # 3 levels: 3 skip forks + residual forks at levels 2, 3 and the bottom = 6 full-tensor adds saved
-    assert grads[False][1] - grads[True][1] >= 6, (grads[False][1], grads[True][1])
+    # 3 levels: 3 skip forks + residual forks at levels 2, 3 and the bottom = 6 full-tensor adds saved; in bf16 mode also the
+    # level-1 block (ONE convolution: the other gradient is that convolution's own dy -> added out of place in its epilogue)
+    assert grads[False][1] - grads[True][1] >= (7 if compute == "bf16" else 6), (grads[False][1], grads[True][1])
 
 
 @pytest.mark.parametrize("mode,ks,stride,shape,Cin,Cout,residual", [

@@ -36,6 +36,7 @@ struct ConvArgs {
     int upO;           // UP: real output channels O (N' = 8*O)
     int nz;            // tap (dz) splits per K-split: deep levels have too few bricks to fill 256 CUs
     int accum;         // 1: y += result (backward-data into a gradient another consumer of the same tensor already wrote)
+    const float* accsrc;   // bf16 kernels, accum: read the other gradient from HERE (y0's layout) instead of y0 -- out of place
     // batch-norm statistics of the output in the epilogue (round 2): per-workgroup partial sums of v = y (+ res) and v^2 per
     // channel, row [2][Cout] per brick (or per reduce block for split-K launches); the batch-norm that consumes y then
     // only runs its finalize.  res: optional residual that is added in front of that batch-norm (networks.py:318).
@@ -422,7 +423,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv_kernel(ConvArgs a) {
 // y = sum_s part[s] + bias, scattered to the (possibly dual) NDHWC destination
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, size_t part_stride, int nsplit,
                                      const float* __restrict__ bias, float* y0, float* y1, int Cy0, int Cy1,
-                                     int CoutP, size_t nvox, int accum, const float* __restrict__ res, float* __restrict__ stats) {
+                                     int CoutP, size_t nvox, int accum, const float* __restrict__ res, float* __restrict__ stats,
+                                     const float* accsrc = nullptr) {
     const int Cout = Cy0 + Cy1;
     const size_t total = nvox * (size_t)Cout;
     // statistics (stats != NULL): 256 % Cout == 0, so a thread meets ONE channel (tid % Cout) on its whole grid-stride walk
@@ -433,7 +435,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, size_t part
         for (int k = 0; k < nsplit; ++k) s += part[k * part_stride + v * CoutP + c];
         if (stats) { const float w = s + (res ? res[idx] : 0.f); t1 += w; t2 += w * w; }
         float* dst = (c < Cy0) ? y0 + v * Cy0 + c : y1 + v * Cy1 + (c - Cy0);
-        *dst = accum ? *dst + s : s;
+        *dst = accum ? (accsrc ? accsrc[idx] : *dst) + s : s;      // accsrc: single output (Cy1 == 0), same layout as y0
     }
     if (stats) {
         __shared__ float sh[2][256];
@@ -1239,7 +1241,10 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
                         for (int k = 0; k < 4; ++k) { s1[n][g][k] += vv[k]; s2[n][g][k] += vv[k] * vv[k]; }
                     }
                     float* p = (co < a.Cy0) ? a.y0 + ov * a.Cy0 + co : a.y1 + ov * a.Cy1 + (co - a.Cy0);
-                    if (a.accum) { const float4 old = *reinterpret_cast<const float4*>(p); e[0] += old.x; e[1] += old.y; e[2] += old.z; e[3] += old.w; }
+                    if (a.accum) {
+                        const float4 old = *reinterpret_cast<const float4*>(a.accsrc ? a.accsrc + ov * a.Cy0 + co : p);
+                        e[0] += old.x; e[1] += old.y; e[2] += old.z; e[3] += old.w;
+                    }
                     *reinterpret_cast<float4*>(p) = make_float4(e[0], e[1], e[2], e[3]);
                 } else {
 #pragma unroll
@@ -1247,7 +1252,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
                         const int ck = co + k;
                         if (ck >= a.Cout) break;
                         float* dst = (ck < a.Cy0) ? a.y0 + ov * a.Cy0 + ck : a.y1 + ov * a.Cy1 + (ck - a.Cy0);
-                        *dst = e[k] + (a.bias ? a.bias[ck] : 0.f) + (a.accum ? *dst : 0.f);
+                        *dst = e[k] + (a.bias ? a.bias[ck] : 0.f) + (a.accum ? (a.accsrc ? a.accsrc[ov * a.Cy0 + ck] : *dst) : 0.f);
                     }
                 }
             }
@@ -1500,7 +1505,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     for (int k = 0; k < 4; ++k) { s1[k] += vv[k]; s2[k] += vv[k] * vv[k]; }
                 }
                 float* p = (co < a.Cy0) ? a.y0 + ov * a.Cy0 + co : a.y1 + ov * a.Cy1 + (co - a.Cy0);
-                if (a.accum) { const float4 old = *reinterpret_cast<const float4*>(p); e[0] += old.x; e[1] += old.y; e[2] += old.z; e[3] += old.w; }
+                if (a.accum) {
+                    const float4 old = *reinterpret_cast<const float4*>(a.accsrc ? a.accsrc + ov * a.Cy0 + co : p);
+                    e[0] += old.x; e[1] += old.y; e[2] += old.z; e[3] += old.w;
+                }
                 *reinterpret_cast<float4*>(p) = make_float4(e[0], e[1], e[2], e[3]);
             }
             if constexpr (STATS) {
@@ -2055,7 +2063,7 @@ static int conv_fwd_bf16_go(ConvArgs& a, const Bf16Plan& p, int nslab, int C0, i
 static int conv_fwd_bf16_impl(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
                               float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
                               void* ws, size_t ws_bytes, void* stream, int accum, const float* res = nullptr, float* stats = nullptr,
-                              bool src16 = false) {
+                              bool src16 = false, const float* accsrc = nullptr) {
     if (!x0 || !wp || !y0 || C0 <= 0 || Cy0 <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return VNET_E_BADARG;
     if ((C1 > 0 && !x1) || (Cy1 > 0 && !y1) || C1 < 0 || Cy1 < 0) return VNET_E_BADARG;
     if (src16 && ((C0 & 7) || (C1 & 7) || ((reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(x1)) & 15))) return VNET_E_UNSUPPORTED;
@@ -2070,6 +2078,10 @@ static int conv_fwd_bf16_impl(const float* x0, int C0, const float* x1, int C1, 
     a.vec_in = (C0 % 4 == 0) && (C1 % 4 == 0);
     a.vec_out = (Cy0 % 4 == 0) && (Cy1 % 4 == 0);
     a.pad = 2; a.padx = 2; a.accum = accum; a.res = res; a.stats = stats;
+    if (accsrc && accsrc != y0) {
+        if (!accum || Cy1 > 0) return VNET_E_BADARG;
+        a.accsrc = accsrc;
+    }
     if (stats && vnet_conv_bf16_stats_rows(a.Cin, Cy0, Cy1, C0, C1, B, D, H, W) == 0) return VNET_E_UNSUPPORTED;
     Bf16Plan p = plan_conv_bf16(a.Cin, a.Cout, B, D, H, W);
     a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.cps = p.cps; a.nz = p.nz;
@@ -2088,7 +2100,7 @@ static int conv_fwd_bf16_impl(const float* x0, int C0, const float* x1, int C1, 
         const size_t total = nvox * a.Cout;
         const int blocks = (int)min((size_t)2048, (total + 255) / 256);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, a.part_stride, nslab, bias,
-                           y0, y1, Cy0, Cy1, a.CoutP, nvox, a.accum, a.res, a.stats);
+                           y0, y1, Cy0, Cy1, a.CoutP, nvox, a.accum, a.res, a.stats, a.accsrc);
         VNET_LAUNCH_CHECK();
     }
     return VNET_OK;
@@ -2112,10 +2124,10 @@ int vnet_conv_fwd_bf16_stats(const float* x0, int C0, const float* x1, int C1, c
 }
 int vnet_conv_fwd_bf16_x16(const void* x0h, int C0, const void* x1h, int C1, const void* wp, const float* bias,
                            float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
-                           int accum, const float* res, float* stats, void* ws, size_t ws_bytes, void* stream) {
+                           const float* acc, const float* res, float* stats, void* ws, size_t ws_bytes, void* stream) {
     if (stats && Cy1 > 0) return VNET_E_BADARG;
     return conv_fwd_bf16_impl(reinterpret_cast<const float*>(x0h), C0, reinterpret_cast<const float*>(x1h), C1, wp, bias,
-                              y0, Cy0, y1, Cy1, B, D, H, W, ws, ws_bytes, stream, accum ? 1 : 0, res, stats, true);
+                              y0, Cy0, y1, Cy1, B, D, H, W, ws, ws_bytes, stream, acc ? 1 : 0, res, stats, true, acc);
 }
 
 }  // extern "C"

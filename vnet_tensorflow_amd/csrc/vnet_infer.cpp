@@ -272,7 +272,7 @@ private:
             if (vnet_conv_bf16_ws_bytes(Cin, Cout, x0.B, Do, Ho, Wo) > ws_bytes_) { std::fprintf(stderr, "workspace too small\n"); std::exit(1); }
             if (x0.h && (!x1 || x1->h))         // every source carries its bf16 image: stage that (half the bytes, no conversion)
                 ABI_OK(vnet_conv_fwd_bf16_x16(x0.h, x0.C, x1 ? x1->h : nullptr, x1 ? x1->C : 0, wpb, var(sc + "/biases").dev,
-                                              y.p, Cout, nullptr, 0, x0.B, x0.D, x0.H, x0.W, 0, nullptr, nullptr, ws_, ws_bytes_, st_));
+                                              y.p, Cout, nullptr, 0, x0.B, x0.D, x0.H, x0.W, nullptr, nullptr, nullptr, ws_, ws_bytes_, st_));
             else
                 ABI_OK(vnet_conv_fwd_bf16(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, wpb, var(sc + "/biases").dev,
                                           y.p, Cout, nullptr, 0, x0.B, x0.D, x0.H, x0.W, ws_, ws_bytes_, st_));

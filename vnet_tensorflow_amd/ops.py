@@ -379,8 +379,9 @@ def _conv_call(ks, stride, up, x0, x1, wp, bias, y0, y1, dims_in, dims_out, kx=0
                  _ptr(ws), nb, _stream()), "vnet_conv_fwd")
 
 
-def _conv_bf16_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res=None):
-    """5^3 stride-1 conv with bf16 operands / fp32 accumulation (vnet_conv_fwd_bf16)."""
+def _conv_bf16_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res=None, acc_src=None):
+    """5^3 stride-1 conv with bf16 operands / fp32 accumulation (vnet_conv_fwd_bf16).
+    accum: y0 += conv; acc_src (needs the bf16 shadows): y0 = conv + acc_src, out of place."""
     L = _lib.lib()
     B = x0.shape[0]
     C0, C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
@@ -394,9 +395,12 @@ def _conv_bf16_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res
     h0, h1 = _shadow_ptr(x0), _shadow_ptr(x1)
     with _Timed(tag, flops, nbytes):
         if h0 is not None and (x1 is None or h1 is not None) and C0 % 8 == 0 and C1 % 8 == 0:
+            acc = _ptr(acc_src) if acc_src is not None else (_ptr(y0) if accum else None)
             check(L.vnet_conv_fwd_bf16_x16(h0, C0, h1, C1, _ptr(wp), _ptr(bias), _ptr(y0), Cy0, _ptr(y1), Cy1, B, *dims,
-                                           int(bool(accum)), _ptr(res), _ptr(stats), _ptr(ws), nb, _stream()), "vnet_conv_fwd_bf16_x16")
+                                           acc, _ptr(res), _ptr(stats), _ptr(ws), nb, _stream()), "vnet_conv_fwd_bf16_x16")
             return
+        if acc_src is not None:
+            raise VnetHipError("out-of-place accumulation needs the bf16 shadows of the convolution's input")
         if stats is not None:
             check(L.vnet_conv_fwd_bf16_stats(_ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias), _ptr(y0), Cy0, B, *dims,
                                              _ptr(res), _ptr(stats), _ptr(ws), nb, _stream()), "vnet_conv_fwd_bf16_stats")
@@ -465,10 +469,11 @@ def colsum(x2d_like, C, out=None):
 # whose backward runs FIRST leaves its gradient tensor in the slot, the second one runs its backward-data kernel in
 # accumulate mode (y += ...) on that tensor and reports no gradient of its own, so the sum costs no extra pass.
 class _GradSlot(object):
-    __slots__ = ("first",)
+    __slots__ = ("first", "total")
 
     def __init__(self):
         self.first = None
+        self.total = None        # the SUM of both gradients, written out of place by the second consumer (see _ConvFn.backward)
 
 
 class _ForkFn(torch.autograd.Function):
@@ -480,7 +485,10 @@ class _ForkFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, ga, gb):
+        total, ctx.slot.total = ctx.slot.total, None
         ctx.slot.first = None    # drop the slot's reference: a leaf behind this node can then take the gradient without a copy
+        if total is not None:
+            return total, None   # one consumer's kernel already added the other's gradient (out of place)
         if gb is None:
             return ga, None
         if ga is None:
@@ -662,6 +670,13 @@ class _ConvFn(torch.autograd.Function):
             slot0, slot1 = ctx.slots
             # x0 has a second consumer whose gradient exists already: add this one into it (single-source convs only)
             acc = _slot_target(slot0, dy, x0.shape) if x1 is None else None
+            # one-convolution residual block: the other gradient of x0 IS this node's dy (batch-norm's ds serves the conv
+            # output and the residual) -- no in-place sum, but the bf16 kernels can add it on the way out: dx0 = conv(dy) + dy
+            oop = None
+            if (acc is None and x1 is None and ctx.bf16 and slot0 is not None and slot0.first is not None
+                    and slot0.first.data_ptr() == dy.data_ptr() and tuple(dy.shape) == tuple(x0.shape)
+                    and _shadow_ptr(dy) is not None and C0 % 8 == 0):
+                oop = dy
             dx0 = acc if acc is not None else torch.empty_like(x0)
             dx1 = torch.empty_like(x1) if x1 is not None else None
             accum = acc is not None
@@ -672,7 +687,9 @@ class _ConvFn(torch.autograd.Function):
                 wp = packed_weights(w, PACK_UP, 8, O, I)
                 _conv_call(2, 2, 1, dy, None, wp, None, dx0, None, dout, din, accum=accum)
             elif ctx.bf16:
-                _conv_bf16_call(dy, None, packed_weights(w, PACK_BWD_BF16, 125, I, O), None, dx0, dx1, din, accum=accum)
+                _conv_bf16_call(dy, None, packed_weights(w, PACK_BWD_BF16, 125, I, O), None, dx0, dx1, din, accum=accum, acc_src=oop)
+                if oop is not None:
+                    slot0.total = dx0
             else:
                 wp = packed_weights(w, PACK_BWD, ks ** 3, I, O)
                 _conv_call(ks, 1, 0, dy, None, wp, None, dx0, dx1, dout, din, accum=accum)
