@@ -93,6 +93,9 @@ def test_producers_write_rne_shadows(dev):
         assert ops._shadow_ptr(d) is not None
         sh = torch.empty(0, dtype=torch.bfloat16, device=dev).set_(d.untyped_storage(), 2 * n, (n,))
         assert torch.equal(sh, d.reshape(-1).to(torch.bfloat16))
+        # a look-alike is not a shadow: first two of three slabs = offset 0, contiguous, storage exactly 1.5x the view
+        look = torch.randn(3, 4, 4, 4, 16, device=dev)[:2]
+        assert look.untyped_storage().nbytes() == look.numel() * 6 and ops._shadow_ptr(look) is None
         # fp32 mode: plain allocations
         ops.set_compute_dtype("fp32")
         y32 = ops.bn_act(x.detach(), gamma.detach(), beta.detach(), "prelu", alpha.detach())

@@ -318,8 +318,8 @@ class _Timed(object):
 # Every input of a bf16-operand 5^3 convolution is written by a batch-norm / dropout kernel (forward) or a batch-norm backward
 # kernel (dy).  Those producers write, behind the fp32 tensor IN THE SAME ALLOCATION, its bf16 image (round-to-nearest-even,
 # the rounding the convolution kernels apply while staging), and the convolutions stage that image instead: half the bytes
-# through L2, no conversion, bit-identical results (include/vnet_hip.h: *_x16).  A tensor carries a shadow iff its storage is
-# exactly 6 bytes per element -- only _alloc_shadowed() makes those, and only next to the call that fills the shadow.
+# through L2, no conversion, bit-identical results (include/vnet_hip.h: *_x16).  A tensor carries a shadow iff its storage was
+# made by _alloc_shadowed() (tagged, exactly 6 bytes per element) -- which is only called next to the kernel that fills it.
 def _want_shadow(C):
     return _COMPUTE["dtype"] == "bf16" and _FUSE["bf16_shadow"] and C % 8 == 0
 
@@ -330,6 +330,7 @@ def _alloc_shadowed(shape, device):
     for v in shape:
         n *= int(v)
     st = torch.UntypedStorage(n * 6, device=device)
+    st._vnet_shadow = True          # (the storage's Python object lives as long as the storage: the tag travels with every view)
     y = torch.empty(0, dtype=torch.float32, device=device).set_(st, 0, tuple(int(v) for v in shape))
     return y, y.data_ptr() + n * 4
 
@@ -350,7 +351,8 @@ def _shadow_ptr(x):
     if x is None or not _FUSE["bf16_shadow"] or x.dtype != torch.float32 or x.storage_offset() != 0 or not x.is_contiguous():
         return None
     n = x.numel()
-    if n == 0 or x.untyped_storage().nbytes() != n * 6:
+    st = x.untyped_storage()
+    if n == 0 or st.nbytes() != n * 6 or not getattr(st, "_vnet_shadow", False):
         return None
     return x.data_ptr() + n * 4
 
