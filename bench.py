@@ -180,7 +180,7 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
         ops.profile_start(None if full_table else fam)
     nprep = 3 if graph else 0                # prepare: 2 eager steps + the capture (and first replay) of the step graph
     if mode == "segmented":
-        nprep += 10                          # + the data-parallel start-up autotune: 5 segmented-graph steps, 5 eager steps
+        nprep += 15                          # + the data-parallel start-up autotune: 5 steps each of segmented / serial / eager
     for _ in range(nprep):
         loss = m.train_step(images, labels)
     mode = m.step_mode()                     # (the autotune may have picked the eager enqueue)
@@ -215,9 +215,11 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
 
     res = {"value": round(world * batch * args.steps / dt, 4), "ms_per_step": round(dt / args.steps * 1e3, 3),
            "final_loss": round(final_loss, 6), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
-           "dp_autotune_ms": ([round(t * 1e3, 3) for t in m._tuner.times] if getattr(m, "_tuner", None) is not None else None),
+           "dp_autotune_ms": ({c: round(t * 1e3, 3) for c, t in zip(m._tuner.candidates, m._tuner.times)}
+                              if getattr(m, "_tuner", None) is not None else None),
            "step_enqueue": {"off": "eager (one ctypes launch per kernel)", "whole": "hipGraph replay of the whole step",
-                            "segmented": "hipGraph(gradients) + eager RCCL bucket all-reduces + hipGraph(optimiser)"}[mode],
+                            "segmented": "hipGraph(gradients) + eager RCCL bucket all-reduces + hipGraph(optimiser)",
+                            "serial": "hipGraph(gradients) + eager RCCL bucket all-reduces after backward + hipGraph(optimiser)"}.get(mode, mode),
            "roofline": None}
     if rank != 0:
         return res

@@ -242,7 +242,7 @@ def test_bench_contract_two_ranks(tmp_path, backend):
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 2 and out["scaling"] == "weak"
     assert out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 2
     assert out["config"]["ranks"] == 2 and out["config"]["backend"] == backend          # the process group really has N ranks
-    assert out["step_enqueue"].startswith(("hipGraph(gradients)", "eager")) and len(out["dp_autotune_ms"]) == 2
+    assert out["step_enqueue"].startswith(("hipGraph(gradients)", "eager")) and sorted(out["dp_autotune_ms"]) == ["off", "segmented", "serial"]
     assert abs(out["value"] - 2 * 1 * 1000.0 / out["ms_per_step"]) < 1e-2 * out["value"]
     assert out["roofline"] is None or out["roofline"]["frac"] > 0
     assert "cpu_baseline" not in out                     # rank 0 at N=1 only

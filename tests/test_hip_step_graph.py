@@ -152,6 +152,8 @@ def _dp_worker(rank, world, port, out, mode):
                       VNET_DP_FORCE="1", VNET_DP_BUCKET_BYTES=str(16 << 10))
     os.environ["VNET_STEP_GRAPH"] = "0" if mode.startswith("eager") else "1"
     os.environ["VNET_DP_TWO_PASS"] = "0" if mode.endswith("1p") else "1"
+    if mode == "serial":
+        os.environ["VNET_DP_MODE"] = "serial"
     import torch.distributed as dist
     from vnet_tensorflow_amd.model import image2label
     from oracle.vnet_oracle import synthetic_batch
@@ -169,6 +171,8 @@ def _dp_worker(rank, world, port, out, mode):
     losses = [float(m.train_step(x, l)) for _ in range(5)]
     torch.cuda.synchronize()
     assert m._graph_mode() == ("off" if mode.startswith("eager") else "segmented")
+    if mode == "serial":
+        assert m.step_mode() == "serial" and m.sync.launch_log and len(m.sync.launch_log) == len(m.sync.buckets)
     assert m._two_pass == (not mode.endswith("1p"))
     if not mode.startswith("eager"):
         # gradients graph 1 (forward + decoder / bottom backward), [gradients graph 2 (encoder backward)], optimiser graph
@@ -189,11 +193,13 @@ def test_data_parallel_segmented_graph_rccl_group_of_one(tmp_path, dev):
     eager      : kernel-by-kernel enqueue, bucket all-reduces launched from the gradient hooks (overlapping backward);
     segmented  : gradients graph 1 (forward, decoder + bottom-level backward) -> all-reduce of those buckets, asynchronous
                  -> gradients graph 2 (encoder backward) -> remaining buckets -> optimiser graph;
+    serial     : the segmented graphs replayed with every all-reduce after the second gradients graph (no collective shares
+                 the CUs with backward);
     *1p        : the same with a single backward pass (VNET_DP_TWO_PASS=0: gradients graph -> all buckets -> optimiser).
     No collective is captured (a captured RCCL all-reduce trips ProcessGroupNCCL's watchdog: hipErrorCapturedEvent).
-    All four must produce the same losses and parameters bit for bit (the cut adds the two gradients of a skip tensor with
+    All five must produce the same losses and parameters bit for bit (the cut adds the two gradients of a skip tensor with
     an add kernel instead of in the backward-data epilogue: the same two fp32 numbers)."""
-    modes = ("eager", "eager1p", "segmented", "segmented1p")
+    modes = ("eager", "eager1p", "segmented", "serial", "segmented1p")
     for md in modes:
         mp.spawn(_dp_worker, args=(1, _free_port(), str(tmp_path), md), nprocs=1, join=True)
     a = torch.load(tmp_path / "dp_eager.pt")

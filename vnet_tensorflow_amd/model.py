@@ -523,7 +523,7 @@ class image2label(object):
                 mode = tuner.mode()
                 tuner.before()
         if self.sync is not None:
-            self.sync.hold_all = (mode == "segmented")       # eager: buckets go out from the hooks, overlapping backward
+            self.sync.hold_all = (mode in ("segmented", "serial"))       # eager: buckets go out from the hooks, overlapping backward
         if mode == "off":
             loss = self._train_step_eager(images, labels, dropout)
         else:
@@ -550,12 +550,17 @@ class image2label(object):
         return mode
 
     def _dp_tuner(self):
-        """Data parallel: 5 steps as segmented graph replay, 5 steps eager, keep the faster (parallel.StepModeAutotune);
-        TrainingSetting.DpAutotune / VNET_DP_AUTOTUNE = 0 pins the segmented graph."""
+        """Data parallel: 5 steps as segmented graph replay (all-reduce of pass 1's buckets under the encoder's backward), 5 with
+        the same graphs but every all-reduce AFTER backward ('serial': the collective never shares the CUs with an MFMA
+        kernel whose grid was sized for all 256 -- DESIGN section 5), 5 steps eager; keep the fastest
+        (parallel.StepModeAutotune).  TrainingSetting.DpAutotune / VNET_DP_AUTOTUNE = 0 pins the segmented graph."""
         if getattr(self, "_tuner", None) is None:
             on = os.environ.get("VNET_DP_AUTOTUNE")
             on = getattr(self, "dp_autotune", True) if on is None else on not in ("0", "off", "false")
-            cands = ["segmented", "off"] if on else ["segmented"]
+            cands = (["segmented"] + (["serial"] if self._two_pass else []) + ["off"]) if on else ["segmented"]
+            pin = os.environ.get("VNET_DP_MODE")               # segmented | serial | off: no measurement, this one
+            if pin in cands or pin in ("segmented", "off"):
+                cands = [pin]
             self._tuner = parallel.StepModeAutotune(cands, steps=int(os.environ.get("VNET_DP_AUTOTUNE_STEPS", "5")),
                                                     sync=self._device_sync)
         return self._tuner
@@ -570,6 +575,7 @@ class image2label(object):
             self._g_warm += 1
             return self._train_step_eager(images, labels, dropout)
         shape = (tuple(images.shape), tuple(labels.shape), dropout)
+        serial, mode = (mode == "serial"), ("segmented" if mode == "serial" else mode)       # same graphs, other replay order
         if self._graphs is not None and (shape != self._g_shape or mode != self._g_mode):
             return self._train_step_eager(images, labels, dropout)        # e.g. an odd-sized batch: not the captured shape
         lr = optim.exponential_decay(self.initial_learning_rate, self.global_step, self.decay_steps, self.decay_factor)
@@ -593,7 +599,10 @@ class image2label(object):
         ops.set_step_state(self._step_state, lr, self.optimizer.schedule(lr), self.global_step)
         self._graphs[0].replay()
         if mode == "segmented":
-            if len(self._graphs) == 3:
+            if len(self._graphs) == 3 and serial:
+                self._graphs[1].replay()
+                self.sync.reduce_all()
+            elif len(self._graphs) == 3:
                 self.sync.reduce_prefix()        # pass 1's buckets (decoder, bottom level) start their all-reduce ...
                 self._graphs[1].replay()         # ... while the encoder's backward runs
                 self.sync.reduce_rest()          # the rest, then wait for all of them
