@@ -905,10 +905,16 @@ ConvPlan plan_conv(int ks, int stride, int up, int Cin, int Cout, int B, int Do,
     }
     const int nwg = B * p.nbz * p.nby * p.nbx * p.ncob;
     p.nsplit = 1;
-    if (!up && nwg < 256 && nchunks > 1) p.nsplit = min(nchunks, ceil_div(512, nwg));
+#ifdef VNET_PLAN_ENV
+    static const int tgt = getenv("VNET_F32_SPLIT_TARGET") ? atoi(getenv("VNET_F32_SPLIT_TARGET")) : 512;
+    static const int nzmin = getenv("VNET_F32_NZ_MIN") ? atoi(getenv("VNET_F32_NZ_MIN")) : 256;
+#else
+    constexpr int tgt = 512, nzmin = 256;
+#endif
+    if (!up && nwg < 256 && nchunks > 1) p.nsplit = min(nchunks, ceil_div(tgt, nwg));
     p.cps = ceil_div(nchunks, p.nsplit);
     p.nsplit = ceil_div(nchunks, p.cps);
-    p.nz = (ks == 5 && !up && nwg * p.nsplit < 256) ? 5 : 1;
+    p.nz = (ks == 5 && !up && nwg * p.nsplit < nzmin) ? 5 : 1;
     return p;
 }
 
@@ -1806,10 +1812,19 @@ Bf16Plan plan_conv_bf16(int Cin, int Cout, int B, int Do, int Ho, int Wo) {
     p.ncobg = ncob / p.nsb;
     const long nwg = nb * p.ncobg;
     p.nsplit = 1;
-    if (nwg < 256 && nchunks > 1) p.nsplit = (int)min((long)nchunks, (long)ceil_div(512, (int)nwg));
+    // split-K target 512 workgroups; the tap (dz) split only below 64: it multiplies the partial slabs by 5, and at 8^3
+    // 256->256 (8 x 16 = 128 workgroups) 80 slabs cost 52 us against 26 us with 16 (profiles/ab_plan.sh sweep, round 2:
+    // targets 64..1024 x dz-split thresholds 0 / 256 / 1024 on the five deep-level shapes)
+#ifdef VNET_PLAN_ENV
+    static const int tgt = getenv("VNET_BF16_SPLIT_TARGET") ? atoi(getenv("VNET_BF16_SPLIT_TARGET")) : 512;
+    static const int nzmin = getenv("VNET_BF16_NZ_MIN") ? atoi(getenv("VNET_BF16_NZ_MIN")) : 64;
+#else
+    constexpr int tgt = 512, nzmin = 64;
+#endif
+    if (nwg < 256 && nchunks > 1) p.nsplit = (int)min((long)nchunks, (long)ceil_div(tgt, (int)nwg));
     p.cps = ceil_div(nchunks, p.nsplit);
     p.nsplit = ceil_div(nchunks, p.cps);
-    p.nz = (nwg * p.nsplit < 256) ? 5 : 1;
+    p.nz = (nwg * p.nsplit < nzmin) ? 5 : 1;
     return p;
 }
 
@@ -2162,7 +2177,12 @@ WgradPlan plan_wgrad(int ks, int kx, int stride, int Cin, int Cout, int B, int D
     p.ntg = ceil_div(T3, 8 * p.tw);
     p.nbrick = B * p.nbz * p.nby * p.nbx;
     const int base = (round_up(Cin, 16) / 16) * p.ncob * p.ntg;
-    p.nsplit = max(1, min(p.nbrick, ceil_div(256, base)));
+#ifdef VNET_PLAN_ENV
+    static const int wtgt = getenv("VNET_WGRAD_TARGET") ? atoi(getenv("VNET_WGRAD_TARGET")) : 256;
+#else
+    constexpr int wtgt = 256;
+#endif
+    p.nsplit = max(1, min(p.nbrick, ceil_div(wtgt, base)));
     return p;
 }
 
