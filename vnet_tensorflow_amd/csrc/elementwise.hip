@@ -12,7 +12,10 @@ namespace {
 #define VNET_BN_RED_U 2
 #endif
 constexpr int EW_BLOCK = 256;
-constexpr int EW_MAXBLK = 2048;   // partial rows per reduction
+#ifndef VNET_EW_MAXBLK
+#define VNET_EW_MAXBLK 1024
+#endif
+constexpr int EW_MAXBLK = VNET_EW_MAXBLK;   // partial rows per reduction (A/B round 2, fp32 / C5 step: 512 +0.2 / +0.13 ms, 1024 -0.06 / -0.12, 4096 +0.1 / +0.1 vs 2048)
 constexpr int MAXC = 1024;
 
 inline int ew_blocks(size_t work_items) {
