@@ -151,6 +151,15 @@ size_t vnet_wgrad_bf16_ws_bytes(int Cin, int Cout, int B, int D, int H, int W);
 int vnet_conv_wgrad_bf16(const float* x0, int C0, const float* x1, int C1, const float* dy, int Cout, float* dw,
                          int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream);
 
+/* Deferred reduces of the filter-gradient slabs.  vnet_wgrad_defer(1): vnet_conv_wgrad / vnet_conv_wgrad_bf16[_x16] leave
+ * their partial slabs in the caller's workspace (which must then stay untouched, one per layer) and queue the reduce;
+ * vnet_wgrad_flush runs all queued reduces in one launch (the host's end-of-backward hook; model.py:660-666 has the
+ * gradients complete only when compute_gradients returns, too).  Returns the previous setting / the queue length / status.
+ * Results are bit-identical to the immediate per-layer reduce. */
+int vnet_wgrad_defer(int on);
+int vnet_wgrad_pending(void);
+int vnet_wgrad_flush(void* stream);
+
 /* ---- convolution filter gradient (the Conv3DBackpropFilterV2 autodiff builds at model.py:660)
  *   dw[t][ci][co] = sum_v x[v*stride + t - pad][ci] * dy[v][co]     (TF layout, unpadded)
  * x is the (possibly two-source) forward input, dy the gradient at the conv output [B,Do,Ho,Wo,Cout].

@@ -326,3 +326,39 @@ def test_bf16_16cout_kernel_ragged(dev, shape, C0, C1, Cout):
             check_close("c16 accumulate", acc, ref - b.numpy().astype(np.float64) + 0.5, 2e-6)
     finally:
         ops.set_compute_dtype("fp32")
+
+
+@pytest.mark.parametrize("compute,cin", [("fp32", 1), ("fp32", 2), ("bf16", 4)])
+def test_deferred_batched_filter_gradient_reduce(dev, compute, cin):
+    """ops.deferred_wgrad_reduce: the filter-gradient launches leave their partial slabs in per-layer buffers and ONE launch
+    reduces all of them at the end of the backward pass (vnet_wgrad_defer / vnet_wgrad_flush).  Same summation order as the
+    per-layer reduce: every gradient bit-identical; the queue really fills and really drains; the fused input block's G
+    (consumed inside backward) is still reduced on the spot."""
+    from vnet_tensorflow_amd import networks, ops, optim
+    from vnet_tensorflow_amd._lib import lib
+    L = lib()
+    x, lab = O.synthetic_batch(1, 32, cin, 3, seed=5)
+    grads, queued = {}, {}
+    ops.set_compute_dtype(compute)
+    try:
+        for defer in (True, False):
+            np.random.seed(11)
+            net = networks.VNet(3, 0.0, 16, 3, (1, 2, 3), 2, True, "prelu", device=dev)
+            net.build(x.shape)
+            flat = optim.FlatParams(net.named_parameters())
+            for rep in range(2):                   # second pass: the per-layer slab buffers are reused
+                flat.zero_grad()
+                loss, _, _, _ = ops.softmax_loss(net.GetNetwork(g(x, dev)), g(lab, dev, torch.int32), "sorensen")
+                with ops.deferred_wgrad_reduce(defer):
+                    loss.backward()
+                    ops.join_param_grad_stream()
+                    queued[defer] = L.vnet_wgrad_pending()
+                assert L.vnet_wgrad_pending() == 0
+            torch.cuda.synchronize()
+            grads[defer] = {n: p.grad.detach().cpu().numpy().copy() for n, p in net.named_parameters()}
+    finally:
+        ops.set_compute_dtype("fp32")
+    assert queued[False] == 0 and queued[True] >= 10, queued
+    for n in grads[True]:
+        assert np.array_equal(grads[True][n], grads[False][n]), n
+    assert all(np.isfinite(v).all() for v in grads[True].values())

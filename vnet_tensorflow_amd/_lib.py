@@ -38,6 +38,9 @@ SIGNATURES = {
     "vnet_conv_fwd_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "vnet_wgrad_bf16_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "vnet_conv_wgrad_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "vnet_wgrad_defer": (_i, [_i]),
+    "vnet_wgrad_pending": (_i, []),
+    "vnet_wgrad_flush": (_i, [_vp]),
     "vnet_conv_wgrad_bf16_x16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "vnet_conv_fwd_bf16_x16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vnet_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),

@@ -18,6 +18,8 @@
 // The same file holds the bf16-operand variants of the 5^3 convolution and of its filter gradient (BASELINE
 // config C5: v_mfma_f32_32x32x16_bf16 / v_mfma_f32_16x16x32_bf16 with LDS transpose reads) further down.
 #include "common.h"
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -626,16 +628,17 @@ __global__ void __launch_bounds__(512) wgrad_kernel(WgradArgs a) {
 // 4 consecutive cout (16-byte accesses; needs Cout % 4 == 0), otherwise one output.  Four independent partial sums per
 // lane: the slab loads of one output are 256 KB or more apart, so a serial chain would wait one HBM round trip per slab
 // (the summation order is fixed -> deterministic).
+// blk / nblk: this workgroup's index and the number of workgroups that share the job (the whole grid, or one job's slice of a batch)
 template <bool VEC>
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int T3, int CinP, int CoutP,
-                                                           int Cin, int Cout, float* __restrict__ dw) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, int nsplit, int T3, int CinP, int CoutP,
+                                                  int Cin, int Cout, float* __restrict__ dw, unsigned blk, unsigned nblk) {
     constexpr int W = VEC ? 4 : 1;
     __shared__ float sh[4][64 * W];
     const size_t total = (size_t)T3 * Cin * Cout / W;               // output groups
     const size_t sstride = (size_t)T3 * CinP * CoutP;
     const int CoutG = Cout / W;
     const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
+    for (size_t base = (size_t)blk * 64; base < total; base += (size_t)nblk * 64) {
         const size_t idx = base + o;
         float s[W];
 #pragma unroll
@@ -674,8 +677,43 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     }
 }
 
+template <bool VEC>
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int T3, int CinP, int CoutP,
+                                                           int Cin, int Cout, float* __restrict__ dw) {
+    wgrad_reduce_body<VEC>(part, nsplit, T3, CinP, CoutP, Cin, Cout, dw, blockIdx.x, gridDim.x);
+}
+
+// Deferred reduces (round 2): with vnet_wgrad_defer(1) the filter-gradient entry points leave their partial slabs in the caller's
+// workspace and queue the reduce; vnet_wgrad_flush() runs every queued reduce in ONE launch (26 launches of ~7 us per V-Net
+// step otherwise).  The job table travels by value in the kernel arguments (a captured graph keeps it), results are bit-identical
+// to the per-layer reduce (same summation order).
+struct ReduceJob { const float* part; float* dw; int nsplit, T3, CinP, CoutP, Cin, Cout, vec; unsigned blk0; };
+constexpr int REDUCE_BATCH = 32;
+struct ReduceBatch { ReduceJob job[REDUCE_BATCH]; int n; };
+
+__global__ void __launch_bounds__(256) wgrad_reduce_batched_kernel(ReduceBatch b) {
+    int j = 0;
+#pragma unroll 1
+    for (int k = 1; k < b.n; ++k) if (blockIdx.x >= b.job[k].blk0) j = k;
+    const ReduceJob& q = b.job[j];
+    const unsigned nblk = (j + 1 < b.n ? b.job[j + 1].blk0 : gridDim.x) - q.blk0;
+    if (q.vec) wgrad_reduce_body<true>(q.part, q.nsplit, q.T3, q.CinP, q.CoutP, q.Cin, q.Cout, q.dw, blockIdx.x - q.blk0, nblk);
+    else wgrad_reduce_body<false>(q.part, q.nsplit, q.T3, q.CinP, q.CoutP, q.Cin, q.Cout, q.dw, blockIdx.x - q.blk0, nblk);
+}
+
+struct DeferState { std::mutex mu; bool on = false; std::vector<ReduceJob> pending; };
+DeferState& defer_state() { static DeferState s; return s; }
+
 void launch_wgrad_reduce(const float* part, int nsplit, int T3, int CinP, int CoutP, int Cin, int Cout, float* dw, hipStream_t st) {
     const bool vec = (Cout % 4 == 0) && (CoutP % 4 == 0) && ((reinterpret_cast<uintptr_t>(dw) | reinterpret_cast<uintptr_t>(part)) & 15) == 0;
+    {
+        DeferState& ds = defer_state();
+        std::lock_guard<std::mutex> lk(ds.mu);
+        if (ds.on) {
+            ds.pending.push_back(ReduceJob{part, dw, nsplit, T3, CinP, CoutP, Cin, Cout, vec ? 1 : 0, 0u});
+            return;
+        }
+    }
     const size_t total = (size_t)T3 * Cin * Cout / (vec ? 4 : 1);
     const int blocks = (int)min((size_t)4096, (total + 63) / 64);
     if (vec) hipLaunchKernelGGL(wgrad_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, part, nsplit, T3, CinP, CoutP, Cin, Cout, dw);
@@ -2200,6 +2238,44 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
 }  // namespace
 
 extern "C" {
+
+int vnet_wgrad_defer(int on) {
+    DeferState& ds = defer_state();
+    std::lock_guard<std::mutex> lk(ds.mu);
+    const int prev = ds.on ? 1 : 0;
+    ds.on = on != 0;
+    return prev;
+}
+
+int vnet_wgrad_pending(void) {
+    DeferState& ds = defer_state();
+    std::lock_guard<std::mutex> lk(ds.mu);
+    return (int)ds.pending.size();
+}
+
+int vnet_wgrad_flush(void* stream) {
+    DeferState& ds = defer_state();
+    std::vector<ReduceJob> jobs;
+    {
+        std::lock_guard<std::mutex> lk(ds.mu);
+        jobs.swap(ds.pending);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    for (size_t i0 = 0; i0 < jobs.size(); i0 += REDUCE_BATCH) {
+        ReduceBatch b{};
+        b.n = (int)min((size_t)REDUCE_BATCH, jobs.size() - i0);
+        unsigned blk = 0;
+        for (int k = 0; k < b.n; ++k) {
+            b.job[k] = jobs[i0 + k];
+            b.job[k].blk0 = blk;
+            const size_t total = (size_t)b.job[k].T3 * b.job[k].Cin * b.job[k].Cout / (b.job[k].vec ? 4 : 1);
+            blk += (unsigned)min((size_t)1024, (total + 63) / 64);
+        }
+        hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(blk), dim3(256), 0, st, b);
+        VNET_LAUNCH_CHECK();
+    }
+    return VNET_OK;
+}
 
 size_t vnet_wgrad_ws_bytes(int ks, int kx, int stride, int Cin, int Cout, int B, int Do, int Ho, int Wo) {
     if (kx == 0) kx = ks;

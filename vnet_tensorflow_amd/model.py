@@ -394,17 +394,26 @@ class image2label(object):
         _, loss, _, _ = self.forward(images, labels, dropout)
         if getattr(self, "_one", None) is None:
             self._one = torch.ones((), dtype=torch.float32, device=self.device)     # autograd would fill a fresh one every step
-        loss.backward(self._one)
-        ops.join_param_grad_stream()          # filter / bias gradients were enqueued on their own stream
+        with ops.deferred_wgrad_reduce(self._defer_wgrad_reduce()):
+            loss.backward(self._one)
+            ops.join_param_grad_stream()      # filter / bias gradients were enqueued on their own stream
         return loss
+
+    def _defer_wgrad_reduce(self):
+        """One batched reduce of the filter-gradient slabs at the end of the backward pass instead of one per layer -- unless the
+        data-parallel buckets leave from the gradient hooks while backward runs (eager step).  VNET_WGRAD_BATCH=0: off."""
+        if os.environ.get("VNET_WGRAD_BATCH", "1") == "0" or self.device.type != "cuda":
+            return False
+        return self.sync is None or bool(self.sync.hold_all)
 
     def _backward_rest(self):
         """Second backward pass of a split step: from the cut tensors through the encoder."""
         cuts = [(o, l.grad) for o, l in self.network.backward_cuts if l.grad is not None]
         self.network.backward_cuts = []
-        if cuts:
-            torch.autograd.backward([o for o, _ in cuts], [g for _, g in cuts])
-        ops.join_param_grad_stream()
+        with ops.deferred_wgrad_reduce(self._defer_wgrad_reduce()):
+            if cuts:
+                torch.autograd.backward([o for o, _ in cuts], [g for _, g in cuts])
+            ops.join_param_grad_stream()
 
     def _train_step_eager(self, images, labels, dropout):
         lr = optim.exponential_decay(self.initial_learning_rate, self.global_step, self.decay_steps, self.decay_factor)

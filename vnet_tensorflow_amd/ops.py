@@ -412,6 +412,56 @@ def _conv_bf16_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res
                  B, *dims, _ptr(ws), nb, _stream()), "vnet_conv_fwd_bf16")
 
 
+# ---- deferred reduces of the filter-gradient slabs (include/vnet_hip.h: vnet_wgrad_defer / vnet_wgrad_flush) ------------------
+# Inside `deferred_wgrad_reduce()` the filter-gradient launches leave their partial slabs in a per-layer buffer and ONE batched
+# launch reduces all of them when the context ends (26 reduce launches of ~7 us per V-Net step otherwise).  Only for a backward
+# pass whose filter gradients nobody reads before it ends (model.image2label: not the eager data-parallel step, whose bucket
+# all-reduces start from the gradient hooks).
+_DEFER = {"on": False, "ws": {}}
+
+
+@contextlib.contextmanager
+def deferred_wgrad_reduce(on=True):
+    if not on or _DEFER["on"]:
+        yield
+        return
+    L = _lib.lib()
+    _DEFER["on"] = True
+    L.vnet_wgrad_defer(1)
+    try:
+        yield
+    finally:
+        _DEFER["on"] = False
+        L.vnet_wgrad_defer(0)
+        check(L.vnet_wgrad_flush(_stream()), "vnet_wgrad_flush")
+
+
+def _wgrad_workspace(dw, nbytes, immediate):
+    """Scratch for the partial slabs: the shared workspace, or (deferred reduce) a buffer of this layer's own that lives on."""
+    if not _DEFER["on"] or immediate:
+        return workspace(nbytes, dw.device)
+    key = (dw.data_ptr(), dw.device.index)
+    buf = _DEFER["ws"].get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dw.device)
+        _DEFER["ws"][key] = buf
+    return buf
+
+
+@contextlib.contextmanager
+def _immediate_reduce(immediate):
+    """A filter gradient that is consumed right away (the fused input block's G): reduce it now even inside a deferring pass."""
+    if not (immediate and _DEFER["on"]):
+        yield
+        return
+    L = _lib.lib()
+    L.vnet_wgrad_defer(0)
+    try:
+        yield
+    finally:
+        L.vnet_wgrad_defer(1)
+
+
 def _wgrad_bf16_call(x0, x1, dy, dw, dims):
     """Filter gradient of the 5^3 stride-1 conv with bf16 operands / fp32 accumulation (vnet_conv_wgrad_bf16)."""
     L = _lib.lib()
@@ -419,7 +469,7 @@ def _wgrad_bf16_call(x0, x1, dy, dw, dims):
     C0, C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
     Co = dy.shape[-1]
     nb = L.vnet_wgrad_bf16_ws_bytes(C0 + C1, Co, B, *dims)
-    ws = workspace(nb, x0.device)
+    ws = _wgrad_workspace(dw, nb, False)
     nvox = B * dims[0] * dims[1] * dims[2]
     flops = 2.0 * nvox * 125 * (C0 + C1) * Co
     nbytes = 4.0 * (nvox * (C0 + C1 + Co) + 125 * (C0 + C1) * Co)
@@ -434,19 +484,19 @@ def _wgrad_bf16_call(x0, x1, dy, dw, dims):
                                      _ptr(ws), nb, _stream()), "vnet_conv_wgrad_bf16")
 
 
-def _wgrad_call(ks, stride, x0, x1, dy, dw, dims_in, dims_out, kx=0):
+def _wgrad_call(ks, stride, x0, x1, dy, dw, dims_in, dims_out, kx=0, immediate=False):
     L = _lib.lib()
     B = x0.shape[0]
     C0, C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
     Co = dy.shape[-1]
     nb = L.vnet_wgrad_ws_bytes(ks, kx, stride, C0 + C1, Co, B, *dims_out)
-    ws = workspace(nb, x0.device)
+    ws = _wgrad_workspace(dw, nb, immediate)
     nin, nout = B * dims_in[0] * dims_in[1] * dims_in[2], B * dims_out[0] * dims_out[1] * dims_out[2]
     taps = ks * ks * (kx or ks)
     flops = 2.0 * nout * taps * (C0 + C1) * Co
     nbytes = 4.0 * (nin * (C0 + C1) + nout * Co + taps * (C0 + C1) * Co)
     tag = _wgrad_tag(False, ks, kx, stride, dims_out[2], B, C0 + C1, Co)
-    with _Timed(tag, flops, nbytes):
+    with _Timed(tag, flops, nbytes), _immediate_reduce(immediate):
         check(L.vnet_conv_wgrad(ks, kx, stride, _ptr(x0), C0, _ptr(x1), C1, _ptr(dy), Co, _ptr(dw),
                                 B, *dims_in, *dims_out, _ptr(ws), nb, _stream()), "vnet_conv_wgrad")
 
@@ -752,7 +802,7 @@ class _InputConvFn(torch.autograd.Function):
             db, sb = _grad_out(bref)
             colsum(dy, O, out=db)
         G = torch.empty((25, 16, O), dtype=torch.float32, device=dev)
-        _wgrad_call(5, 1, xv, None, dy, G, (D, H, W), (D, H, W), kx=1)
+        _wgrad_call(5, 1, xv, None, dy, G, (D, H, W), (D, H, W), kx=1, immediate=True)     # G is folded right below
         dw, sw = _grad_out(wref)
         gpar, bpar = ctx.gb
         gs, bs = getattr(gpar, "_vnet_sink", None), getattr(bpar, "_vnet_sink", None)
