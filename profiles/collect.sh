@@ -4,7 +4,8 @@
 # 1. the bench line exactly as the driver runs it (incl. c5_bf16 and cpu_baseline),
 # 2. rocprofv3 --kernel-trace --stats of the same command (without the CPU leg, which launches no kernels),
 # 3./4. separate --pmc FETCH_SIZE / WRITE_SIZE passes (never combined with other trace domains),
-# 5. the product training loop (image2label.train(), PCIe-inclusive).
+# 5. the product training loop (image2label.train(), PCIe-inclusive),
+# 6. the per-layer table of the 5^3 / 2^3 launches (fp32 net, then the C5 bf16 net).
 # Every step is bounded by `timeout`; python is the program right after `--`.
 OUT=gpurun_out/${1:-prof}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -15,6 +16,8 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OU
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1
 timeout 300 python profiles/train_loop_bench.py > $OUT/train_loop.json 2> $OUT/train_loop.err
 timeout 300 python profiles/train_loop_bench.py 128 bf16 4 5 > $OUT/train_loop_c5.json 2> $OUT/train_loop_c5.err
+BENCH_KERNEL_TABLE=1 timeout 600 python bench.py --gpus 1 --steps 10 --no-cpu-baseline > /dev/null 2> $OUT/layer_table.err
+grep "^#" $OUT/layer_table.err > $OUT/layer_table.txt
 rm -f $OUT/*_kernel_trace.csv $OUT/fetch_counter_collection.csv.bak
 ls -la $OUT | head -30
 cut -c1-700 $OUT/bench_line.json

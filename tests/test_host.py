@@ -231,3 +231,20 @@ def test_tf_metrics_auc_restatement_known_answers():
     assert abs(O.tf_metrics_auc(lab, np.array([0.5, 0.5, 0.5, 0.5])) - 0.5) < 1e-6            # one ROC step: area 1/2
     # TF's doc example: labels [0,0,1,1], predictions [0.1,0.4,0.35,0.8] -> 0.75
     assert abs(O.tf_metrics_auc(lab, np.array([0.1, 0.4, 0.35, 0.8])) - 0.75) < 1e-6
+
+
+def test_make_batch_into_caller_buffers_equals_stacked_batches():
+    """The prefetch threads crop straight into pinned host tensors (VolumeDataset.make_batch(out=...)): same batch, same
+    dtypes as the stacking path, with and without a transform pipeline."""
+    import numpy as np
+    from vnet_tensorflow_amd import data as vd
+    ds = vd.VolumeDataset("synthetic", ["a.npy", "b.npy"], "l.npy", [0, 1, 2], [12, 16, 8], 3, train=True,
+                          synthetic={"Cases": 6, "Shape": [20, 18, 12]})
+    (cases, seeds), = ds.epoch_plan()[:1]
+    ref_i, ref_l = ds.make_batch(cases, seeds)
+    si, sl = ds.batch_shapes()
+    assert tuple(ref_i.shape) == si and tuple(ref_l.shape) == sl
+    oi, ol = np.full(si, np.nan, np.float32), np.full(sl, -7, np.int32)
+    got = ds.make_batch(cases, seeds, out=(oi, ol))
+    assert got[0] is oi and got[1] is ol
+    assert np.array_equal(oi, ref_i) and np.array_equal(ol, ref_l) and ol.dtype == np.int32

@@ -164,9 +164,15 @@ class VolumeDataset(object):
             plan.append((order[i:i + self.batch], [int(v) for v in self.rng.integers(0, 2 ** 62, size=self.batch)]))
         return plan
 
-    def make_batch(self, cases, seeds):
+    def batch_shapes(self):
+        """(image shape, label shape) of one batch: [B, *patch, Cin] float32 and [B, *patch, 1] int32."""
+        return (self.batch,) + tuple(self.patch) + (len(self.image_filenames),), (self.batch,) + tuple(self.patch) + (1,)
+
+    def make_batch(self, cases, seeds, out=None):
+        """out = (image float32 [B,*P,Cin], label int32 [B,*P,1]) NumPy arrays to fill (e.g. views of pinned host tensors: the
+        crop is then the ONLY copy between the cached volume and the DMA source); None: new arrays."""
         imgs, labs = [], []
-        for case, sd in zip(cases, seeds):
+        for i, (case, sd) in enumerate(zip(cases, seeds)):
             image, label = self._load(case)
             if self.transforms is not None:
                 from .transforms import apply_pipeline
@@ -176,8 +182,14 @@ class VolumeDataset(object):
                                      "PatchShape, like the reference's pipeline3D.yaml)" % (tuple(label.shape), self.patch))
             else:
                 image, label = random_crop(image, label, self.patch, np.random.default_rng(sd))
+            if out is not None:
+                np.copyto(out[0][i], image, casting="unsafe")
+                np.copyto(out[1][i, ..., 0], label, casting="unsafe")
+                continue
             imgs.append(image)
             labs.append(label[..., None])
+        if out is not None:
+            return out
         return np.stack(imgs).astype(np.float32, copy=False), np.stack(labs).astype(np.int32, copy=False)
 
     def __iter__(self):
@@ -196,6 +208,14 @@ class Prefetcher(object):
 
     def _job(self, cases, seeds):
         import torch
+        if self.pin and torch.cuda.is_available() and len(cases) == self.dataset.batch and hasattr(self.dataset, "batch_shapes"):
+            # crop straight into pinned memory (torch's caching host allocator hands a block out again only after the
+            # asynchronous copies that read it have finished): one host copy per batch instead of three
+            si, sl = self.dataset.batch_shapes()
+            ti = torch.empty(si, dtype=torch.float32, pin_memory=True)
+            tl = torch.empty(sl, dtype=torch.int32, pin_memory=True)
+            self.dataset.make_batch(cases, seeds, out=(ti.numpy(), tl.numpy()))
+            return ti, tl
         img, lab = self.dataset.make_batch(cases, seeds)
         ti, tl = torch.from_numpy(img), torch.from_numpy(lab)
         if self.pin and torch.cuda.is_available():
