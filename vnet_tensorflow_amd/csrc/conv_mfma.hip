@@ -1842,11 +1842,17 @@ Bf16Plan plan_conv_bf16(int Cin, int Cout, int B, int Do, int Ho, int Wo) {
     p.small = Wo < 16;
     // few wide bricks (32^3 and below): 4x8x8 bricks with 4-wave workgroups double the workgroup count (+21 % at 32^3
     // 64->64); with many bricks the two shapes measure the same, the wide one stages less halo
-    p.half = !p.small && (long)B * ceil_div(Do, 4) * ceil_div(Ho, 8) * ceil_div(Wo, 16) <= 256;
+#ifdef VNET_PLAN_ENV
+    static const int halfmax = getenv("VNET_BF16_HALF_MAX") ? atoi(getenv("VNET_BF16_HALF_MAX")) : 256;
+    static const int nsbmin = getenv("VNET_BF16_NSB_MIN") ? atoi(getenv("VNET_BF16_NSB_MIN")) : 256;
+#else
+    constexpr int halfmax = 256, nsbmin = 256;
+#endif
+    p.half = !p.small && (long)B * ceil_div(Do, 4) * ceil_div(Ho, 8) * ceil_div(Wo, 16) <= halfmax;
     if (p.small) { p.nbz = ceil_div(Do, 8); p.nby = ceil_div(Ho, 8); p.nbx = ceil_div(Wo, 8); }
     else { p.nbz = ceil_div(Do, 4); p.nby = ceil_div(Ho, 8); p.nbx = ceil_div(Wo, p.half ? 8 : 16); }
     const long nb = (long)B * p.nbz * p.nby * p.nbx;
-    p.nsb = (ncob % 2 == 0 && nb * (ncob / 2) >= 256) ? 2 : 1;
+    p.nsb = (ncob % 2 == 0 && nb * (ncob / 2) >= nsbmin) ? 2 : 1;
     p.ncobg = ncob / p.nsb;
     const long nwg = nb * p.ncobg;
     p.nsplit = 1;
