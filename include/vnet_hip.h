@@ -8,9 +8,11 @@
  * Conventions
  *   - all tensors are float32, channels-last (NDHWC), contiguous; labels are int32.
  *   - every pointer is a DEVICE pointer owned by the caller (incl. workspace `ws`); the library
- *     allocates nothing and keeps no state; all work is enqueued on `stream` (hipStream_t);
- *     no hidden synchronisation -> safe to overlap with RCCL on another stream and to capture
- *     into a hipGraph.
+ *     allocates nothing and keeps no state (one opt-in exception: the queue of deferred
+ *     filter-gradient reduces between vnet_wgrad_defer(1) and vnet_wgrad_flush); all work is
+ *     enqueued on `stream` (hipStream_t); no hidden synchronisation -> safe to overlap with RCCL
+ *     on another stream and to capture into a hipGraph.  bf16 shadows (`*_x16`) are 2-byte images
+ *     of fp32 tensors that the caller allocates next to them.
  *   - return value: 0 on success, a negative VNET_E_* code for argument errors, or a positive
  *     hipError_t from the launch.  Nothing throws, nothing exits.
  */
