@@ -128,6 +128,7 @@ int vnet_conv_fwd_bf16_acc(const float* x0, int C0, const float* x1, int C1, con
                            void* ws, size_t ws_bytes, void* stream);     /* y += conv(x), see vnet_conv_fwd_acc */
 
 int vnet_conv_bf16_stats_rows(int Cin, int Cy0, int Cy1, int C0, int C1, int B, int D, int H, int W);
+int vnet_conv_bf16_stats_rows_x16(int Cin, int Cy0, int Cy1, int C0, int C1, int B, int D, int H, int W);   /* for vnet_conv_fwd_bf16_x16 (its own brick shapes) */
 int vnet_conv_fwd_bf16_stats(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
                              float* y, int Cout, int B, int D, int H, int W,
                              const float* res, float* stats, void* ws, size_t ws_bytes, void* stream);   /* see vnet_conv_fwd_stats */

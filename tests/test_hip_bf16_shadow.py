@@ -23,6 +23,9 @@ def _shadowed(ops, t):
     ((2, 12, 20, 24), 32, 32, 64),     # half bricks, NSB 2
     ((1, 8, 8, 8), 64, 0, 128),        # small bricks, split-K
     ((1, 7, 9, 5), 8, 8, 24),          # 8-channel sources, ragged everything
+    ((1, 64, 64, 64), 16, 0, 32),      # row-pair kernel (32-cout blocks, >= 256 items): one chunk
+    ((1, 36, 70, 50), 8, 0, 64),       # row-pair kernel: ragged bricks, half-filled chunk, two cout blocks
+    ((1, 32, 64, 64), 16, 16, 32),     # row-pair kernel: two sources = two chunks per brick
 ])
 def test_conv_and_wgrad_from_shadows_bit_identical(dev, shape, cin, cin1, cout):
     from vnet_tensorflow_amd import ops
@@ -145,3 +148,33 @@ def test_network_step_bit_identical_with_and_without_shadows(dev, variant, cin, 
         assert (ga[n] is None) == (gb[n] is None), n
         if ga[n] is not None:
             assert torch.equal(ga[n], gb[n]), n
+
+
+@pytest.mark.parametrize("shape,cin,cout,residual", [((1, 64, 64, 64), 32, 32, True), ((1, 36, 70, 50), 16, 64, False)])
+def test_row_pair_kernel_epilogue_statistics(dev, shape, cin, cout, residual):
+    """conv5_bf16_r32_kernel<STATS>: one partial row [sum | sum of squares] per 4x16x16 brick (vnet_conv_bf16_stats_rows_x16),
+    of y (+ residual), voxels outside a ragged volume not counted; the output itself is the plain launch's, bit for bit."""
+    from vnet_tensorflow_amd import ops
+    from vnet_tensorflow_amd._lib import lib
+    B, D, H, W = shape
+    gen = torch.Generator().manual_seed(cin + cout)
+    x = ops.with_shadow((torch.randn(B, D, H, W, cin, generator=gen) * 1.5 + 0.2).to(dev))
+    w = (torch.randn(5, 5, 5, cin, cout, generator=gen) * 0.05).to(dev)
+    b = torch.randn(cout, generator=gen).to(dev)
+    res = (torch.randn(B, D, H, W, cout, generator=gen) * 2.0).to(dev) if residual else None
+    ops.set_compute_dtype("bf16")
+    try:
+        rows = lib().vnet_conv_bf16_stats_rows_x16(cin, cout, 0, cin, 0, B, D, H, W)
+        assert rows == B * -(-D // 4) * -(-H // 16) * -(-W // 16)
+        with torch.no_grad():
+            y = ops.conv(x, w, b, 5, bn_stats=True, bn_residual=res)
+            st = y._vnet_stats
+            assert st.rows == rows and tuple(st.partial.shape) == (rows, 2 * cout)
+            plain = ops.conv(x, w, b, 5)
+        assert torch.equal(y, plain)
+        v = (y + res if residual else y).double().reshape(-1, cout)
+        tot = st.partial.double().sum(0)
+        assert torch.allclose(tot[:cout], v.sum(0), rtol=1e-5, atol=1e-2)
+        assert torch.allclose(tot[cout:], (v * v).sum(0), rtol=1e-5, atol=1e-2)
+    finally:
+        ops.set_compute_dtype("fp32")

@@ -32,6 +32,7 @@ SIGNATURES = {
     "vnet_conv_fwd_stats": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i,
                                  _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "vnet_conv_bf16_stats_rows": (_i, [_i] * 9),
+    "vnet_conv_bf16_stats_rows_x16": (_i, [_i] * 9),
     "vnet_conv_fwd_bf16_stats": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "vnet_bn_finalize_partial": (_i, [_vp, _i, _i, _d, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "vnet_conv_bf16_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
@@ -126,7 +127,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
-            if name.endswith("_ws_bytes") or name.endswith("_stats_rows") or name == "vnet_conv_stats_from_reduce" or name == "vnet_packed_weight_floats":
+            if name.endswith("_ws_bytes") or name.endswith("_stats_rows") or name.endswith("_stats_rows_x16") or name == "vnet_conv_stats_from_reduce" or name == "vnet_packed_weight_floats":
                 setattr(L, name, _memo(fn))    # pure size queries, asked before every launch: answer repeats from a dict
         _lib = L
     return _lib

@@ -1222,15 +1222,18 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
             for (int m = 0; m < MS; ++m) bf[0][m] = *reinterpret_cast<const bf16x8*>(tp + boff[m]);
 #pragma unroll
             for (int n = 0; n < NSB; ++n) af[0][n] = *reinterpret_cast<const bf16x8*>(wa + n * 64);
+            // taps of a plane in (dx, dy) order -- the order of the row-pair kernel below, so that both kernels add the
+            // same products in the same sequence (bit-identical results whichever one a launch takes)
 #pragma unroll
             for (int t = 0; t < 25; ++t) {
                 if (t + 1 < 25) {
                     const int tn = t + 1;
-                    const int o = ((tn / 5) * G::IX + (tn % 5)) * 16;
+                    const int tap = (tn % 5) * 5 + tn / 5;                  // dy = tn % 5, dx = tn / 5
+                    const int o = ((tn % 5) * G::IX + (tn / 5)) * 16;
 #pragma unroll
                     for (int m = 0; m < MS; ++m) bf[tn & 1][m] = *reinterpret_cast<const bf16x8*>(tp + boff[m] + o);
 #pragma unroll
-                    for (int n = 0; n < NSB; ++n) af[tn & 1][n] = *reinterpret_cast<const bf16x8*>(wa + (tn * NSB + n) * 64);
+                    for (int n = 0; n < NSB; ++n) af[tn & 1][n] = *reinterpret_cast<const bf16x8*>(wa + (tap * NSB + n) * 64);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
@@ -1576,6 +1579,181 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 32-output-channel blocks on many bricks, bf16 shadows only (round 2).  The generic kernel above reads 1.5 KB of LDS
+// fragments per MFMA (two B + one A for two MFMAs), and on this part fragment delivery and MFMA issue add up rather than
+// overlap (LDS-active + MFMA-busy cycles = the step time).  Here a wave owns FOUR 32-voxel subtiles = 8
+// x-rows adjacent in y, so the B fragment of (subtile m, tap dy) -- rows 2m+dy, 2m+dy+1 -- is fragment F[2m+dy]: per (dz, dx)
+// a wave reads 11 row-pair fragments + 5 A fragments for 20 MFMAs = 0.8 KB per MFMA.  Brick 4 x 16 x 16 (8 waves), persistent
+// workgroups walk (brick, cout block) items, the next tile is prefetched global -> registers during the MFMAs, and the filter
+// streams through TWO LDS plane buffers (one dz plane of one cout block each, 25 KB): one barrier per plane instead of two.
+// ------------------------------------------------------------------------------------------
+template <bool STATS = false>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv5_bf16_r32_kernel(ConvArgs a) {
+    constexpr int TZ = 4, TY = 16, TX = 16, NT = 512;
+    using G = Bf16Geom<TZ, TY, TX>;
+    using XH = XTileH<G::IZ, G::IY, G::IX, NT>;
+    constexpr int WUNITS = 25 * 64, WPER = (WUNITS + NT - 1) / NT, WBUF = WUNITS * 16 + 16;      // + one dump slot behind each slab
+    constexpr int ROWB = G::IX * 16, PLANEB = G::IY * G::IX * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* tile = smem;
+    unsigned char* wbuf = smem + G::TILE_BYTES;                          // two plane buffers
+    unsigned char* dump = smem + G::TILE_BYTES + 2 * WBUF + (threadIdx.x & 63) * 16;
+    float* red = reinterpret_cast<float*>(smem + G::TILE_BYTES + 2 * WBUF + 64 * 16);            // [8 waves][2 x 32] epilogue statistics
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p32 = lane & 31, half = lane >> 5;
+    const int q32 = (p32 >= 16) ? 16 + ((p32 + 12) & 15) : p32;         // second row rotated by 12: conflict-free ds_read_b128 lane groups
+    const int vz = wave >> 1, vy0 = (wave & 1) * 8;
+    const unsigned char* bb = tile + half * G::PLANE + ((vz * G::IY + vy0 + (q32 >> 4)) * G::IX + (q32 & 15)) * 16;
+    const int aoff = (half * 32 + p32) * 16;
+
+    const int ncob = a.CoutP / 32;
+    const int nbrick = a.B * a.nbz * a.nby * a.nbx;
+    const int nitem = nbrick * ncob;
+    const int G8 = gridDim.x >> 3;
+    const int per_xcd = (nitem + 7) >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int i_lo = xcd * per_xcd, i_hi = min(nitem, i_lo + per_xcd);
+    if (i_lo + slot >= i_hi) return;
+    const int nmine = (i_hi - i_lo - slot + G8 - 1) / G8;
+    const int nch = a.nchunks;
+    const int nsteps = nmine * nch;
+    const u32x4* wg = reinterpret_cast<const u32x4*>(a.wp);
+
+    auto step_of = [&](int s, int& brick, int& cob, int& ch) {
+        const int it = s / nch; ch = s - it * nch;
+        const int gid = i_lo + slot + it * G8;
+        brick = gid / ncob; cob = gid - brick * ncob;
+    };
+    auto origin = [&](int brick, int& b, int& bz, int& by, int& bx) {
+        bx = brick % a.nbx; brick /= a.nbx;
+        by = brick % a.nby; brick /= a.nby;
+        bz = brick % a.nbz; b = brick / a.nbz;
+    };
+    u32x4 hv[XH::PER];
+    auto tile_issue = [&](int brick, int ch) {
+        int b, bz, by, bx;
+        origin(brick, b, bz, by, bx);
+        XH::template issue_part<0, XH::PER>(hv, reinterpret_cast<const unsigned short*>(a.x0), reinterpret_cast<const unsigned short*>(a.x1),
+                                            a.C0, a.C1, ch, b, bz * TZ - 2, by * TY - 2, bx * TX - 2, a.Di, a.Hi, a.Wi, tid);
+    };
+    u32x4 wreg[WPER];
+    auto wsrc = [&](int ch, int dz, int cob) { return wg + ((size_t)(ch * 125 + dz * 25) * ncob + cob) * 64; };
+
+    int brick, cob, ch;
+    step_of(0, brick, cob, ch);
+    bf16_w_issue<1, WPER, NT>(wreg, wsrc(ch, 0, cob), ncob, tid);
+    tile_issue(brick, ch);
+    bf16_w_commit<1, WPER, NT>(reinterpret_cast<u32x4*>(wbuf), wreg, tid);
+    bf16_tile_commit_h<G, XH, 0, XH::PER>(tile, dump, hv, tid);
+    __syncthreads();
+
+    f32x16 acc[4];
+    int cur = 0;                                   // plane buffer that holds the current dz plane
+    for (int step = 0; step < nsteps; ++step) {
+        step_of(step, brick, cob, ch);
+        const bool more = step + 1 < nsteps;
+        int nbrick_ = brick, ncob_ = cob, nch_ = ch;
+        if (more) {
+            step_of(step + 1, nbrick_, ncob_, nch_);
+            tile_issue(nbrick_, nch_);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ch == 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        }
+        for (int dz = 0; dz < 5; ++dz) {
+            const bool wnext = dz < 4 || more;
+            if (wnext) {
+                bf16_w_issue<1, WPER, NT>(wreg, dz < 4 ? wsrc(ch, dz + 1, cob) : wsrc(nch_, 0, ncob_), ncob, tid);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const unsigned char* bp = bb + dz * PLANEB;
+            const unsigned char* wa = wbuf + cur * WBUF + aoff;
+#pragma unroll
+            for (int dx = 0; dx < 5; ++dx) {
+                bf16x8 F[11], A[5];
+#pragma unroll
+                for (int p = 0; p < 11; ++p) F[p] = *reinterpret_cast<const bf16x8*>(bp + p * ROWB + dx * 16);
+#pragma unroll
+                for (int dy = 0; dy < 5; ++dy) A[dy] = *reinterpret_cast<const bf16x8*>(wa + (dy * 5 + dx) * 1024);
+#pragma unroll
+                for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[dy], F[2 * m + dy], acc[m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (wnext) bf16_w_commit<1, WPER, NT>(reinterpret_cast<u32x4*>(wbuf + (cur ^ 1) * WBUF), wreg, tid);
+            if (dz < 4) __syncthreads();           // (the last plane's barrier follows the epilogue)
+            cur ^= 1;
+        }
+        if (ch == nch - 1) {
+            // epilogue: register r of lane = cout co0 + 8*(r/4) + 4*half + r%4 of voxel (subtile m, q32)
+            int b, bz, by, bx;
+            origin(brick, b, bz, by, bx);
+            const int co0 = cob * 32;
+            const int oz = bz * TZ + vz, ox = bx * TX + (q32 & 15);
+            float s1[4][4], s2[4][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s1[g][k] = s2[g][k] = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int oy = by * TY + vy0 + 2 * m + (q32 >> 4);
+                if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
+                const size_t ov = ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = co0 + g * 8 + half * 4;
+                    if (co >= a.Cout) continue;
+                    float e[4] = {acc[m][g * 4], acc[m][g * 4 + 1], acc[m][g * 4 + 2], acc[m][g * 4 + 3]};
+                    if (a.bias) { e[0] += a.bias[co]; e[1] += a.bias[co + 1]; e[2] += a.bias[co + 2]; e[3] += a.bias[co + 3]; }
+                    if constexpr (STATS) {
+                        float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (a.res) rr = *reinterpret_cast<const float4*>(a.res + ov * a.Cout + co);
+                        const float vv[4] = {e[0] + rr.x, e[1] + rr.y, e[2] + rr.z, e[3] + rr.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { s1[g][k] += vv[k]; s2[g][k] += vv[k] * vv[k]; }
+                    }
+                    float* p = (co < a.Cy0) ? a.y0 + ov * a.Cy0 + co : a.y1 + ov * a.Cy1 + (co - a.Cy0);
+                    if (a.accum) {
+                        const float4 old = *reinterpret_cast<const float4*>(a.accsrc ? a.accsrc + ov * a.Cy0 + co : p);
+                        e[0] += old.x; e[1] += old.y; e[2] += old.z; e[3] += old.w;
+                    }
+                    *reinterpret_cast<float4*>(p) = make_float4(e[0], e[1], e[2], e[3]);
+                }
+            }
+            if constexpr (STATS) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                        for (int off = 1; off < 32; off <<= 1) {
+                            s1[g][k] += __shfl_xor(s1[g][k], off, 64);
+                            s2[g][k] += __shfl_xor(s2[g][k], off, 64);
+                        }
+                        if (p32 == 0) {
+                            red[wave * 64 + g * 8 + half * 4 + k] = s1[g][k];
+                            red[wave * 64 + 32 + g * 8 + half * 4 + k] = s2[g][k];
+                        }
+                    }
+            }
+        }
+        __syncthreads();                               // every wave is done with the tile (and the last filter plane; red is complete)
+        if constexpr (STATS) if (ch == nch - 1) stats_row_write<8, 32>(red, a.stats, (size_t)brick, cob * 32, a.Cout, tid);
+        if (more) bf16_tile_commit_h<G, XH, 0, XH::PER>(tile, dump, hv, tid);
+        __syncthreads();
+    }
+}
+
 __global__ void pack_bf16_kernel(int mode, const float* __restrict__ w, unsigned short* __restrict__ wp, int T, int I, int O,
                                  int ncob, size_t total) {
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
@@ -1878,6 +2056,16 @@ bool conv_bf16_use_c16(int Cin, int Cout, int C0, int C1, int Cy0, int Cy1, int 
     return (long)B * ceil_div(D, 4) * ceil_div(H, 8) * ceil_div(W, 16) >= 256;
 }
 
+// row-pair kernel: whole 32-cout blocks, vector-aligned outputs, >= 256 (brick of 4x16x16, cout block) items
+bool conv_bf16_use_r32(int Cout, int Cy0, int Cy1, int B, int D, int H, int W) {
+#ifdef VNET_PLAN_ENV
+    static const int off = getenv("VNET_BF16_R32") ? (atoi(getenv("VNET_BF16_R32")) == 0) : 0;
+    if (off) return false;
+#endif
+    if ((Cout & 31) || (Cy0 & 3) || (Cy1 & 3) || W < 16 || H < 16) return false;
+    return (long)B * ceil_div(D, 4) * ceil_div(H, 16) * ceil_div(W, 16) * (Cout / 32) >= 256;
+}
+
 template <int TZ, int TY, int TX, int WAVES, bool STATS = false, bool H = false>
 int launch_conv_bf16(const ConvArgs& a, const Bf16Plan& p, hipStream_t st) {
     using G = Bf16Geom<TZ, TY, TX>;
@@ -2076,6 +2264,15 @@ size_t vnet_conv_bf16_ws_bytes(int Cin, int Cout, int B, int D, int H, int W) {
     return (size_t)p.nsplit * p.nz * B * D * H * W * round_up(Cout, 32) * sizeof(float);
 }
 
+int vnet_conv_bf16_stats_rows_x16(int Cin, int Cy0, int Cy1, int C0, int C1, int B, int D, int H, int W) {
+    if (Cy1 != 0 || Cy0 <= 0 || (Cy0 & 3) || Cin <= 0 || B <= 0) return 0;
+    if (!conv_bf16_use_c16(Cin, Cy0, C0, C1, Cy0, 0, B, D, H, W) && conv_bf16_use_r32(Cy0, Cy0, 0, B, D, H, W)) {
+        Bf16Plan p = plan_conv_bf16(Cin, Cy0, B, D, H, W);
+        if (p.nsplit * p.nz == 1) return B * ceil_div(D, 4) * ceil_div(H, 16) * ceil_div(W, 16);      // row-pair kernel: one row per 4x16x16 brick
+    }
+    return vnet_conv_bf16_stats_rows(Cin, Cy0, Cy1, C0, C1, B, D, H, W);
+}
+
 int vnet_conv_bf16_stats_rows(int Cin, int Cy0, int Cy1, int C0, int C1, int B, int D, int H, int W) {
     if (Cy1 != 0 || Cy0 <= 0 || (Cy0 & 3) || Cin <= 0 || B <= 0) return 0;
     if (conv_bf16_use_c16(Cin, Cy0, C0, C1, Cy0, 0, B, D, H, W)) return B * ceil_div(D, 4) * ceil_div(H, 8) * ceil_div(W, 16);
@@ -2110,6 +2307,27 @@ static int conv_fwd_bf16_go(ConvArgs& a, const Bf16Plan& p, int nslab, int C0, i
         VNET_LAUNCH_CHECK();
         return -1;            // done, no reduce
     }
+    if constexpr (HS) {
+        if (conv_bf16_use_r32(a.Cout, Cy0, Cy1, B, D, H, W) && nslab == 1) {
+            // 32-cout blocks, many bricks, bf16 shadows: the row-pair kernel (11 B + 5 A fragments per 20 MFMAs)
+            using GR = Bf16Geom<4, 16, 16>;
+            a.nbz = ceil_div(D, 4); a.nby = ceil_div(H, 16); a.nbx = ceil_div(W, 16);
+            const size_t lds = (size_t)GR::TILE_BYTES + 2 * (25 * 1024 + 16) + 64 * 16 + 8 * 64 * 4;
+            if (a.stats) {
+                auto k = conv5_bf16_r32_kernel<true>;
+                static unsigned long long attr_done = 0;
+                if (int ae = ensure_lds(k, lds, attr_done)) return ae;
+                hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, st, a);
+            } else {
+                auto k = conv5_bf16_r32_kernel<false>;
+                static unsigned long long attr_done = 0;
+                if (int ae = ensure_lds(k, lds, attr_done)) return ae;
+                hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, st, a);
+            }
+            VNET_LAUNCH_CHECK();
+            return -1;
+        }
+    }
     return (a.stats && nslab == 1)
          ? (p.small ? launch_conv_bf16<8, 8, 8, 8, true, HS>(a, p, st)
             : p.half ? launch_conv_bf16<4, 8, 8, 4, true, HS>(a, p, st) : launch_conv_bf16<4, 8, 16, 8, true, HS>(a, p, st))
@@ -2141,7 +2359,8 @@ static int conv_fwd_bf16_impl(const float* x0, int C0, const float* x1, int C1, 
         if (!accum || Cy1 > 0) return VNET_E_BADARG;
         a.accsrc = accsrc;
     }
-    if (stats && vnet_conv_bf16_stats_rows(a.Cin, Cy0, Cy1, C0, C1, B, D, H, W) == 0) return VNET_E_UNSUPPORTED;
+    if (stats && (src16 ? vnet_conv_bf16_stats_rows_x16(a.Cin, Cy0, Cy1, C0, C1, B, D, H, W)
+                        : vnet_conv_bf16_stats_rows(a.Cin, Cy0, Cy1, C0, C1, B, D, H, W)) == 0) return VNET_E_UNSUPPORTED;
     Bf16Plan p = plan_conv_bf16(a.Cin, a.Cout, B, D, H, W);
     a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.cps = p.cps; a.nz = p.nz;
     const int nslab = p.nsplit * p.nz;

@@ -867,7 +867,9 @@ def _epilogue_stats_buffer(bf16, ks, kx, stride, x0, x1, O, dims_out):
     L = _lib.lib()
     B, C0, C1 = x0.shape[0], x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
     if bf16:
-        rows = L.vnet_conv_bf16_stats_rows(C0 + C1, O, 0, C0, C1, B, *dims_out)
+        # (the kernels that stage bf16 shadows have their own brick shapes: one partial row per brick)
+        x16 = _shadow_ptr(x0) is not None and (x1 is None or _shadow_ptr(x1) is not None) and C0 % 8 == 0 and C1 % 8 == 0
+        rows = (L.vnet_conv_bf16_stats_rows_x16 if x16 else L.vnet_conv_bf16_stats_rows)(C0 + C1, O, 0, C0, C1, B, *dims_out)
     else:
         # fp32 MFMA kernels: measured (profiles/r02_epilogue_stats.txt) the STATS instantiations lose in their main loop most of
         # what the statistics pass costs (+1..3 % per launch, residual re-read on the input conv): the fused form is worth
