@@ -34,7 +34,8 @@ for (P, B, cin, K, net, nch, lev, convs, bot, comp, loss, opt) in cases:
         "SegmentationClasses": list(range(K)), "BatchSize": B, "PatchShape": list(P), "ComputeDtype": comp,
         "Networks": {"Name": net, "Dropout": 0.0, "NumChannel": nch, "NumLevels": lev, "NumConvolutions": convs, "BottomConvolutions": bot},
         "Optimizer": {"Name": opt, "InitialLearningRate": 1e-3, "Momentum": 0.9, "Decay": {"Factor": 0.99, "Steps": 100}},
-        "Loss": {"Name": loss, "Weights": [1.0 / (k + 1) for k in range(K)], "Alpha": 0.5}}}
+        "Loss": {"Name": loss, "Weights": [1.0 / (k + 1) for k in range(K)], "Alpha": 0.5,
+                 "AllowPlainXent": True}}}       # (the reference itself exits on "xent": model.py:495-559)
     tag = "%s B%d cin%d K%d %s nch%d L%d %s %s %s" % (P, B, cin, K, net, nch, lev, comp, loss, opt)
     try:
         np.random.seed(1)
