@@ -178,3 +178,32 @@ def test_row_pair_kernel_epilogue_statistics(dev, shape, cin, cout, residual):
         assert torch.allclose(tot[cout:], (v * v).sum(0), rtol=1e-5, atol=1e-2)
     finally:
         ops.set_compute_dtype("fp32")
+
+
+def test_row_pair_kernel_random_shapes_bit_identical_to_generic(dev):
+    """Property test: on random ragged volumes with >= 256 (brick, cout block) items the shadow path takes the row-pair kernel
+    and must reproduce the generic fp32-source kernel bit for bit (same products, same order), forward and accumulate mode."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from vnet_tensorflow_amd import ops
+
+    @settings(max_examples=12, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(D=st.integers(33, 72), H=st.integers(49, 80), W=st.integers(49, 80), cin=st.sampled_from([8, 16, 24, 32]),
+           cout=st.sampled_from([32, 64]), two=st.booleans(), seed=st.integers(0, 10 ** 6))
+    def run(D, H, W, cin, cout, two, seed):
+        gen = torch.Generator().manual_seed(seed)
+        x0 = torch.randn(1, D, H, W, cin, generator=gen).to(dev)
+        x1 = torch.randn(1, D, H, W, 8, generator=gen).to(dev) if two else None
+        w = (torch.randn(5, 5, 5, cin + (8 if two else 0), cout, generator=gen) * 0.05).to(dev)
+        b = torch.randn(cout, generator=gen).to(dev)
+        wp = ops.packed_weights(w, ops.PACK_FWD_BF16, 125, cin + (8 if two else 0), cout)
+        ref = torch.randn(1, D, H, W, cout, generator=gen).to(dev)
+        got = ref.clone()
+        ops._conv_bf16_call(x0, x1, wp, b, ref, None, (D, H, W), accum=True)
+        ops._conv_bf16_call(ops.with_shadow(x0), ops.with_shadow(x1) if two else None, wp, b, got, None, (D, H, W), accum=True)
+        assert torch.equal(got, ref), (D, H, W, cin, cout, two)
+
+    ops.set_compute_dtype("bf16")
+    try:
+        run()
+    finally:
+        ops.set_compute_dtype("fp32")
