@@ -1,0 +1,21 @@
+import sys, torch
+sys.path.insert(0, '.')
+from vnet_tensorflow_amd import ops
+dev = torch.device('cuda', 0)
+ops.set_compute_dtype('bf16')
+gen = torch.Generator().manual_seed(1)
+shp, ci, co = (1, 128, 128, 128), 16, 16
+x = ops.with_shadow(torch.randn(*shp, ci, generator=gen).to(dev))
+w = (torch.randn(5, 5, 5, ci, co, generator=gen) * 0.05).to(dev)
+b = torch.randn(co, generator=gen).to(dev)
+wp = ops.packed_weights(w, ops.PACK_FWD_BF16, 125, ci, co)
+y = torch.empty(*shp, co, device=dev)
+dbg = torch.zeros(4096 * 32, dtype=torch.float32, device=dev)
+for _ in range(3):
+    ops._conv_bf16_call(x, None, wp, b, y, None, shp[1:], stats=dbg)
+torch.cuda.synchronize()
+t = dbg.view(torch.int64)[:96].cpu().numpy().reshape(4, 24)
+for wv in range(4):
+    r = t[wv]
+    d = [int(r[k + 1] - r[k]) for k in range(20)]
+    print("wave", wv, "issue", d[0], "groups", d[1:16], "epilogue", d[16], "barrier", d[17], "commit", d[18], "barrier", d[19], "total", int(r[20] - r[0]))

@@ -999,6 +999,19 @@ struct Bf16Geom {
     static constexpr int TILE_BYTES = 2 * PLANE;
 };
 
+// 64 bytes of zeros in device memory: masked-off lanes of a register prefetch load from HERE (an address select) instead of
+// loading anywhere and selecting the DATA afterwards -- a data select makes the wave wait for the load right where it was
+// issued (hipcc emitted s_waitcnt vmcnt(0) in front of the MFMA loop: measured 4-5 K cycles per brick step, s_memtime stamps),
+// i.e. the "prefetch" was synchronous.
+__device__ __attribute__((aligned(64))) const unsigned int vnet_zero_line[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+// (explicit global address space: with a plain pointer select hipcc falls back to flat_load, which also counts on lgkmcnt
+// and would then be waited for by the first LDS fragment read of the MFMA loop)
+typedef const __attribute__((address_space(1))) u32x4* gvec16_t;
+__device__ __forceinline__ u32x4 load16_or_zero(const unsigned short* p, bool ok) {
+    gvec16_t src = ok ? (gvec16_t)(p) : (gvec16_t)(vnet_zero_line);
+    return *src;
+}
+
 // bf16-source twin of XTile (round 2: activations that carry a bf16 shadow, see vnet_conv_fwd_bf16_x16): a thread owns one
 // (x, cin half) column = 8 channels = ONE 16-byte unit per row, loaded as it will sit in LDS -- half the bytes through L2,
 // half the load/store instructions and no conversion.  Channel counts must be multiples of 8.
@@ -1029,10 +1042,7 @@ struct XTileH {
         for (int k = 0; k < KN; ++k) {
             const int gz = gz0 + iz, gy = gy0 + iy;
             const bool ok = colok && row < ROWS && (unsigned)gz < (unsigned)Di && (unsigned)gy < (unsigned)Hi;
-            const int off = ok ? gz * planestride + gy * rowstride : 0;
-            const u32x4 t = *reinterpret_cast<const u32x4*>(bp + off);
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            v[k] = ok ? t : z;
+            v[k] = load16_or_zero(bp + (ok ? gz * planestride + gy * rowstride : 0), ok);
             row += RPI; iy += DIY; iz += DIZ;
             if (iy >= IY) { iy -= IY; ++iz; }
         }
@@ -1856,9 +1866,7 @@ __global__ void __launch_bounds__(512) wgrad5_bf16_kernel(WgradArgs a) {
                 const int c = co0 + cu * 8;
                 const bool ok = q < NQH && oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout;
                 const size_t ov = ok ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
-                const u32x4 t = *reinterpret_cast<const u32x4*>(dyh + ov * a.Cout + (ok ? c : 0));
-                const u32x4 z = {0u, 0u, 0u, 0u};
-                hd[k] = ok ? t : z;
+                hd[k] = load16_or_zero(dyh + ov * a.Cout + (ok ? c : 0), ok);
             }
         } else {
             XT::issue(px, a.x0, a.x1, a.C0, a.C1, chunk, b, bz * TZ - 2, by * TY - 2, bx * TX - 2, a.Di, a.Hi, a.Wi, tid);
