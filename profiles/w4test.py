@@ -14,8 +14,8 @@ dbg = torch.zeros(4096 * 32, dtype=torch.float32, device=dev)
 for _ in range(3):
     ops._conv_bf16_call(x, None, wp, b, y, None, shp[1:], stats=dbg)
 torch.cuda.synchronize()
-t = dbg.view(torch.int64)[:96].cpu().numpy().reshape(4, 24)
-for wv in range(4):
+t = dbg.view(torch.int64)[:64].cpu().numpy().reshape(8, 8)
+names = ["tile_issue", "dz pairs (200 MFMA)", "pack + dz=4 (60 MFMA)", "epilogue", "barrier", "commit", "barrier"]
+for wv in range(8):
     r = t[wv]
-    d = [int(r[k + 1] - r[k]) for k in range(20)]
-    print("wave", wv, "issue", d[0], "groups", d[1:16], "epilogue", d[16], "barrier", d[17], "commit", d[18], "barrier", d[19], "total", int(r[20] - r[0]))
+    print("wave", wv, " ".join("%s %d" % (n, int(r[k + 1] - r[k])) for k, n in enumerate(names)), "total", int(r[7] - r[0]))
