@@ -1,3 +1,7 @@
+"""Prints the s_memtime stamps of one brick step of conv5_bf16_c16_kernel (profiles/r02_c16_step_stamps.txt).  Needs the
+experiment build: the stamp patch of DESIGN section 8 applied to csrc/conv_mfma.hip (ts[] = __builtin_readcyclecounter() around
+the phases, written through ConvArgs.stats for one workgroup), compiled with -DVNET_PLAN_ENV into a library named by VNET_HIP_LIB,
+and VNET_C16_DBG=1 so that the plain kernel runs with the debug buffer in `stats`.  With the shipped library it prints zeros."""
 import sys, torch
 sys.path.insert(0, '.')
 from vnet_tensorflow_amd import ops
