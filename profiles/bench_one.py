@@ -9,11 +9,16 @@ kind, mode, P, ci, co = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 10
 dev = torch.device('cuda', 0)
 ops.set_compute_dtype(mode)
+import os
 x = torch.randn(1, P, P, P, ci, device=dev)
 w = torch.nn.Parameter(torch.randn(5, 5, 5, ci, co, device=dev) * 0.05)
 b = torch.zeros(co, device=dev)
 dy = torch.randn(1, P, P, P, co, device=dev)
 dw = torch.empty(5, 5, 5, ci, co, device=dev)
+if os.environ.get("BENCH_ZERO"):          # DVFS probe: all-zero operands toggle no datapath bits (MI355X_MICROARCH.md "DVFS give-back")
+    x.zero_(); dy.zero_()
+    with torch.no_grad():
+        w.zero_()
 if mode == 'bf16' and ci % 8 == 0 and co % 8 == 0:          # as in a training step: producers leave bf16 shadows (VNET_BF16_SHADOW=0: off)
     x, dy = ops.with_shadow(x), ops.with_shadow(dy)
 
