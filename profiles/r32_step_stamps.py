@@ -1,3 +1,6 @@
+"""Prints the s_memtime stamps of one brick step of conv5_bf16_r32_kernel (profiles/r02_dvfs_probe.txt, last section).  Needs an
+experiment build like profiles/c16_step_stamps.py: ts[] = __builtin_readcyclecounter() around the phases of the kernel, written
+through ConvArgs.stats for one workgroup; -DVNET_PLAN_ENV library in VNET_HIP_LIB, VNET_C16_DBG=1.  Zeros with the shipped library."""
 import sys, torch
 sys.path.insert(0, '.')
 from vnet_tensorflow_amd import ops
