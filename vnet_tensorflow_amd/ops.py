@@ -239,10 +239,11 @@ class GradSink(object):
     straight into its slice of the flat gradient buffer (no temporary, no autograd accumulate kernel) and
     then call `ready` (the data-parallel bucket countdown).  `written` guards against a parameter that is
     used twice in one backward pass: the second use falls back to autograd's accumulation."""
-    __slots__ = ("view", "written", "ready")
+    __slots__ = ("view", "written", "ready", "ws")
 
     def __init__(self, view):
         self.view, self.written, self.ready = view, False, None
+        self.ws = None           # this parameter's own slab buffer of the deferred filter-gradient reduce (lives as long as the sink)
 
 
 def _grad_out(p):
@@ -417,7 +418,7 @@ def _conv_bf16_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res
 # launch reduces all of them when the context ends (26 reduce launches of ~7 us per V-Net step otherwise).  Only for a backward
 # pass whose filter gradients nobody reads before it ends (model.image2label: not the eager data-parallel step, whose bucket
 # all-reduces start from the gradient hooks).
-_DEFER = {"on": False, "ws": {}}
+_DEFER = {"on": False}
 
 
 @contextlib.contextmanager
@@ -436,16 +437,14 @@ def deferred_wgrad_reduce(on=True):
         check(L.vnet_wgrad_flush(_stream()), "vnet_wgrad_flush")
 
 
-def _wgrad_workspace(dw, nbytes, immediate):
-    """Scratch for the partial slabs: the shared workspace, or (deferred reduce) a buffer of this layer's own that lives on."""
-    if not _DEFER["on"] or immediate:
+def _wgrad_workspace(dw, nbytes, immediate, owner):
+    """Scratch for the partial slabs: the shared workspace, or (deferred reduce) a buffer of this layer's own, kept on the
+    parameter's gradient sink so that it lives exactly as long as the parameter does (a captured step graph holds its address)."""
+    if not _DEFER["on"] or immediate or owner is None:
         return workspace(nbytes, dw.device)
-    key = (dw.data_ptr(), dw.device.index)
-    buf = _DEFER["ws"].get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dw.device)
-        _DEFER["ws"][key] = buf
-    return buf
+    if owner.ws is None or owner.ws.numel() < nbytes or owner.ws.device != dw.device:
+        owner.ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dw.device)
+    return owner.ws
 
 
 @contextlib.contextmanager
@@ -462,20 +461,20 @@ def _immediate_reduce(immediate):
         L.vnet_wgrad_defer(1)
 
 
-def _wgrad_bf16_call(x0, x1, dy, dw, dims):
+def _wgrad_bf16_call(x0, x1, dy, dw, dims, owner=None):
     """Filter gradient of the 5^3 stride-1 conv with bf16 operands / fp32 accumulation (vnet_conv_wgrad_bf16)."""
     L = _lib.lib()
     B = x0.shape[0]
     C0, C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
     Co = dy.shape[-1]
     nb = L.vnet_wgrad_bf16_ws_bytes(C0 + C1, Co, B, *dims)
-    ws = _wgrad_workspace(dw, nb, False)
+    ws = _wgrad_workspace(dw, nb, False, owner)
     nvox = B * dims[0] * dims[1] * dims[2]
     flops = 2.0 * nvox * 125 * (C0 + C1) * Co
     nbytes = 4.0 * (nvox * (C0 + C1 + Co) + 125 * (C0 + C1) * Co)
     tag = _wgrad_tag(True, 5, 0, 1, dims[2], B, C0 + C1, Co)
     h0, h1, hd = _shadow_ptr(x0), _shadow_ptr(x1), _shadow_ptr(dy)
-    with _Timed(tag, flops, nbytes):
+    with _Timed(tag, flops, nbytes), _immediate_reduce(owner is None):
         if h0 is not None and hd is not None and (x1 is None or h1 is not None) and C0 % 8 == 0 and C1 % 8 == 0 and Co % 8 == 0:
             check(L.vnet_conv_wgrad_bf16_x16(h0, C0, h1, C1, hd, Co, _ptr(dw), B, *dims, _ptr(ws), nb, _stream()),
                   "vnet_conv_wgrad_bf16_x16")
@@ -484,13 +483,14 @@ def _wgrad_bf16_call(x0, x1, dy, dw, dims):
                                      _ptr(ws), nb, _stream()), "vnet_conv_wgrad_bf16")
 
 
-def _wgrad_call(ks, stride, x0, x1, dy, dw, dims_in, dims_out, kx=0, immediate=False):
+def _wgrad_call(ks, stride, x0, x1, dy, dw, dims_in, dims_out, kx=0, immediate=False, owner=None):
     L = _lib.lib()
+    immediate = immediate or owner is None          # no sink to keep the slabs on: reduce on the spot
     B = x0.shape[0]
     C0, C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
     Co = dy.shape[-1]
     nb = L.vnet_wgrad_ws_bytes(ks, kx, stride, C0 + C1, Co, B, *dims_out)
-    ws = _wgrad_workspace(dw, nb, immediate)
+    ws = _wgrad_workspace(dw, nb, immediate, owner)
     nin, nout = B * dims_in[0] * dims_in[1] * dims_in[2], B * dims_out[0] * dims_out[1] * dims_out[2]
     taps = ks * ks * (kx or ks)
     flops = 2.0 * nout * taps * (C0 + C1) * Co
@@ -709,11 +709,11 @@ class _ConvFn(torch.autograd.Function):
                 colsum(dy, O, out=db)
             if dw is not None:
                 if up:      # dw[a][o][ci] = sum_i dy[2i+a][o] * x[i][ci]  == filter grad of the 2^3 down conv (fine -> coarse)
-                    _wgrad_call(2, 2, dy, None, x0, dw, dout, din)
+                    _wgrad_call(2, 2, dy, None, x0, dw, dout, din, owner=sw)
                 elif ctx.bf16:
-                    _wgrad_bf16_call(x0, x1, dy, dw, din)
+                    _wgrad_bf16_call(x0, x1, dy, dw, din, owner=sw)
                 else:
-                    _wgrad_call(ks, stride, x0, x1, dy, dw, din, dout)
+                    _wgrad_call(ks, stride, x0, x1, dy, dw, din, dout, owner=sw)
         finally:
             _LAUNCH_ON[0] = None
         dx0 = dx1 = None
