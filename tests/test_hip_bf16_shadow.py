@@ -107,7 +107,7 @@ def test_producers_write_rne_shadows(dev):
         ops.set_compute_dtype("fp32")
 
 
-@pytest.mark.parametrize("variant,cin,dropout", [("networks", 4, 0.0), ("networks", 1, 0.0), ("VNet", 2, 0.0)])
+@pytest.mark.parametrize("variant,cin,dropout", [("networks", 4, 0.0), ("networks", 1, 0.0), ("VNet", 2, 0.0), ("networks", 3, 0.15)])
 def test_network_step_bit_identical_with_and_without_shadows(dev, variant, cin, dropout):
     """Whole forward + loss + backward of a bf16-mode network: logits, loss and every gradient bit-identical."""
     from vnet_tensorflow_amd import ops, networks, VNet
@@ -121,6 +121,7 @@ def test_network_step_bit_identical_with_and_without_shadows(dev, variant, cin, 
             ops.set_bf16_shadows(on)
             torch.manual_seed(0)
             np.random.seed(0)
+            ops._DROP_SEED[0] = 0x5EED            # the same dropout masks in both runs (the dropout kernel writes shadows, too)
             if variant == "networks":
                 net = networks.VNet(K, dropout, C0, levels, ncv, nb, True, "prelu", device=dev)
             else:
