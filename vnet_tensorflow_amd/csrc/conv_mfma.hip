@@ -915,8 +915,11 @@ ConvPlan plan_conv(int ks, int stride, int up, int Cin, int Cout, int B, int Do,
     p.ns = pick_ns(CoutP);
     p.ncob = CoutP / (16 * p.ns);
     p.small = gridW < 16;
-    if (stride == 2 && !up) { if (p.small) brick_counts<2, 8, 8>(Do, Ho, Wo, p); else brick_counts<2, 4, 16>(Do, Ho, Wo, p); }
+    // 2^3 stride-2 conv, W >= 16: 1x4x16 output bricks (32 KB input tile, four workgroups per CU) instead of 2x4x16: these launches are
+    // load latency / bandwidth, more tiles in flight per CU help (128^3 -> 64^3: 47.8 -> 38.8 us, profiles/bench_updown.py)
+    if (stride == 2 && !up) { if (p.small) brick_counts<2, 8, 8>(Do, Ho, Wo, p); else brick_counts<1, 4, 16>(Do, Ho, Wo, p); }
     else if (ks == 5 && !up && !p.small) { p.half = 1; brick_counts<4, 8, 8>(Do, Ho, Wo, p); }
+    else if (up && !p.small) brick_counts<2, 4, 16>(Do, Ho, Wo, p);       // transposed conv: 128 input voxels per 4-wave workgroup (55.5 -> 52.5 us at 128^3)
     else { if (p.small) brick_counts<8, 8, 8>(Do, Ho, Wo, p); else brick_counts<4, 8, 16>(Do, Ho, Wo, p); }
     const int nchunks = round_up(Cin, 16) / 16;
     // deep levels have few bricks: prefer more, narrower cout blocks (each a full workgroup of equal work) until
@@ -2244,16 +2247,16 @@ static int conv_fwd_impl(int ks, int kx, int stride, int up, const float* x0, in
             if (kx == 1) e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false, 1, true>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 8, 4, 4, false, 1, true>(a, p, st);
             else e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false, 5, true>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 8, 4, 4, false, 5, true>(a, p, st);
         } else {
-            e = p.small ? launch_conv_ns<2, 2, 2, 8, 8, 4, 2, false, 2, true>(a, p, st) : launch_conv_ns<2, 2, 2, 4, 16, 4, 2, false, 2, true>(a, p, st);
+            e = p.small ? launch_conv_ns<2, 2, 2, 8, 8, 4, 2, false, 2, true>(a, p, st) : launch_conv_ns<2, 2, 1, 4, 16, 4, 1, false, 2, true>(a, p, st);
         }
     } else if (is5) {
         if (kx == 1) e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false, 1>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 8, 4, 4, false, 1>(a, p, st);
         else e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 8, 4, 4, false>(a, p, st);
     } else if (isdown) {
-        e = p.small ? launch_conv_ns<2, 2, 2, 8, 8, 4, 2, false>(a, p, st) : launch_conv_ns<2, 2, 2, 4, 16, 4, 2, false>(a, p, st);
+        e = p.small ? launch_conv_ns<2, 2, 2, 8, 8, 4, 2, false>(a, p, st) : launch_conv_ns<2, 2, 1, 4, 16, 4, 1, false>(a, p, st);
     } else {
         e = p.tiny ? launch_conv_ns<1, 1, 2, 8, 8, 4, 2, true>(a, p, st)
-          : p.small ? launch_conv_ns<1, 1, 8, 8, 8, 8, 4, true>(a, p, st) : launch_conv_ns<1, 1, 4, 8, 16, 8, 4, true>(a, p, st);
+          : p.small ? launch_conv_ns<1, 1, 8, 8, 8, 8, 4, true>(a, p, st) : launch_conv_ns<1, 1, 2, 4, 16, 4, 2, true>(a, p, st);
     }
     if (e) return e;
     if (nslab > 1) {
