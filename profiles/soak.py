@@ -1,7 +1,7 @@
 """Soak: N replayed training steps at 128^3 over four alternating batches (default 3000, ~80 s), memory and loss sampled on the
-way -- the replayed step graph must neither leak nor stall.  Round 2 on one MI355X: allocated 1851.6 MB / reserved 3734.0 MB
-at steps 10, 150, 750 and 1499 (of which ~680 MB are the per-layer filter-gradient slabs of the batched reduce), loss
-0.558 -> 0.0031, 25.70 ms/step sustained; bf16 (1 modality): 1024.6 MB, 7.77 ms/step over 2000 steps.
+way -- the replayed step graph must neither leak nor stall.  Round 2 on one MI355X, 8000 steps each: fp32 allocated 1851.6 MB /
+reserved 3736.0 MB at steps 10, 800, 4000 and 7999 (~680 MB of it the per-layer filter-gradient slabs of the batched reduce), loss
+0.558 -> 0.00007, 25.43 ms/step sustained; bf16 (1 modality) 1642.1 / 4032.0 MB, 7.24 ms/step.
     python profiles/soak.py [steps] [fp32|bf16]"""
 import sys
 import time
