@@ -45,6 +45,9 @@ extern "C" {
 #define VNET_PACK_FWD_BF16 3   /* conv forward, operands rounded to bf16 (RNE)                              */
 #define VNET_PACK_BWD_BF16 4   /* conv backward-data (flipped taps, cin<->cout), bf16                       */
 
+/* or-ed into VNET_PACK_FWD / _BWD / _UP: the fp32 image holds the filter ROUNDED to bf16 (bf16-storage mode of the 2^3 convs) */
+#define VNET_PACK_ROUND_BF16 16
+
 /* loss kinds for vnet_softmax_dice_* (model.py:495-558) */
 #define VNET_LOSS_SORENSEN 0
 #define VNET_LOSS_JACCARD  1
@@ -357,6 +360,65 @@ int vnet_auc_histogram(const float* softmax, const int32_t* labels, int64_t n, i
 /* ---- sliding-window accumulation for evaluate (model.py:919-929) ----------------------------- */
 int vnet_accumulate_patch(const float* patch, float* vol, float* count, int K,
                           int pz, int py, int px, int z0, int y0, int x0, int D, int H, int W, void* stream);
+
+/* ==== bf16-STORAGE mode (`*_b16`): BASELINE config C5 as SURVEY 8(d) states it =============================================
+ * "bf16 activations/weights into MFMA, fp32 accumulate, fp32 BN stats and Dice sums".  Activations, skip tensors and their
+ * gradients are bf16 NDHWC tensors (`void*`, 2 bytes per element, 16-byte aligned, channel counts multiples of 8 -- and of the
+ * form 8 * 2^k for the batch-norm kernels); every kernel computes in fp32 and rounds its output ONCE (round-to-nearest-even,
+ * v_cvt_pk_bf16_f32).  Filters, biases, batch-norm parameters / statistics, logits, loss and every parameter gradient stay
+ * fp32.  Same reference call sites as the fp32 entry points they mirror (layers2.py:59-99, networks.py:259...361,
+ * model.py:660); argument meaning as there unless noted. */
+
+/* network input: fp32 [M][C] -> bf16 [M][Cpad], channels C..Cpad-1 zero (Cpad % 8 == 0): the multi-modality image padded to
+ * the 16-byte unit the convolution kernels stage (the filter's packed image is zero-padded to 16 input channels anyway) */
+int vnet_cast_bf16(const float* x, void* y16, int64_t M, int C, int Cpad, void* stream);
+
+/* 5^3 stride-1 convolution, bf16 in / bf16 out; forward (VNET_PACK_FWD_BF16) and backward-data (VNET_PACK_BWD_BF16).
+ * acc16: NULL, or a bf16 tensor of y0's shape that is added before the rounding (== y0: in place; else out of place, Cy1 = 0);
+ * res16 / stats: batch-norm statistics of the ROUNDED output (+ res16) in the epilogue, rows = vnet_conv_bf16_stats_rows_x16;
+ * ws >= vnet_conv_bf16_ws_bytes.  Result == RNE(what vnet_conv_fwd_bf16_x16 writes in fp32), bit for bit. */
+int vnet_conv_fwd_b16(const void* x0, int C0, const void* x1, int C1, const void* wp, const float* bias,
+                      void* y0, int Cy0, void* y1, int Cy1, int B, int D, int H, int W,
+                      const void* acc16, const void* res16, float* stats, void* ws, size_t ws_bytes, void* stream);
+/* its filter gradient: x, dy bf16, dw fp32 [125][Cin_dw][Cout] with Cin_dw <= C0 + C1 (the leading input channels: a
+ * zero-padded network input); ws >= vnet_wgrad_bf16_ws_bytes(C0 + C1, ...) */
+int vnet_conv_wgrad_b16(const void* x0, int C0, const void* x1, int C1, const void* dy, int Cout, float* dw, int Cin_dw,
+                        int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream);
+/* 2^3 stride-2 convolution (up = 0) / 2^3 transposed convolution (up = 1), bf16 in / bf16 out.  wp: the fp32 packed image of
+ * the bf16-ROUNDED filter, vnet_pack_weights(VNET_PACK_FWD | VNET_PACK_ROUND_BF16, 8, Cin, Cout) resp. VNET_PACK_UP | ...;
+ * accum: y += result (one rounding of the sum); stats (up = 0 only): rows = vnet_conv_stats_rows(2, 0, 2, 0, ...);
+ * ws >= vnet_conv_ws_bytes(2, 0, 2, up, ...).  Channel counts multiples of 4. */
+int vnet_conv2_fwd_b16(int up, const void* x, int Cin, const float* wp, const float* bias, void* y, int Cout,
+                       int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                       int accum, float* stats, void* ws, size_t ws_bytes, void* stream);
+/* filter gradient of the 2^3 stride-2 convolution: x = fine tensor [B,Di,Hi,Wi,Cin], dy = coarse tensor [B,Do,Ho,Wo,Cout],
+ * dw fp32 [8][Cin][Cout]; ws >= vnet_wgrad_ws_bytes(2, 0, 2, ...) */
+int vnet_conv2_wgrad_b16(const void* x, int Cin, const void* dy, int Cout, float* dw,
+                         int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, void* ws, size_t ws_bytes, void* stream);
+
+/* batch-norm (+ residual, + activation) on bf16 tensors; statistics and parameter gradients fp32 (float64 partial sums).
+ * bcast = 1: x is the fp32 1-channel image [M] broadcast to C channels (tf.tile, networks.py:258), y still bf16 [M][C]. */
+int vnet_bn_stats_b16(const void* x16, const void* r16, int64_t M, int C, float eps, float momentum,
+                      float* mean, float* invstd, float* moving_mean, float* moving_var, void* ws, size_t ws_bytes, void* stream);
+int vnet_bn_moments_b16(const void* x16, const void* r16, int64_t M, int C, double* sums, void* ws, size_t ws_bytes, void* stream);
+int vnet_bn_act_fwd_b16(const void* x, const void* r16, int bcast, int64_t M, int C,
+                        const float* mean, const float* invstd, const float* gamma, const float* beta,
+                        int act, const float* alpha, void* y16, void* stream);
+int vnet_bn_act_bwd_reduce_b16(const void* dy16, const void* x, const void* r16, int bcast, int64_t M, int C,
+                               const float* mean, const float* invstd, const float* gamma, const float* beta,
+                               int act, const float* alpha, float* dgamma, float* dbeta, float* dalpha,
+                               void* ws, size_t ws_bytes, void* stream);
+int vnet_bn_act_bwd_apply_b16(const void* dy16, const void* x, const void* r16, int bcast, int64_t M, int C,
+                              const float* mean, const float* invstd, const float* gamma, const float* beta,
+                              int act, const float* alpha, const float* sum_dz, const float* sum_dz_xhat, double M_total,
+                              const float* xhat_coef, void* ds16, void* stream);
+/* 1x1x1 output head: bf16 activations in, fp32 logits out (K <= 8); backward: fp32 dy, bf16 dx (NULL to skip), fp32 dw / db */
+int vnet_head_fwd_b16(const void* x16, const float* w, const float* bias, float* y, int64_t M, int C, int K, void* stream);
+int vnet_head_bwd_b16(const void* x16, const float* w, const float* dy, void* dx16, float* dw, float* db,
+                      int64_t M, int C, int K, void* ws, size_t ws_bytes, void* stream);
+/* dropout on bf16 tensors (n % 8 == 0); the mask stream is the fp32 kernel's (same seed -> same mask) */
+int vnet_dropout_fwd_b16(const void* x16, void* y16, uint8_t* mask, int64_t n, float rate, uint64_t seed, const void* state, void* stream);
+int vnet_dropout_bwd_b16(const void* dy16, const uint8_t* mask, void* dx16, int64_t n, float rate, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,44 @@ import torch.nn.functional as F
 
 BN_EPS = 1e-3
 
+# Independent restatement of the bf16-storage mode of round 3 (vnet_oracle.ACT_STORAGE): STORAGE = "bf16" makes `_store` round a
+# tensor to bfloat16 forward AND the gradient that flows back through it (torch's own round-to-nearest-even conversion, through
+# float32 like the device), and every convolution with a spatial kernel round its filter (straight-through: the filter
+# gradient, a product of bf16 tensors, goes to the fp32 master weights unrounded).
+STORAGE = None
+
+
+def _rb(t):
+    return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+class _StoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _rb(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _rb(g)
+
+
+class _RoundSTE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w):
+        return _rb(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _store(x):
+    return _StoreFn.apply(x) if STORAGE == "bf16" else x
+
+
+def _operand(t, k):
+    return _RoundSTE.apply(t) if (STORAGE == "bf16" and k > 1) else t
+
 
 def _same_pad(n, k, s):
     out = -(-n // s)
@@ -39,6 +77,7 @@ def convolution(x, w, b, stride=1):
     for a in reversed(range(r)):            # F.pad wants last spatial dim first
         _, lo, hi = _same_pad(x.shape[1 + a], w.shape[a], stride)
         pads += [lo, hi]
+    x, w = _operand(x, w.shape[0]), _operand(w, w.shape[0])
     xc = F.pad(_to_ncx(x), pads)
     wt = w.permute(r + 1, r, *range(r))     # [Co,Ci,*k]
     conv = F.conv3d if r == 3 else F.conv2d
@@ -48,6 +87,7 @@ def convolution(x, w, b, stride=1):
 def deconvolution(x, w, b, out_spatial, stride=2):
     """layers2.py:65-74 (tf.nn.conv3d_transpose SAME), w [*k,Cout,Cin]."""
     r = x.dim() - 2
+    w = _operand(w, w.shape[0])
     wt = w.permute(r + 1, r, *range(r))     # [Cin,Cout,*k] = torch conv_transpose layout
     convt = F.conv_transpose3d if r == 3 else F.conv_transpose2d
     k = w.shape[0]
@@ -137,12 +177,12 @@ class TorchVNet(object):
         inp, C, k = x, x.shape[-1], [5] * (x.dim() - 2)
         for i in range(n):
             self.scope.append('conv_%d' % (i + 1))
-            x = self._conv(x, k + [C, C])
+            x = _store(self._conv(x, k + [C, C]))
             if self.variant == 'legacy':
-                x = self._bn(x)
+                x = _store(self._bn(x))
             if i == n - 1:
                 x = x + inp
-            x = self._act(self._bn(x))
+            x = _store(self._act(self._bn(x)))
             self.scope.pop()
         return x
 
@@ -151,25 +191,27 @@ class TorchVNet(object):
         x = torch.cat((x, f), dim=-1)
         legacy = self.variant == 'legacy'
         self.scope.append('conv_1')
-        x = self._bn(self._conv(x, k + [2 * C, C]))
+        x = self._bn(_store(self._conv(x, k + [2 * C, C])))
         if n == 1:
-            if not legacy:
+            if legacy:
+                x = _store(x)
+            else:
                 inp = self._bn(x)
-            x = self._act(self._bn(x + inp))
+            x = _store(self._act(self._bn(x + inp)))
             self.scope.pop()
             return x
-        x = self._act(x)
+        x = _store(self._act(x))
         self.scope.pop()
         for i in range(1, n):
             self.scope.append('conv_%d' % (i + 1))
-            x = self._conv(x, k + [C, C])
+            x = _store(self._conv(x, k + [C, C]))
             if legacy:
-                x = self._bn(x)
+                x = _store(self._bn(x))
             else:
                 inp = self._bn(x)
             if i == n - 1:
                 x = x + inp
-            x = self._act(self._bn(x))
+            x = _store(self._act(self._bn(x)))
             self.scope.pop()
         return x
 
@@ -178,9 +220,9 @@ class TorchVNet(object):
         r, cin = x.dim() - 2, x.shape[-1]
         self.scope = ['vnet/input_layer']
         if cin == 1:
-            x = self._bn(x.repeat(*([1] * (r + 1)), self.C0))
+            x = _store(self._bn(x.repeat(*([1] * (r + 1)), self.C0)))
         else:
-            x = self._act(self._bn(self._conv(x, [5] * r + [cin, self.C0])))
+            x = _store(self._act(self._bn(_store(self._conv(x, [5] * r + [cin, self.C0])))))
         feats = []
         for l in range(self.L):
             self.scope = ['vnet/encoder/level_%d' % (l + 1)]
@@ -188,7 +230,7 @@ class TorchVNet(object):
             feats.append(x)
             self.scope.append('down_convolution')
             C = x.shape[-1]
-            x = self._act(self._bn(self._conv(x, [2] * r + [C, 2 * C], 2)))
+            x = _store(self._act(self._bn(_store(self._conv(x, [2] * r + [C, 2 * C], 2)))))
         self.scope = ['vnet/bottom_level']
         x = self._block(x, self.nb)
         for l in reversed(range(self.L)):
@@ -196,7 +238,7 @@ class TorchVNet(object):
             f, C = feats[l], x.shape[-1]
             w = self._get('weights', tuple([2] * r + [C // 2, C]))
             b = self._get('biases', (C // 2,), 0.0)
-            x = self._act(self._bn(deconvolution(x, w, b, f.shape[1:-1], 2)))
+            x = _store(self._act(self._bn(_store(deconvolution(x, w, b, f.shape[1:-1], 2)))))
             self.scope.pop()
             x = self._block2(x, f, self.ncv[l])
         self.scope = ['vnet/output_layer']

@@ -189,11 +189,36 @@ def _unbroadcast(g, shape):
 CONV5_OPERAND_ROUNDING = None
 
 
+# Round 3, config C5 as SURVEY 8(d) words it ("bf16 activations/weights into MFMA, fp32 accumulate, fp32 BN stats and Dice
+# sums"): with ACT_STORAGE = "bf16" every activation tensor the network keeps -- and every gradient of one -- is STORED as
+# bfloat16: `store()` marks those tensors in the wiring below (forward value rounded once; the gradient that arrives, summed over
+# the consumers, rounded once on its way to the producer).  Every convolution with a spatial kernel (5^k and 2^k, forward, backward-
+# data and filter gradient) then takes bf16 operands (the filter is rounded, the tensors are bf16 already); the 1^k output head
+# keeps its fp32 filter and fp32 logits; batch-norm statistics, parameter gradients, softmax and Dice are full precision.
+ACT_STORAGE = None
+
+
+def store(x):
+    """A tensor the bf16-storage mode writes to memory (identity otherwise)."""
+    if ACT_STORAGE != "bf16":
+        return x
+    out = Var(round_bf16(x.v), (x,))
+    out._bw = lambda g: x._acc(round_bf16(g))
+    return out
+
+
+def _operand_rounding(w, stride):
+    k = w.shape[0]
+    if ACT_STORAGE == "bf16" and k > 1:
+        return round_bf16
+    if CONV5_OPERAND_ROUNDING == "bf16" and stride == 1 and k == 5:
+        return round_bf16
+    return (lambda a: a)
+
+
 def convolution(x, w, b, stride=1):
     """layers2.py:59-63: tf.nn.convolution(x, w, 'SAME', strides) + b."""
-    rb = (lambda a: a)
-    if CONV5_OPERAND_ROUNDING == "bf16" and stride == 1 and w.v.shape[0] == 5:
-        rb = round_bf16
+    rb = _operand_rounding(w.v, stride)
     y = conv_nd_fwd(rb(x.v), rb(w.v), stride) + b.v
     out = Var(y, (x, w, b))
 
@@ -209,13 +234,14 @@ def convolution(x, w, b, stride=1):
 def deconvolution(x, w, b, out_spatial, stride=2):
     """layers2.py:65-74: tf.nn.conv3d_transpose(x, w, output_shape, strides, 'SAME') + b,
     w [*k, Cout, Cin], b has filter[-2] = Cout elements."""
-    y = conv_nd_transpose_fwd(x.v, w.v, out_spatial, stride) + b.v
+    rb = round_bf16 if ACT_STORAGE == "bf16" else (lambda a: a)
+    y = conv_nd_transpose_fwd(rb(x.v), rb(w.v), out_spatial, stride) + b.v
     out = Var(y, (x, w, b))
 
     def bw(g):
         # y = d/dX conv(X, w) . x  ==> dx = conv(g, w) ; dw = conv-filter-grad(X:=g, dy:=x)
-        x._acc(conv_nd_fwd(g, w.v, stride))
-        _, dw = conv_nd_bwd(g, w.v, x.v, stride, need_dx=False)
+        x._acc(conv_nd_fwd(rb(g), rb(w.v), stride))
+        _, dw = conv_nd_bwd(rb(g), w.v, rb(x.v), stride, need_dx=False)
         w._acc(dw)
         b._acc(g.reshape(-1, g.shape[-1]).sum(0))
     out._bw = bw
@@ -308,7 +334,7 @@ def dropout(x, rate, mask=None):
     sc = mask / (1.0 - rate)
     out = Var(x.v * sc, (x,))
     out._bw = lambda g: x._acc(g * sc)
-    return out
+    return store(out)
 
 
 def softmax(z):
@@ -542,13 +568,13 @@ class VNetOracle(object):
         k = [5] * (x.v.ndim - 2)
         for i in range(n):
             with ps.variable_scope('conv_%d' % (i + 1)):
-                x = L_convolution(ps, x, k + [C, C])
+                x = store(L_convolution(ps, x, k + [C, C]))
                 if self.variant == "legacy":
-                    x = L_batch_norm(ps, x)
+                    x = store(L_batch_norm(ps, x))
                 if i == n - 1:
                     x = add(x, layer_input)
                 x = L_batch_norm(ps, x)
-                x = L_activation(ps, x, self.act)
+                x = store(L_activation(ps, x, self.act))      # residual add + batch-norm + activation: one fused kernel, one tensor
                 x = dropout(x, self.dropout_rate)
         return x
 
@@ -560,33 +586,37 @@ class VNetOracle(object):
         k = [5] * (x.v.ndim - 2)
         x = concat_channels(x, f)
         legacy = self.variant == "legacy"
+        # (storage marks: the networks.py batch-norm chains BN -> BN -> add -> BN -> act are ONE fused normalisation of the stored
+        #  conv output in the build (closed form), so nothing in between is stored; the legacy wiring runs two kernels)
         if n == 1:
             with ps.variable_scope('conv_1'):
-                x = L_convolution(ps, x, k + [2 * C, C])
+                x = store(L_convolution(ps, x, k + [2 * C, C]))
                 x = L_batch_norm(ps, x)
-                if not legacy:
+                if legacy:
+                    x = store(x)
+                else:
                     layer_input = L_batch_norm(ps, x)       # networks.py:335
                 x = add(x, layer_input)
                 x = L_batch_norm(ps, x)
-                x = L_activation(ps, x, self.act)
+                x = store(L_activation(ps, x, self.act))
                 x = dropout(x, self.dropout_rate)
             return x
         with ps.variable_scope('conv_1'):
-            x = L_convolution(ps, x, k + [2 * C, C])
+            x = store(L_convolution(ps, x, k + [2 * C, C]))
             x = L_batch_norm(ps, x)
-            x = L_activation(ps, x, self.act)
+            x = store(L_activation(ps, x, self.act))
             x = dropout(x, self.dropout_rate)
         for i in range(1, n):
             with ps.variable_scope('conv_%d' % (i + 1)):
-                x = L_convolution(ps, x, k + [C, C])
+                x = store(L_convolution(ps, x, k + [C, C]))
                 if legacy:
-                    x = L_batch_norm(ps, x)                  # VNet.py:65
+                    x = store(L_batch_norm(ps, x))           # VNet.py:65
                 else:
                     layer_input = L_batch_norm(ps, x)        # networks.py:358 (dead unless last)
                 if i == n - 1:
                     x = add(x, layer_input)
                 x = L_batch_norm(ps, x)
-                x = L_activation(ps, x, self.act)
+                x = store(L_activation(ps, x, self.act))
                 x = dropout(x, self.dropout_rate)
         return x
 
@@ -600,29 +630,29 @@ class VNetOracle(object):
         with ps.variable_scope('vnet/input_layer'):
             if cin == 1:
                 x = tile_channels(x, self.num_channels)
-                x = L_batch_norm(ps, x)
+                x = store(L_batch_norm(ps, x))
             else:
-                x = L_convolution(ps, x, [5] * rank + [cin, self.num_channels])
+                x = store(L_convolution(ps, x, [5] * rank + [cin, self.num_channels]))     # (the conv rounds the fp32 image itself)
                 x = L_batch_norm(ps, x)
-                x = L_activation(ps, x, self.act)
+                x = store(L_activation(ps, x, self.act))
         feats = []
         for l in range(self.num_levels):
             with ps.variable_scope('vnet/encoder/level_%d' % (l + 1)):
                 x = self.convolution_block(x, self.num_convolutions[l])
                 feats.append(x)
                 with ps.variable_scope('down_convolution'):
-                    x = L_down_convolution(ps, x, 2, [2] * rank)
+                    x = store(L_down_convolution(ps, x, 2, [2] * rank))
                     x = L_batch_norm(ps, x)
-                    x = L_activation(ps, x, self.act)
+                    x = store(L_activation(ps, x, self.act))
         with ps.variable_scope('vnet/bottom_level'):
             x = self.convolution_block(x, self.bottom_convolutions)
         for l in reversed(range(self.num_levels)):
             with ps.variable_scope('vnet/decoder/level_%d' % (l + 1)):
                 f = feats[l]
                 with ps.variable_scope('up_convolution'):
-                    x = L_up_convolution(ps, x, f.v.shape[1:-1], 2, [2] * rank)
+                    x = store(L_up_convolution(ps, x, f.v.shape[1:-1], 2, [2] * rank))
                     x = L_batch_norm(ps, x)
-                    x = L_activation(ps, x, self.act)
+                    x = store(L_activation(ps, x, self.act))
                 x = self.convolution_block_2(x, f, self.num_convolutions[l])
         with ps.variable_scope('vnet/output_layer'):
             logits = L_convolution(ps, x, [1] * rank + [self.num_channels, self.num_classes])

@@ -91,6 +91,21 @@ SIGNATURES = {
     "vnet_auc_ws_bytes": (_sz, [_i]),
     "vnet_auc_histogram": (_i, [_vp, _vp, _i64, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "vnet_accumulate_patch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    # bf16-storage mode
+    "vnet_cast_bf16": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    "vnet_conv_fwd_b16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vnet_conv_wgrad_b16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "vnet_conv2_fwd_b16": (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "vnet_conv2_wgrad_b16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "vnet_bn_stats_b16": (_i, [_vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vnet_bn_moments_b16": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
+    "vnet_bn_act_fwd_b16": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "vnet_bn_act_bwd_reduce_b16": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vnet_bn_act_bwd_apply_b16": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp, _vp]),
+    "vnet_head_fwd_b16": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "vnet_head_bwd_b16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _sz, _vp]),
+    "vnet_dropout_fwd_b16": (_i, [_vp, _vp, _vp, _i64, _f, _u64, _vp, _vp]),
+    "vnet_dropout_bwd_b16": (_i, [_vp, _vp, _vp, _i64, _f, _vp]),
 }
 
 ERRORS = {-1: "VNET_E_BADARG", -2: "VNET_E_UNSUPPORTED", -3: "VNET_E_WORKSPACE"}

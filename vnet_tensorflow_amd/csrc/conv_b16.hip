@@ -1,0 +1,193 @@
+// conv_b16.hip -- bf16-STORAGE entry points of the convolution family (BASELINE config C5 as SURVEY 8(d) states it: bf16
+// activations and weights into the matrix cores, fp32 accumulation).  Activations, skip tensors and their gradients are bf16
+// tensors in HBM (NDHWC, 2 bytes per element); parameter gradients, batch-norm statistics and biases stay fp32.
+//   * 5^3 stride-1 convolution (forward and backward-data): the bf16 MFMA kernels of conv_kernels.h with bf16 sources (H) and
+//     bf16 outputs (O16): y = RNE(fp32 accumulator + bias [+ stored gradient]) -- bit-for-bit the rounding of what
+//     vnet_conv_fwd_bf16_x16 writes in fp32 (same kernels, same summation order);
+//   * 5^3 filter gradient: wgrad5_bf16_kernel on the bf16 tensors, fp32 dw;
+//   * 2^3 stride-2 down convolution / 2^3 transposed convolution and their filter gradient: the fp32 MFMA kernels with bf16
+//     tensors converted while staging and a packed filter of bf16-rounded values (VNET_PACK_ROUND_BF16): every product is the
+//     exact bf16 x bf16 product, accumulated in fp32 -- the arithmetic of the matrix cores' bf16 path; these launches are
+//     HBM-bound, what matters is that they move 2-byte elements.
+// Reference call sites replaced: layers2.py:59-63, 65-74, 78-94 (forward), model.py:660 (their gradients).
+#include "conv_kernels.h"
+
+namespace {
+inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline bool al8p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
+}  // namespace
+
+extern "C" {
+
+int vnet_conv_fwd_b16(const void* x0, int C0, const void* x1, int C1, const void* wp, const float* bias,
+                      void* y0, int Cy0, void* y1, int Cy1, int B, int D, int H, int W,
+                      const void* acc16, const void* res16, float* stats, void* ws, size_t ws_bytes, void* stream) {
+    if (!x0 || !wp || !y0 || C0 <= 0 || Cy0 <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return VNET_E_BADARG;
+    if ((C1 > 0 && !x1) || (Cy1 > 0 && !y1) || C1 < 0 || Cy1 < 0) return VNET_E_BADARG;
+    if (stats && Cy1 > 0) return VNET_E_BADARG;
+    if ((C0 & 7) || (C1 & 7) || (Cy0 & 3) || (Cy1 & 3) || !al16p(x0) || !al16p(x1) || !al8p(y0) || !al8p(y1) || !al8p(acc16) || !al8p(res16))
+        return VNET_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    ConvArgs a{};
+    a.x0 = reinterpret_cast<const float*>(x0); a.x1 = reinterpret_cast<const float*>(x1); a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1;
+    a.wp = reinterpret_cast<const float4*>(wp); a.bias = bias;
+    a.y0 = reinterpret_cast<float*>(y0); a.y1 = reinterpret_cast<float*>(y1); a.Cy0 = Cy0; a.Cy1 = Cy1; a.Cout = Cy0 + Cy1;
+    a.B = B; a.Di = D; a.Hi = H; a.Wi = W; a.Do = D; a.Ho = H; a.Wo = W;
+    a.nchunks = round_up(a.Cin, 16) / 16; a.CQ = a.nchunks * 4;
+    a.CoutP = round_up(a.Cout, 32);
+    a.vec_in = 1; a.vec_out = 1;
+    a.pad = 2; a.padx = 2; a.accum = acc16 ? 1 : 0; a.res = reinterpret_cast<const float*>(res16); a.stats = stats;
+    if (acc16 && acc16 != y0) {
+        if (Cy1 > 0) return VNET_E_BADARG;
+        a.accsrc = reinterpret_cast<const float*>(acc16);
+    }
+    if (stats && vnet_conv_bf16_stats_rows_x16(a.Cin, Cy0, Cy1, C0, C1, B, D, H, W) == 0) return VNET_E_UNSUPPORTED;
+    Bf16Plan p = plan_conv_bf16(a.Cin, a.Cout, B, D, H, W);
+    a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.cps = p.cps; a.nz = p.nz;
+    const int nslab = p.nsplit * p.nz;
+    const size_t nvox = (size_t)B * D * H * W;
+    if (nslab > 1) {
+        const size_t need = (size_t)nslab * nvox * a.CoutP * sizeof(float);
+        if (!ws || ws_bytes < need) return VNET_E_WORKSPACE;
+        a.part = reinterpret_cast<float*>(ws); a.part_stride = nvox * a.CoutP;
+    }
+    const int e = conv_fwd_bf16_go<true, true>(a, p, nslab, C0, C1, Cy0, Cy1, B, D, H, W, st);
+    if (e == -1) return VNET_OK;
+    if (e) return e;
+    if (nslab > 1) {
+        const size_t total = nvox * a.Cout;
+        const int blocks = (int)min((size_t)2048, (total + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_b16_kernel, dim3(blocks), dim3(256), 0, st, a.part, a.part_stride, nslab, bias,
+                           reinterpret_cast<unsigned short*>(y0), reinterpret_cast<unsigned short*>(y1), Cy0, Cy1, a.CoutP, nvox, a.accum,
+                           reinterpret_cast<const unsigned short*>(res16), a.stats, reinterpret_cast<const unsigned short*>(a.accsrc));
+        VNET_LAUNCH_CHECK();
+    }
+    return VNET_OK;
+}
+
+int vnet_conv_wgrad_b16(const void* x0, int C0, const void* x1, int C1, const void* dy, int Cout, float* dw, int Cin_dw,
+                        int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    if (!x0 || !dy || !dw || C0 <= 0 || Cout <= 0 || B <= 0 || C1 < 0 || (C1 > 0 && !x1)) return VNET_E_BADARG;
+    if (D <= 0 || H <= 0 || W <= 0 || Cin_dw <= 0 || Cin_dw > C0 + C1) return VNET_E_BADARG;
+    if ((C0 & 7) || (C1 & 7) || (Cout & 7) || !al16p(x0) || !al16p(x1) || !al16p(dy)) return VNET_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    WgradArgs a{};
+    a.x0 = reinterpret_cast<const float*>(x0); a.x1 = reinterpret_cast<const float*>(x1); a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1;
+    a.dy = reinterpret_cast<const float*>(dy); a.Cout = Cout;
+    a.B = B; a.Di = D; a.Hi = H; a.Wi = W; a.Do = D; a.Ho = H; a.Wo = W;
+    a.CinP = round_up(a.Cin, 16); a.CoutP = round_up(Cout, 16);
+    a.pad = 2; a.padx = 2; a.vec_in = 1; a.vec_dy = 1;
+    WgradPlan p = plan_wgrad(5, 5, 1, a.Cin, Cout, B, D, H, W, true);
+    a.ncob = p.ncob; a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.nbrick = p.nbrick; a.nsplit = p.nsplit;
+    const size_t need = (size_t)p.nsplit * 125 * a.CinP * a.CoutP * sizeof(float);
+    // one slab and no channel padding: the slab IS dw (TF layout [tap][Cin][Cout]) -> no reduce pass
+    const bool direct = p.nsplit == 1 && a.CinP == Cin_dw && a.CoutP == Cout;
+    if (!direct && (!ws || ws_bytes < need)) return VNET_E_WORKSPACE;
+    a.part = direct ? dw : reinterpret_cast<float*>(ws);
+    int e;
+    if (p.small) {
+        e = p.ns == 2 ? launch_wgrad_bf16<4, 8, 8, 2, 8, true>(a, p.nsplit, p.ncob, p.ntg, st)
+                      : launch_wgrad_bf16<4, 8, 8, 1, 16, true>(a, p.nsplit, p.ncob, p.ntg, st);
+    } else {
+        e = p.ns == 2 ? launch_wgrad_bf16<4, 4, 16, 2, 8, true>(a, p.nsplit, p.ncob, p.ntg, st)
+                      : launch_wgrad_bf16<4, 4, 16, 1, 16, true>(a, p.nsplit, p.ncob, p.ntg, st);
+    }
+    if (e) return e;
+    if (direct) return VNET_OK;
+    // (Cin_dw < C0 + C1: the leading input channels only -- a network input that was zero-padded to the 16-byte unit)
+    launch_wgrad_reduce(a.part, p.nsplit, 125, a.CinP, a.CoutP, Cin_dw, Cout, dw, st);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+// 2^3 stride-2 convolution (up = 0: [B,Di,Hi,Wi,Cin] -> [B,Do,Ho,Wo,Cout]) or 2^3 transposed convolution (up = 1) on bf16
+// tensors.  wp: vnet_pack_weights(VNET_PACK_FWD | VNET_PACK_ROUND_BF16, 8, Cin, Cout) resp. (VNET_PACK_UP | VNET_PACK_ROUND_BF16).
+int vnet_conv2_fwd_b16(int up, const void* x, int Cin, const float* wp, const float* bias, void* y, int Cout,
+                       int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                       int accum, float* stats, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !wp || !y || Cin <= 0 || Cout <= 0 || B <= 0) return VNET_E_BADARG;
+    if (Di <= 0 || Hi <= 0 || Wi <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return VNET_E_BADARG;
+    if ((Cin & 3) || (Cout & 3) || !al8p(x) || !al8p(y)) return VNET_E_UNSUPPORTED;
+    if (stats && (up || accum)) return VNET_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    ConvArgs a{};
+    a.x0 = reinterpret_cast<const float*>(x); a.x1 = nullptr; a.C0 = Cin; a.C1 = 0; a.Cin = Cin;
+    a.wp = reinterpret_cast<const float4*>(wp); a.bias = bias;
+    a.y0 = reinterpret_cast<float*>(y); a.y1 = nullptr; a.Cy0 = Cout; a.Cy1 = 0; a.Cout = Cout;
+    a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
+    a.CQ = round_up(Cin, 16) / 4; a.nchunks = a.CQ / 4;
+    a.vec_in = 1; a.vec_out = 1; a.accum = accum ? 1 : 0; a.stats = stats; a.pad = 0; a.padx = 0;
+    if (stats && vnet_conv_stats_rows(2, 0, 2, 0, Cin, Cout, 0, B, Do, Ho, Wo) == 0) return VNET_E_UNSUPPORTED;
+    if (up) { a.CoutP = round_up(8 * Cout, 16); a.upO = Cout; }
+    else a.CoutP = round_up(Cout, 16);
+    const int gD = up ? Di : Do, gH = up ? Hi : Ho, gW = up ? Wi : Wo;
+    ConvPlan p = plan_conv(2, 2, up, Cin, Cout, B, gD, gH, gW, gW);
+    a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.cps = p.cps; a.nz = p.nz;
+    const int nslab = p.nsplit * p.nz;
+    const size_t nvox = (size_t)B * Do * Ho * Wo;
+    if (nslab > 1) {
+        const size_t need = (size_t)nslab * nvox * a.CoutP * sizeof(float);
+        if (!ws || ws_bytes < need) return VNET_E_WORKSPACE;
+        a.part = reinterpret_cast<float*>(ws); a.part_stride = nvox * a.CoutP;
+    }
+    int e;
+    if (up) {
+        e = p.tiny ? launch_conv_ns<1, 1, 2, 8, 8, 4, 2, true, 1, false, true>(a, p, st)
+          : p.small ? launch_conv_ns<1, 1, 8, 8, 8, 8, 4, true, 1, false, true>(a, p, st)
+                    : launch_conv_ns<1, 1, 2, 4, 16, 4, 2, true, 1, false, true>(a, p, st);
+    } else if (stats && nslab == 1) {
+        e = p.small ? launch_conv_ns<2, 2, 2, 8, 8, 4, 2, false, 2, true, true>(a, p, st)
+                    : launch_conv_ns<2, 2, 1, 4, 16, 4, 1, false, 2, true, true>(a, p, st);
+    } else {
+        e = p.small ? launch_conv_ns<2, 2, 2, 8, 8, 4, 2, false, 2, false, true>(a, p, st)
+                    : launch_conv_ns<2, 2, 1, 4, 16, 4, 1, false, 2, false, true>(a, p, st);
+    }
+    if (e) return e;
+    if (nslab > 1) {
+        const size_t total = nvox * a.Cout;
+        const int blocks = (int)min((size_t)2048, (total + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_b16_kernel, dim3(blocks), dim3(256), 0, st, a.part, a.part_stride, nslab, bias,
+                           reinterpret_cast<unsigned short*>(y), (unsigned short*)nullptr, Cout, 0, a.CoutP, nvox, a.accum,
+                           (const unsigned short*)nullptr, a.stats, (const unsigned short*)nullptr);
+        VNET_LAUNCH_CHECK();
+    }
+    return VNET_OK;
+}
+
+// filter gradient of the 2^3 stride-2 convolution on bf16 tensors: x = the FINE tensor [B,Di,Hi,Wi,Cin], dy = the COARSE one
+// [B,Do,Ho,Wo,Cout]; dw fp32 [8][Cin][Cout].  (For the transposed convolution call it with the roles it has there: x = its output
+// gradient, dy = its input, see vnet_conv_wgrad.)
+int vnet_conv2_wgrad_b16(const void* x, int Cin, const void* dy, int Cout, float* dw,
+                         int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !dy || !dw || Cin <= 0 || Cout <= 0 || B <= 0) return VNET_E_BADARG;
+    if (Di <= 0 || Hi <= 0 || Wi <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0) return VNET_E_BADARG;
+    if ((Cin & 3) || (Cout & 3) || !al8p(x) || !al8p(dy)) return VNET_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    WgradArgs a{};
+    a.x0 = reinterpret_cast<const float*>(x); a.x1 = nullptr; a.C0 = Cin; a.C1 = 0; a.Cin = Cin;
+    a.dy = reinterpret_cast<const float*>(dy); a.Cout = Cout;
+    a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
+    a.CinP = round_up(Cin, 16); a.CoutP = round_up(Cout, 16);
+    a.pad = 0; a.padx = 0; a.vec_in = 1; a.vec_dy = 1;
+    WgradPlan p = plan_wgrad(2, 2, 2, Cin, Cout, B, Do, Ho, Wo);
+    a.ncob = p.ncob; a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.nbrick = p.nbrick; a.nsplit = p.nsplit;
+    const size_t need = (size_t)p.nsplit * 8 * a.CinP * a.CoutP * sizeof(float);
+    const bool direct = p.nsplit == 1 && a.CinP == Cin && a.CoutP == Cout;
+    if (!direct && (!ws || ws_bytes < need)) return VNET_E_WORKSPACE;
+    a.part = direct ? dw : reinterpret_cast<float*>(ws);
+    int e;
+    if (p.small) {
+        e = p.ns == 4 ? launch_wgrad<2, 2, 2, 8, 8, 4, 1, 2, true>(a, p, st) : p.ns == 2 ? launch_wgrad<2, 2, 2, 8, 8, 2, 1, 2, true>(a, p, st)
+                                                                                       : launch_wgrad<2, 2, 2, 8, 8, 1, 1, 2, true>(a, p, st);
+    } else {
+        e = p.ns == 4 ? launch_wgrad<2, 2, 2, 4, 16, 4, 1, 2, true>(a, p, st) : p.ns == 2 ? launch_wgrad<2, 2, 2, 4, 16, 2, 1, 2, true>(a, p, st)
+                                                                                        : launch_wgrad<2, 2, 2, 4, 16, 1, 1, 2, true>(a, p, st);
+    }
+    if (e) return e;
+    if (direct) return VNET_OK;
+    launch_wgrad_reduce(a.part, p.nsplit, 8, a.CinP, a.CoutP, Cin, Cout, dw, st);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+}  // extern "C"

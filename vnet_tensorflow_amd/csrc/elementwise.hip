@@ -66,9 +66,35 @@ __device__ __forceinline__ void block_reduce_vec(float4 (&acc)[NACC], int CQ, in
     }
 }
 
+// the same in float64 (batch-norm backward sums: dbeta = sum dz is a sum of terms that cancel almost completely, so the
+// round-off of fp32 partial sums shows up 1e3..1e5 times larger in the result)
+template <int NACC>
+__device__ __forceinline__ void block_reduce_vec_d(double (&acc)[NACC][4], int CQ, int C, double* __restrict__ prow) {
+    __shared__ double shd[EW_BLOCK][4];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) shd[tid][k] = acc[a][k];
+        __syncthreads();
+        for (int off = EW_BLOCK / 2; off >= CQ; off >>= 1) {
+            if (tid < off) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) shd[tid][k] += shd[tid + off][k];
+            }
+            __syncthreads();
+        }
+        if (tid < CQ) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) prow[a * C + tid * 4 + k] = shd[tid][k];
+        }
+    }
+}
+
 // block-level reduction for the row path (every thread holds all C<=8 channels)
-template <int NACC, int CMAX>
-__device__ __forceinline__ void block_reduce_row(float (&acc)[NACC][CMAX], int C, float* __restrict__ prow) {
+template <int NACC, int CMAX, typename T = float>
+__device__ __forceinline__ void block_reduce_row(float (&acc)[NACC][CMAX], int C, T* __restrict__ prow) {
     __shared__ float sh[4][NACC * CMAX];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -134,7 +160,8 @@ __global__ void __launch_bounds__(EW_BLOCK) bn_stats_generic_kernel(const float*
 }
 
 // ---- finalize kernels: one workgroup per output column sums <= EW_MAXBLK partial rows in float64 ----
-__device__ __forceinline__ double block_colsum_d(const float* __restrict__ partial, int nblk, size_t row_stride, size_t col) {
+template <typename T>
+__device__ __forceinline__ double block_colsum_d(const T* __restrict__ partial, int nblk, size_t row_stride, size_t col) {
     __shared__ double shd[4];
     double s = 0.0;
     for (int b = threadIdx.x; b < nblk; b += blockDim.x) s += (double)partial[(size_t)b * row_stride + col];
@@ -146,15 +173,15 @@ __device__ __forceinline__ double block_colsum_d(const float* __restrict__ parti
 }
 
 // up to three columns (col0 + a*col_step) in ONE sweep over the partial rows and one block reduction
-template <int NA>
-__device__ __forceinline__ void block_colsum_multi(const float* __restrict__ partial, int nblk, size_t row_stride, size_t col0,
+template <int NA, typename T>
+__device__ __forceinline__ void block_colsum_multi(const T* __restrict__ partial, int nblk, size_t row_stride, size_t col0,
                                                    size_t col_step, double (&out)[NA]) {
     __shared__ double shm[4][NA];
     double s[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) s[a] = 0.0;
     for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
-        const float* row = partial + (size_t)b * row_stride + col0;
+        const T* row = partial + (size_t)b * row_stride + col0;
 #pragma unroll
         for (int a = 0; a < NA; ++a) s[a] += (double)row[a * col_step];
     }
@@ -208,7 +235,8 @@ __global__ void __launch_bounds__(256) bn_finalize_sums_kernel(const double* __r
     }
 }
 
-__global__ void __launch_bounds__(256) sum_finalize_kernel(const float* __restrict__ partial, int nblk, int nacc, int C,
+template <typename T>
+__global__ void __launch_bounds__(256) sum_finalize_kernel(const T* __restrict__ partial, int nblk, int nacc, int C,
                                                            float* o0, float* o1, float* o2) {
     const int c = blockIdx.x;
     if (nacc == 3) {
@@ -313,7 +341,7 @@ struct BnP {
     const float* x; const float* r; const float* dy;
     const float* mean; const float* invstd; const float* gamma; const float* beta; const float* alpha;
     const float* dgamma; const float* dbeta;
-    float* out; float* partial;
+    float* out; float* partial; double* partiald;      // partiald: float64 partial rows of the backward reduce
     size_t M; int C; int bcast; int act; float invM; int identity;
     const float* extra;      // optional per-channel coefficient of xhat added to ds (batch-norm chains: variance-dependent scale)
     unsigned short* outh;    // optional bf16 shadow of `out` (RNE), what the bf16-operand convolutions stage instead of the fp32 tensor
@@ -373,7 +401,11 @@ __global__ void __launch_bounds__(EW_BLOCK) bn_act_bwd_reduce_kernel(BnP p) {
     if (MODE == 0) {
         const int CQ = C >> 2;
         const size_t nq = p.M * CQ;
-        float4 acc[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+        double acc[3][4];                          // float64 accumulation (see block_reduce_vec_d)
+#pragma unroll
+        for (int a3 = 0; a3 < 3; ++a3)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[a3][k] = 0.0;
         const int c = (int)(start % CQ) * 4;      // fixed per thread (grid*256 % CQ == 0)
         float scv[4], sfv[4], alv[4], muv[4], isv[4];
 #pragma unroll
@@ -398,20 +430,16 @@ __global__ void __launch_bounds__(EW_BLOCK) bn_act_bwd_reduce_kernel(BnP p) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w}, gg[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
-                float a0[4], a1[4], a2[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float z = vv[k] * scv[k] + sfv[k];
                     const float dz = gg[k] * act_grad(z, p.act, alv[k]);
                     const float xh = (vv[k] - muv[k]) * isv[k];
-                    a0[k] = dz; a1[k] = dz * xh; a2[k] = gg[k] * fminf(z, 0.f);
+                    acc[0][k] += (double)dz; acc[1][k] += (double)(dz * xh); acc[2][k] += (double)(gg[k] * fminf(z, 0.f));
                 }
-                acc[0].x += a0[0]; acc[0].y += a0[1]; acc[0].z += a0[2]; acc[0].w += a0[3];
-                acc[1].x += a1[0]; acc[1].y += a1[1]; acc[1].z += a1[2]; acc[1].w += a1[3];
-                acc[2].x += a2[0]; acc[2].y += a2[1]; acc[2].z += a2[2]; acc[2].w += a2[3];
             }
         }
-        block_reduce_vec<3>(acc, CQ, C, p.partial + (size_t)blockIdx.x * 3 * C);
+        block_reduce_vec_d<3>(acc, CQ, C, p.partiald + (size_t)blockIdx.x * 3 * C);
     } else if (MODE == 1) {
         float acc[3][8];
 #pragma unroll
@@ -428,7 +456,7 @@ __global__ void __launch_bounds__(EW_BLOCK) bn_act_bwd_reduce_kernel(BnP p) {
                     acc[0][c] += dz; acc[1][c] += p.identity ? 0.f : dz * (v - p.mean[c]) * p.invstd[c]; acc[2][c] += g * fminf(z, 0.f);
                 }
         }
-        block_reduce_row<3, 8>(acc, C, p.partial + (size_t)blockIdx.x * 3 * C);
+        block_reduce_row<3, 8, double>(acc, C, p.partiald + (size_t)blockIdx.x * 3 * C);
     } else {
         __shared__ float sh[3 * MAXC];
         for (int c = threadIdx.x; c < 3 * C; c += EW_BLOCK) sh[c] = 0.f;
@@ -445,7 +473,7 @@ __global__ void __launch_bounds__(EW_BLOCK) bn_act_bwd_reduce_kernel(BnP p) {
             atomicAdd(&sh[2 * C + c], g * fminf(z, 0.f));
         }
         __syncthreads();
-        for (int c = threadIdx.x; c < 3 * C; c += EW_BLOCK) p.partial[(size_t)blockIdx.x * 3 * C + c] = sh[c];
+        for (int c = threadIdx.x; c < 3 * C; c += EW_BLOCK) p.partiald[(size_t)blockIdx.x * 3 * C + c] = (double)sh[c];
     }
 }
 
@@ -928,6 +956,357 @@ __global__ void __launch_bounds__(256) loss_colsum_kernel(const float* __restric
     if (threadIdx.x == 0) sums[b * NS + col] = s;
 }
 
+
+// =======================================================================================================
+// bf16-storage variants (BASELINE config C5 as SURVEY 8(d) states it: bf16 activations and weights into the matrix cores,
+// fp32 accumulation, fp32 batch-norm statistics and Dice sums).  Activations and their gradients live in HBM as bf16 ONLY
+// (2 bytes per element instead of the 4 + 2 of the round-2 shadows); every kernel reads bf16, computes in fp32 and rounds its
+// output once (RNE, v_cvt_pk_bf16_f32).  One thread owns 8 channels of a voxel = one 16-byte access; channel counts are
+// C = 8 * 2^k (every V-Net width), so a thread keeps ONE channel octet on its whole grid-stride walk and its per-channel
+// coefficients sit in registers.
+// =======================================================================================================
+__device__ __forceinline__ void unpack8(const u32x4 w, float (&f)[8]) {
+    f[0] = __uint_as_float(w[0] << 16); f[1] = __uint_as_float(w[0] & 0xffff0000u);
+    f[2] = __uint_as_float(w[1] << 16); f[3] = __uint_as_float(w[1] & 0xffff0000u);
+    f[4] = __uint_as_float(w[2] << 16); f[5] = __uint_as_float(w[2] & 0xffff0000u);
+    f[6] = __uint_as_float(w[3] << 16); f[7] = __uint_as_float(w[3] & 0xffff0000u);
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+    const u32x4 r = {pk_bf16(f[0], f[1]), pk_bf16(f[2], f[3]), pk_bf16(f[4], f[5]), pk_bf16(f[6], f[7])};
+    return r;
+}
+
+struct BnP16 {
+    const void* x; const void* r; const void* dy;       // bf16 [M][C]; with bcast: x = float32 [M] (the 1-channel image)
+    const float* mean; const float* invstd; const float* gamma; const float* beta; const float* alpha;
+    const float* dgamma; const float* dbeta; const float* extra;
+    void* out; float* partial; double* partiald;
+    size_t M; int C; int bcast; int act; float invM;
+};
+
+// per-thread coefficients of channel octet c0..c0+7
+struct Coef8 { float sc[8], sf[8], al[8]; };
+__device__ __forceinline__ void load_coef8(const BnP16& p, int c0, Coef8& k) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float s = p.gamma[c0 + j] * p.invstd[c0 + j];
+        k.sc[j] = s; k.sf[j] = p.beta[c0 + j] - p.mean[c0 + j] * s;
+        k.al[j] = (p.act == VNET_ACT_PRELU) ? p.alpha[c0 + j] : 0.f;
+    }
+}
+
+// s = x (+ r) of one 16-byte unit as 8 floats
+template <bool BCAST>
+__device__ __forceinline__ void load_s8(const BnP16& p, size_t j, int CO, float (&v)[8]) {
+    if (BCAST) {
+        const float t = reinterpret_cast<const float*>(p.x)[j / CO];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = t;
+    } else {
+        unpack8(reinterpret_cast<const u32x4*>(p.x)[j], v);
+    }
+    if (p.r) {
+        float t[8];
+        unpack8(reinterpret_cast<const u32x4*>(p.r)[j], t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += t[k];
+    }
+}
+
+// 8-wide block reduction over the threads that share a channel octet (tid % CO), float64 partial rows
+template <int NACC>
+__device__ __forceinline__ void block_reduce_oct_d(double (&acc)[NACC][8], int CO, int C, double* __restrict__ prow) {
+    __shared__ double sho[EW_BLOCK][8];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sho[tid][k] = acc[a][k];
+        __syncthreads();
+        for (int off = EW_BLOCK / 2; off >= CO; off >>= 1) {
+            if (tid < off) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sho[tid][k] += sho[tid + off][k];
+            }
+            __syncthreads();
+        }
+        if (tid < CO) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) prow[a * C + tid * 8 + k] = sho[tid][k];
+        }
+    }
+}
+
+// statistics of s = x (+ r): per-channel sum and sum of squares -> float partial rows [blk][2][C] (bn_finalize_kernel's format)
+__global__ void __launch_bounds__(EW_BLOCK) bn_stats_b16_kernel(BnP16 p) {
+    const int CO = p.C >> 3;
+    const size_t n8 = p.M * CO, stride = (size_t)gridDim.x * EW_BLOCK, start = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x;
+    float a1[8], a2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a1[k] = a2[k] = 0.f;
+    for (size_t idx = start; idx < n8; idx += 2 * stride) {
+        float v0[8], v1[8];
+        const size_t j1 = idx + stride;
+        const bool ok1 = j1 < n8;
+        load_s8<false>(p, idx, CO, v0);
+        load_s8<false>(p, ok1 ? j1 : idx, CO, v1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float w = ok1 ? v1[k] : 0.f;
+            a1[k] += v0[k] + w; a2[k] += v0[k] * v0[k] + w * w;
+        }
+    }
+    __shared__ float shs[EW_BLOCK][8];
+    const int tid = threadIdx.x, C = p.C;
+    float* prow = p.partial + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) shs[tid][k] = a ? a2[k] : a1[k];
+        __syncthreads();
+        for (int off = EW_BLOCK / 2; off >= CO; off >>= 1) {
+            if (tid < off) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) shs[tid][k] += shs[tid + off][k];
+            }
+            __syncthreads();
+        }
+        if (tid < CO) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) prow[a * C + tid * 8 + k] = shs[tid][k];
+        }
+    }
+}
+
+template <bool BCAST>
+__global__ void __launch_bounds__(EW_BLOCK) bn_act_fwd_b16_kernel(BnP16 p) {
+    const int CO = p.C >> 3;
+    const size_t n8 = p.M * CO, stride = (size_t)gridDim.x * EW_BLOCK, start = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x;
+    Coef8 k8;
+    load_coef8(p, (int)(start % CO) * 8, k8);
+    u32x4* out = reinterpret_cast<u32x4*>(p.out);
+    for (size_t idx = start; idx < n8; idx += 2 * stride) {
+        float v0[8], v1[8];
+        const size_t j1 = idx + stride;
+        const bool ok1 = j1 < n8;
+        load_s8<BCAST>(p, idx, CO, v0);
+        load_s8<BCAST>(p, ok1 ? j1 : idx, CO, v1);
+        float o0[8], o1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            o0[k] = act_fwd(v0[k] * k8.sc[k] + k8.sf[k], p.act, k8.al[k]);
+            o1[k] = act_fwd(v1[k] * k8.sc[k] + k8.sf[k], p.act, k8.al[k]);
+        }
+        out[idx] = pack8(o0);
+        if (ok1) out[j1] = pack8(o1);
+    }
+}
+
+// backward pass 1: per-channel sums of dz, dz*xhat, dy*min(0,z) in float64
+template <bool BCAST>
+__global__ void __launch_bounds__(EW_BLOCK) bn_act_bwd_reduce_b16_kernel(BnP16 p) {
+    const int CO = p.C >> 3;
+    const size_t n8 = p.M * CO, stride = (size_t)gridDim.x * EW_BLOCK, start = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x;
+    const int c0 = (int)(start % CO) * 8;
+    Coef8 k8;
+    load_coef8(p, c0, k8);
+    float mu[8], is[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { mu[k] = p.mean[c0 + k]; is[k] = p.invstd[c0 + k]; }
+    double acc[3][8];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[a][k] = 0.0;
+    for (size_t idx = start; idx < n8; idx += 2 * stride) {
+        float v[2][8], g[2][8];
+        const size_t j1 = idx + stride;
+        const bool ok1 = j1 < n8;
+        load_s8<BCAST>(p, idx, CO, v[0]);
+        load_s8<BCAST>(p, ok1 ? j1 : idx, CO, v[1]);
+        unpack8(reinterpret_cast<const u32x4*>(p.dy)[idx], g[0]);
+        unpack8(reinterpret_cast<const u32x4*>(p.dy)[ok1 ? j1 : idx], g[1]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float gg = (u == 0 || ok1) ? g[u][k] : 0.f;         // dy = 0 contributes nothing to any of the three sums
+                const float z = v[u][k] * k8.sc[k] + k8.sf[k];
+                const float dz = gg * act_grad(z, p.act, k8.al[k]);
+                const float xh = (v[u][k] - mu[k]) * is[k];
+                acc[0][k] += (double)dz; acc[1][k] += (double)(dz * xh); acc[2][k] += (double)(gg * fminf(z, 0.f));
+            }
+    }
+    block_reduce_oct_d<3>(acc, CO, p.C, p.partiald + (size_t)blockIdx.x * 3 * p.C);
+}
+
+// backward pass 2: ds = gamma*invstd*(dz - dbeta/M - xhat*dgamma/M) (+ xhat * extra), rounded to bf16
+template <bool BCAST>
+__global__ void __launch_bounds__(EW_BLOCK) bn_act_bwd_apply_b16_kernel(BnP16 p) {
+    const int CO = p.C >> 3;
+    const size_t n8 = p.M * CO, stride = (size_t)gridDim.x * EW_BLOCK, start = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x;
+    const int c0 = (int)(start % CO) * 8;
+    Coef8 k8;
+    load_coef8(p, c0, k8);
+    float mu[8], is[8], k1[8], k2[8], ex[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mu[k] = p.mean[c0 + k]; is[k] = p.invstd[c0 + k];
+        k1[k] = p.dbeta[c0 + k] * p.invM; k2[k] = p.dgamma[c0 + k] * p.invM;
+        ex[k] = p.extra ? p.extra[c0 + k] : 0.f;
+    }
+    u32x4* out = reinterpret_cast<u32x4*>(p.out);
+    for (size_t idx = start; idx < n8; idx += 2 * stride) {
+        float v[2][8], g[2][8];
+        const size_t j1 = idx + stride;
+        const bool ok1 = j1 < n8;
+        load_s8<BCAST>(p, idx, CO, v[0]);
+        load_s8<BCAST>(p, ok1 ? j1 : idx, CO, v[1]);
+        unpack8(reinterpret_cast<const u32x4*>(p.dy)[idx], g[0]);
+        unpack8(reinterpret_cast<const u32x4*>(p.dy)[ok1 ? j1 : idx], g[1]);
+        float o[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float z = v[u][k] * k8.sc[k] + k8.sf[k];
+                const float dz = g[u][k] * act_grad(z, p.act, k8.al[k]);
+                const float xh = (v[u][k] - mu[k]) * is[k];
+                o[u][k] = k8.sc[k] * (dz - k1[k] - xh * k2[k]) + xh * ex[k];
+            }
+        out[idx] = pack8(o[0]);
+        if (ok1) out[j1] = pack8(o[1]);
+    }
+}
+
+// fp32 [M][C] -> bf16 [M][Cpad] (zero-padded channels): the network input of a multi-modality net, padded to the 16-byte unit
+__global__ void __launch_bounds__(EW_BLOCK) cast_pad_bf16_kernel(const float* __restrict__ x, u32x4* __restrict__ y, size_t M, int C, int Cpad) {
+    const int CO = Cpad >> 3;
+    const size_t n8 = M * CO;
+    for (size_t idx = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x; idx < n8; idx += (size_t)gridDim.x * EW_BLOCK) {
+        const size_t row = idx / CO;
+        const int c0 = (int)(idx - row * CO) * 8;
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = (c0 + k < C) ? x[row * C + c0 + k] : 0.f;
+        y[idx] = pack8(f);
+    }
+}
+
+// 1x1x1 output head on bf16 activations: logits stay fp32 (K <= 8 classes: the softmax / Dice sums want them exact)
+template <int K>
+__global__ void __launch_bounds__(EW_BLOCK) head_fwd_b16_kernel(const u32x4* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, float* __restrict__ y, size_t M, int C) {
+    __shared__ float ws[1024];
+    for (int t = threadIdx.x; t < C * K; t += EW_BLOCK) ws[t] = w[t];
+    __syncthreads();
+    const int CO = C >> 3;
+    const size_t stride = (size_t)gridDim.x * EW_BLOCK;
+    for (size_t row = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x; row < M; row += stride) {
+        float o[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) o[k] = bias ? bias[k] : 0.f;
+        for (int q = 0; q < CO; ++q) {
+            float v[8];
+            unpack8(x[row * CO + q], v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int k = 0; k < K; ++k) o[k] += v[j] * ws[(q * 8 + j) * K + k];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) y[row * K + k] = o[k];
+    }
+}
+
+// backward: dx (bf16) = dy w^T; dw[c][k] = sum_rows x*dy; db[k] = sum dy.  One thread per (row, channel octet).
+template <int K>
+__global__ void __launch_bounds__(EW_BLOCK) head_bwd_b16_kernel(const u32x4* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ dy, u32x4* __restrict__ dx,
+                                                                size_t M, int C, float* __restrict__ partial) {
+    __shared__ float ws[1024];
+    __shared__ float red[EW_BLOCK];
+    for (int t = threadIdx.x; t < C * K; t += EW_BLOCK) ws[t] = w[t];
+    __syncthreads();
+    const int CO = C >> 3;
+    const size_t n8 = M * CO, stride = (size_t)gridDim.x * EW_BLOCK, start = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x;
+    const int co = (int)(start % CO), c0 = co * 8;
+    float aw[8][K], ab[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        ab[k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) aw[j][k] = 0.f;
+    }
+    for (size_t idx = start; idx < n8; idx += stride) {
+        const size_t row = idx / CO;
+        float v[8], g[K], o[8];
+        unpack8(x[idx], v);
+#pragma unroll
+        for (int k = 0; k < K; ++k) g[k] = dy[row * K + k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            o[j] = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) { o[j] += g[k] * ws[(c0 + j) * K + k]; aw[j][k] += v[j] * g[k]; }
+        }
+        if (co == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) ab[k] += g[k];
+        }
+        if (dx) dx[idx] = pack8(o);
+    }
+    float* prow = partial + (size_t)blockIdx.x * (C * K + K);
+#pragma unroll
+    for (int s = 0; s < 9 * K; ++s) {
+        const int j = s / K, k = s % K;
+        __syncthreads();
+        float t = ab[k];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) if (j == jj) t = aw[jj][k];
+        red[threadIdx.x] = t;
+        __syncthreads();
+        for (int off = EW_BLOCK / 2; off >= CO; off >>= 1) {
+            if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (j < 8) { if (threadIdx.x < CO) prow[(threadIdx.x * 8 + j) * K + k] = red[threadIdx.x]; }
+        else if (threadIdx.x == 0) prow[C * K + k] = red[0];
+    }
+}
+
+__global__ void dropout_fwd_b16_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, uint8_t* __restrict__ mask,
+                                       size_t n8, float rate, uint64_t seed, const StepState* __restrict__ st) {
+    const float sc = 1.f / (1.f - rate);
+    if (st) seed += st->step * 0xD1342543DE82EF95ULL;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        float v[8];
+        unpack8(x[i], v);
+        uint32_t m0 = 0, m1 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float u = (mix32(seed * 0x9E3779B97F4A7C15ULL + (i * 8 + k)) >> 8) * (1.f / 16777216.f);   // same stream as the fp32 kernel
+            const uint32_t keep = u >= rate;
+            v[k] = keep ? v[k] * sc : 0.f;
+            if (k < 4) m0 |= keep << (8 * k); else m1 |= keep << (8 * (k - 4));
+        }
+        reinterpret_cast<uint2*>(mask)[i] = make_uint2(m0, m1);
+        y[i] = pack8(v);
+    }
+}
+__global__ void dropout_bwd_b16_kernel(const u32x4* __restrict__ dy, const uint8_t* __restrict__ mask, u32x4* __restrict__ dx, size_t n8, float rate) {
+    const float sc = 1.f / (1.f - rate);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        float v[8];
+        unpack8(dy[i], v);
+        const uint2 m = reinterpret_cast<const uint2*>(mask)[i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (((k < 4 ? m.x : m.y) >> (8 * (k & 3))) & 0xffu) ? v[k] * sc : 0.f;
+        dx[i] = pack8(v);
+    }
+}
 }  // namespace
 
 #define K_SWITCH(K, STMT)                                                   \
@@ -945,7 +1324,7 @@ __global__ void __launch_bounds__(256) loss_colsum_kernel(const float* __restric
 
 extern "C" {
 
-size_t vnet_bn_ws_bytes(int C) { return (size_t)EW_MAXBLK * 3 * (C > 8 ? C : 8) * sizeof(float); }
+size_t vnet_bn_ws_bytes(int C) { return (size_t)EW_MAXBLK * 3 * (C > 8 ? C : 8) * sizeof(double); }
 size_t vnet_colsum_ws_bytes(int C) { return (size_t)EW_MAXBLK * (C > 8 ? C : 8) * sizeof(float); }
 size_t vnet_head_ws_bytes(int C, int K) { return (size_t)EW_MAXBLK * (C * K + K) * sizeof(float); }
 size_t vnet_loss_ws_bytes(int B, int K) { return (size_t)B * EW_MAXBLK * (3 * K + 1) * sizeof(float) + (size_t)B * (3 * K + 1) * sizeof(double) + 16; }
@@ -1057,14 +1436,14 @@ int vnet_bn_act_bwd_reduce(const float* dy, const float* x, const float* r, int 
     if (!ws || ws_bytes < vnet_bn_ws_bytes(C)) return VNET_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     BnP p{}; bn_bwd_fill(p, dy, x, r, bcast, M, C, mean, invstd, gamma, beta, act, alpha);
-    p.partial = (float*)ws;
+    p.partiald = (double*)ws;
     const int mode = red_mode(C);
     int nblk;
     if (mode == 0) { nblk = ew_blocks((size_t)M * C / 4 / 4 + 1); hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<0>, dim3(nblk), dim3(EW_BLOCK), 0, st, p); }
     else if (mode == 1) { nblk = ew_blocks((size_t)M); hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<1>, dim3(nblk), dim3(EW_BLOCK), 0, st, p); }
     else { nblk = ew_blocks((size_t)M * C / 4 + 1); hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<2>, dim3(nblk), dim3(EW_BLOCK), 0, st, p); }
     VNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(C), dim3(256), 0, st, p.partial, nblk, 3, C, dbeta, dgamma,
+    hipLaunchKernelGGL(sum_finalize_kernel<double>, dim3(C), dim3(256), 0, st, (const double*)p.partiald, nblk, 3, C, dbeta, dgamma,
                        act == VNET_ACT_PRELU ? dalpha : (float*)nullptr);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
@@ -1156,7 +1535,7 @@ int vnet_act_bwd(const float* dy, const float* x, int64_t M, int C, int act, con
     if (act == VNET_ACT_PRELU && (!alpha || !dalpha)) return VNET_E_BADARG;
     if (!ws || ws_bytes < vnet_bn_ws_bytes(C)) return VNET_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    BnP p{}; p.x = x; p.dy = dy; p.alpha = alpha; p.partial = (float*)ws; p.M = (size_t)M; p.C = C; p.act = act; p.identity = 1;
+    BnP p{}; p.x = x; p.dy = dy; p.alpha = alpha; p.partiald = (double*)ws; p.M = (size_t)M; p.C = C; p.act = act; p.identity = 1;
     if (act == VNET_ACT_PRELU) {
         const int mode = red_mode(C);
         int nblk;
@@ -1164,7 +1543,7 @@ int vnet_act_bwd(const float* dy, const float* x, int64_t M, int C, int act, con
         else if (mode == 1) { nblk = ew_blocks((size_t)M); hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<1>, dim3(nblk), dim3(EW_BLOCK), 0, st, p); }
         else { nblk = ew_blocks((size_t)M * C / 4 + 1); hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<2>, dim3(nblk), dim3(EW_BLOCK), 0, st, p); }
         VNET_LAUNCH_CHECK();
-        hipLaunchKernelGGL(sum_finalize_kernel, dim3(C), dim3(256), 0, st, p.partial, nblk, 3, C, (float*)nullptr, (float*)nullptr, dalpha);
+        hipLaunchKernelGGL(sum_finalize_kernel<double>, dim3(C), dim3(256), 0, st, (const double*)p.partiald, nblk, 3, C, (float*)nullptr, (float*)nullptr, dalpha);
         VNET_LAUNCH_CHECK();
     }
     p.out = dx;
@@ -1189,7 +1568,7 @@ int vnet_colsum(const float* x, float* out, int64_t M, int C, void* ws, size_t w
         hipLaunchKernelGGL(colsum_generic_kernel, dim3(nblk), dim3(EW_BLOCK), 0, st, x, (size_t)M * C, C, partial);
     }
     VNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, 1, C, out, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(sum_finalize_kernel<float>, dim3(C), dim3(256), 0, st, (const float*)partial, nblk, 1, C, out, (float*)nullptr, (float*)nullptr);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
 }
@@ -1376,6 +1755,165 @@ int vnet_accumulate_patch(const float* patch, float* vol, float* count, int K,
     if (!patch || !vol || K <= 0 || pz <= 0 || py <= 0 || px <= 0 || z0 < 0 || y0 < 0 || x0 < 0) return VNET_E_BADARG;
     hipLaunchKernelGGL(accumulate_patch_kernel, dim3(ew_blocks((size_t)pz * py * px)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
                        patch, vol, count, K, pz, py, px, z0, y0, x0, D, H, W);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+// ---- bf16-storage entry points -------------------------------------------------------------------------------------------
+static inline bool b16_channels_ok(int C) { return C >= 8 && C <= MAXC && (C & 7) == 0 && is_pow2(C >> 3) && (C >> 3) <= EW_BLOCK; }
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int b16_blocks(size_t n8) { return ew_blocks(n8 / 2 + 1); }       // two 16-byte units per thread and trip
+
+int vnet_cast_bf16(const float* x, void* y16, int64_t M, int C, int Cpad, void* stream) {
+    if (!x || !y16 || M <= 0 || C <= 0 || Cpad < C) return VNET_E_BADARG;
+    if ((Cpad & 7) || !al16(y16)) return VNET_E_UNSUPPORTED;
+    hipLaunchKernelGGL(cast_pad_bf16_kernel, dim3(ew_blocks((size_t)M * (Cpad / 8) / 2 + 1)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       x, reinterpret_cast<u32x4*>(y16), (size_t)M, C, Cpad);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+static int bn_partial_moments_b16(const void* x16, const void* r16, int64_t M, int C, float* partial, hipStream_t st, int* nblk_out) {
+    if (!b16_channels_ok(C) || !al16(x16) || !al16(r16)) return VNET_E_UNSUPPORTED;
+    BnP16 p{}; p.x = x16; p.r = r16; p.M = (size_t)M; p.C = C; p.partial = partial;
+    const int nblk = b16_blocks((size_t)M * (C / 8));
+    hipLaunchKernelGGL(bn_stats_b16_kernel, dim3(nblk), dim3(EW_BLOCK), 0, st, p);
+    VNET_LAUNCH_CHECK();
+    *nblk_out = nblk;
+    return VNET_OK;
+}
+
+int vnet_bn_stats_b16(const void* x16, const void* r16, int64_t M, int C, float eps, float momentum,
+                      float* mean, float* invstd, float* moving_mean, float* moving_var, void* ws, size_t ws_bytes, void* stream) {
+    if (!x16 || !mean || !invstd || M <= 0 || C <= 0) return VNET_E_BADARG;
+    if (!ws || ws_bytes < vnet_bn_ws_bytes(C)) return VNET_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int nblk;
+    const int rc = bn_partial_moments_b16(x16, r16, M, C, (float*)ws, st, &nblk);
+    if (rc != VNET_OK) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, (const float*)ws, nblk, C, C, (double)M, eps, momentum,
+                       mean, invstd, moving_mean, moving_var);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_bn_moments_b16(const void* x16, const void* r16, int64_t M, int C, double* sums, void* ws, size_t ws_bytes, void* stream) {
+    if (!x16 || !sums || M <= 0 || C <= 0) return VNET_E_BADARG;
+    if (!ws || ws_bytes < vnet_bn_ws_bytes(C)) return VNET_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int nblk;
+    const int rc = bn_partial_moments_b16(x16, r16, M, C, (float*)ws, st, &nblk);
+    if (rc != VNET_OK) return rc;
+    hipLaunchKernelGGL(bn_moments_kernel, dim3(C), dim3(256), 0, st, (const float*)ws, nblk, C, C, sums);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+static int bn16_fill(BnP16& p, const void* dy, const void* x, const void* r, int bcast, int64_t M, int C, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, int act, const float* alpha) {
+    if (!x || !mean || !invstd || !gamma || !beta || M <= 0 || C <= 0) return VNET_E_BADARG;
+    if (act == VNET_ACT_PRELU && !alpha) return VNET_E_BADARG;
+    if (act < 0 || act > 3 || !b16_channels_ok(C) || (bcast && r)) return VNET_E_UNSUPPORTED;
+    if ((!bcast && !al16(x)) || !al16(r) || !al16(dy)) return VNET_E_UNSUPPORTED;
+    p.x = x; p.r = r; p.dy = dy; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.alpha = alpha;
+    p.M = (size_t)M; p.C = C; p.bcast = bcast; p.act = act;
+    return VNET_OK;
+}
+
+int vnet_bn_act_fwd_b16(const void* x, const void* r16, int bcast, int64_t M, int C,
+                        const float* mean, const float* invstd, const float* gamma, const float* beta,
+                        int act, const float* alpha, void* y16, void* stream) {
+    if (!y16) return VNET_E_BADARG;
+    BnP16 p{};
+    const int rc = bn16_fill(p, nullptr, x, r16, bcast, M, C, mean, invstd, gamma, beta, act, alpha);
+    if (rc != VNET_OK) return rc;
+    if (!al16(y16)) return VNET_E_UNSUPPORTED;
+    p.out = y16;
+    const int nblk = b16_blocks((size_t)M * (C / 8));
+    if (bcast) hipLaunchKernelGGL(bn_act_fwd_b16_kernel<true>, dim3(nblk), dim3(EW_BLOCK), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(bn_act_fwd_b16_kernel<false>, dim3(nblk), dim3(EW_BLOCK), 0, (hipStream_t)stream, p);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_bn_act_bwd_reduce_b16(const void* dy16, const void* x, const void* r16, int bcast, int64_t M, int C,
+                               const float* mean, const float* invstd, const float* gamma, const float* beta,
+                               int act, const float* alpha, float* dgamma, float* dbeta, float* dalpha,
+                               void* ws, size_t ws_bytes, void* stream) {
+    if (!dy16 || !dgamma || !dbeta) return VNET_E_BADARG;
+    if (act == VNET_ACT_PRELU && !dalpha) return VNET_E_BADARG;
+    BnP16 p{};
+    const int rc = bn16_fill(p, dy16, x, r16, bcast, M, C, mean, invstd, gamma, beta, act, alpha);
+    if (rc != VNET_OK) return rc;
+    if (!ws || ws_bytes < vnet_bn_ws_bytes(C)) return VNET_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    p.partiald = (double*)ws;
+    const int nblk = b16_blocks((size_t)M * (C / 8));
+    if (bcast) hipLaunchKernelGGL(bn_act_bwd_reduce_b16_kernel<true>, dim3(nblk), dim3(EW_BLOCK), 0, st, p);
+    else hipLaunchKernelGGL(bn_act_bwd_reduce_b16_kernel<false>, dim3(nblk), dim3(EW_BLOCK), 0, st, p);
+    VNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_finalize_kernel<double>, dim3(C), dim3(256), 0, st, (const double*)p.partiald, nblk, 3, C, dbeta, dgamma,
+                       act == VNET_ACT_PRELU ? dalpha : (float*)nullptr);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_bn_act_bwd_apply_b16(const void* dy16, const void* x, const void* r16, int bcast, int64_t M, int C,
+                              const float* mean, const float* invstd, const float* gamma, const float* beta,
+                              int act, const float* alpha, const float* sum_dz, const float* sum_dz_xhat, double M_total,
+                              const float* xhat_coef, void* ds16, void* stream) {
+    if (!dy16 || !sum_dz || !sum_dz_xhat || !ds16 || M_total <= 0.0) return VNET_E_BADARG;
+    BnP16 p{};
+    const int rc = bn16_fill(p, dy16, x, r16, bcast, M, C, mean, invstd, gamma, beta, act, alpha);
+    if (rc != VNET_OK) return rc;
+    if (!al16(ds16)) return VNET_E_UNSUPPORTED;
+    p.invM = (float)(1.0 / M_total); p.extra = xhat_coef; p.out = ds16; p.dgamma = sum_dz_xhat; p.dbeta = sum_dz;
+    const int nblk = b16_blocks((size_t)M * (C / 8));
+    if (bcast) hipLaunchKernelGGL(bn_act_bwd_apply_b16_kernel<true>, dim3(nblk), dim3(EW_BLOCK), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(bn_act_bwd_apply_b16_kernel<false>, dim3(nblk), dim3(EW_BLOCK), 0, (hipStream_t)stream, p);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_head_fwd_b16(const void* x16, const float* w, const float* bias, float* y, int64_t M, int C, int K, void* stream) {
+    if (!x16 || !w || !y || M <= 0 || C <= 0 || K <= 0) return VNET_E_BADARG;
+    if (C * K > 1024 || (C & 7) || !al16(x16)) return VNET_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = ew_blocks((size_t)M / 2 + 1);
+    K_SWITCH(K, hipLaunchKernelGGL(head_fwd_b16_kernel<KK>, dim3(nblk), dim3(EW_BLOCK), 0, st, (const u32x4*)x16, w, bias, y, (size_t)M, C));
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_head_bwd_b16(const void* x16, const float* w, const float* dy, void* dx16, float* dw, float* db,
+                      int64_t M, int C, int K, void* ws, size_t ws_bytes, void* stream) {
+    if (!x16 || !w || !dy || !dw || !db || M <= 0 || C <= 0 || K <= 0) return VNET_E_BADARG;
+    if (C * K > 1024 || !b16_channels_ok(C) || !al16(x16) || !al16(dx16)) return VNET_E_UNSUPPORTED;
+    if (!ws || ws_bytes < vnet_head_ws_bytes(C, K)) return VNET_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)ws;
+    const int nblk = ew_blocks((size_t)M * (C / 8) / 2 + 1);
+    K_SWITCH(K, hipLaunchKernelGGL(head_bwd_b16_kernel<KK>, dim3(nblk), dim3(EW_BLOCK), 0, st, (const u32x4*)x16, w, dy, (u32x4*)dx16,
+                                   (size_t)M, C, partial));
+    VNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(C * K + K), dim3(256), 0, st, partial, nblk, C * K, K, dw, db);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+int vnet_dropout_fwd_b16(const void* x16, void* y16, uint8_t* mask, int64_t n, float rate, uint64_t seed, const void* state, void* stream) {
+    if (!x16 || !y16 || !mask || n <= 0 || rate < 0.f || rate >= 1.f) return VNET_E_BADARG;
+    if ((n & 7) || !al16(x16) || !al16(y16) || (reinterpret_cast<uintptr_t>(mask) & 7)) return VNET_E_UNSUPPORTED;
+    hipLaunchKernelGGL(dropout_fwd_b16_kernel, dim3(ew_blocks((size_t)n / 8 / 2 + 1)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       (const u32x4*)x16, (u32x4*)y16, mask, (size_t)n / 8, rate, seed, (const StepState*)state);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+int vnet_dropout_bwd_b16(const void* dy16, const uint8_t* mask, void* dx16, int64_t n, float rate, void* stream) {
+    if (!dy16 || !dx16 || !mask || n <= 0 || rate < 0.f || rate >= 1.f) return VNET_E_BADARG;
+    if ((n & 7) || !al16(dy16) || !al16(dx16) || (reinterpret_cast<uintptr_t>(mask) & 7)) return VNET_E_UNSUPPORTED;
+    hipLaunchKernelGGL(dropout_bwd_b16_kernel, dim3(ew_blocks((size_t)n / 8 / 2 + 1)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       (const u32x4*)dy16, mask, (u32x4*)dx16, (size_t)n / 8, rate);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
 }

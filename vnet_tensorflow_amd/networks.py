@@ -87,12 +87,15 @@ class VNet(object):
             input_channels = int(x.shape[-1])
             with store.variable_scope('vnet/input_layer'):
                 tiled = None
+                store16 = ops.storage_is_bf16() and x.device.type != "meta"
                 if input_channels == 1:
                     # tile + BN; the first 5^3 conv then runs on the un-tiled image (layers2.convolution_tiled)
                     x, tiled = L.batch_normalization(x, tile=True, channels=self.num_channels, want_stats=True)
-                    if self.num_channels > 16 or not self.fuse_input_block:
-                        tiled = None
+                    if self.num_channels > 16 or not self.fuse_input_block or store16:
+                        tiled = None          # (bf16 storage: the tiled batch-norm writes a bf16 tensor, conv_1 is an ordinary bf16 conv)
                 else:
+                    if store16:
+                        x = ops.cast_input(x)     # bf16, channels zero-padded to the 16-byte unit; from here on every tensor is bf16
                     x = L.convolution(x, [5, 5, 5, input_channels, self.num_channels], bn_stats=self.fuse_bn_stats)
                     x = L.batch_normalization(x, activation=act)
 

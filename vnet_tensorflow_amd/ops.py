@@ -24,17 +24,33 @@ PACK_FWD, PACK_BWD, PACK_UP, PACK_FWD_BF16, PACK_BWD_BF16 = 0, 1, 2, 3, 4
 # Arithmetic of the 5x5x5 convolutions (forward, backward-data and filter gradient): "fp32" = exact fp32 MFMA (the reference's
 # arithmetic), "bf16" = operands rounded to bf16, fp32 accumulation (BASELINE config C5).  Everything else
 # (2^3 down/up convolutions, the fused 1-channel input block, batch-norm, loss, optimiser) is fp32 in both modes.
-_COMPUTE = {"dtype": "fp32"}
+#   "bf16"          (round 3, BASELINE config C5 as SURVEY 8(d) states it): bf16 STORAGE -- activations, skip tensors and their
+#                   gradients are torch.bfloat16 tensors, every kernel on them computes in fp32 and rounds once (include/vnet_hip.h,
+#                   `*_b16`); 5^3 AND 2^3 convolutions take bf16 operands; statistics, parameter gradients, logits and loss fp32.
+#                   The ops below dispatch on the tensor dtype, so the mode only decides what the network input is turned into.
+#   "bf16_operands" (round 2): fp32 tensors (+ bf16 shadows), only the 5^3 convolutions round their operands.
+_COMPUTE = {"dtype": "fp32", "store16": False, "name": "fp32"}
+PACK_ROUND16 = 16
 
 
 def set_compute_dtype(dtype):
-    if dtype not in ("fp32", "bf16"):
-        raise VnetHipError("compute dtype must be 'fp32' or 'bf16', got %r" % (dtype,))
-    _COMPUTE["dtype"] = dtype
+    if dtype not in ("fp32", "bf16", "bf16_operands"):
+        raise VnetHipError("compute dtype must be 'fp32', 'bf16' or 'bf16_operands', got %r" % (dtype,))
+    _COMPUTE["dtype"] = "fp32" if dtype == "fp32" else "bf16"
+    _COMPUTE["store16"] = dtype == "bf16"
+    _COMPUTE["name"] = dtype
 
 
 def get_compute_dtype():
-    return _COMPUTE["dtype"]
+    return _COMPUTE["name"]
+
+
+def storage_is_bf16():
+    return _COMPUTE["store16"]
+
+
+def _is16(t):
+    return t is not None and t.dtype == torch.bfloat16
 LOSS_KIND = {"sorensen": 0, "jaccard": 1, "xent": 2}
 LOSS_WEIGHTED, LOSS_MIXED = 16, 32
 
@@ -87,11 +103,11 @@ def use_step_state(state):
         _STEP_STATE["active"] = prev
 
 
-def _need_gpu(t, what):
+def _need_gpu(t, what, allow16=False):
     if not t.is_cuda:
         raise VnetHipError("%s: tensor on %s -- the HIP library is the only compute path (no CPU fallback)" % (what, t.device))
-    if t.dtype != torch.float32:
-        raise VnetHipError("%s: expected float32, got %s" % (what, t.dtype))
+    if t.dtype != torch.float32 and not (allow16 and t.dtype == torch.bfloat16):
+        raise VnetHipError("%s: expected float32%s, got %s" % (what, " or bfloat16" if allow16 else "", t.dtype))
 
 
 # ---- workspace (caller-owned, per device) -----------------------------------------------------
@@ -322,7 +338,7 @@ class _Timed(object):
 # through L2, no conversion, bit-identical results (include/vnet_hip.h: *_x16).  A tensor carries a shadow iff its storage was
 # made by _alloc_shadowed() (tagged, exactly 6 bytes per element) -- which is only called next to the kernel that fills it.
 def _want_shadow(C):
-    return _COMPUTE["dtype"] == "bf16" and _FUSE["bf16_shadow"] and C % 8 == 0
+    return _COMPUTE["dtype"] == "bf16" and not _COMPUTE["store16"] and _FUSE["bf16_shadow"] and C % 8 == 0
 
 
 def _alloc_shadowed(shape, device):
@@ -411,6 +427,93 @@ def _conv_bf16_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res
         fn = L.vnet_conv_fwd_bf16_acc if accum else L.vnet_conv_fwd_bf16
         check(fn(_ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias), _ptr(y0), Cy0, _ptr(y1), Cy1,
                  B, *dims, _ptr(ws), nb, _stream()), "vnet_conv_fwd_bf16")
+
+
+# ---- bf16-storage convolution calls (include/vnet_hip.h: vnet_conv_fwd_b16, vnet_conv2_fwd_b16, ...) ----------------------------
+def _conv5_b16_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res=None, acc_src=None):
+    L = _lib.lib()
+    B = x0.shape[0]
+    C0, C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
+    Cy0, Cy1 = y0.shape[-1], (y1.shape[-1] if y1 is not None else 0)
+    nb = L.vnet_conv_bf16_ws_bytes(C0 + C1, Cy0 + Cy1, B, *dims)
+    ws = workspace(nb, x0.device) if nb else None
+    nvox = B * dims[0] * dims[1] * dims[2]
+    flops = 2.0 * nvox * 125 * (C0 + C1) * (Cy0 + Cy1)
+    nbytes = 2.0 * nvox * (C0 + C1 + Cy0 + Cy1) + 2.0 * 125 * (C0 + C1) * (Cy0 + Cy1)
+    tag = "conv-bf16 k5 s1 %d^3x%d %d->%d" % (dims[2], B, C0 + C1, Cy0 + Cy1)
+    acc = _ptr(acc_src) if acc_src is not None else (_ptr(y0) if accum else None)
+    with _Timed(tag, flops, nbytes):
+        check(L.vnet_conv_fwd_b16(_ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias), _ptr(y0), Cy0, _ptr(y1), Cy1, B, *dims,
+                                  acc, _ptr(res), _ptr(stats), _ptr(ws), nb, _stream()), "vnet_conv_fwd_b16")
+
+
+def _wgrad5_b16_call(x0, x1, dy, dw, dims, cin_dw, owner=None):
+    L = _lib.lib()
+    B = x0.shape[0]
+    C0, C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
+    Co = dy.shape[-1]
+    nb = L.vnet_wgrad_bf16_ws_bytes(C0 + C1, Co, B, *dims)
+    ws = _wgrad_workspace(dw, nb, False, owner)
+    nvox = B * dims[0] * dims[1] * dims[2]
+    flops = 2.0 * nvox * 125 * (C0 + C1) * Co
+    nbytes = 2.0 * nvox * (C0 + C1 + Co) + 4.0 * 125 * (C0 + C1) * Co
+    tag = _wgrad_tag(True, 5, 0, 1, dims[2], B, C0 + C1, Co)
+    with _Timed(tag, flops, nbytes), _immediate_reduce(owner is None):
+        check(L.vnet_conv_wgrad_b16(_ptr(x0), C0, _ptr(x1), C1, _ptr(dy), Co, _ptr(dw), int(cin_dw), B, *dims, _ptr(ws), nb, _stream()),
+              "vnet_conv_wgrad_b16")
+
+
+def _conv2_b16_call(up, x, wp, bias, y, dims_in, dims_out, accum=False, stats=None):
+    L = _lib.lib()
+    B, Cin, Cout = x.shape[0], x.shape[-1], y.shape[-1]
+    nb = L.vnet_conv_ws_bytes(2, 0, 2, up, Cin, Cout, B, *dims_out)
+    ws = workspace(nb, x.device) if nb else None
+    nin, nout = B * dims_in[0] * dims_in[1] * dims_in[2], B * dims_out[0] * dims_out[1] * dims_out[2]
+    flops = 2.0 * (nin if up else nout) * 8 * Cin * Cout
+    nbytes = 2.0 * (nin * Cin + nout * Cout) + 4.0 * 8 * Cin * Cout
+    tag = "conv-b16 k2 s2%s %d^3x%d %d->%d" % (" up" if up else "", dims_out[2], B, Cin, Cout)
+    with _Timed(tag, flops, nbytes):
+        check(L.vnet_conv2_fwd_b16(int(up), _ptr(x), Cin, _ptr(wp), _ptr(bias), _ptr(y), Cout, B, *dims_in, *dims_out,
+                                   int(bool(accum)), _ptr(stats), _ptr(ws), nb, _stream()), "vnet_conv2_fwd_b16")
+
+
+def _wgrad2_b16_call(xfine, dycoarse, dw, dims_fine, dims_coarse, owner=None):
+    L = _lib.lib()
+    immediate = owner is None
+    B, Cin, Co = xfine.shape[0], xfine.shape[-1], dycoarse.shape[-1]
+    nb = L.vnet_wgrad_ws_bytes(2, 0, 2, Cin, Co, B, *dims_coarse)
+    ws = _wgrad_workspace(dw, nb, immediate, owner)
+    nout = B * dims_coarse[0] * dims_coarse[1] * dims_coarse[2]
+    tag = "wgrad-b16 k2 s2 %d^3x%d %d->%d" % (dims_coarse[2], B, Cin, Co)
+    with _Timed(tag, 2.0 * nout * 8 * Cin * Co, 2.0 * nout * (8 * Cin + Co) + 4.0 * 8 * Cin * Co), _immediate_reduce(immediate):
+        check(L.vnet_conv2_wgrad_b16(_ptr(xfine), Cin, _ptr(dycoarse), Co, _ptr(dw), B, *dims_fine, *dims_coarse, _ptr(ws), nb, _stream()),
+              "vnet_conv2_wgrad_b16")
+
+
+def cast_input(img):
+    """bf16-storage mode: the fp32 network input [.., Cin] as a bf16 tensor [.., Cin padded to a multiple of 8] (zero channels);
+    the filters' packed images are zero-padded to 16 input channels anyway (vnet_cast_bf16).  Not differentiable: the reference's
+    input is a placeholder (model.py:262)."""
+    _need_gpu(img, "cast_input")
+    img = img.contiguous()
+    C = int(img.shape[-1])
+    Cp = -(-C // 8) * 8
+    y = torch.empty(img.shape[:-1] + (Cp,), dtype=torch.bfloat16, device=img.device)
+    check(_lib.lib().vnet_cast_bf16(_ptr(img), _ptr(y), img.numel() // C, C, Cp, _stream()), "vnet_cast_bf16")
+    return y
+
+
+def colsum16(x16, C, out):
+    """Per-channel sum of a bf16 channels-last tensor (bias gradients outside the networks' closed form), via the float64
+    moments of vnet_bn_moments_b16."""
+    L = _lib.lib()
+    M = x16.numel() // C
+    sums = torch.empty(2 * C, dtype=torch.float64, device=x16.device)
+    nb = L.vnet_bn_ws_bytes(C)
+    ws = workspace(nb, x16.device)
+    check(L.vnet_bn_moments_b16(_ptr(x16), None, M, C, _ptr(sums), _ptr(ws), nb, _stream()), "vnet_bn_moments_b16")
+    out.copy_(sums[:C])
+    return out
 
 
 # ---- deferred reduces of the filter-gradient slabs (include/vnet_hip.h: vnet_wgrad_defer / vnet_wgrad_flush) ------------------
@@ -632,18 +735,30 @@ class _ConvFn(torch.autograd.Function):
         if up:
             O, I = w.shape[-2], w.shape[-1]
             dims_out = tuple(int(v) for v in out_spatial)
-            wp = packed_weights(w, PACK_UP, 8, I, O)
+            wp = packed_weights(w, PACK_UP, 8, I, O) if not _is16(x0) else None
         else:
             I, O = w.shape[-2], w.shape[-1]
             dims_out = (_same_out(Di, stride), _same_out(Hi, stride), _same_out(Wi, stride))
             wp = None
-        if I != C0 + C1:
+        b16 = _is16(x0)            # bf16-storage mode: bf16 tensors in and out (the network input may be zero-padded to 8 channels)
+        if I != C0 + C1 and not (b16 and x1 is None and C0 == -(-I // 8) * 8):
             raise VnetHipError("conv: filter expects %d input channels, got %d" % (I, C0 + C1))
-        y = torch.empty((B,) + dims_out + (O,), dtype=torch.float32, device=x0.device)
-        bf16 = (not up) and ks == 5 and stride == 1 and _COMPUTE["dtype"] == "bf16"
+        if b16 and (_is16(x1) != (x1 is not None) or (res is not None and not _is16(res))):
+            raise VnetHipError("conv: bf16 and float32 tensors mixed")
+        y = torch.empty((B,) + dims_out + (O,), dtype=torch.bfloat16 if b16 else torch.float32, device=x0.device)
+        bf16 = (not up) and ks == 5 and stride == 1 and (_COMPUTE["dtype"] == "bf16" or b16)
         if res is not None:
             res = res.contiguous()
-        if bf16:
+        if b16:
+            if x1 is not None and (up or ks != 5):
+                raise VnetHipError("conv: the two-source form exists for the 5^3 convolution only")
+            if up:
+                _conv2_b16_call(1, x0, packed_weights(w, PACK_UP | PACK_ROUND16, 8, I, O), b, y, (Di, Hi, Wi), dims_out)
+            elif ks == 2:
+                _conv2_b16_call(0, x0, packed_weights(w, PACK_FWD | PACK_ROUND16, 8, I, O), b, y, (Di, Hi, Wi), dims_out, stats=stats)
+            else:
+                _conv5_b16_call(x0, x1, packed_weights(w, PACK_FWD_BF16, 125, I, O), b, y, None, dims_out, stats=stats, res=res)
+        elif bf16:
             _conv_bf16_call(x0, x1, packed_weights(w, PACK_FWD_BF16, 125, I, O), b, y, None, dims_out, stats=stats, res=res)
         else:
             if wp is None:
@@ -653,6 +768,7 @@ class _ConvFn(torch.autograd.Function):
         ctx.params = (w, b)
         ctx.cfg = (ks, stride, up, (Di, Hi, Wi), dims_out, C0, C1, I, O)
         ctx.bf16 = bf16
+        ctx.b16 = b16
         ctx.bias_zero = _FUSE["zero_bias_grad"] and b is not None
         ctx.slots = (slot0, slot1)
         return y
@@ -704,10 +820,21 @@ class _ConvFn(torch.autograd.Function):
                 with torch.cuda.stream(side):
                     torch.cuda._sleep(int(_PG["test_delay"]))    # tests: let the side stream lag far behind
             _LAUNCH_ON[0] = side.cuda_stream             # launches (and their scratch buffer) go to the side stream
+        b16 = ctx.b16
         try:
             if db is not None:
-                colsum(dy, O, out=db)
-            if dw is not None:
+                if b16:
+                    colsum16(dy, O, db)
+                else:
+                    colsum(dy, O, out=db)
+            if dw is not None and b16:
+                if up:
+                    _wgrad2_b16_call(dy, x0, dw, dout, din, owner=sw)
+                elif stride == 2:
+                    _wgrad2_b16_call(x0, dy, dw, din, dout, owner=sw)
+                else:
+                    _wgrad5_b16_call(x0, x1, dy, dw, din, I, owner=sw)
+            elif dw is not None:
                 if up:      # dw[a][o][ci] = sum_i dy[2i+a][o] * x[i][ci]  == filter grad of the 2^3 down conv (fine -> coarse)
                     _wgrad_call(2, 2, dy, None, x0, dw, dout, din, owner=sw)
                 elif ctx.bf16:
@@ -727,12 +854,20 @@ class _ConvFn(torch.autograd.Function):
             oop = None
             if (acc is None and x1 is None and ctx.bf16 and slot0 is not None and slot0.first is not None
                     and slot0.first.data_ptr() == dy.data_ptr() and tuple(dy.shape) == tuple(x0.shape)
-                    and _shadow_ptr(dy) is not None and C0 % 8 == 0):
+                    and (b16 or _shadow_ptr(dy) is not None) and C0 % 8 == 0):
                 oop = dy
             dx0 = acc if acc is not None else torch.empty_like(x0)
             dx1 = torch.empty_like(x1) if x1 is not None else None
             accum = acc is not None
-            if up:          # backward-data of the transposed conv = the 2^3 stride-2 conv with the same filter
+            if b16 and up:      # backward-data of the transposed conv = the 2^3 stride-2 conv with the same filter
+                _conv2_b16_call(0, dy, packed_weights(w, PACK_FWD | PACK_ROUND16, 8, O, I), None, dx0, dout, din, accum=accum)
+            elif b16 and stride == 2:
+                _conv2_b16_call(1, dy, packed_weights(w, PACK_UP | PACK_ROUND16, 8, O, I), None, dx0, dout, din, accum=accum)
+            elif b16:
+                _conv5_b16_call(dy, None, packed_weights(w, PACK_BWD_BF16, 125, I, O), None, dx0, dx1, din, accum=accum, acc_src=oop)
+                if oop is not None:
+                    slot0.total = dx0
+            elif up:        # backward-data of the transposed conv = the 2^3 stride-2 conv with the same filter
                 wp = packed_weights(w, PACK_FWD, 8, O, I)
                 _conv_call(2, 2, 0, dy, None, wp, None, dx0, None, dout, din, accum=accum)
             elif stride == 2:   # backward-data of the down conv = the 2^3 transposed conv with the same filter
@@ -866,9 +1001,13 @@ def _epilogue_stats_buffer(bf16, ks, kx, stride, x0, x1, O, dims_out):
         return None
     L = _lib.lib()
     B, C0, C1 = x0.shape[0], x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
-    if bf16:
-        # (the kernels that stage bf16 shadows have their own brick shapes: one partial row per brick)
-        x16 = _shadow_ptr(x0) is not None and (x1 is None or _shadow_ptr(x1) is not None) and C0 % 8 == 0 and C1 % 8 == 0
+    if _is16(x0) and not bf16:                # bf16-storage 2^3 stride-2 convolution: the fp32 MFMA kernel's brick rows
+        if O % 4:
+            return None
+        rows = L.vnet_conv_stats_rows(ks, kx, stride, 0, C0 + C1, O, 0, B, *dims_out)
+    elif bf16:
+        # (the kernels that stage bf16 sources have their own brick shapes: one partial row per brick)
+        x16 = _is16(x0) or (_shadow_ptr(x0) is not None and (x1 is None or _shadow_ptr(x1) is not None) and C0 % 8 == 0 and C1 % 8 == 0)
         rows = (L.vnet_conv_bf16_stats_rows_x16 if x16 else L.vnet_conv_bf16_stats_rows)(C0 + C1, O, 0, C0, C1, B, *dims_out)
     else:
         # fp32 MFMA kernels: measured (profiles/r02_epilogue_stats.txt) the STATS instantiations lose in their main loop most of
@@ -891,11 +1030,11 @@ def conv(x0, w, b, ks, stride=1, x1=None, bn_stats=False, bn_residual=None):
     if _meta(x0):
         B, D, H, W, _ = x0.shape
         return torch.empty((B, _same_out(D, stride), _same_out(H, stride), _same_out(W, stride), w.shape[-1]), device="meta")
-    _need_gpu(x0, "conv")
+    _need_gpu(x0, "conv", allow16=True)
     stats = None
     if bn_stats and _FUSE["bn_stats"]:
         dims_out = tuple(_same_out(int(v), stride) for v in x0.shape[1:4])
-        bf16 = ks == 5 and stride == 1 and _COMPUTE["dtype"] == "bf16"
+        bf16 = ks == 5 and stride == 1 and (_COMPUTE["dtype"] == "bf16" or _is16(x0))
         stats = _epilogue_stats_buffer(bf16, ks, 0, stride, x0, x1, w.shape[-1], dims_out)
     dy16 = ks == 5 and stride == 1 and _want_shadow(int(w.shape[-1]))
     if stats is None:
@@ -916,7 +1055,7 @@ def conv_transpose2(x, w, b, out_spatial):
         raise NotImplementedError("only the 3-D (NDHWC) path is built")
     if _meta(x):
         return torch.empty((x.shape[0],) + tuple(out_spatial) + (w.shape[-2],), device="meta")
-    _need_gpu(x, "conv_transpose2")
+    _need_gpu(x, "conv_transpose2", allow16=True)
     return _ConvFn.apply(x, None, w, b, 2, 2, True, tuple(out_spatial))
 
 
@@ -950,13 +1089,21 @@ def _bn_statistics(L, x, r, bcast, M, C, mean, invstd, mm, mv, ws, nb, pre=None,
         check(L.vnet_bn_finalize_partial(_ptr(pre.partial), pre.rows, C, float(M), BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(invstd),
                                          _ptr(mm), _ptr(mv), _stream()), "vnet_bn_finalize_partial")
         return float(M)
+    x16 = _is16(x)
     if _SYNC_BN is None:
-        check(L.vnet_bn_stats(_ptr(x), _ptr(r), int(bcast), M, C, BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(invstd),
-                              _ptr(mm), _ptr(mv), _ptr(ws), nb, _stream()), "vnet_bn_stats")
+        if x16:
+            check(L.vnet_bn_stats_b16(_ptr(x), _ptr(r), M, C, BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(invstd),
+                                      _ptr(mm), _ptr(mv), _ptr(ws), nb, _stream()), "vnet_bn_stats_b16")
+        else:
+            check(L.vnet_bn_stats(_ptr(x), _ptr(r), int(bcast), M, C, BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(invstd),
+                                  _ptr(mm), _ptr(mv), _ptr(ws), nb, _stream()), "vnet_bn_stats")
         return float(M)
     all_reduce, world = _SYNC_BN
     sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
-    check(L.vnet_bn_moments(_ptr(x), _ptr(r), int(bcast), M, C, _ptr(sums), _ptr(ws), nb, _stream()), "vnet_bn_moments")
+    if x16:
+        check(L.vnet_bn_moments_b16(_ptr(x), _ptr(r), M, C, _ptr(sums), _ptr(ws), nb, _stream()), "vnet_bn_moments_b16")
+    else:
+        check(L.vnet_bn_moments(_ptr(x), _ptr(r), int(bcast), M, C, _ptr(sums), _ptr(ws), nb, _stream()), "vnet_bn_moments")
     all_reduce(sums)
     check(L.vnet_bn_finalize(_ptr(sums), float(M) * world, C, BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(invstd),
                              _ptr(mm), _ptr(mv), _stream()), "vnet_bn_finalize")
@@ -981,12 +1128,22 @@ class _BnActFn(torch.autograd.Function):
         ws = workspace(nb, dev)
         ctx.m_total = _bn_statistics(L, x, r, bcast, M, C, mean, invstd, mm, mv, ws, nb, pre, r_orig)
         ctx.sync = _SYNC_BN
-        if _want_shadow(C):
-            y, yh = _alloc_shadowed(x.shape[:-1] + (C,), dev)
+        # bf16-storage: a bf16 input, or the tiled fp32 1-channel image in that mode (C = 8 * 2^k; the 2..5-class batch-norm of the
+        # logits stays on the fp32 kernels)
+        ctx.b16 = b16 = _is16(x) or (bcast and _COMPUTE["store16"] and C % 8 == 0)
+        if b16:
+            if r is not None and not _is16(r):
+                raise VnetHipError("bn_act: bf16 and float32 tensors mixed")
+            y = torch.empty(x.shape[:-1] + (C,), dtype=torch.bfloat16, device=dev)
+            check(L.vnet_bn_act_fwd_b16(_ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
+                                        act, _ptr(alpha), _ptr(y), _stream()), "vnet_bn_act_fwd_b16")
         else:
-            y, yh = torch.empty(x.shape[:-1] + (C,), dtype=torch.float32, device=dev), None
-        check(L.vnet_bn_act_fwd_x16(_ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
-                                    act, _ptr(alpha), _ptr(y), yh, _stream()), "vnet_bn_act_fwd")
+            if _want_shadow(C):
+                y, yh = _alloc_shadowed(x.shape[:-1] + (C,), dev)
+            else:
+                y, yh = torch.empty(x.shape[:-1] + (C,), dtype=torch.float32, device=dev), None
+            check(L.vnet_bn_act_fwd_x16(_ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
+                                        act, _ptr(alpha), _ptr(y), yh, _stream()), "vnet_bn_act_fwd")
         ctx.save_for_backward(x, r, gamma, beta, alpha, mean, invstd)
         ctx.params = (gamma, beta, alpha)
         ctx.cfg = (act, bcast, M, C)
@@ -1007,13 +1164,31 @@ class _BnActFn(torch.autograd.Function):
         dalpha, sa = _grad_out(aref) if alpha is not None else (None, None)
         need_ds = ctx.needs_input_grad[0] or (r is not None and ctx.needs_input_grad[1])
         dsh = None
-        if need_ds and ctx.dy16 and not bcast and _want_shadow(C):
+        if ctx.b16:
+            ds = torch.empty(dy.shape, dtype=torch.bfloat16, device=dev) if need_ds else None
+        elif need_ds and ctx.dy16 and not bcast and _want_shadow(C):
             ds, dsh = _alloc_shadowed(dy.shape, dev)
         else:
             ds = torch.empty(dy.shape, dtype=torch.float32, device=dev) if need_ds else None
         nb = L.vnet_bn_ws_bytes(C)
         ws = workspace(nb, dev)
-        if ctx.sync is None and dsh is not None:
+        if ctx.b16:
+            if not _is16(dy):
+                raise VnetHipError("bn_act backward: expected a bfloat16 gradient")
+            check(L.vnet_bn_act_bwd_reduce_b16(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd),
+                                               _ptr(gamma), _ptr(beta), act, _ptr(alpha), _ptr(dgamma), _ptr(dbeta),
+                                               _ptr(dalpha), _ptr(ws), nb, _stream()), "vnet_bn_act_bwd_reduce_b16")
+            if ds is not None:
+                if ctx.sync is None:
+                    sdz, sdzx = dbeta, dgamma
+                else:
+                    tot = torch.cat([dbeta.reshape(-1), dgamma.reshape(-1)])
+                    ctx.sync[0](tot)
+                    sdz, sdzx = tot, tot[C:]
+                check(L.vnet_bn_act_bwd_apply_b16(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd),
+                                                  _ptr(gamma), _ptr(beta), act, _ptr(alpha), _ptr(sdz), _ptr(sdzx),
+                                                  ctx.m_total, None, _ptr(ds), _stream()), "vnet_bn_act_bwd_apply_b16")
+        elif ctx.sync is None and dsh is not None:
             check(L.vnet_bn_act_bwd_reduce(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd),
                                            _ptr(gamma), _ptr(beta), act, _ptr(alpha), _ptr(dgamma), _ptr(dbeta),
                                            _ptr(dalpha), _ptr(ws), nb, _stream()), "vnet_bn_act_bwd_reduce")
@@ -1074,12 +1249,18 @@ class _BnChainFn(torch.autograd.Function):
         check(L.vnet_bn_chain_coef_fwd(kind, C, BN_EPS, BN_MOMENTUM, _ptr(mean), _ptr(invstd), _ptr(g1), _ptr(b1), _ptr(g2), _ptr(b2),
                                        _ptr(g3), _ptr(b3), _ptr(ceff), _ptr(deff), _ptr(mm2), _ptr(mv2), _ptr(mm3), _ptr(mv3),
                                        _stream()), "vnet_bn_chain_coef_fwd")
-        if _want_shadow(C):
-            y, yh = _alloc_shadowed(x.shape, dev)
+        ctx.b16 = _is16(x)
+        if ctx.b16:
+            y = torch.empty(x.shape, dtype=torch.bfloat16, device=dev)
+            check(L.vnet_bn_act_fwd_b16(_ptr(x), None, 0, M, C, _ptr(mean), _ptr(invstd), _ptr(ceff), _ptr(deff),
+                                        act, _ptr(alpha), _ptr(y), _stream()), "vnet_bn_act_fwd_b16")
         else:
-            y, yh = torch.empty(x.shape, dtype=torch.float32, device=dev), None
-        check(L.vnet_bn_act_fwd_x16(_ptr(x), None, 0, M, C, _ptr(mean), _ptr(invstd), _ptr(ceff), _ptr(deff),
-                                    act, _ptr(alpha), _ptr(y), yh, _stream()), "vnet_bn_act_fwd")
+            if _want_shadow(C):
+                y, yh = _alloc_shadowed(x.shape, dev)
+            else:
+                y, yh = torch.empty(x.shape, dtype=torch.float32, device=dev), None
+            check(L.vnet_bn_act_fwd_x16(_ptr(x), None, 0, M, C, _ptr(mean), _ptr(invstd), _ptr(ceff), _ptr(deff),
+                                        act, _ptr(alpha), _ptr(y), yh, _stream()), "vnet_bn_act_fwd")
         ctx.save_for_backward(x, alpha, g1, g2, g3, mean, invstd, ceff, deff)
         ctx.params = (alpha, g1, b1, g2, b2, g3, b3)
         ctx.cfg = (kind, act, M, C)
@@ -1098,9 +1279,14 @@ class _BnChainFn(torch.autograd.Function):
         dalpha, sa = _grad_out(aref) if alpha is not None else (None, None)
         nb = L.vnet_bn_ws_bytes(C)
         ws = workspace(nb, dev)
-        check(L.vnet_bn_act_bwd_reduce(_ptr(dy), _ptr(x), None, 0, M, C, _ptr(mean), _ptr(invstd), _ptr(ceff), _ptr(deff),
-                                       act, _ptr(alpha), _ptr(dC), _ptr(dD), _ptr(dalpha), _ptr(ws), nb, _stream()),
-              "vnet_bn_act_bwd_reduce")
+        if ctx.b16:
+            check(L.vnet_bn_act_bwd_reduce_b16(_ptr(dy), _ptr(x), None, 0, M, C, _ptr(mean), _ptr(invstd), _ptr(ceff), _ptr(deff),
+                                               act, _ptr(alpha), _ptr(dC), _ptr(dD), _ptr(dalpha), _ptr(ws), nb, _stream()),
+                  "vnet_bn_act_bwd_reduce_b16")
+        else:
+            check(L.vnet_bn_act_bwd_reduce(_ptr(dy), _ptr(x), None, 0, M, C, _ptr(mean), _ptr(invstd), _ptr(ceff), _ptr(deff),
+                                           act, _ptr(alpha), _ptr(dC), _ptr(dD), _ptr(dalpha), _ptr(ws), nb, _stream()),
+                  "vnet_bn_act_bwd_reduce")
         if ctx.sync is None:
             tot = None
             dCg, dDg = dC, dD
@@ -1115,7 +1301,12 @@ class _BnChainFn(torch.autograd.Function):
                                        _ptr(dC), _ptr(dD), _ptr(dCg), _ptr(dg1), _ptr(db1), _ptr(dg2), _ptr(db2), _ptr(dg3), _ptr(db3),
                                        _ptr(extra), _stream()), "vnet_bn_chain_coef_bwd")
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.b16:
+            dx = torch.empty(dy.shape, dtype=torch.bfloat16, device=dev)
+            check(L.vnet_bn_act_bwd_apply_b16(_ptr(dy), _ptr(x), None, 0, M, C, _ptr(mean), _ptr(invstd), _ptr(ceff), _ptr(deff),
+                                              act, _ptr(alpha), _ptr(dDg), _ptr(dCg), ctx.m_total, _ptr(extra), _ptr(dx),
+                                              _stream()), "vnet_bn_act_bwd_apply_b16")
+        elif ctx.needs_input_grad[0]:
             if ctx.dy16 and _want_shadow(C):
                 dx, dxh = _alloc_shadowed(dy.shape, dev)
             else:
@@ -1135,7 +1326,7 @@ def bn_chain(x, kind, act, alpha, g1, b1, g2, b2, g3=None, b3=None, moving=(None
     a = ACT[act]
     if _meta(x):
         return torch.empty(x.shape, device="meta")
-    _need_gpu(x, "bn_chain")
+    _need_gpu(x, "bn_chain", allow16=True)
     if a == 2 and alpha is None:
         raise VnetHipError("prelu needs alpha")
     if kind == 0 and (g3 is None or b3 is None):
@@ -1157,7 +1348,7 @@ def bn_act(x, gamma, beta, act=None, alpha=None, residual=None, tile=False, movi
     if _meta(x):
         y = torch.empty(x.shape[:-1] + (gamma.numel(),), device="meta")
         return (y, None, None) if want_stats else y
-    _need_gpu(x, "bn_act")
+    _need_gpu(x, "bn_act", allow16=True)
     if a == 2 and alpha is None:
         raise VnetHipError("prelu needs alpha")
     y, mean, invstd = _BnActFn.apply(x, residual, gamma, beta, alpha if a == 2 else None, a, bool(tile), moving_mean, moving_var)
@@ -1225,8 +1416,11 @@ class _HeadFn(torch.autograd.Function):
         x = x.contiguous()
         C, K = w.shape[-2], w.shape[-1]
         M = x.numel() // C
-        y = torch.empty(x.shape[:-1] + (K,), dtype=torch.float32, device=x.device)
-        check(L.vnet_head_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), M, C, K, _stream()), "vnet_head_fwd")
+        y = torch.empty(x.shape[:-1] + (K,), dtype=torch.float32, device=x.device)        # logits stay fp32 in every mode
+        if _is16(x):
+            check(L.vnet_head_fwd_b16(_ptr(x), _ptr(w), _ptr(b), _ptr(y), M, C, K, _stream()), "vnet_head_fwd_b16")
+        else:
+            check(L.vnet_head_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), M, C, K, _stream()), "vnet_head_fwd")
         ctx.save_for_backward(x, w)
         ctx.params = (w, b)
         return y
@@ -1243,8 +1437,12 @@ class _HeadFn(torch.autograd.Function):
         db, sb = _grad_out(ctx.params[1])
         nb = L.vnet_head_ws_bytes(C, K)
         ws = workspace(nb, x.device)
-        check(L.vnet_head_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), M, C, K, _ptr(ws), nb, _stream()),
-              "vnet_head_bwd")
+        if _is16(x):
+            check(L.vnet_head_bwd_b16(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), M, C, K, _ptr(ws), nb, _stream()),
+                  "vnet_head_bwd_b16")
+        else:
+            check(L.vnet_head_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), M, C, K, _ptr(ws), nb, _stream()),
+                  "vnet_head_bwd")
         return dx, _grad_ret(dw, sw), _grad_ret(db, sb)
 
 
@@ -1252,7 +1450,7 @@ def head_conv(x, w, b):
     """convolution(x, [1,1,1,C,K]) of the output layer (reference networks.py:298-302)."""
     if _meta(x):
         return torch.empty(x.shape[:-1] + (w.shape[-1],), device="meta")
-    _need_gpu(x, "head_conv")
+    _need_gpu(x, "head_conv", allow16=True)
     return _HeadFn.apply(x, w, b)
 
 
@@ -1358,13 +1556,17 @@ class _DropoutFn(torch.autograd.Function):
     def forward(ctx, x, rate, seed):
         L = _lib.lib()
         x = x.contiguous()
-        if x.dim() == 5 and _want_shadow(int(x.shape[-1])):
-            y, yh = _alloc_shadowed(x.shape, x.device)
-        else:
-            y, yh = torch.empty(x.shape, dtype=torch.float32, device=x.device), None
         mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
         st = _STEP_STATE["active"]
-        check(L.vnet_dropout_fwd_x16(_ptr(x), _ptr(y), yh, _ptr(mask), x.numel(), rate, seed, _ptr(st), _stream()), "vnet_dropout_fwd")
+        if _is16(x):
+            y = torch.empty_like(x)
+            check(L.vnet_dropout_fwd_b16(_ptr(x), _ptr(y), _ptr(mask), x.numel(), rate, seed, _ptr(st), _stream()), "vnet_dropout_fwd_b16")
+        else:
+            if x.dim() == 5 and _want_shadow(int(x.shape[-1])):
+                y, yh = _alloc_shadowed(x.shape, x.device)
+            else:
+                y, yh = torch.empty(x.shape, dtype=torch.float32, device=x.device), None
+            check(L.vnet_dropout_fwd_x16(_ptr(x), _ptr(y), yh, _ptr(mask), x.numel(), rate, seed, _ptr(st), _stream()), "vnet_dropout_fwd")
         ctx.save_for_backward(mask)
         ctx.rate = rate
         return y
@@ -1375,6 +1577,9 @@ class _DropoutFn(torch.autograd.Function):
         (mask,) = ctx.saved_tensors
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
+        if _is16(dy):
+            check(L.vnet_dropout_bwd_b16(_ptr(dy), _ptr(mask), _ptr(dx), dy.numel(), ctx.rate, _stream()), "vnet_dropout_bwd_b16")
+            return dx, None, None
         check(L.vnet_dropout_bwd(_ptr(dy), _ptr(mask), _ptr(dx), dy.numel(), ctx.rate, _stream()), "vnet_dropout_bwd")
         return dx, None, None
 
@@ -1387,7 +1592,7 @@ def dropout(x, rate):
     rate = float(rate)
     if rate == 0.0 or _meta(x):
         return x
-    _need_gpu(x, "dropout")
+    _need_gpu(x, "dropout", allow16=True)
     if _STEP_STATE["active"] is not None:
         # graph-replayable: the seed of a layer is its position in the pass, the step number comes from the device state
         _DROP_SEED[1] += 1
