@@ -16,7 +16,9 @@ convolution with 16 output channels at 128^3: forward (32->16), backward-data (1
 algorithmic each.  Events cannot be timed inside a replayed hipGraph on this runtime (profiles/probes/graph_event_probe.py),
 so in graph mode the family is timed in R eager steps of the same model that follow the timed region.
 `c5_bf16` (N=1 only): the same measurement for BASELINE configs[4]'s per-GPU workload (4 modalities, 5
-classes, bf16 conv operands / fp32 accumulate), outside the headline's timed region.  `cpu_baseline`: the CPU
+classes; bf16 activations / gradients in HBM, bf16 operands into the matrix cores, fp32 accumulate, fp32 batch-norm statistics
+and Dice sums -- SURVEY 8(d)), outside the headline's timed region.  `sustained`: >= 400 further replays after the timed
+region (ms/step, shader clock and power from rocm-smi when readable).  `cpu_baseline`: the CPU
 restatement (oracle/torch_ref.py: same graph on PyTorch-CPU oneDNN fp32 incl. backward + Adam) timed on the real
 128^3 step on rank 0 at N=1.
 """
@@ -45,12 +47,13 @@ def parse():
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="skip the bf16 / 4-modality / 5-class sub-measurement (N=1)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 400 extra replays after the timed region (N=1)")
     ap.add_argument("--cpu-patch", type=int, default=0, help="CPU baseline patch edge (0 = the benchmarked patch itself)")
     ap.add_argument("--pin-core", type=int, default=-1,
                     help="pin this process to ONE host core before the GPU is initialised (host-overhead experiment)")
     ap.add_argument("--compute", choices=("fp32", "bf16"), default="fp32",
-                    help="arithmetic of the 5^3 convolutions: fp32 = the reference's (headline metric); bf16 = operands rounded "
-                         "to bf16, fp32 accumulate (BASELINE config C5 with --channels 4 --classes 5)")
+                    help="fp32 = the reference's arithmetic (headline metric); bf16 = bf16 activations in HBM and bf16 operands "
+                         "into the matrix cores, fp32 accumulate (BASELINE config C5 with --channels 4 --classes 5)")
     return ap.parse_args()
 
 
@@ -124,6 +127,54 @@ def cpu_baseline(args):
     return {"value": scale / dt, "unit": "patches/s", "cores": threads, "kind": "port", "sample": sample,
             "cpu_model": model, "physical_cores": phys, "threads": threads, "seconds_per_step": round(dt, 3),
             "c1_32cube": {"value": round(1.0 / dt32, 4), "unit": "patches/s", "seconds_per_step": round(dt32, 4), "steps": n32}}
+
+
+def latest_pmc():
+    """The newest committed profiles/rNN_pmc.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))
+    return files[-1] if files else None
+
+
+def smi_sample():
+    """One reading of shader clock and power from rocm-smi while the GPU is busy (None if it cannot be read)."""
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=30).stdout
+        card = json.loads(out)
+        card = card.get("card0", next(iter(card.values())))
+        sclk = power = None
+        for k, v in card.items():
+            kl = k.lower()
+            if "sclk" in kl and "clock" in kl and sclk is None:
+                sclk = "".join(ch for ch in str(v) if ch.isdigit() or ch == ".")
+            if "power" in kl and "(w)" in kl and power is None:
+                power = v
+        return {"sclk_mhz": float(sclk) if sclk else None, "power_w": float(power) if power not in (None, "N/A") else None}
+    except Exception:
+        return None
+
+
+def sustained_run(m, images, labels, ms_per_step):
+    """>= 400 more replays of the step AFTER (outside) the timed region: a DVFS-settled figure next to the K-step one, long
+    enough for the driver's GPU sampler to see the device busy.  rocm-smi is read once from a second thread mid-run."""
+    import threading
+    import torch
+    n = int(min(1500, max(400, 8000.0 / max(ms_per_step, 1e-3))))
+    box = []
+    th = threading.Thread(target=lambda: (time.sleep(1.0), box.append(smi_sample())))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    th.start()
+    for _ in range(n):
+        m.train_step(images, labels)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    th.join()
+    smi = box[0] if box and box[0] else {}
+    return {"steps": n, "ms_per_step": round(dt / n * 1e3, 3), "seconds": round(dt, 2),
+            "sclk_mhz": smi.get("sclk_mhz"), "power_w": smi.get("power_w"),
+            "note": "graph replays after the timed region (not part of `value`)"}
 
 
 def family_tags(P, B, bf16):
@@ -212,6 +263,10 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
             m.train_step(images, labels)
     recs = ops.profile_stop()
     barrier()
+    sustained = None
+    if world == 1 and rank == 0 and not args.no_sustained:
+        m.force_eager = False
+        sustained = sustained_run(m, images, labels, dt / args.steps * 1e3)
 
     res = {"value": round(world * batch * args.steps / dt, 4), "ms_per_step": round(dt / args.steps * 1e3, 3),
            "final_loss": round(final_loss, 6), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
@@ -220,7 +275,7 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
            "step_enqueue": {"off": "eager (one ctypes launch per kernel)", "whole": "hipGraph replay of the whole step",
                             "segmented": "hipGraph(gradients) + eager RCCL bucket all-reduces + hipGraph(optimiser)",
                             "serial": "hipGraph(gradients) + eager RCCL bucket all-reduces after backward + hipGraph(optimiser)"}.get(mode, mode),
-           "roofline": None}
+           "roofline": None, "sustained": sustained}
     if rank != 0:
         return res
     fl = by = ms = 0.0
@@ -233,20 +288,22 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
             fl += f; by += b; ms += t; nl += 1
     if nl:
         ach = fl / (ms * 1e-3) / 1e12
-        traffic = tsrc = None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc.json")      # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        if os.path.exists(pmc) and patch == 128 and batch == 1:
+        traffic = tsrc = tper = None
+        pmc = latest_pmc()                                        # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        if pmc and patch == 128 and batch == 1:
             fams = json.load(open(pmc)).get("families", {})
             ent = fams.get("bf16" if bf16 else "fp32")
             if ent:
-                traffic = ent["hbm_bytes_per_launch"]
-                tsrc = "profiles/r02_pmc.json: rocprofv3 --pmc passes of this command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), not this run"
+                traffic = ent["hbm_bytes_per_launch"]             # mean over the family's three launches
+                tper = ent.get("per_kernel")                      # forward / backward-data / filter gradient, each per launch
+                tsrc = "profiles/%s: rocprofv3 --pmc passes of this command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), not this run" % os.path.basename(pmc)
         peak = PEAK_BF16_TFLOPS if bf16 else PEAK_FP32_TFLOPS
         kname = ("conv5_bf16_c16_kernel (fwd 32->16) + conv5_bf16_kernel (bwd-data 16->32) + wgrad5_bf16_kernel" if bf16
                  else "conv_kernel<5,1,4,8,8,4,4,{1,2}> (fwd 32->16, bwd-data 16->32) + wgrad_kernel<5,1,4,4,16,1,16>")
         res["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "traffic": traffic, "traffic_source": tsrc,
+            "traffic": traffic, "traffic_per_kernel": tper,
+            "traffic_over_algorithmic": (round(traffic / (by / nl), 3) if traffic else None), "traffic_source": tsrc,
             "kernel": kname + ": decoder level 1 conv_1, the 5^3 conv with 16 output channels @%d^3 -- forward, backward-data "
                               "and filter-gradient launches" % patch,
             "launches": nl, "avg_ms": round(ms / nl, 4), "flops_per_launch": fl / nl, "algorithmic_bytes_per_launch": by / nl,
@@ -297,7 +354,7 @@ def main():
                           "ranks": world, "backend": (dist.get_backend() if world > 1 else None)},
                "final_loss": r["final_loss"], "host_enqueue_ms_per_step": r["host_enqueue_ms_per_step"],
                "step_enqueue": r["step_enqueue"], "dp_autotune_ms": r.get("dp_autotune_ms"), "pinned_to_core": args.pin_core if args.pin_core >= 0 else None,
-               "roofline": r["roofline"]}
+               "roofline": r["roofline"], "sustained": r.get("sustained")}
         for k in ("conv_ms_per_step", "conv_tflops"):
             if k in r:
                 out[k] = r[k]
@@ -305,7 +362,7 @@ def main():
         # BASELINE configs[4] per-GPU workload on the same record (outside the headline's timed region)
         c5 = measure(args, args.patch, args.batch, 4, 5, "bf16", rank, local, world)
         ops.set_compute_dtype("fp32")
-        c5["metric"] = "training patches/sec (128^3x4ch, 5 classes, bf16 conv operands / fp32 accumulate), 1 GPU"
+        c5["metric"] = "training patches/sec (128^3x4ch, 5 classes, bf16 storage + bf16 conv operands / fp32 accumulate, fp32 BN statistics and Dice sums), 1 GPU"
         c5["dtype"] = "bf16"
         c5["steps"], c5["warmup"] = args.steps, args.warmup
         out["c5_bf16"] = c5

@@ -493,9 +493,18 @@ def _conv_vars(ps, filt, bias_len):
     return w, b
 
 
+# Teacher forcing (tests/golden/make_golden_full.py): with CAPTURE = {} every convolution call site records its (input Var,
+# output Var) under its 'weights' name; after backward() the entry holds what the layer saw -- input values and the gradient
+# that arrived at its output.
+CAPTURE = None
+
+
 def L_convolution(ps, x, filt, stride=1):
     w, b = _conv_vars(ps, filt, filt[-1])
-    return convolution(x, w, b, stride)
+    y = convolution(x, w, b, stride)
+    if CAPTURE is not None:
+        CAPTURE[w.name] = (x, y)
+    return y
 
 
 def L_down_convolution(ps, x, factor, kernel_size):

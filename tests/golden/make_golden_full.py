@@ -3,7 +3,10 @@
 
     c3_128cube.npz       configs[2]/[3]: 128^3, B=1, 1 modality, 2 classes, full-width net, fp32 arithmetic
     c2_64cube_b2.npz     configs[1]:     64^3,  B=2, 1 modality, 2 classes, full-width net
-    c5_128cube_bf16.npz  configs[4]:     128^3, B=1, 4 modalities, 5 classes, bf16 conv operands / wide accumulate
+    c5_128cube_bf16.npz  configs[4]:     128^3, B=1, 4 modalities, 5 classes, bf16 conv operands / wide accumulate (round-2 mode)
+    c5_128cube_b16.npz   configs[4] as SURVEY 8(d) words it: bf16 STORAGE of activations and their gradients (oracle.ACT_STORAGE);
+                         also holds, for six 5^3 layers, a crop of the layer's actual input and of the gradient that arrived
+                         at its output (bf16 bit patterns) -- the teacher-forcing data of tests/test_hip_golden_full.py
 
 The reference itself (TF 1.15) cannot run here, so these are ORACLE outputs, not reference outputs
 (parity unpinned -- DESIGN.md section 2).  Weights come from a recipe (the reference's own initialisers drawn
@@ -32,7 +35,39 @@ CASES = {
     "c3": ("c3_128cube.npz", 128, 1, 1, 2, 1000, None),
     "c2": ("c2_64cube_b2.npz", 64, 2, 1, 2, 3000, None),
     "c5": ("c5_128cube_bf16.npz", 128, 1, 4, 5, 1000, "bf16"),
+    "c5s": ("c5_128cube_b16.npz", 128, 1, 4, 5, 1000, "storage"),
 }
+
+# teacher-forcing crops (case c5s): layer -> origin of an 8 x 8 x 16 box of OUTPUT voxels (clipped to the level's size); the
+# stored input crop carries the 2-voxel halo, the stored output-gradient crop a 2-voxel halo as well (for backward-data).
+TF_LAYERS = {
+    "vnet/input_layer/weights": (0, 60, 56),                        # 4 -> 16 @128^3, touches the z = 0 face (zero padding)
+    "vnet/encoder/level_1/conv_1/weights": (60, 120, 112),          # 16 -> 16 @128^3, touches the y / x high faces
+    "vnet/decoder/level_1/conv_1/weights": (33, 47, 21),            # 32 -> 16 @128^3 (the roofline layer), interior
+    "vnet/encoder/level_2/conv_2/weights": (28, 30, 40),            # 32 -> 32 @64^3
+    "vnet/encoder/level_3/conv_3/weights": (12, 24, 16),            # 64 -> 64 @32^3
+    "vnet/bottom_level/conv_2/weights": (0, 0, 0),                  # 256 -> 256 @8^3: the whole volume
+}
+TF_BOX = (8, 8, 16)
+
+
+def bf16_bits(a):
+    """bf16-representable float64 array -> uint16 bit patterns."""
+    u = np.ascontiguousarray(np.asarray(a, dtype=np.float32)).view(np.uint32)
+    assert not (u & 0xFFFF).any(), "value is not bf16-representable"
+    return (u >> 16).astype(np.uint16)
+
+
+def from_bf16_bits(u):
+    return (np.asarray(u, dtype=np.uint32) << 16).view(np.float32).astype(np.float64)
+
+
+def tf_crop(t, origin, halo=2):
+    """(crop of t [1, D, H, W, C] around the TF_BOX at `origin` incl. `halo`, clipped to the volume; the crop's low corner)."""
+    lo = [max(0, o - halo) for o in origin]
+    hi = [min(t.shape[1 + a], origin[a] + TF_BOX[a] + halo) for a in range(3)]
+    return t[:, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2], :], lo
+
 
 
 def sample_indices(i, n):
@@ -48,11 +83,25 @@ def make(case):
     ps = O.ParamStore(rng=np.random.default_rng(42))
     net = O.VNetOracle(K, 0.0, 16, 4, (1, 2, 3, 3), 3, "prelu", "networks", ps)
     x, lab = O.synthetic_batch(B, P, cin, K, seed=seed)
-    O.CONV5_OPERAND_ROUNDING = rounding
+    O.CONV5_OPERAND_ROUNDING = rounding if rounding == "bf16" else None
+    O.ACT_STORAGE = "bf16" if rounding == "storage" else None
+    O.CAPTURE = {} if rounding == "storage" else None
+    tf = {}
     try:
         res = O.run_step(x.astype(np.float64), lab, net, "sorensen")
+        if O.CAPTURE is not None:
+            for name, origin in TF_LAYERS.items():
+                xin, yout = O.CAPTURE[name]
+                xv = O.round_bf16(xin.v) if name.startswith("vnet/input_layer") else xin.v      # (the fp32 image: the conv rounds it)
+                cx, lo = tf_crop(xv, origin)
+                cg, _ = tf_crop(yout.g, origin)
+                tf["tf:%s:x" % name] = bf16_bits(cx)
+                tf["tf:%s:dy" % name] = bf16_bits(cg)
+                tf["tf:%s:lo" % name] = np.asarray(lo, dtype=np.int32)
     finally:
         O.CONV5_OPERAND_ROUNDING = None
+        O.ACT_STORAGE = None
+        O.CAPTURE = None
     sm = res["softmax"]
     oh = (lab[..., 0][..., None] == np.arange(K)).astype(np.float64)
     ax = (1, 2, 3)
@@ -71,6 +120,7 @@ def make(case):
            "oracle_seconds": np.float64(time.time() - t0)}
     for k, v in ps.state.items():
         out["state:" + k] = v.astype(np.float32)
+    out.update(tf)
     np.savez_compressed(os.path.join(HERE, fname), **out)
     print(case, "loss %.9f" % res["loss"], "seconds %.0f" % (time.time() - t0), flush=True)
 

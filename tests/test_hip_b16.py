@@ -1,0 +1,450 @@
+"""-m gpu: the bf16-STORAGE mode (BASELINE config C5 as SURVEY 8(d) words it; include/vnet_hip.h `*_b16`).
+
+Every kernel reads bf16 tensors, computes in fp32 and rounds its output once, so the bar per op is "the stored bf16 value is a
+correct rounding of the exact result": |got - exact| <= half a bf16 ulp of the exact value (+ fp32 accumulation noise), with the
+exact result from the fp64 oracle on the SAME bf16-valued inputs; >= 99.5 % of the values must equal RNE(exact) outright.  The
+5^3 kernels are additionally held BIT-EXACTLY to the round-2 kernels they share their main loop with: out16 == RNE(out32)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vnet_oracle as O
+from tests.util import g, check_close
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rb(a):
+    return O.round_bf16(a)
+
+
+def g16(a, dev):
+    """bf16 device tensor holding exactly the (already bf16-valued) float64 array."""
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(dev).to(BF)
+
+
+def check_bf16(name, got, exact, noise=4e-6, min_equal=0.995):
+    """`got` (bf16 tensor) is a correct rounding of `exact` (float64, unrounded)."""
+    assert got.dtype == BF, "%s: dtype %s" % (name, got.dtype)
+    gv = got.detach().float().cpu().numpy().astype(np.float64)
+    ex = np.asarray(exact, dtype=np.float64)
+    assert gv.shape == ex.shape, "%s: shape %s vs %s" % (name, gv.shape, ex.shape)
+    assert np.isfinite(gv).all(), name
+    scale = float(np.abs(ex).max()) + 1e-30
+    tol = np.abs(ex) * (2.0 ** -8) * (1 + 1e-3) + noise * scale
+    bad = np.abs(gv - ex) > tol
+    assert not bad.any(), "%s: %d of %d values are not a correct rounding (worst %.3e vs tol %.3e)" % (
+        name, int(bad.sum()), bad.size, float(np.abs(gv - ex)[bad].max()), float(tol[bad].min()))
+    eq = float((gv == rb(ex)).mean())
+    assert eq >= min_equal, "%s: only %.4f of the values equal RNE(exact)" % (name, eq)
+    return eq
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# 5^3 convolution: forward / backward-data / filter gradient
+# ---------------------------------------------------------------------------------------------------------------------------
+CONV5_SHAPES = [
+    (1, 8, 16, 32, 16, 0, 16),     # 16 cout, few bricks: generic kernel, one cout block padded to 32
+    (1, 16, 32, 64, 16, 0, 16),    # 16 cout, >= 256 bricks: persistent 16-cout kernel, one chunk
+    (1, 16, 32, 64, 16, 16, 16),   # ... two chunks (paired bricks), two sources (decoder concat)
+    (1, 16, 32, 64, 8, 0, 16),     # the zero-padded network input (4 modalities -> 8 channels)
+    (2, 5, 9, 17, 16, 16, 16),     # ragged dims, batch 2
+    (1, 8, 32, 64, 32, 0, 32),     # row-pair kernel (32-cout blocks, >= 256 items would need more bricks: generic here)
+    (1, 16, 64, 64, 32, 0, 32),    # row-pair kernel
+    (1, 8, 16, 32, 64, 0, 64),     # two cout blocks per workgroup
+    (1, 8, 8, 8, 32, 32, 32),      # cube brick, split-K (bf16 reduce kernel)
+    (1, 4, 4, 4, 128, 0, 128),     # split-K + dz split
+]
+
+
+def _conv5_inputs(shape, seed):
+    B, D, H, W, C0, C1, Co = shape
+    rng = np.random.default_rng(seed)
+    x0 = rb(rng.standard_normal((B, D, H, W, C0)))
+    x1 = rb(rng.standard_normal((B, D, H, W, C1))) if C1 else None
+    w = rng.standard_normal((5, 5, 5, C0 + C1, Co)) * 0.1
+    b = rng.standard_normal(Co)
+    dy = rb(rng.standard_normal((B, D, H, W, Co)))
+    return x0, x1, w, b, dy
+
+
+@pytest.mark.parametrize("shape", CONV5_SHAPES)
+def test_conv5_b16_against_oracle_and_fp32_output_kernels(dev, shape):
+    from vnet_tensorflow_amd import ops
+    B, D, H, W, C0, C1, Co = shape
+    x0, x1, w, b, dy = _conv5_inputs(shape, sum(shape) + 3)
+    xcat = x0 if x1 is None else np.concatenate((x0, x1), -1)
+    y_ex = O.conv_nd_fwd(xcat, rb(w), 1) + b
+    dx_ex, dw_ex = O.conv_nd_bwd(xcat, rb(w), dy, 1)
+    tx0 = g16(x0, dev).requires_grad_(True)
+    tx1 = g16(x1, dev).requires_grad_(True) if C1 else None
+    tw, tb = g(w, dev).requires_grad_(True), g(b, dev).requires_grad_(True)
+    y = ops.conv(tx0, tw, tb, 5, 1, x1=tx1)
+    tag = "conv5-b16 %s" % (shape,)
+    check_bf16(tag + " fwd", y, y_ex)
+    y.backward(g16(dy, dev))
+    check_bf16(tag + " dx0", tx0.grad, dx_ex[..., :C0])
+    if C1:
+        check_bf16(tag + " dx1", tx1.grad, dx_ex[..., C0:])
+    check_close(tag + " dw", tw.grad, dw_ex, 2e-6)
+    assert tw.grad.dtype == torch.float32 and tb.grad.dtype == torch.float32
+    check_close(tag + " db", tb.grad, dy.reshape(-1, Co).sum(0), 2e-6, atol=1e-6 * float(np.abs(dy).reshape(-1, Co).sum(0).max()))
+    # bit-exact link to the round-2 kernels (bf16 sources, fp32 outputs): same main loop, same summation order
+    ops.set_compute_dtype("bf16_operands")
+    try:
+        fx0 = ops.with_shadow(tx0.detach().float()).requires_grad_(True)
+        fx1 = ops.with_shadow(tx1.detach().float()).requires_grad_(True) if C1 else None
+        fw, fb = tw.detach().clone().requires_grad_(True), tb.detach().clone().requires_grad_(True)
+        y32 = ops.conv(fx0, fw, fb, 5, 1, x1=fx1)
+        assert torch.equal(y32.detach().to(BF), y.detach()), tag + ": forward is not RNE(fp32-output kernel)"
+        y32.backward(ops.with_shadow(g16(dy, dev).float()))
+        assert torch.equal(fx0.grad.to(BF), tx0.grad), tag + ": backward-data is not RNE(fp32-output kernel)"
+        if C1:
+            assert torch.equal(fx1.grad.to(BF), tx1.grad)
+        assert torch.equal(fw.grad, tw.grad), tag + ": filter gradient differs from the round-2 kernel"
+    finally:
+        ops.set_compute_dtype("fp32")
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 32, 64, 16, 0, 16), (1, 16, 64, 64, 32, 0, 32), (1, 8, 16, 32, 64, 0, 64), (1, 8, 8, 8, 32, 0, 32)])
+def test_conv5_b16_epilogue_statistics_and_accumulation(dev, shape):
+    """Statistics of the ROUNDED output (+ bf16 residual) from the epilogue == a separate statistics pass over the stored tensor;
+    accumulate mode (in place and out of place) rounds the SUM once."""
+    from vnet_tensorflow_amd import ops, _lib
+    L = _lib.lib()
+    B, D, H, W, C0, C1, Co = shape
+    x0, _, w, b, dy = _conv5_inputs(shape, sum(shape) + 11)
+    rng = np.random.default_rng(5)
+    res = rb(rng.standard_normal((B, D, H, W, Co)))
+    tx, tw, tb, tres = g16(x0, dev), g(w, dev), g(b, dev), g16(res, dev)
+    y = ops.conv(tx, tw, tb, 5, 1, bn_stats=True, bn_residual=tres)
+    st = getattr(y, "_vnet_stats", None)
+    assert st is not None, "this shape should produce epilogue statistics"
+    part = st.partial.double().sum(0).cpu().numpy()
+    v = (y.detach().float() + tres.float()).double().reshape(-1, Co).cpu().numpy()
+    assert np.allclose(part[:Co], v.sum(0), rtol=2e-5, atol=1e-6 * np.abs(v).sum(0).max())
+    assert np.allclose(part[Co:], (v * v).sum(0), rtol=2e-5)
+    # accumulate: y2 = RNE(float(prev) + conv), in place and out of place
+    wp = ops.packed_weights(tw, ops.PACK_FWD_BF16, 125, C0, Co)
+    prev = g16(rb(rng.standard_normal((B, D, H, W, Co))), dev)
+    exact = O.conv_nd_fwd(x0, rb(w), 1) + prev.float().double().cpu().numpy()
+    out = torch.empty_like(prev)
+    ops._conv5_b16_call(tx, None, wp, None, out, None, (D, H, W), acc_src=prev)
+    check_bf16("accumulate out of place %s" % (shape,), out, exact)
+    inpl = prev.clone()
+    ops._conv5_b16_call(tx, None, wp, None, inpl, None, (D, H, W), accum=True)
+    assert torch.equal(inpl, out)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# 2^3 stride-2 convolution and 2^3 transposed convolution
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [
+    (1, 16, 16, 32, 16),      # level 1 shapes: 1x4x16 bricks
+    (2, 9, 11, 17, 16),       # odd dims (SAME pads on the high side), batch 2
+    (1, 8, 8, 8, 64),         # W < 16: 2x8x8 bricks
+    (1, 4, 4, 4, 128),        # coarse level: narrow cout blocks, split-K
+])
+def test_conv2_down_and_up_b16(dev, shape):
+    from vnet_tensorflow_amd import ops
+    B, D, H, W, C = shape
+    rng = np.random.default_rng(sum(shape))
+    # down: [.., C] -> [.., 2C]
+    x = rb(rng.standard_normal((B, D, H, W, C)))
+    w = rng.standard_normal((2, 2, 2, C, 2 * C)) * 0.2
+    b = rng.standard_normal(2 * C)
+    y_ex = O.conv_nd_fwd(x, rb(w), 2) + b
+    dy = rb(rng.standard_normal(y_ex.shape))
+    dx_ex, dw_ex = O.conv_nd_bwd(x, rb(w), dy, 2)
+    tx, tw, tb = g16(x, dev).requires_grad_(True), g(w, dev).requires_grad_(True), g(b, dev).requires_grad_(True)
+    y = ops.conv(tx, tw, tb, 2, 2, bn_stats=True)
+    tag = "down-b16 %s" % (shape,)
+    check_bf16(tag + " fwd", y, y_ex)
+    st = getattr(y, "_vnet_stats", None)
+    if st is not None:
+        v = y.detach().float().double().reshape(-1, 2 * C).cpu().numpy()
+        part = st.partial.double().sum(0).cpu().numpy()
+        assert np.allclose(part[:2 * C], v.sum(0), rtol=2e-5, atol=1e-6 * np.abs(v).sum(0).max())
+        assert np.allclose(part[2 * C:], (v * v).sum(0), rtol=2e-5)
+    y.backward(g16(dy, dev))
+    check_bf16(tag + " dx", tx.grad, dx_ex)
+    check_close(tag + " dw", tw.grad, dw_ex, 2e-6)
+    # up: [.., 2C] at the coarse size -> [.., C] at (D, H, W)
+    Dc, Hc, Wc = -(-D // 2), -(-H // 2), -(-W // 2)
+    xc = rb(rng.standard_normal((B, Dc, Hc, Wc, 2 * C)))
+    wu = rng.standard_normal((2, 2, 2, C, 2 * C)) * 0.2
+    bu = rng.standard_normal(C)
+    yu_ex = O.conv_nd_transpose_fwd(xc, rb(wu), (D, H, W), 2) + bu
+    dyu = rb(rng.standard_normal(yu_ex.shape))
+    dxu_ex = O.conv_nd_fwd(dyu, rb(wu), 2)
+    _, dwu_ex = O.conv_nd_bwd(dyu, wu, xc, 2, need_dx=False)
+    txc, twu, tbu = g16(xc, dev).requires_grad_(True), g(wu, dev).requires_grad_(True), g(bu, dev).requires_grad_(True)
+    yu = ops.conv_transpose2(txc, twu, tbu, (D, H, W))
+    tag = "up-b16 %s" % (shape,)
+    check_bf16(tag + " fwd", yu, yu_ex)
+    yu.backward(g16(dyu, dev))
+    check_bf16(tag + " dx", txc.grad, dxu_ex)
+    check_close(tag + " dw", twu.grad, dwu_ex, 2e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# batch-norm (+ residual, + activation, + tile), chains, head, dropout
+# ---------------------------------------------------------------------------------------------------------------------------
+def _bn_reference(x, r, gamma, beta, act, alpha, dy):
+    xv = O.Var(x)
+    s = O.add(xv, O.Var(r)) if r is not None else xv
+    gv, bv = O.Var(gamma), O.Var(beta)
+    y = O.batch_norm_train(s, gv, bv)
+    av = None
+    if act == "prelu":
+        av = O.Var(alpha)
+        y = O.prelu(y, av)
+    elif act == "relu":
+        y = O.relu(y)
+    O.backward(y, seed=dy)
+    return y.v, xv.g, gv.g, bv.g, (av.g if av is not None else None)
+
+
+@pytest.mark.parametrize("M,C,act,res", [((2, 6, 7, 9), 16, "prelu", True), ((1, 8, 8, 8), 32, "relu", False),
+                                         ((1, 4, 4, 4), 256, "prelu", True), ((1, 5, 3, 7), 8, None, False),
+                                         ((1, 32, 32, 32), 16, "prelu", False)])
+def test_bn_act_b16(dev, M, C, act, res):
+    from vnet_tensorflow_amd import ops
+    rng = np.random.default_rng(C + len(M))
+    shape = M + (C,)
+    x = rb(rng.standard_normal(shape) * 2 + 0.5)
+    r = rb(rng.standard_normal(shape)) if res else None
+    gamma, beta = 1 + 0.3 * rng.standard_normal(C), 0.3 * rng.standard_normal(C)
+    alpha = 0.1 + 0.05 * rng.standard_normal(C)
+    dy = rb(rng.standard_normal(shape))
+    y_ex, dx_ex, dg_ex, db_ex, da_ex = _bn_reference(x, r, gamma, beta, act, alpha, dy)
+    tx = g16(x, dev).requires_grad_(True)
+    tr = g16(r, dev).requires_grad_(True) if res else None
+    tg, tb, ta = g(gamma, dev).requires_grad_(True), g(beta, dev).requires_grad_(True), g(alpha, dev).requires_grad_(True)
+    y = ops.bn_act(tx, tg, tb, act, ta if act == "prelu" else None, residual=tr)
+    tag = "bn-b16 %s C=%d %s" % (M, C, act)
+    check_bf16(tag + " fwd", y, y_ex, noise=2e-6)
+    y.backward(g16(dy, dev))
+    check_bf16(tag + " ds", tx.grad, dx_ex, noise=2e-5, min_equal=0.98)
+    if res:
+        assert torch.equal(tr.grad, tx.grad)
+    check_close(tag + " dgamma", tg.grad, dg_ex, 1e-5)
+    check_close(tag + " dbeta", tb.grad, db_ex, 1e-5, atol=1e-6 * float(np.abs(dy).sum()))
+    if act == "prelu":
+        check_close(tag + " dalpha", ta.grad, da_ex, 1e-5)
+
+
+def test_bn_tile_and_chain_b16(dev):
+    """tf.tile of the fp32 1-channel image + batch-norm -> bf16 (networks.py:254-259), and the decoder chains on bf16."""
+    from vnet_tensorflow_amd import ops
+    rng = np.random.default_rng(3)
+    img = rng.standard_normal((1, 6, 8, 10, 1)) * 40 + 100
+    gamma, beta = 1 + 0.3 * rng.standard_normal(16), 0.3 * rng.standard_normal(16)
+    xv = O.Var(img)
+    ref = O.batch_norm_train(O.tile_channels(xv, 16), O.Var(gamma), O.Var(beta))
+    ops.set_compute_dtype("bf16")
+    try:
+        y = ops.bn_act(g(img, dev), g(gamma, dev), g(beta, dev), None, None, tile=True)
+    finally:
+        ops.set_compute_dtype("fp32")
+    check_bf16("tile+bn", y, ref.v, noise=2e-6)
+    # chains: kind 0  act(BN3(BN1(x) + BN2(BN1(x)))),  kind 1  act(BNb(x + BNa(x)))
+    for kind in (0, 1):
+        C = 32
+        x = rb(rng.standard_normal((2, 5, 6, 7, C)) * 1.5 + 0.3)
+        ps = [(1 + 0.3 * rng.standard_normal(C), 0.3 * rng.standard_normal(C)) for _ in range(3)]
+        alpha = 0.1 + 0.05 * rng.standard_normal(C)
+        dy = rb(rng.standard_normal(x.shape))
+        xv = O.Var(x)
+        vs = [(O.Var(a), O.Var(b)) for a, b in ps]
+        av = O.Var(alpha)
+        if kind == 0:
+            y1 = O.batch_norm_train(xv, *vs[0]); y2 = O.batch_norm_train(y1, *vs[1])
+            out = O.prelu(O.batch_norm_train(O.add(y1, y2), *vs[2]), av)
+        else:
+            r_ = O.batch_norm_train(xv, *vs[0])
+            out = O.prelu(O.batch_norm_train(O.add(xv, r_), *vs[1]), av)
+        O.backward(out, seed=dy)
+        tx = g16(x, dev).requires_grad_(True)
+        tp = [(g(a, dev).requires_grad_(True), g(b, dev).requires_grad_(True)) for a, b in ps]
+        ta = g(alpha, dev).requires_grad_(True)
+        y = ops.bn_chain(tx, kind, "prelu", ta, tp[0][0], tp[0][1], tp[1][0], tp[1][1],
+                         tp[2][0] if kind == 0 else None, tp[2][1] if kind == 0 else None)
+        check_bf16("chain %d fwd" % kind, y, out.v, noise=5e-5, min_equal=0.97)
+        y.backward(g16(dy, dev))
+        check_bf16("chain %d dx" % kind, tx.grad, xv.g, noise=2e-4, min_equal=0.9)
+        for i in range(3 if kind == 0 else 2):
+            check_close("chain %d dgamma%d" % (kind, i), tp[i][0].grad, vs[i][0].g, 1e-4, atol=1e-5 * float(np.abs(vs[i][0].g).max() + 1))
+        check_close("chain %d dalpha" % kind, ta.grad, av.g, 1e-4)
+
+
+@pytest.mark.parametrize("K", [2, 5])
+def test_head_and_dropout_b16(dev, K):
+    from vnet_tensorflow_amd import ops
+    rng = np.random.default_rng(K)
+    x = rb(rng.standard_normal((2, 5, 6, 7, 16)))
+    w = rng.standard_normal((1, 1, 1, 16, K)) * 0.3
+    b = rng.standard_normal(K)
+    dy = rng.standard_normal((2, 5, 6, 7, K))
+    tx, tw, tb = g16(x, dev).requires_grad_(True), g(w, dev).requires_grad_(True), g(b, dev).requires_grad_(True)
+    y = ops.head_conv(tx, tw, tb)
+    assert y.dtype == torch.float32                      # logits stay fp32
+    check_close("head fwd", y, x @ w[0, 0, 0] + b, 2e-6)
+    y.backward(g(dy, dev))
+    dy32 = np.asarray(g(dy, dev).cpu().numpy(), dtype=np.float64)
+    check_bf16("head dx", tx.grad, dy32 @ w[0, 0, 0].T, noise=2e-6)
+    check_close("head dw", tw.grad, (x.reshape(-1, 16).T @ dy32.reshape(-1, K)).reshape(w.shape), 5e-6)
+    check_close("head db", tb.grad, dy32.reshape(-1, K).sum(0), 5e-6, atol=1e-5)
+    # dropout: same mask stream as the fp32 kernel; kept values scaled and rounded once
+    t = g16(x, dev).requires_grad_(True)
+    ops._DROP_SEED[0] = 41
+    yd = ops.dropout(t, 0.3)
+    ops._DROP_SEED[0] = 41
+    yf = ops.dropout(t.detach().float(), 0.3)
+    keep = (yf != 0) | (t.detach().float() == 0)
+    assert torch.equal(yd.detach() != 0, (yf != 0))
+    check_bf16("dropout fwd", yd, (t.detach().float().double() * keep.double() / 0.7).cpu().numpy(), noise=1e-7)
+    yd.backward(torch.ones_like(yd))
+    check_bf16("dropout bwd", t.grad, (keep.double() / 0.7).cpu().numpy(), noise=1e-7)
+    assert 0.25 < 1.0 - float(keep.float().mean()) < 0.35
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# whole networks in bf16-storage mode against the oracle's ACT_STORAGE restatement
+# ---------------------------------------------------------------------------------------------------------------------------
+def _run_network(dev, variant, cin, K, P, B, C0, levels, ncv, nb, loss, seed=5):
+    from vnet_tensorflow_amd import networks, VNet as legacy, ops, optim
+    images, labels = O.synthetic_batch(B, P, cin, K, seed=1000 + seed)
+    ps = O.ParamStore(rng=np.random.default_rng(seed), perturb=0.2)
+    ref_net = O.VNetOracle(K, 0.0, C0, levels, ncv, nb, "prelu", variant, ps)
+    O.ACT_STORAGE = "bf16"
+    try:
+        ref = O.run_step(images.astype(np.float64), labels, ref_net, loss)
+    finally:
+        O.ACT_STORAGE = None
+    ops.set_compute_dtype("bf16")
+    try:
+        if variant == "networks":
+            net = networks.VNet(K, 0.0, C0, levels, ncv, nb, True, "prelu", device=dev)
+            fwd = net.GetNetwork
+        else:
+            net = legacy.VNet(K, 1.0, C0, levels, ncv, nb, True, "prelu", device=dev)
+            fwd = net.network_fn
+        net.variables.values = {k: v.v for k, v in ps.vars.items()}
+        net.build((B, P, P, P, cin))
+        optim.FlatParams(net.named_parameters())
+        logits = fwd(torch.from_numpy(images).to(dev))
+        ls, dice, _, _ = ops.softmax_loss(logits, torch.from_numpy(labels).to(dev), loss)
+        ls.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_compute_dtype("fp32")
+    return ref, net, logits, ls
+
+
+@pytest.mark.parametrize("variant,cin,K", [("networks", 4, 5), ("networks", 1, 2), ("legacy", 2, 3)])
+def test_small_network_bf16_storage_against_oracle(dev, variant, cin, K):
+    """Whole networks against the oracle's storage-mode restatement.  Rounding is discontinuous: one stored value that lands on
+    the other bf16 neighbour (fp32 vs fp64 accumulation) perturbs everything downstream by far more than fp32 round-off, which
+    flips more roundings.  MEASURED on the oracle itself (these networks, inputs scaled by 1 +- 1e-7; profiles note in
+    DESIGN.md section 6): its own storage-mode logits move by 8.2e-3 .. 1.3e-2 (rel-L2), its loss by up to 1.5e-5, its gradient
+    tensors by 8e-2 .. 1.1e-1 (median) and up to 2.4 (a near-zero tensor) -- that sensitivity, not fp32 round-off, is the
+    network-level yardstick; the HIP path must agree with the oracle as well as the oracle agrees with itself.  What pins the
+    kernels and the PLACEMENT of every rounding is test_forward_ops_in_situ below (each op of this very network against
+    RNE(oracle op) on the op's actual input) and the per-op tests above."""
+    ref, net, logits, ls = _run_network(dev, variant, cin, K, P=16, B=1, C0=8, levels=2, ncv=(1, 2), nb=1, loss="sorensen")
+    assert logits.dtype == torch.float32
+    lg = logits.detach().double().cpu().numpy()
+    rel = np.linalg.norm(lg - ref["logits"]) / np.linalg.norm(ref["logits"])
+    assert rel < 2e-2, rel
+    assert abs(float(ls.detach()) - ref["loss"]) < 1e-4
+    errs = []
+    for name, p in net.named_parameters():
+        rr = ref["grads"][name]
+        if np.linalg.norm(rr) > 1e-9 and not name.endswith("biases"):
+            errs.append(float(np.linalg.norm(p.grad.double().cpu().numpy() - rr) / np.linalg.norm(rr)))
+    assert np.median(errs) < 0.2, (np.median(errs), max(errs))
+    num = sum(float(np.linalg.norm(p.grad.double().cpu().numpy() - ref["grads"][n])) ** 2 for n, p in net.named_parameters())
+    den = sum(float(np.linalg.norm(v)) ** 2 for v in ref["grads"].values())
+    assert (num / den) ** 0.5 < 0.2, (num / den) ** 0.5
+
+
+@pytest.mark.parametrize("variant,cin,K", [("networks", 4, 5), ("networks", 1, 2), ("legacy", 2, 3)])
+def test_forward_ops_in_situ(dev, variant, cin, K, monkeypatch):
+    """Teacher forcing, forward: every fused op of a storage-mode network run is re-evaluated by the oracle FROM THE OP'S ACTUAL
+    INPUT (as the HIP path stored it) and the HIP output must be a correct rounding of that -- per-op parity on realistic data
+    without the chaotic amplification of a whole-network comparison, and a check that no op leaves an unrounded (or doubly
+    rounded) tensor behind."""
+    from vnet_tensorflow_amd import ops
+    rec = []
+
+    def wrap(name):
+        orig = getattr(ops, name)
+
+        def f(*a, **k):
+            out = orig(*a, **k)
+            if not any(isinstance(t, torch.Tensor) and t.device.type == "meta" for t in a):
+                rec.append((name, a, k, out))
+            return out
+        monkeypatch.setattr(ops, name, f)
+    for n in ("conv", "conv_transpose2", "bn_act", "bn_chain", "head_conv"):
+        wrap(n)
+    _run_network(dev, variant, cin, K, P=16, B=1, C0=8, levels=2, ncv=(1, 2), nb=1, loss="sorensen")
+
+    def f64(t):
+        return None if t is None else t.detach().float().double().cpu().numpy()
+
+    def bn(s, gamma, beta):
+        ax = tuple(range(s.ndim - 1))
+        mu, var = s.mean(axis=ax), s.var(axis=ax)
+        return (s - mu) / np.sqrt(var + 1e-3) * f64(gamma) + f64(beta)
+
+    def act(z, kind, alpha):
+        if kind == "prelu":
+            return np.maximum(z, 0) + f64(alpha) * np.minimum(z, 0)
+        return np.maximum(z, 0) if kind == "relu" else z
+    seen = set()
+    for name, a, k, out in rec:
+        seen.add(name)
+        if name == "conv":
+            x0, w, b, ks, stride = a[0], a[1], a[2], a[3], (a[4] if len(a) > 4 else k.get("stride", 1))
+            x = f64(x0)
+            if k.get("x1") is not None:
+                x = np.concatenate((x, f64(k["x1"])), -1)
+            x = x[..., :w.shape[-2]]                                  # (zero-padded network input)
+            check_bf16("in situ conv k%d %s" % (ks, tuple(w.shape)), out, O.conv_nd_fwd(x, rb(f64(w)), stride) + f64(b))
+        elif name == "conv_transpose2":
+            x, w, b, osp = a
+            check_bf16("in situ up conv", out, O.conv_nd_transpose_fwd(f64(x), rb(f64(w)), tuple(osp), 2) + f64(b))
+        elif name == "head_conv":
+            x, w, b = a
+            check_close("in situ head", out, f64(x) @ f64(w)[0, 0, 0] + f64(b), 1e-5)
+        elif name == "bn_act":
+            x, gamma, beta = a[0], a[1], a[2]
+            kind = a[3] if len(a) > 3 else k.get("act")
+            alpha = a[4] if len(a) > 4 else k.get("alpha")
+            r = a[5] if len(a) > 5 else k.get("residual")
+            tile = a[6] if len(a) > 6 else k.get("tile", False)
+            s = f64(x)
+            if tile:
+                s = np.tile(s, (1, 1, 1, 1, gamma.numel()))
+            if r is not None:
+                s = s + f64(r)
+            exact = act(bn(s, gamma, beta), kind, alpha)
+            o = out[0] if isinstance(out, tuple) else out
+            if o.dtype == BF:
+                check_bf16("in situ bn_act C=%d" % gamma.numel(), o, exact, noise=4e-6)
+            else:
+                check_close("in situ bn_act (logits)", o, exact, 1e-5)
+        elif name == "bn_chain":
+            x, kind, kact, alpha, g1, b1, g2, b2 = a[:8]
+            g3, b3 = (a[8] if len(a) > 8 else k.get("g3")), (a[9] if len(a) > 9 else k.get("b3"))
+            xv = f64(x)
+            if kind == 0:
+                y1 = bn(xv, g1, b1)
+                exact = act(bn(y1 + bn(y1, g2, b2), g3, b3), kact, alpha)
+            else:
+                exact = act(bn(xv + bn(xv, g1, b1), g2, b2), kact, alpha)
+            check_bf16("in situ bn_chain %d" % kind, out, exact, noise=5e-5, min_equal=0.97)
+    assert {"conv", "conv_transpose2", "bn_act", "head_conv"} <= seen and (variant == "legacy" or "bn_chain" in seen), seen

@@ -29,7 +29,7 @@ def _shadowed(ops, t):
 ])
 def test_conv_and_wgrad_from_shadows_bit_identical(dev, shape, cin, cin1, cout):
     from vnet_tensorflow_amd import ops
-    ops.set_compute_dtype("bf16")
+    ops.set_compute_dtype("bf16_operands")
     try:
         gen = torch.Generator(device="cpu").manual_seed(cin * 131 + cout)
         B, D, H, W = shape
@@ -70,7 +70,7 @@ def test_conv_and_wgrad_from_shadows_bit_identical(dev, shape, cin, cin1, cout):
 
 def test_producers_write_rne_shadows(dev):
     from vnet_tensorflow_amd import ops
-    ops.set_compute_dtype("bf16")
+    ops.set_compute_dtype("bf16_operands")
     try:
         gen = torch.Generator(device="cpu").manual_seed(5)
         x = torch.randn(1, 6, 10, 12, 16, generator=gen).to(dev).requires_grad_(True)
@@ -115,7 +115,7 @@ def test_network_step_bit_identical_with_and_without_shadows(dev, variant, cin, 
     K, C0, levels, ncv, nb = 3, 8, 2, [1, 2], 2
     x, lab = synthetic_batch(2, 16, cin, K, seed=11)
     results = []
-    ops.set_compute_dtype("bf16")
+    ops.set_compute_dtype("bf16_operands")
     try:
         for on in (True, False):
             ops.set_bf16_shadows(on)
@@ -163,7 +163,7 @@ def test_row_pair_kernel_epilogue_statistics(dev, shape, cin, cout, residual):
     w = (torch.randn(5, 5, 5, cin, cout, generator=gen) * 0.05).to(dev)
     b = torch.randn(cout, generator=gen).to(dev)
     res = (torch.randn(B, D, H, W, cout, generator=gen) * 2.0).to(dev) if residual else None
-    ops.set_compute_dtype("bf16")
+    ops.set_compute_dtype("bf16_operands")
     try:
         rows = lib().vnet_conv_bf16_stats_rows_x16(cin, cout, 0, cin, 0, B, D, H, W)
         assert rows == B * -(-D // 4) * -(-H // 16) * -(-W // 16)
@@ -203,7 +203,7 @@ def test_row_pair_kernel_random_shapes_bit_identical_to_generic(dev):
         ops._conv_bf16_call(ops.with_shadow(x0), ops.with_shadow(x1) if two else None, wp, b, got, None, (D, H, W), accum=True)
         assert torch.equal(got, ref), (D, H, W, cin, cout, two)
 
-    ops.set_compute_dtype("bf16")
+    ops.set_compute_dtype("bf16_operands")
     try:
         run()
     finally:

@@ -62,7 +62,7 @@ def test_conv5_full_resolution_against_oracle_crops(dev, mode, C0, C1, Co):
     tx0 = x0.to(dev).requires_grad_(True)
     tx1 = x1.to(dev).requires_grad_(True) if C1 else None
     tw, tb = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
-    ops.set_compute_dtype(mode)
+    ops.set_compute_dtype("bf16_operands" if mode == "bf16" else mode)
     try:
         y = ops.conv(tx0, tw, tb, 5, 1, x1=tx1)
         xcat = x0.numpy() if x1 is None else np.concatenate((x0.numpy(), x1.numpy()), -1)
@@ -143,7 +143,7 @@ def test_conv_identities_full_resolution(dev, mode):
     dw_dir = q(torch.randn(5, 5, 5, Ci, Co, device=dev) * 0.05)
     zero_b = torch.zeros(Co, device=dev)
     yv = q(torch.randn(1, P, P, P, Co, device=dev))
-    ops.set_compute_dtype(mode)
+    ops.set_compute_dtype("bf16_operands" if mode == "bf16" else mode)
     try:
         xr = x.clone().requires_grad_(True)
         cx = ops.conv(xr, w, zero_b, 5, 1)

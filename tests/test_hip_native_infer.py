@@ -23,7 +23,8 @@ def test_native_driver_matches_python_evaluate(tmp_path, dev, cin, K, levels, co
                                "SegmentationClasses": list(range(K)), "BatchSize": 1, "PatchShape": [16, 16, 16],
                                "Networks": {"Name": "VNet", "Dropout": 0.0, "NumChannel": 8, "NumLevels": levels,
                                             "NumCovolutions": convs, "BottomConvolutions": bottom},
-                               "ComputeDtype": compute,
+                               # (the native driver's --compute bf16 is the round-2 operand mode: fp32 tensors + bf16 shadows)
+                               "ComputeDtype": "bf16_operands" if compute == "bf16" else compute,
                                "Optimizer": {"Name": "Adam", "InitialLearningRate": 1e-3, "Decay": {"Factor": 0.99, "Steps": 100}},
                                "Loss": {"Name": "sorensen"}},
            "EvaluationSetting": {"Stride": [8, 12, 16], "BatchSize": batch, "ProbabilityOutput": True}}

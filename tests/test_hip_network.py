@@ -86,7 +86,7 @@ def test_small_network_bf16_compute_golden(dev):
     variant, cin, K, P, B, C0, levels, ncv, nb, loss, wts = SMALL_BF16[name]
     z = np.load(os.path.join(GOLD, name + ".npz"))
     values = {k[6:]: z[k] for k in z.files if k.startswith("param:")}
-    ops.set_compute_dtype("bf16")
+    ops.set_compute_dtype("bf16_operands")
     try:
         net = _build(dev, variant, K, C0, levels, ncv, nb, values, z["images"].shape)
         logits, l, sm, pred = _fwd_bwd(net, variant, z["images"], z["labels"], loss, wts, dev)

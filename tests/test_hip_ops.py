@@ -82,7 +82,7 @@ def test_conv5_bf16(dev, shape):
     tx0 = g(x0, dev).requires_grad_(True)
     tx1 = g(x1, dev).requires_grad_(True) if C1 else None
     tw, tb = g(w, dev).requires_grad_(True), g(b, dev).requires_grad_(True)
-    ops.set_compute_dtype("bf16")
+    ops.set_compute_dtype("bf16_operands")
     try:
         y = ops.conv(tx0, tw, tb, 5, 1, x1=tx1)
         tag = "conv-bf16 [%d,%d,%d,%d] %d+%d->%d" % shape

@@ -181,7 +181,7 @@ def test_conv_bias_gradient_closed_form(dev, variant):
     assert nb >= 8
 
 
-@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+@pytest.mark.parametrize("compute", ["fp32", "bf16_operands"])
 def test_gradient_accumulation_in_the_producing_kernel(dev, compute):
     """Tensors with two consumers (skip connection, residual block input): the second gradient is added by the backward-data
     kernel that produces it (y += ..., ops.fork) instead of an autodiff add kernel.  Same two fp32 numbers are added either
@@ -212,7 +212,7 @@ def test_gradient_accumulation_in_the_producing_kernel(dev, compute):
         assert np.array_equal(grads[True][0][n], grads[False][0][n]), n
     # 3 levels: 3 skip forks + residual forks at levels 2, 3 and the bottom = 6 full-tensor adds saved; in bf16 mode also the
     # level-1 block (ONE convolution: the other gradient is that convolution's own dy -> added out of place in its epilogue)
-    assert grads[False][1] - grads[True][1] >= (7 if compute == "bf16" else 6), (grads[False][1], grads[True][1])
+    assert grads[False][1] - grads[True][1] >= (7 if compute == "bf16_operands" else 6), (grads[False][1], grads[True][1])
 
 
 @pytest.mark.parametrize("mode,ks,stride,shape,Cin,Cout,residual", [
@@ -220,9 +220,9 @@ def test_gradient_accumulation_in_the_producing_kernel(dev, compute):
     ("fp32", 5, 1, (2, 24, 20, 28), 8, 24, False),        # ragged bricks: voxels outside the volume must not be counted
     ("fp32", 5, 1, (1, 8, 8, 8), 64, 64, True),           # split-K: statistics come from the reduce kernel
     ("fp32", 2, 2, (1, 32, 32, 32), 16, 32, False),       # 2^3 stride-2 down convolution
-    ("bf16", 5, 1, (1, 64, 64, 128), 16, 16, True),       # 16-output-channel bf16 kernel (persistent workgroups)
-    ("bf16", 5, 1, (1, 32, 32, 32), 32, 32, False),       # generic bf16 kernel
-    ("bf16", 5, 1, (1, 8, 8, 8), 128, 128, True),         # bf16 split-K
+    ("bf16_operands", 5, 1, (1, 64, 64, 128), 16, 16, True),       # 16-output-channel bf16 kernel (persistent workgroups)
+    ("bf16_operands", 5, 1, (1, 32, 32, 32), 32, 32, False),       # generic bf16 kernel
+    ("bf16_operands", 5, 1, (1, 8, 8, 8), 128, 128, True),         # bf16 split-K
 ])
 def test_batch_norm_statistics_from_the_conv_epilogue(dev, mode, ks, stride, shape, Cin, Cout, residual):
     """The convolution writes per-workgroup partial sums of y (+ residual) and its square; the batch-norm behind it only
@@ -305,7 +305,7 @@ def test_bf16_16cout_kernel_ragged(dev, shape, C0, C1, Cout):
     b = torch.randn(Cout, generator=gen)
     xcat = x0.numpy() if x1 is None else np.concatenate((x0.numpy(), x1.numpy()), -1)
     ref = O.conv_nd_fwd(O.round_bf16(xcat.astype(np.float64)), O.round_bf16(w.numpy().astype(np.float64)), 1) + b.numpy().astype(np.float64)
-    ops.set_compute_dtype("bf16")
+    ops.set_compute_dtype("bf16_operands")
     try:
         with torch.no_grad():
             tx0, tx1 = x0.to(dev), (x1.to(dev) if C1 else None)
@@ -328,7 +328,7 @@ def test_bf16_16cout_kernel_ragged(dev, shape, C0, C1, Cout):
         ops.set_compute_dtype("fp32")
 
 
-@pytest.mark.parametrize("compute,cin", [("fp32", 1), ("fp32", 2), ("bf16", 4)])
+@pytest.mark.parametrize("compute,cin", [("fp32", 1), ("fp32", 2), ("bf16", 4), ("bf16_operands", 4)])
 def test_deferred_batched_filter_gradient_reduce(dev, compute, cin):
     """ops.deferred_wgrad_reduce: the filter-gradient launches leave their partial slabs in per-layer buffers and ONE launch
     reduces all of them at the end of the backward pass (vnet_wgrad_defer / vnet_wgrad_flush).  Same summation order as the

@@ -234,3 +234,59 @@ def test_refused_capture_falls_back_to_eager_steps(dev, monkeypatch):
     ref, _, _, _ = _run(dev, False, 6, monkeypatch)
     # same seed, same first batch repeated vs alternating batches: only the first step is comparable
     assert losses[0] == ref[0] and all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(opt="SGD", compute="bf16", cin=4, K=5)], ids=["fp32", "c5-bf16"])
+def test_step_without_gradient_memset_never_reads_stale_gradients(dev, monkeypatch, kw):
+    """FlatParams.begin_step() replaces the per-step memset of the gradient buffer, which is sound only if every
+    gradient of a step is WRITTEN before anything adds to it.  Here every slice a backward kernel wrote is poisoned with NaN
+    between steps: a gradient that was accumulated onto last step's value (instead of written) would turn into NaN.  Losses
+    and parameters must equal, bit for bit, the run that clears the buffer every step; the slices nobody writes (conv biases in
+    front of batch-norms, dead batch-norms, padding) must stay exactly zero; and the guard itself must notice an autograd
+    accumulation (p.grad += g)."""
+    from vnet_tensorflow_amd import ops
+    from vnet_tensorflow_amd.model import image2label
+    from oracle.vnet_oracle import synthetic_batch
+    monkeypatch.setenv("VNET_STEP_GRAPH", "0")
+    cfg = _cfg(**kw)
+    T = cfg["TrainingSetting"]
+    cin, K, P = len(T["Data"]["ImageFilenames"]), len(T["SegmentationClasses"]), T["PatchShape"][0]
+    x, l = synthetic_batch(2, P, cin, K, seed=40)
+    out = {}
+    try:
+        for mode in ("poisoned", "memset"):
+            np.random.seed(7)
+            m = image2label(None, cfg, device=dev, verbose=False)
+            m.read_config(); m.build_model_graph(); m._setup_training()
+            xt, lt = torch.from_numpy(x).to(dev), torch.from_numpy(l).to(dev)
+            m.flat.needs_zero = mode == "memset"
+            losses, untouched = [], None
+            for step in range(5):
+                losses.append(float(m.train_step(xt, lt)))
+                written = [p._vnet_sink.written for p in m.flat.params]
+                if mode == "poisoned":
+                    assert not m.flat.needs_zero, "the networks' own backward must not accumulate through autograd"
+                    assert torch.isfinite(m.flat.grad).all()
+                    for n, p, w in zip(m.flat.names, m.flat.params, written):
+                        if w and not n.endswith("biases"):      # (conv biases: closed form, "written" without a kernel write)
+                            p.grad.fill_(float("nan"))
+                    untouched = [p for p, w in zip(m.flat.params, written) if not w]
+            torch.cuda.synchronize()
+            out[mode] = (losses, m.flat.data.clone())
+            if mode == "poisoned":
+                assert sum(written) > 20 and all(float(p.grad.abs().max()) == 0.0 for p in untouched)
+    finally:
+        ops.set_compute_dtype("fp32")
+    assert out["poisoned"][0] == out["memset"][0], (out["poisoned"][0], out["memset"][0])
+    assert torch.equal(out["poisoned"][1], out["memset"][1])
+    # the guard: an in-place autograd accumulation into the buffer is noticed (first step of a buffer: cleared anyway)
+    from vnet_tensorflow_amd import optim
+    p = torch.nn.Parameter(torch.ones(8, device=dev))
+    flat = optim.FlatParams([("p", p)])
+    flat.begin_step()
+    (p * 2.0).sum().backward()                     # plain autograd: AccumulateGrad adds into the flat buffer's view
+    flat.check_accumulation()
+    assert flat.needs_zero and torch.equal(p.grad, torch.full((8,), 2.0, device=dev))
+    flat.begin_step()
+    (p * 3.0).sum().backward()
+    assert torch.equal(p.grad, torch.full((8,), 3.0, device=dev))      # cleared first: not 5

@@ -78,6 +78,8 @@ def test_loss_decreases_on_fixed_batch(dev, compute, cin, K):
     np.random.seed(1)
     cfg = _cfg(pathlib.Path("/tmp"), ComputeDtype=compute, SegmentationClasses=list(range(K)))
     cfg["TrainingSetting"]["Data"]["ImageFilenames"] = ["image%d.npy" % i for i in range(cin)]
+    if compute == "bf16":
+        cfg["TrainingSetting"]["Networks"]["NumChannel"] = 8          # bf16 storage: 16-byte channel units
     m = image2label(None, cfg, device=dev, verbose=False)
     try:
         m.read_config()

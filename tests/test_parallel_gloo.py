@@ -194,6 +194,21 @@ def test_dataset_refuses_a_rank_without_work():
         data.VolumeDataset("synthetic", ["image.npy"], "label.npy", [0, 1], (8, 8, 8), 2, synthetic={"Cases": 3}, rank=0, world=2)
 
 
+def test_test_dataset_is_not_sharded():
+    """the TEST pass holds no collective, so a test set smaller than world x batch must not abort data-parallel
+    training, and no test case may be dropped because of the rank count (reference model.py:289-295: one unsharded pipeline)."""
+    from vnet_tensorflow_amd import data
+    plans = []
+    for rank in range(8):
+        ds = data.VolumeDataset("synthetic", ["image.npy"], "label.npy", [0, 1], (8, 8, 8), 1, train=False,
+                                synthetic={"Cases": 4}, rank=rank, world=8)            # 4 cases, 8 ranks: used to raise
+        assert ds.steps_per_epoch() == 4
+        plans.append([c for cases, _ in ds.epoch_plan() for c in cases])
+    assert all(p == [0, 1, 2, 3] for p in plans), plans
+    ds = data.VolumeDataset("synthetic", ["image.npy"], "label.npy", [0, 1], (8, 8, 8), 2, train=False, synthetic={"Cases": 5}, rank=1, world=2)
+    assert [c for cases, _ in ds.epoch_plan() for c in cases] == [0, 1, 2, 3]          # drop_remainder, like the reference
+
+
 def test_prefetcher_keeps_order_and_content():
     from vnet_tensorflow_amd import data
     mk = lambda: data.VolumeDataset("synthetic", ["image.npy"], "label.npy", [0, 1, 2], (8, 8, 8), 2, train=True, seed=1,

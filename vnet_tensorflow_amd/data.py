@@ -107,7 +107,8 @@ class VolumeDataset(object):
     Data parallel: every rank shuffles with the SAME generator (seed + epoch), the order is truncated to
     a multiple of world * batch and strided by rank, so the shards are disjoint and every rank yields the same number
     of batches (the gradient all-reduces of the ranks pair up one to one; a rank with fewer steps would leave the
-    others blocked in RCCL).  Crop windows are drawn from a per-rank generator."""
+    others blocked in RCCL).  Crop windows are drawn from a per-rank generator.  train=False (the test pass, which holds no
+    collective) is not sharded: every rank iterates all cases."""
 
     def __init__(self, data_dir, image_filenames, label_filename, classes, patch_shape, batch_size,
                  train=True, seed=0, synthetic=None, rank=0, world=1, cache=None, transforms=None):
@@ -130,11 +131,16 @@ class VolumeDataset(object):
                 raise FileNotFoundError("data directory %s does not exist" % data_dir)
             self.cases = sorted(os.path.join(data_dir, d) for d in os.listdir(data_dir)
                                 if os.path.isdir(os.path.join(data_dir, d)))
-        if self.steps_per_epoch() == 0:
+        if self.train and self.steps_per_epoch() == 0:
             raise ValueError("%d cases give no full batch for %d rank(s) x batch %d: every rank needs at least one batch per "
                              "epoch (a rank without work would sit in no collective at all)" % (len(self.cases), world, self.batch))
 
     def steps_per_epoch(self):
+        # the TEST pass holds no collective (model.image2label.train: forward + metrics per rank), so it is not sharded: every
+        # rank walks every test case, drop_remainder like the reference (model.py:293) -- a test set smaller than
+        # world x batch must neither abort the job nor lose cases
+        if not self.train:
+            return len(self.cases) // self.batch
         return len(self.cases) // (self.world * self.batch)
 
     def _load(self, case):
@@ -157,8 +163,11 @@ class VolumeDataset(object):
         if self.train:
             np.random.default_rng(self.seed + 104729 * self.epoch).shuffle(order)     # identical on every rank
         self.epoch += 1
-        per = self.world * self.batch
-        order = order[:len(order) // per * per][self.rank::self.world]
+        if self.train:
+            per = self.world * self.batch
+            order = order[:len(order) // per * per][self.rank::self.world]
+        else:
+            order = order[:len(order) // self.batch * self.batch]
         plan = []
         for i in range(0, len(order), self.batch):
             plan.append((order[i:i + self.batch], [int(v) for v in self.rng.integers(0, 2 ** 62, size=self.batch)]))

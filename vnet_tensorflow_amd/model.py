@@ -375,9 +375,12 @@ class image2label(object):
                 # single-device BatchSize = world x per-rank batch semantics of the reference (networks.py:319);
                 # the default (per-replica statistics) equals the reference run on each rank's batch alone
                 ops.set_sync_batch_norm()
-        if self._pg_env is None and not hasattr(self, "param_grad_stream") and self._graph_mode() != "off":
+        if self._pg_env is None and not hasattr(self, "param_grad_stream") and (self._graph_mode() != "off" or ops.storage_is_bf16()):
             # the replayed step graph is single-stream (see _build_step_graph); its few eager steps (warm-up, odd batch
-            # shapes) then use one stream too, so every launch of the process has the same schedule
+            # shapes) then use one stream too, so every launch of the process has the same schedule.  bf16-storage mode is
+            # single-stream in every step mode: with the side stream the second gradient of a two-consumer tensor cannot be
+            # accumulated by the producing kernel (ops._slot_target) and autograd's add rounds twice (RNE(RNE(a) + RNE(b)) instead
+            # of RNE(RNE(a) + b)) -- the eager step would no longer be bit-identical to the replayed one
             ops.set_param_grad_stream(False)
 
     # -- one training step (reference model.py:743-748: ONE sess.run per step) ------------------------------------
@@ -397,6 +400,8 @@ class image2label(object):
         with ops.deferred_wgrad_reduce(self._defer_wgrad_reduce()):
             loss.backward(self._one)
             ops.join_param_grad_stream()      # filter / bias gradients were enqueued on their own stream
+        if not torch.cuda.is_current_stream_capturing():
+            self.flat.check_accumulation()
         return loss
 
     def _defer_wgrad_reduce(self):
@@ -414,6 +419,8 @@ class image2label(object):
             if cuts:
                 torch.autograd.backward([o for o, _ in cuts], [g for _, g in cuts])
             ops.join_param_grad_stream()
+        if not torch.cuda.is_current_stream_capturing():
+            self.flat.check_accumulation()
 
     def _train_step_eager(self, images, labels, dropout):
         lr = optim.exponential_decay(self.initial_learning_rate, self.global_step, self.decay_steps, self.decay_factor)

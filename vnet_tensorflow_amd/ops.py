@@ -1383,6 +1383,7 @@ class _ActFn(torch.autograd.Function):
         check(L.vnet_act_fwd(_ptr(x), M, C, act, _ptr(alpha), _ptr(y), _stream()), "vnet_act_fwd")
         ctx.save_for_backward(x, alpha)
         ctx.act = act
+        ctx.aref = alpha
         return y
 
     @staticmethod
@@ -1393,12 +1394,12 @@ class _ActFn(torch.autograd.Function):
         M = x.numel() // C
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dalpha = torch.empty_like(alpha) if alpha is not None else None
+        dalpha, sa = _grad_out(ctx.aref) if alpha is not None else (None, None)      # straight into the flat gradient buffer when there is one
         nb = L.vnet_bn_ws_bytes(C)
         ws = workspace(nb, x.device)
         check(L.vnet_act_bwd(_ptr(dy), _ptr(x), M, C, ctx.act, _ptr(alpha), _ptr(dalpha), _ptr(dx), _ptr(ws), nb, _stream()),
               "vnet_act_bwd")
-        return dx, dalpha, None
+        return dx, (_grad_ret(dalpha, sa) if alpha is not None else None), None
 
 
 def activation(x, act, alpha=None):

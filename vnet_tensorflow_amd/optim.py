@@ -35,19 +35,49 @@ class FlatParams(object):
                 p.grad = self.grad[o:o + n].view(p.shape)
                 p._vnet_sink = ops.GradSink(p.grad)      # backward kernels write here directly
         ops.invalidate_packed()
+        self.needs_zero = False     # set when autograd was seen accumulating into the buffer (see begin_step / check_accumulation)
+        self._ver = None
+        self._steps = 0
 
     def begin_step(self):
         """Start of a training step WITHOUT re-zeroing the gradient buffer: every gradient the networks produce is written
         (not accumulated) by its backward kernel straight into its slice, a variable that gets a second contribution from
         autograd receives it as `+=` AFTER that write (the AccumulateGrad node runs when all its edges have reported), and
         the slices nobody writes -- conv biases in front of batch-norms (closed form, exact 0), the dead batch-norms,
-        alignment padding -- still hold the zeros of construction.  Saves a 176 MB memset per step."""
+        alignment padding -- still hold the zeros of construction.  Saves a 176 MB memset per step.
+
+        That is only sound while NO gradient reaches a variable purely through autograd's AccumulateGrad (`p.grad += g` onto the
+        previous step's -- under data parallelism already all-reduced -- value): a parameter used outside the fused ops, a
+        data-parallel hook folding a temporary back, a skipped backward cut.  Such an in-place add bumps the
+        version counter the .grad views share with the flat buffer, kernel writes through raw pointers do not; so the first
+        step of a FlatParams clears the buffer like zero_grad(), every pass is checked (check_accumulation), and once an
+        accumulation has been seen every later step clears first.  (A replayed step graph repeats the launches of the eager
+        steps it was captured from, which were checked.)"""
+        self._steps += 1
+        if self.needs_zero or self._steps == 1:
+            self.zero_grad()
+            self._ver = self.grad._version
+            return
+        self._ver = self.grad._version
         for p, o in zip(self.params, self.offsets):
             p._vnet_sink.written = False
             g = p.grad
             if g is None or g.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
                 p._vnet_sink.view = p.grad
+
+    def check_accumulation(self):
+        """After a backward pass that began with begin_step(): did autograd add into the buffer in place?"""
+        if self._ver is None or self.grad._version == self._ver:
+            return
+        if not self.needs_zero and self._steps > 1:
+            self.needs_zero = True
+            raise ops.VnetHipError(
+                "a gradient was accumulated by autograd (p.grad += g) onto the previous step's value: the gradient buffer was not "
+                "cleared for this step (FlatParams.begin_step).  This step's gradients are invalid; later steps clear the buffer "
+                "first.  (A parameter used outside the fused ops / a changed network between steps; call flat.zero_grad() "
+                "yourself or set flat.needs_zero = True before training.)")
+        self.needs_zero = True
 
     def zero_grad(self):
         self.grad.zero_()
