@@ -566,10 +566,10 @@ class image2label(object):
         return mode
 
     def _dp_tuner(self):
-        """Data parallel: 5 steps as segmented graph replay (all-reduce of pass 1's buckets under the encoder's backward), 5 with
-        the same graphs but every all-reduce AFTER backward ('serial': the collective never shares the CUs with an MFMA
-        kernel whose grid was sized for all 256 -- DESIGN section 5), 5 steps eager; keep the fastest
-        (parallel.StepModeAutotune).  TrainingSetting.DpAutotune / VNET_DP_AUTOTUNE = 0 pins the segmented graph."""
+        """Data parallel: three interleaved rounds of 5 steps each as segmented graph replay (all-reduce of pass 1's buckets under
+        the encoder's backward), as the same graphs with every all-reduce AFTER backward ('serial': the collective never shares
+        the CUs with an MFMA kernel whose grid was sized for all 256 -- DESIGN section 5) and as eager steps; 'serial' stays
+        unless another mode's median is > 2 % faster (parallel.StepModeAutotune).  TrainingSetting.DpAutotune / VNET_DP_AUTOTUNE = 0 pins the segmented graph."""
         if getattr(self, "_tuner", None) is None:
             on = os.environ.get("VNET_DP_AUTOTUNE")
             on = getattr(self, "dp_autotune", True) if on is None else on not in ("0", "off", "false")
@@ -578,6 +578,7 @@ class image2label(object):
             if pin in cands or pin in ("segmented", "off"):
                 cands = [pin]
             self._tuner = parallel.StepModeAutotune(cands, steps=int(os.environ.get("VNET_DP_AUTOTUNE_STEPS", "5")),
+                                                    blocks=int(os.environ.get("VNET_DP_AUTOTUNE_BLOCKS", "3")),
                                                     sync=self._device_sync)
         return self._tuner
 

@@ -226,22 +226,35 @@ class BucketedGradAllReduce(object):
 
 class StepModeAutotune(object):
     """Start-up choice between ways of running the data-parallel step (model.image2label: 'segmented' hipGraph replay with the
-    all-reduce between the two graphs vs the eager kernel-by-kernel enqueue whose bucket all-reduces overlap backward).
-    Which one wins depends on the machine: the eager enqueue costs 6-20 ms of host time per 128^3 step (8 ranks share the
-    host's cores), the segmented graph costs no host time but exposes the all-reduce (~1-2.5 ms).  Every candidate runs
-    `steps` REAL training steps; the wall time of each block is max-reduced over the ranks, so all ranks pick the same
-    winner.  Usage per step:  mode = tuner.mode();  tuner.before();  <run the step in that mode>;  tuner.after()."""
+    all-reduce between the two graphs vs the same graphs with every all-reduce after backward ('serial') vs the eager
+    kernel-by-kernel enqueue whose bucket all-reduces overlap backward).  Which one wins depends on the machine: the eager
+    enqueue costs 6-20 ms of host time per 128^3 step (8 ranks share the host's cores), the serial replay costs no host time but
+    exposes the all-reduce (~1-2.5 ms), the overlapped replay hides it but shares the CUs with a resident collective.
 
-    def __init__(self, candidates, steps=5, group=None, sync=None, clock=None):
+    Round 3 (one noisy 5-step block used to decide the whole job): the candidates are measured in
+    `blocks` >= 3 interleaved rounds (c0 c1 c2 c0 c1 c2 ...) of `steps` REAL training steps each; a block's wall time is
+    max-reduced over the ranks (so every rank sees the same numbers and picks the same winner); a candidate's score is the MEDIAN
+    of its blocks; and `prefer` (the serial replay: no collective ever shares the chip with an MFMA kernel sized for all 256 CUs,
+    the mode whose time is the easiest to predict) is kept unless another candidate's median is more than `margin` (2 %) faster.
+    Usage per step:  mode = tuner.mode();  tuner.before();  <run the step in that mode>;  tuner.after()."""
+
+    def __init__(self, candidates, steps=5, group=None, sync=None, clock=None, blocks=3, prefer="serial", margin=0.02):
         import time
         self.candidates, self.steps, self.group = list(candidates), int(steps), group
+        self.blocks = max(1, int(blocks))
+        self.prefer, self.margin = prefer, float(margin)
         self.sync = sync if sync is not None else (lambda: None)          # device synchronisation
         self.clock = clock if clock is not None else time.perf_counter
+        self.samples = [[] for _ in self.candidates]                      # per candidate: seconds per step of each block
         self.times, self._i, self._n, self._t0 = [], 0, 0, None
         self.choice = self.candidates[0] if len(self.candidates) == 1 else None
 
+    def total_steps(self):
+        """Training steps the measurement takes (0 for a single candidate)."""
+        return 0 if len(self.candidates) == 1 else len(self.candidates) * self.blocks * self.steps
+
     def mode(self):
-        return self.choice if self.choice is not None else self.candidates[self._i]
+        return self.choice if self.choice is not None else self.candidates[self._i % len(self.candidates)]
 
     def before(self):
         if self.choice is None and self._n == 0:
@@ -249,6 +262,12 @@ class StepModeAutotune(object):
             if dist.is_initialized():
                 dist.barrier(group=self.group)
             self._t0 = self.clock()
+
+    @staticmethod
+    def _median(v):
+        v = sorted(v)
+        n = len(v)
+        return v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
 
     def after(self):
         if self.choice is not None:
@@ -262,7 +281,13 @@ class StepModeAutotune(object):
             dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
             t = t.to(dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        self.times.append(float(t.item()) / self.steps)
+        self.samples[self._i % len(self.candidates)].append(float(t.item()) / self.steps)
         self._i, self._n = self._i + 1, 0
-        if self._i == len(self.candidates):
-            self.choice = self.candidates[min(range(len(self.times)), key=lambda k: (self.times[k], k))]
+        if self._i == len(self.candidates) * self.blocks:
+            self.times = [self._median(v) for v in self.samples]
+            best = min(range(len(self.times)), key=lambda k: (self.times[k], k))
+            if self.prefer in self.candidates:
+                k = self.candidates.index(self.prefer)
+                if self.times[best] >= (1.0 - self.margin) * self.times[k]:
+                    best = k                     # nobody beats the preferred mode by more than the margin
+            self.choice = self.candidates[best]
