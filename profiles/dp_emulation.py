@@ -17,7 +17,6 @@ import time
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29531")
 os.environ["VNET_DP_FORCE"] = "1"
-os.environ["VNET_DP_AUTOTUNE"] = "0"
 import numpy as np
 import torch
 import torch.distributed as dist
