@@ -1,5 +1,6 @@
 """Micro-benchmark of ONE 5^3 convolution problem in one mode (for rocprofv3 --pmc passes):
-   python profiles/bench_one.py <conv|wgrad> <fp32|bf16> P Cin Cout [iters]"""
+   python profiles/bench_one.py <conv|wgrad> <fp32|bf16|bf16_operands> P Cin Cout [iters]
+   bf16 = bf16 storage (bf16 tensors in and out), bf16_operands = round 2's fp32 tensors + bf16 shadows"""
 import sys
 import torch
 sys.path.insert(0, '.')
@@ -19,8 +20,10 @@ if os.environ.get("BENCH_ZERO"):          # DVFS probe: all-zero operands toggle
     x.zero_(); dy.zero_()
     with torch.no_grad():
         w.zero_()
-if mode == 'bf16' and ci % 8 == 0 and co % 8 == 0:          # as in a training step: producers leave bf16 shadows (VNET_BF16_SHADOW=0: off)
+if mode == 'bf16_operands' and ci % 8 == 0 and co % 8 == 0:          # as in a training step: producers leave bf16 shadows (VNET_BF16_SHADOW=0: off)
     x, dy = ops.with_shadow(x), ops.with_shadow(dy)
+if mode == 'bf16':
+    x, dy = x.to(torch.bfloat16), dy.to(torch.bfloat16)
 
 
 def run():
@@ -28,6 +31,8 @@ def run():
         with torch.no_grad():
             ops._ConvFn.apply(x, None, w, b, 5, 1, False, None)
     elif mode == 'bf16':
+        ops._wgrad5_b16_call(x, None, dy, dw, (P, P, P), ci)
+    elif mode == 'bf16_operands':
         ops._wgrad_bf16_call(x, None, dy, dw, (P, P, P))
     else:
         ops._wgrad_call(5, 1, x, None, dy, dw, (P, P, P), (P, P, P))

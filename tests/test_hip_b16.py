@@ -70,8 +70,10 @@ def _conv5_inputs(shape, seed):
 
 
 @pytest.mark.parametrize("shape", CONV5_SHAPES)
-def test_conv5_b16_against_oracle_and_fp32_output_kernels(dev, shape):
+def test_conv5_b16_against_oracle_and_fp32_output_kernels(dev, shape, monkeypatch):
     from vnet_tensorflow_amd import ops
+    monkeypatch.setenv("VNET_WGRAD_RR", "0")        # the bit-exact link below is to the generic filter-gradient kernel (the row-reuse
+                                                    # kernel sums in another order: test_row_reuse_filter_gradient)
     B, D, H, W, C0, C1, Co = shape
     x0, x1, w, b, dy = _conv5_inputs(shape, sum(shape) + 3)
     xcat = x0 if x1 is None else np.concatenate((x0, x1), -1)
@@ -448,3 +450,31 @@ def test_forward_ops_in_situ(dev, variant, cin, K, monkeypatch):
                 exact = act(bn(xv + bn(xv, g1, b1), g2, b2), kact, alpha)
             check_bf16("in situ bn_chain %d" % kind, out, exact, noise=5e-5, min_equal=0.97)
     assert {"conv", "conv_transpose2", "bn_act", "head_conv"} <= seen and (variant == "legacy" or "bn_chain" in seen), seen
+
+
+@pytest.mark.parametrize("shape", [
+    (1, 8, 16, 64, 16, 0, 16),     # 2 x 2 x 2 bricks of 4 x 8 x 32, one chunk
+    (1, 8, 16, 32, 16, 16, 16),    # two sources = two chunks
+    (2, 5, 11, 40, 8, 0, 16),      # ragged bricks, batch 2, the zero-padded 8-channel network input (half-filled chunk)
+    (1, 4, 8, 32, 32, 0, 32),      # two cout blocks
+    (1, 6, 9, 33, 64, 0, 32),      # four chunks x two cout blocks, ragged
+])
+def test_row_reuse_filter_gradient(dev, shape, monkeypatch):
+    """wgrad5_bf16_rr_kernel (4 x 8 x 32 bricks, a k-step = one x-row, sliding window of row fragments in registers) forced onto
+    small volumes: same bf16 x bf16 products as the generic kernel, another summation order -> 2e-6 against the oracle, and against
+    the generic kernel."""
+    from vnet_tensorflow_amd import ops
+    B, D, H, W, C0, C1, Co = shape
+    x0, x1, w, b, dy = _conv5_inputs(shape, sum(shape) + 5)
+    xcat = x0 if x1 is None else np.concatenate((x0, x1), -1)
+    _, dw_ex = O.conv_nd_bwd(xcat, rb(w), dy, 1, need_dx=False)
+    got = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("VNET_WGRAD_RR", mode)
+        dw = torch.empty(w.shape, dtype=torch.float32, device=dev)
+        ops._wgrad5_b16_call(g16(x0, dev), g16(x1, dev) if C1 else None, g16(dy, dev), dw, (D, H, W), C0 + C1)
+        torch.cuda.synchronize()
+        got[mode] = dw
+    check_close("rr wgrad %s" % (shape,), got["2"], dw_ex, 2e-6)
+    check_close("generic wgrad %s" % (shape,), got["0"], dw_ex, 2e-6)
+    assert not torch.equal(got["2"], got["0"]) or C0 + C1 <= 16, "the row-reuse kernel did not run (identical bits)"

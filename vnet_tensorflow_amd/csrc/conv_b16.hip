@@ -11,6 +11,7 @@
 //     HBM-bound, what matters is that they move 2-byte elements.
 // Reference call sites replaced: layers2.py:59-63, 65-74, 78-94 (forward), model.py:660 (their gradients).
 #include "conv_kernels.h"
+#include <cstdlib>
 
 namespace {
 inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -81,10 +82,28 @@ int vnet_conv_wgrad_b16(const void* x0, int C0, const void* x1, int C1, const vo
     a.ncob = p.ncob; a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.nbrick = p.nbrick; a.nsplit = p.nsplit;
     const size_t need = (size_t)p.nsplit * 125 * a.CinP * a.CoutP * sizeof(float);
     // one slab and no channel padding: the slab IS dw (TF layout [tap][Cin][Cout]) -> no reduce pass
-    const bool direct = p.nsplit == 1 && a.CinP == Cin_dw && a.CoutP == Cout;
+    bool direct = p.nsplit == 1 && a.CinP == Cin_dw && a.CoutP == Cout;
     if (!direct && (!ws || ws_bytes < need)) return VNET_E_WORKSPACE;
     a.part = direct ? dw : reinterpret_cast<float*>(ws);
     int e;
+    // row-reuse kernel (4 x 8 x 32 bricks, one 16-cout block per workgroup): wide volumes with at least two bricks per workgroup
+    const char* rr_env = getenv("VNET_WGRAD_RR");          // 0: never, 1 (default): where it pays, 2: wherever it applies (tests)
+    const int rr_mode = rr_env ? atoi(rr_env) : 1;
+    const int rr_nbrick = B * ceil_div(D, 4) * ceil_div(H, 8) * ceil_div(W, 32);
+    const int rr_base = (a.CinP / 16) * (a.CoutP / 16);
+    const int rr_nsplit = max(1, min(rr_nbrick, ceil_div(256, rr_base)));
+    if (rr_mode && W >= 32 && H >= 8 && rr_nsplit <= p.nsplit && ((C0 & 15) == 0 || C1 == 0) && (rr_mode == 2 || rr_nbrick >= rr_nsplit)) {
+        a.ncob = a.CoutP / 16; a.nbz = ceil_div(D, 4); a.nby = ceil_div(H, 8); a.nbx = ceil_div(W, 32);
+        a.nbrick = rr_nbrick; a.nsplit = rr_nsplit;
+        direct = rr_nsplit == 1 && a.CinP == Cin_dw && a.CoutP == Cout;
+        a.part = direct ? dw : reinterpret_cast<float*>(ws);
+        e = launch_wgrad_bf16_rr<4>(a, rr_nsplit, a.ncob, st);
+        if (e) return e;
+        if (direct) return VNET_OK;
+        launch_wgrad_reduce(a.part, rr_nsplit, 125, a.CinP, a.CoutP, Cin_dw, Cout, dw, st);
+        VNET_LAUNCH_CHECK();
+        return VNET_OK;
+    }
     if (p.small) {
         e = p.ns == 2 ? launch_wgrad_bf16<4, 8, 8, 2, 8, true>(a, p.nsplit, p.ncob, p.ntg, st)
                       : launch_wgrad_bf16<4, 8, 8, 1, 16, true>(a, p.nsplit, p.ncob, p.ntg, st);

@@ -2128,6 +2128,184 @@ __global__ void __launch_bounds__(512) wgrad5_bf16_kernel(WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Row-reuse filter gradient (round 3; bf16 tensors only).  The kernel above reads one 1 KB B fragment (x, tap-shifted) from LDS per
+// MFMA -- with 16 output channels there is a single cout block to share it with -- and on this part fragment delivery and MFMA issue
+// add up: 1.06 KB per MFMA, LDS-bound.  Here a k-step is ONE x-row of 32 voxels, so the B fragment of
+// (output row y, tap dy) is the fragment of input row y + dy: a wave owns whole dy columns -- three (dz, dx) pairs with all five dy --
+// and keeps a sliding window of five row fragments per pair in registers; per output row it reads 3 new B fragments + 1 A
+// fragment (+ 1 for its share of the 25th pair, whose five taps go to waves 0-4) for 16 MFMAs: 0.41 KB per MFMA.
+//   * brick TZ x 8 x 32 output voxels; x tile (TZ+4) x 12 x 36 voxels x 16 channels and dy tile in LDS as [voxel][16 ch] (32-byte
+//     rows, bf16), fragments by ds_read_b64_tr_b16 like the kernel above;
+//   * k index of lane group g: voxels {4g..4g+3} and {16+4g..16+4g+3} of the row -- groups 0/1 (one LDS service half) read
+//     adjacent 128-byte runs, conflict-free at every tap shift;
+//   * D[cout][cin] per tap, one 16-cin chunk x one 16-cout block per workgroup, bricks split over nsplit workgroups, next brick's
+//     tiles prefetched global -> registers during the MFMAs; partial slabs + the usual reduce.
+// ------------------------------------------------------------------------------------------
+template <int TZ>
+__global__ void __launch_bounds__(512) wgrad5_bf16_rr_kernel(WgradArgs a) {
+    constexpr int TY = 8, TX = 32, IZ = TZ + 4, IY = TY + 4, IX = TX + 4;
+    constexpr int XROWS = IZ * IY, XCOLS = IX * 2, XRPI = 512 / XCOLS, XPER = (XROWS + XRPI - 1) / XRPI;    // x tile: 16-byte units
+    constexpr int XBYTES = XROWS * IX * 32;
+    constexpr int DUNITS = TZ * TY * TX * 2, DPER = DUNITS / 512;                                            // dy tile units per thread
+    static_assert(DUNITS % 512 == 0 && DPER == TZ, "dy tile: one z-slice of 8 x 32 voxels x 2 halves per pass");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xt = smem;
+    unsigned char* dyt = smem + XBYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int split = blockIdx.x;
+    const int chunk = blockIdx.y / a.ncob, cob = blockIdx.y - chunk * a.ncob;
+    const int co0 = cob * 16;
+
+    // this wave's three (dz, dx) pairs: pair index q = 3 * wave + c  (q = dz * 5 + dx, 0..23); pair 24 = (4, 4) is shared: its tap
+    // dy = wave goes to waves 0..4
+    const int lane_off = (4 * g + (i >> 2)) * 32 + (i & 3) * 8;
+    const unsigned char* pb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int q = 3 * wave + c, dz = q / 5, dx = q - dz * 5;
+        pb[c] = xt + ((dz * IY) * IX + dx) * 32 + lane_off;
+    }
+    const bool extra = wave < 5;
+    const unsigned char* pe = xt + ((4 * IY + (extra ? wave : 0)) * IX + 4) * 32 + lane_off;
+    const unsigned char* pa = dyt + lane_off;
+
+    f32x4 acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    u32x4 hx[XPER], hd[DPER];
+    auto brick_coords = [&](int brick, int& b, int& bz, int& by, int& bx) {
+        bx = brick % a.nbx; brick /= a.nbx;
+        by = brick % a.nby; brick /= a.nby;
+        bz = brick % a.nbz; b = brick / a.nbz;
+    };
+    // Prefetch addressing: one UNIFORM 64-bit base per brick (source tensor, batch) + a 32-bit element offset per load that depends
+    // on the brick (one sample's volume x channels stays below 2^31 elements).  XTileH's loop-invariant 64-bit row offsets were
+    // hoisted out of the brick loop by hipcc: 28 registers held for the whole kernel, spilled -- and a scratch reload next to a
+    // register prefetch serialises it.  (A 16-channel chunk never straddles the two sources here: dispatch.)
+    const int xr0 = tid / XCOLS, xcol = tid - xr0 * XCOLS;
+    const int xix = xcol >> 1, xhf = xcol & 1;
+    auto issue = [&](int brick) {
+        int b, bz, by, bx;
+        brick_coords(brick, b, bz, by, bx);
+        const int gz0 = bz * TZ - 2, gy0 = by * TY - 2, gx = bx * TX - 2 + xix;
+        const int c = chunk * 16;
+        const bool first = c < a.C0;
+        const int cs = first ? a.C0 : a.C1;
+        const unsigned short* src = (first ? reinterpret_cast<const unsigned short*>(a.x0) + c
+                                           : reinterpret_cast<const unsigned short*>(a.x1) + (c - a.C0)) + (size_t)b * a.Di * a.Hi * a.Wi * cs;
+        const bool colok = xr0 < XRPI && (unsigned)gx < (unsigned)a.Wi && c + xhf * 8 < a.C0 + a.C1;
+        constexpr int DIZ = XRPI / IY, DIY = XRPI % IY;
+        int row = xr0, jz = xr0 / IY, jy = xr0 - (xr0 / IY) * IY;
+#pragma unroll
+        for (int k = 0; k < XPER; ++k) {
+            const int gz = gz0 + jz, gy = gy0 + jy;
+            const bool ok = colok && row < XROWS && (unsigned)gz < (unsigned)a.Di && (unsigned)gy < (unsigned)a.Hi;
+            const unsigned off = ok ? (unsigned)(((gz * a.Hi + gy) * a.Wi + gx) * cs + xhf * 8) : 0u;
+            hx[k] = load16_or_zero(src + off, ok);
+            row += XRPI; jy += DIY; jz += DIZ;
+            if (jy >= IY) { jy -= IY; ++jz; }
+        }
+        // dy tile: thread (voxel of a z-slice, channel half) -> the same (y, x, half) in each of the TZ slices
+        const unsigned short* dyh = reinterpret_cast<const unsigned short*>(a.dy) + (size_t)b * a.Do * a.Ho * a.Wo * a.Cout;
+        const int v = tid >> 1, hf = tid & 1;
+        const int oy = by * TY + (v >> 5), ox = bx * TX + (v & 31), cd = co0 + hf * 8;
+        const bool dok = oy < a.Ho && ox < a.Wo && cd < a.Cout;
+#pragma unroll
+        for (int k = 0; k < DPER; ++k) {              // (DPER == TZ: 512 units per z-slice)
+            const int oz = bz * TZ + k;
+            const bool ok = dok && oz < a.Do;
+            const unsigned off = ok ? (unsigned)(((oz * a.Ho + oy) * a.Wo + ox) * a.Cout + cd) : 0u;
+            hd[k] = load16_or_zero(dyh + off, ok);
+        }
+    };
+    auto frag = [&](const unsigned char* p, int off) -> bf16x8 {
+        typedef s16x4 __attribute__((address_space(3))) * lp;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p + off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p + off + 512));       // voxels +16..19
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    if (split < a.nbrick) issue(split);
+    for (int brick = split; brick < a.nbrick; brick += a.nsplit) {
+        __syncthreads();                               // every wave is done reading the previous tiles
+        {
+            const int r0 = tid / XCOLS, col = tid - r0 * XCOLS;
+#pragma unroll
+            for (int k = 0; k < XPER; ++k) {
+                const int row = r0 + k * XRPI;
+                if (r0 < XRPI && row < XROWS)
+                    *reinterpret_cast<u32x4*>(xt + (row * IX + (col >> 1)) * 32 + (col & 1) * 16) = hx[k];
+            }
+#pragma unroll
+            for (int k = 0; k < DPER; ++k) *reinterpret_cast<u32x4*>(dyt + (size_t)(tid + k * 512) * 16) = hd[k];
+        }
+        __syncthreads();
+        if (brick + a.nsplit < a.nbrick) {
+            issue(brick + a.nsplit);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll 1
+        for (int z = 0; z < TZ; ++z) {
+            const int zx = z * (IY * IX * 32), zd = z * (TY * TX * 32);
+            // one (dz, dx) pair at a time: the window of five row fragments of ONE pair is live (20 registers; all three pairs in
+            // lockstep -- A read once per row -- needed 60 and spilled next to the prefetch registers); A is re-read per pair
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                bf16x8 F[5];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) F[r] = frag(pb[c], zx + r * (IX * 32));
+                // the fragments of output row y + 1 are read while row y's MFMAs run (one row ahead, pinned by sched_barrier):
+                // the matrix instructions of a row never wait for a read issued in the same row
+                bf16x8 An = frag(pa, zd), Fn = frag(pb[c], zx + 4 * (IX * 32)), En = An;
+                if (c == 0 && extra) En = frag(pe, zx);                              // (wave-uniform)
+#pragma unroll
+                for (int y = 0; y < TY; ++y) {
+                    const bf16x8 A = An, E = En;
+                    F[(y + 4) % 5] = Fn;
+                    if (y + 1 < TY) {
+                        An = frag(pa, zd + (y + 1) * (TX * 32));
+                        Fn = frag(pb[c], zx + (y + 5) * (IX * 32));
+                        if (c == 0 && extra) En = frag(pe, zx + (y + 1) * (IX * 32));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int dy = 0; dy < 5; ++dy)
+                        acc[c * 5 + dy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, F[(y + dy) % 5], acc[c * 5 + dy], 0, 0, 0);
+                    if (c == 0 && extra) acc[15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, E, acc[15], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    // lane holds dW[tap][ci = chunk*16 + i][co = co0 + 4*g + {0..3}]
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        int tap;
+        if (t < 15) { const int q = 3 * wave + t / 5, dz = q / 5, dx = q - dz * 5; tap = (dz * 5 + t % 5) * 5 + dx; }
+        else { if (!extra) continue; tap = (4 * 5 + wave) * 5 + 4; }
+        float* dst = a.part + ((size_t)(split * 125 + tap) * a.CinP + chunk * 16 + i) * a.CoutP + co0 + g * 4;
+        const f32x4 r = acc[t];
+        *reinterpret_cast<float4*>(dst) = make_float4(r.x, r.y, r.z, r.w);
+    }
+}
+
+template <int TZ>
+int launch_wgrad_bf16_rr(const WgradArgs& a, int nsplit, int ncob, hipStream_t st) {
+    constexpr int IZ = TZ + 4, IY = 12, IX = 36;
+    const size_t lds = (size_t)IZ * IY * IX * 32 + (size_t)TZ * 8 * 32 * 32;
+    auto k = wgrad5_bf16_rr_kernel<TZ>;
+    static unsigned long long attr_done = 0;
+    if (int ae = ensure_lds(k, lds, attr_done)) return ae;
+    dim3 grid(nsplit, (a.CinP / 16) * ncob, 1);
+    hipLaunchKernelGGL(k, grid, dim3(512), lds, st, a);
+    return (int)hipGetLastError();
+}
+
 template <int TZ, int TY, int TX, int NS, int TW, bool H = false>
 int launch_wgrad_bf16(const WgradArgs& a, int nsplit, int ncob, int ntg, hipStream_t st) {
     using G = TileGeom<5, 1, TZ, TY, TX, 5>;
