@@ -396,7 +396,18 @@ int vnet_conv2_fwd_b16(int up, const void* x, int Cin, const float* wp, const fl
 int vnet_conv2_wgrad_b16(const void* x, int Cin, const void* dy, int Cout, float* dw,
                          int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, void* ws, size_t ws_bytes, void* stream);
 
-/* batch-norm (+ residual, + activation) on bf16 tensors; statistics and parameter gradients fp32 (float64 partial sums).
+/* The same pair WITHOUT an LDS tile (csrc/conv2_b16.hip): every input element feeds exactly one output voxel's GEMV, so a lane's
+ * MFMA operand is one 16-byte load and its result one 16-byte store -- for the widths of V-Net levels 1 and 2
+ * (vnet_conv2_direct_ok(Cf, Cc): Cf in {16, 32} fine channels, Cc in {32, 64} coarse channels).  w: the fp32 filter in TF layout,
+ * [8][Cf][Cc] for BOTH layers (down_convolution: Cin = Cf; up_convolution: filter [k,k,k,Cout = Cf,Cin = Cc]); rounded to bf16 in
+ * the kernel.  down = 1: coarse out = conv(fine in) + bias[Cc], optional statistics rows (vnet_conv2_direct_stats_rows);
+ * down = 0: fine out (+)= transposed conv(coarse in) + bias[Cf].  Same arithmetic as vnet_conv2_fwd_b16. */
+int vnet_conv2_direct_ok(int Cf, int Cc);
+int vnet_conv2_direct_stats_rows(int Cf, int Cc, int B, int Dc, int Hc, int Wc);
+int vnet_conv2_direct_b16(int down, const void* in, void* out, const float* w, const float* bias, int Cf, int Cc,
+                          int B, int Df, int Hf, int Wf, int Dc, int Hc, int Wc, int accum, float* stats, void* stream);
+
+/* batch-norm (+ residual, + activation) on bf16 tensors; statistics and parameter gradients fp32 (partial rows summed in float64).
  * bcast = 1: x is the fp32 1-channel image [M] broadcast to C channels (tf.tile, networks.py:258), y still bf16 [M][C]. */
 int vnet_bn_stats_b16(const void* x16, const void* r16, int64_t M, int C, float eps, float momentum,
                       float* mean, float* invstd, float* moving_mean, float* moving_var, void* ws, size_t ws_bytes, void* stream);

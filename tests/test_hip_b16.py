@@ -142,15 +142,19 @@ def test_conv5_b16_epilogue_statistics_and_accumulation(dev, shape):
 # ---------------------------------------------------------------------------------------------------------------------------
 # 2^3 stride-2 convolution and 2^3 transposed convolution
 # ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("direct", [True, False])
 @pytest.mark.parametrize("shape", [
     (1, 16, 16, 32, 16),      # level 1 shapes: 1x4x16 bricks
+    (1, 9, 10, 35, 32),       # level 2 widths, odd / ragged dims
     (2, 9, 11, 17, 16),       # odd dims (SAME pads on the high side), batch 2
     (1, 8, 8, 8, 64),         # W < 16: 2x8x8 bricks
     (1, 4, 4, 4, 128),        # coarse level: narrow cout blocks, split-K
 ])
-def test_conv2_down_and_up_b16(dev, shape):
+def test_conv2_down_and_up_b16(dev, shape, direct):
+    """direct: the LDS-free kernels of csrc/conv2_b16.hip (levels 1-2 widths), else the generic fp32-MFMA kernels on bf16 tensors."""
     from vnet_tensorflow_amd import ops
     B, D, H, W, C = shape
+    ops._DIRECT2["on"] = direct
     rng = np.random.default_rng(sum(shape))
     # down: [.., C] -> [.., 2C]
     x = rb(rng.standard_normal((B, D, H, W, C)))
@@ -188,6 +192,16 @@ def test_conv2_down_and_up_b16(dev, shape):
     yu.backward(g16(dyu, dev))
     check_bf16(tag + " dx", txc.grad, dxu_ex)
     check_close(tag + " dw", twu.grad, dwu_ex, 2e-6)
+    # accumulate mode of both kernels: out = RNE(float(prev) + result)
+    prev_f = rb(rng.standard_normal((B, D, H, W, C)))
+    acc = g16(prev_f, dev)
+    ops._conv2_b16(False, g16(dy, dev), tw.detach(), None, acc, (D, H, W), (Dc, Hc, Wc), C, 2 * C, accum=True)
+    check_bf16(tag + " accumulate (down conv backward-data)", acc, dx_ex + prev_f)
+    prev_c = rb(rng.standard_normal((B, Dc, Hc, Wc, 2 * C)))
+    acc = g16(prev_c, dev)
+    ops._conv2_b16(True, g16(dyu, dev), twu.detach(), None, acc, (D, H, W), (Dc, Hc, Wc), C, 2 * C, accum=True)
+    check_bf16(tag + " accumulate (transposed conv backward-data)", acc, dxu_ex + prev_c)
+    ops._DIRECT2["on"] = True
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

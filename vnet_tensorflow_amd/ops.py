@@ -8,6 +8,7 @@ for shape inference only, so a network can create its variables before the first
 import contextlib
 import ctypes
 import math
+import os as _os
 import weakref
 
 import torch
@@ -477,6 +478,30 @@ def _conv2_b16_call(up, x, wp, bias, y, dims_in, dims_out, accum=False, stats=No
                                    int(bool(accum)), _ptr(stats), _ptr(ws), nb, _stream()), "vnet_conv2_fwd_b16")
 
 
+_DIRECT2 = {"on": _os.environ.get("VNET_CONV2_DIRECT", "1") != "0"}          # (tests / A-B: False = always the generic kernels)
+
+
+def _conv2_b16(down, x, w, bias, y, dims_fine, dims_coarse, Cf, Cc, accum=False, stats=None):
+    """The 2^3 stride-2 pair on bf16 tensors.  down: coarse y = conv(fine x); else fine y (+)= transposed conv(coarse x).
+    w: the fp32 filter in TF layout -- [2,2,2,Cf,Cc] for BOTH layers2.down_convolution (Cin = Cf) and layers2.up_convolution
+    (filter [k,k,k,Cout = Cf,Cin = Cc]).  Levels 1-2 of the V-Net (Cf 16 / 32) take the LDS-free direct kernels
+    (csrc/conv2_b16.hip: one 16-byte load = one MFMA operand), other widths the generic fp32-MFMA kernels on packed weights."""
+    L = _lib.lib()
+    B = x.shape[0]
+    if _DIRECT2["on"] and L.vnet_conv2_direct_ok(Cf, Cc):
+        nf = B * dims_fine[0] * dims_fine[1] * dims_fine[2]
+        nc = B * dims_coarse[0] * dims_coarse[1] * dims_coarse[2]
+        tag = "conv-b16 k2 s2%s %d^3x%d %d->%d" % ("" if down else " up", (dims_coarse if down else dims_fine)[2], B, Cf if down else Cc, Cc if down else Cf)
+        with _Timed(tag, 2.0 * nc * 8 * Cf * Cc, 2.0 * (nf * Cf + nc * Cc) + 4.0 * 8 * Cf * Cc):
+            check(L.vnet_conv2_direct_b16(int(bool(down)), _ptr(x), _ptr(y), _ptr(w), _ptr(bias), Cf, Cc, B, *dims_fine, *dims_coarse,
+                                          int(bool(accum)), _ptr(stats), _stream()), "vnet_conv2_direct_b16")
+        return
+    if down:
+        _conv2_b16_call(0, x, packed_weights(w, PACK_FWD | PACK_ROUND16, 8, Cf, Cc), bias, y, dims_fine, dims_coarse, accum=accum, stats=stats)
+    else:
+        _conv2_b16_call(1, x, packed_weights(w, PACK_UP | PACK_ROUND16, 8, Cc, Cf), bias, y, dims_coarse, dims_fine, accum=accum)
+
+
 def _wgrad2_b16_call(xfine, dycoarse, dw, dims_fine, dims_coarse, owner=None):
     L = _lib.lib()
     immediate = owner is None
@@ -692,7 +717,6 @@ def _slot_target(slot, dy, shape):
 # in exact arithmetic (the fp64 oracle gets ~1e-12).  Inside this context the convolutions take the closed form: the bias
 # gradient is left at exactly 0 in the flat gradient buffer and the 29 column-sum + 29 finalize launches per step are not
 # made.  Stand-alone layers2.convolution (outside the networks) keeps the generic column sum.
-import os as _os
 _FUSE = {"zero_bias_grad": False, "bn_stats": _os.environ.get("VNET_BN_STATS", "1") != "0",
          "bf16_shadow": _os.environ.get("VNET_BF16_SHADOW", "1") != "0",
          "bn_stats_fp32_direct": _os.environ.get("VNET_BN_STATS_FP32", "1") == "1"}     # (environment: A/B measurements)
@@ -752,10 +776,10 @@ class _ConvFn(torch.autograd.Function):
         if b16:
             if x1 is not None and (up or ks != 5):
                 raise VnetHipError("conv: the two-source form exists for the 5^3 convolution only")
-            if up:
-                _conv2_b16_call(1, x0, packed_weights(w, PACK_UP | PACK_ROUND16, 8, I, O), b, y, (Di, Hi, Wi), dims_out)
-            elif ks == 2:
-                _conv2_b16_call(0, x0, packed_weights(w, PACK_FWD | PACK_ROUND16, 8, I, O), b, y, (Di, Hi, Wi), dims_out, stats=stats)
+            if up:          # w [2,2,2,O,I]: fine channels O, coarse channels I
+                _conv2_b16(False, x0, w, b, y, dims_out, (Di, Hi, Wi), O, I)
+            elif ks == 2:   # w [2,2,2,I,O]: fine channels I, coarse channels O
+                _conv2_b16(True, x0, w, b, y, (Di, Hi, Wi), dims_out, I, O, stats=stats)
             else:
                 _conv5_b16_call(x0, x1, packed_weights(w, PACK_FWD_BF16, 125, I, O), b, y, None, dims_out, stats=stats, res=res)
         elif bf16:
@@ -860,9 +884,9 @@ class _ConvFn(torch.autograd.Function):
             dx1 = torch.empty_like(x1) if x1 is not None else None
             accum = acc is not None
             if b16 and up:      # backward-data of the transposed conv = the 2^3 stride-2 conv with the same filter
-                _conv2_b16_call(0, dy, packed_weights(w, PACK_FWD | PACK_ROUND16, 8, O, I), None, dx0, dout, din, accum=accum)
+                _conv2_b16(True, dy, w, None, dx0, dout, din, O, I, accum=accum)
             elif b16 and stride == 2:
-                _conv2_b16_call(1, dy, packed_weights(w, PACK_UP | PACK_ROUND16, 8, O, I), None, dx0, dout, din, accum=accum)
+                _conv2_b16(False, dy, w, None, dx0, din, dout, I, O, accum=accum)
             elif b16:
                 _conv5_b16_call(dy, None, packed_weights(w, PACK_BWD_BF16, 125, I, O), None, dx0, dx1, din, accum=accum, acc_src=oop)
                 if oop is not None:
@@ -1001,10 +1025,12 @@ def _epilogue_stats_buffer(bf16, ks, kx, stride, x0, x1, O, dims_out):
         return None
     L = _lib.lib()
     B, C0, C1 = x0.shape[0], x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
-    if _is16(x0) and not bf16:                # bf16-storage 2^3 stride-2 convolution: the fp32 MFMA kernel's brick rows
-        if O % 4:
+    if _is16(x0) and not bf16:                # bf16-storage 2^3 stride-2 convolution: one row per workgroup of the direct kernel,
+        if O % 4:                             # or the generic fp32 MFMA kernel's brick rows
             return None
-        rows = L.vnet_conv_stats_rows(ks, kx, stride, 0, C0 + C1, O, 0, B, *dims_out)
+        rows = L.vnet_conv2_direct_stats_rows(C0, O, B, *dims_out) if _DIRECT2["on"] else 0
+        if rows <= 0:
+            rows = L.vnet_conv_stats_rows(ks, kx, stride, 0, C0 + C1, O, 0, B, *dims_out)
     elif bf16:
         # (the kernels that stage bf16 sources have their own brick shapes: one partial row per brick)
         x16 = _is16(x0) or (_shadow_ptr(x0) is not None and (x1 is None or _shadow_ptr(x1) is not None) and C0 % 8 == 0 and C1 % 8 == 0)
