@@ -55,6 +55,13 @@ def write_nifti(path, arr, pixdim=(1.0, 1.0, 1.0)):
         f.write(np.asfortranarray(arr).tobytes(order="F"))
 
 
+def volume_spacing(path):
+    """Voxel spacing (pixdim) of a volume file; (1, 1, 1) for .npy arrays, which carry none."""
+    if path.endswith(".nii"):
+        return tuple(float(v) for v in read_nifti(path)[1]["pixdim"])
+    return (1.0, 1.0, 1.0)
+
+
 def load_volume(path):
     if path.endswith(".npy"):
         return np.load(path)

@@ -828,7 +828,17 @@ class image2label(object):
 
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=int(os.environ.get("VNET_LOADER_THREADS", "3"))) as pool:
-            feeder = _DeviceFeeder(self.device, pool.map(crop, batches))
+            def windowed(depth=3):
+                # a bounded window of crop jobs in flight (Executor.map would submit -- and pin -- every patch of the volume at once)
+                from collections import deque
+                q, it = deque(), iter(batches)
+                for bd in it:
+                    q.append(pool.submit(crop, bd))
+                    if len(q) >= depth:
+                        yield q.popleft().result()
+                while q:
+                    yield q.popleft().result()
+            feeder = _DeviceFeeder(self.device, windowed())
             for bd, (batch, _) in zip(batches, feeder):
                 sm = self._infer(batch)
                 for j, idx in enumerate(bd['indexes']):
@@ -866,15 +876,17 @@ class image2label(object):
             label = label[tuple(slice(0, n) for n in chans[0].shape)]
             if softmax is not None:
                 softmax = softmax[(slice(None),) + tuple(slice(0, n) for n in chans[0].shape)]
+            # physical voxel size of the input (the reference compares GetPhysicalSize against VolumeThreshold, model.py:117-140)
+            spacing = vdata.volume_spacing(os.path.join(cdir, self.evaluate_image_filenames[0]))
             if self.evaluate_lcc:                                     # model.py:1218-1219
-                label = ExtractLargestConnectedComponents(label)
+                label = ExtractLargestConnectedComponents(label, spacing)
             if self.evaluate_volume_threshold and self.evaluate_volume_threshold > 0:      # model.py:1222-1223
-                label = volume_threshold(label, self.evaluate_volume_threshold)
+                label = volume_threshold(label, self.evaluate_volume_threshold, spacing)
             out = os.path.join(cdir, self.evaluate_label_filename)
             if out.endswith(".npy"):
                 np.save(out, label.astype(np.int16))
             else:
-                vdata.write_nifti(out[:-3] if out.endswith(".gz") else out, label.astype(np.int16))
+                vdata.write_nifti(out[:-3] if out.endswith(".gz") else out, label.astype(np.int16), spacing)
             if self.evaluate_probability_output:
                 for c in range(softmax.shape[0]):
                     name = self.evaluate_probability_filename
@@ -883,5 +895,5 @@ class image2label(object):
                     if ext == ".npy":
                         np.save(pout, softmax[c])
                     else:
-                        vdata.write_nifti(pout, softmax[c].astype(np.float32))
+                        vdata.write_nifti(pout, softmax[c].astype(np.float32), spacing)
             self._print("{}: Evaluation of {} complete".format(_now(), case))

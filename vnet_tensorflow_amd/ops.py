@@ -123,9 +123,11 @@ def workspace(nbytes, device):
     key = (device, _raw_stream())
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
-        if buf is not None and _LAUNCH_ON[0] is not None:
-            _WS_RETIRED.append(buf)     # the allocator files this block under torch's current stream, not the redirected one:
-                                        # never hand it back while launches on that stream may still be using it
+        if buf is not None:
+            # never hand a scratch buffer back: launches on a redirected stream may still be using it (the allocator files the
+            # block under torch's current stream), and a captured step graph replays launches that hold its ADDRESS (ADVICE r2:
+            # an eager step that needs more scratch after the capture would otherwise free memory the graph still writes)
+            _WS_RETIRED.append(buf)
         buf = torch.empty(max(nbytes, 1 << 20) * 5 // 4, dtype=torch.uint8, device=device)
         _WS[key] = buf
     return buf
@@ -559,7 +561,14 @@ def deferred_wgrad_reduce(on=True):
     L.vnet_wgrad_defer(1)
     try:
         yield
-    finally:
+    except BaseException:
+        # the pass failed (e.g. an invalidated stream capture): drain the queue without raising a SECOND error from here, so that
+        # the caller sees the original one (model._train_step_graph turns a refused capture into eager steps)
+        _DEFER["on"] = False
+        L.vnet_wgrad_defer(0)
+        L.vnet_wgrad_flush(_stream())
+        raise
+    else:
         _DEFER["on"] = False
         L.vnet_wgrad_defer(0)
         check(L.vnet_wgrad_flush(_stream()), "vnet_wgrad_flush")
@@ -571,6 +580,8 @@ def _wgrad_workspace(dw, nbytes, immediate, owner):
     if not _DEFER["on"] or immediate or owner is None:
         return workspace(nbytes, dw.device)
     if owner.ws is None or owner.ws.numel() < nbytes or owner.ws.device != dw.device:
+        if owner.ws is not None:
+            _WS_RETIRED.append(owner.ws)          # (a captured graph may hold the old address: keep it alive, see workspace())
         owner.ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dw.device)
     return owner.ws
 
