@@ -406,6 +406,10 @@ int vnet_conv2_direct_ok(int Cf, int Cc);
 int vnet_conv2_direct_stats_rows(int Cf, int Cc, int B, int Dc, int Hc, int Wc);
 int vnet_conv2_direct_b16(int down, const void* in, void* out, const float* w, const float* bias, int Cf, int Cc,
                           int B, int Df, int Hf, int Wf, int Dc, int Hc, int Wc, int accum, float* stats, void* stream);
+/* fp32 twin (the reference's arithmetic, v_mfma_f32_16x16x4_f32): same arguments on float tensors, same widths; replaces
+ * vnet_conv_fwd(ks = 2, stride = 2, up = 0 | 1) / vnet_conv_fwd_acc / vnet_conv_fwd_stats there (layers2.py:78-94). */
+int vnet_conv2_direct_f32(int down, const float* in, float* out, const float* w, const float* bias, int Cf, int Cc,
+                          int B, int Df, int Hf, int Wf, int Dc, int Hc, int Wc, int accum, float* stats, void* stream);
 
 /* batch-norm (+ residual, + activation) on bf16 tensors; statistics and parameter gradients fp32 (partial rows summed in float64).
  * bcast = 1: x is the fp32 1-channel image [M] broadcast to C channels (tf.tile, networks.py:258), y still bf16 [M][C]. */

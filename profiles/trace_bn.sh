@@ -11,7 +11,7 @@ rows = list(csv.DictReader(open('gpurun_out/bntrace/t_kernel_trace.csv')))
 d = collections.defaultdict(list)
 for r in rows:
     n = r['Kernel_Name']
-    m = re.search(r'(bn_act_\w+|bn_stats_\w+|bn_finalize_kernel|sum_finalize_kernel|splitk_reduce_b16_kernel|splitk_reduce_kernel|wgrad_reduce_batched_kernel|adam_kernel|pack_batched_kernel|head_\w+_kernel|conv_kernel<[12], [12][^>]*>|wgrad_kernel<2[^>]*>|conv2_down_b16_kernel<[^>]*>|conv2_up_b16_kernel<[^>]*>)', n)
+    m = re.search(r'(bn_act_\w+|bn_stats_\w+|bn_finalize_kernel|sum_finalize_kernel|splitk_reduce_b16_kernel|splitk_reduce_kernel|wgrad_reduce_batched_kernel|adam_kernel|pack_batched_kernel|head_\w+_kernel|conv_kernel<[12], [12][^>]*>|wgrad_kernel<2[^>]*>|conv2_\w+_kernel<[^>]*>)', n)
     if m:
         d[m.group(1)].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 steps = 132

@@ -100,6 +100,7 @@ SIGNATURES = {
     "vnet_conv2_direct_ok": (_i, [_i, _i]),
     "vnet_conv2_direct_stats_rows": (_i, [_i, _i, _i, _i, _i, _i]),
     "vnet_conv2_direct_b16": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "vnet_conv2_direct_f32": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "vnet_bn_stats_b16": (_i, [_vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vnet_bn_moments_b16": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
     "vnet_bn_act_fwd_b16": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

@@ -233,6 +233,228 @@ __global__ void __launch_bounds__(C2_THREADS) conv2_up_b16_kernel(C2Args a) {
     }
 }
 
+// =====================================================================================================================
+// fp32 twins (the reference's arithmetic): v_mfma_f32_16x16x4_f32, exact fp32.  A lane's operand is one 16-byte load = 4 consecutive
+// channels; the four MFMA steps of a "k quad" take elements x, y, z, w of both fragments (hardware k index g <-> channel 4 g + j: a
+// K permutation shared by both operands, as in conv_kernels.h).  Same decomposition, same permuted output-channel order (a lane
+// ends up with 8 consecutive channels = two adjacent 16-byte stores).  The fp32 filter image needs 16 KB (level 1) / 64 KB (level 2).
+// =====================================================================================================================
+struct C2ArgsF {
+    const float* in; float* out; const float* w; const float* bias; float* stats;
+    int Cf, Cc, B, Df, Hf, Wf, Dc, Hc, Wc;
+    int nseg, segx;
+    int accum;
+};
+
+__device__ __forceinline__ float4 ld16zf(const float* p, bool ok) {
+    typedef const __attribute__((address_space(1))) f32x4* gf4_t;
+    gf4_t src = ok ? (gf4_t)(p) : (gf4_t)(conv2_zero_line);
+    const f32x4 v = *src;
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+template <int CF, int CC, bool STATS>
+__global__ void __launch_bounds__(C2_THREADS) conv2_down_f32_kernel(C2ArgsF a) {
+    constexpr int NQ = 2 * CF / 16, NB = CC / 16, NPAIR = NB / 2;        // k quads per (a,b): 16 channels each
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4* wl = reinterpret_cast<float4*>(smem);                       // [ab 4][q][n][lane 64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    for (int u = tid; u < 4 * NQ * NB * 64; u += C2_THREADS) {
+        const int l = u & 63, n = (u >> 6) % NB, q = ((u >> 6) / NB) % NQ, ab = (u >> 6) / (NB * NQ);
+        const int r = l & 15, gg = l >> 4;
+        const int cc = 32 * (n >> 1) + 8 * (r >> 2) + 4 * (n & 1) + (r & 3);
+        const int kk = 16 * q + 4 * gg, c = kk / CF, cf0 = kk % CF;
+        const float* src = a.w + ((size_t)((ab * 2 + c) * CF + cf0)) * CC + cc;
+        wl[u] = make_float4(src[0], src[(size_t)CC], src[(size_t)2 * CC], src[(size_t)3 * CC]);
+    }
+    __syncthreads();
+    float bia[NPAIR][8];
+#pragma unroll
+    for (int m = 0; m < NPAIR; ++m)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bia[m][e] = a.bias ? a.bias[32 * m + 8 * g + e] : 0.f;
+    float s1[STATS ? NPAIR : 1][8], s2[STATS ? NPAIR : 1][8];
+#pragma unroll
+    for (int m = 0; m < (STATS ? NPAIR : 1); ++m)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1[m][e] = s2[m][e] = 0.f;
+
+    const int nwaves = gridDim.x * (C2_THREADS / 64), w0 = blockIdx.x * (C2_THREADS / 64) + wave;
+    float4 xb[4][NQ];
+    auto issue = [&](int seg) {
+        const int sx = seg % a.segx; int t = seg / a.segx;
+        const int yc = t % a.Hc; t /= a.Hc;
+        const int zc = t % a.Dc, b = t / a.Dc;
+        const int xc = sx * 16 + i;
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+            const int zf = 2 * zc + (ab >> 1), yf = 2 * yc + (ab & 1);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int kk = 16 * q + 4 * g, c = kk / CF, cf0 = kk % CF;
+                const int xf = 2 * xc + c;
+                const bool ok = xc < a.Wc && zf < a.Df && yf < a.Hf && xf < a.Wf;
+                const size_t fv = ok ? ((size_t)(b * a.Df + zf) * a.Hf + yf) * a.Wf + xf : 0;
+                xb[ab][q] = ld16zf(a.in + fv * CF + cf0, ok);
+            }
+        }
+    };
+    if (w0 < a.nseg) issue(w0);
+    for (int seg = w0; seg < a.nseg; seg += nwaves) {
+        float4 xf[4][NQ];
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) xf[ab][q] = xb[ab][q];
+        if (seg + nwaves < a.nseg) issue(seg + nwaves);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    const float4 af = wl[((ab * NQ + q) * NB + n) * 64 + lane];
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, xf[ab][q].x, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, xf[ab][q].y, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, xf[ab][q].z, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, xf[ab][q].w, acc[n], 0, 0, 0);
+                }
+        const int sx = seg % a.segx; int t = seg / a.segx;
+        const int yc = t % a.Hc; t /= a.Hc;
+        const int zc = t % a.Dc, b = t / a.Dc;
+        const int xc = sx * 16 + i;
+        if (xc < a.Wc) {
+            const size_t cv = ((size_t)(b * a.Dc + zc) * a.Hc + yc) * a.Wc + xc;
+#pragma unroll
+            for (int m = 0; m < NPAIR; ++m) {
+                float e[8] = {acc[2 * m][0], acc[2 * m][1], acc[2 * m][2], acc[2 * m][3], acc[2 * m + 1][0], acc[2 * m + 1][1], acc[2 * m + 1][2], acc[2 * m + 1][3]};
+                float4* dst = reinterpret_cast<float4*>(a.out + cv * CC + 32 * m + 8 * g);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) e[k] += bia[m][k];
+                if (a.accum) {
+                    const float4 o0 = dst[0], o1 = dst[1];
+                    e[0] += o0.x; e[1] += o0.y; e[2] += o0.z; e[3] += o0.w; e[4] += o1.x; e[5] += o1.y; e[6] += o1.z; e[7] += o1.w;
+                }
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { s1[m][k] += e[k]; s2[m][k] += e[k] * e[k]; }
+                }
+                dst[0] = make_float4(e[0], e[1], e[2], e[3]);
+                dst[1] = make_float4(e[4], e[5], e[6], e[7]);
+            }
+        }
+    }
+    if constexpr (STATS) {
+        float* red = reinterpret_cast<float*>(smem) + 4 * NQ * NB * 64 * 4;       // behind the filter image
+#pragma unroll
+        for (int m = 0; m < NPAIR; ++m)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) { s1[m][k] += __shfl_xor(s1[m][k], off, 64); s2[m][k] += __shfl_xor(s2[m][k], off, 64); }
+                if (i == 0) { red[wave * 2 * CC + 32 * m + 8 * g + k] = s1[m][k]; red[wave * 2 * CC + CC + 32 * m + 8 * g + k] = s2[m][k]; }
+            }
+        __syncthreads();
+        for (int q = tid; q < 2 * CC; q += C2_THREADS)
+            a.stats[(size_t)blockIdx.x * 2 * CC + q] = red[q] + red[2 * CC + q] + red[4 * CC + q] + red[6 * CC + q];
+    }
+}
+
+template <int CF, int CC>
+__global__ void __launch_bounds__(C2_THREADS) conv2_up_f32_kernel(C2ArgsF a) {
+    constexpr int NQ = CC / 16, NB = 2 * CF / 16, NPAIR = NB / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4* wl = reinterpret_cast<float4*>(smem);                           // [ab 4][q][n][lane 64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    for (int u = tid; u < 4 * NQ * NB * 64; u += C2_THREADS) {
+        const int l = u & 63, n = (u >> 6) % NB, q = ((u >> 6) / NB) % NQ, ab = (u >> 6) / (NB * NQ);
+        const int r = l & 15, gg = l >> 4;
+        const int gp = r >> 2, c = gp >> 1, cf = 8 * (2 * (n >> 1) + (gp & 1)) + 4 * (n & 1) + (r & 3);
+        wl[u] = *reinterpret_cast<const float4*>(a.w + ((size_t)((ab * 2 + c) * CF + cf)) * CC + 16 * q + 4 * gg);
+    }
+    __syncthreads();
+    float bia[NPAIR][8];
+#pragma unroll
+    for (int m = 0; m < NPAIR; ++m)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bia[m][e] = a.bias ? a.bias[8 * (2 * m + (g & 1)) + e] : 0.f;
+
+    const int nwaves = gridDim.x * (C2_THREADS / 64), w0 = blockIdx.x * (C2_THREADS / 64) + wave;
+    float4 xb[NQ];
+    auto issue = [&](int seg) {
+        const int sx = seg % a.segx; const int row = seg / a.segx;
+        const int xc = sx * 16 + i;
+        const bool ok = xc < a.Wc;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) xb[q] = ld16zf(a.in + ((size_t)row * a.Wc + (ok ? xc : 0)) * CC + 16 * q + 4 * g, ok);
+    };
+    if (w0 < a.nseg) issue(w0);
+    for (int seg = w0; seg < a.nseg; seg += nwaves) {
+        float4 xf[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) xf[q] = xb[q];
+        const int sx = seg % a.segx; int t = seg / a.segx;
+        const int yc = t % a.Hc; t /= a.Hc;
+        const int zc = t % a.Dc, b = t / a.Dc;
+        const int xc = sx * 16 + i;
+        if (seg + nwaves < a.nseg) issue(seg + nwaves);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+            f32x4 acc[NB];
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    const float4 af = wl[((ab * NQ + q) * NB + n) * 64 + lane];
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, xf[q].x, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, xf[q].y, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, xf[q].z, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, xf[q].w, acc[n], 0, 0, 0);
+                }
+            const int zf = 2 * zc + (ab >> 1), yf = 2 * yc + (ab & 1), xf_ = 2 * xc + (g >> 1);
+            if (xc < a.Wc && zf < a.Df && yf < a.Hf && xf_ < a.Wf) {
+                const size_t fv = ((size_t)(b * a.Df + zf) * a.Hf + yf) * a.Wf + xf_;
+#pragma unroll
+                for (int m = 0; m < NPAIR; ++m) {
+                    float e[8] = {acc[2 * m][0], acc[2 * m][1], acc[2 * m][2], acc[2 * m][3], acc[2 * m + 1][0], acc[2 * m + 1][1], acc[2 * m + 1][2], acc[2 * m + 1][3]};
+                    float4* dst = reinterpret_cast<float4*>(a.out + fv * CF + 8 * (2 * m + (g & 1)));
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) e[k] += bia[m][k];
+                    if (a.accum) {
+                        const float4 o0 = dst[0], o1 = dst[1];
+                        e[0] += o0.x; e[1] += o0.y; e[2] += o0.z; e[3] += o0.w; e[4] += o1.x; e[5] += o1.y; e[6] += o1.z; e[7] += o1.w;
+                    }
+                    dst[0] = make_float4(e[0], e[1], e[2], e[3]);
+                    dst[1] = make_float4(e[4], e[5], e[6], e[7]);
+                }
+            }
+        }
+    }
+}
+
+template <typename K>
+int c2_launch_f(K kernel, const C2ArgsF& a, int grid, size_t lds, hipStream_t st, unsigned long long& done_mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done_mask & bit)) {        // the level-2 filter image (64 KB) + statistics scratch exceeds the default dynamic-LDS limit
+        const int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e) return e;
+        done_mask |= bit;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(C2_THREADS), lds, st, a);
+    return (int)hipGetLastError();
+}
+
 inline bool c2_widths_ok(int Cf, int Cc) { return (Cf == 16 || Cf == 32) && (Cc == 32 || Cc == 64) && (size_t)8 * Cf * Cc * 2 <= (64u << 10); }
 
 inline int c2_grid(int nseg) {
@@ -289,6 +511,32 @@ int vnet_conv2_direct_b16(int down, const void* in, void* out, const float* w, c
         else return VNET_E_UNSUPPORTED;
     }
     return e;
+}
+
+// fp32 tensors (the reference's arithmetic); arguments as vnet_conv2_direct_b16, float pointers
+int vnet_conv2_direct_f32(int down, const float* in, float* out, const float* w, const float* bias, int Cf, int Cc,
+                          int B, int Df, int Hf, int Wf, int Dc, int Hc, int Wc, int accum, float* stats, void* stream) {
+    if (!in || !out || !w || B <= 0 || Df <= 0 || Hf <= 0 || Wf <= 0 || Dc <= 0 || Hc <= 0 || Wc <= 0) return VNET_E_BADARG;
+    if (!c2_widths_ok(Cf, Cc) || ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(w)) & 15)) return VNET_E_UNSUPPORTED;
+    if (Dc != (Df + 1) / 2 || Hc != (Hf + 1) / 2 || Wc != (Wf + 1) / 2) return VNET_E_BADARG;
+    if (stats && (!down || accum)) return VNET_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    C2ArgsF a{};
+    a.in = in; a.out = out; a.w = w; a.bias = bias; a.stats = stats;
+    a.Cf = Cf; a.Cc = Cc; a.B = B; a.Df = Df; a.Hf = Hf; a.Wf = Wf; a.Dc = Dc; a.Hc = Hc; a.Wc = Wc;
+    a.segx = (Wc + 15) / 16; a.nseg = B * Dc * Hc * a.segx; a.accum = accum ? 1 : 0;
+    const int grid = c2_grid(a.nseg);
+    const size_t wbytes = (size_t)8 * Cf * Cc * 4;
+    const size_t lds = wbytes + (size_t)4 * 2 * Cc * sizeof(float);
+    static unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0;
+    if (down) {
+        if (Cf == 16 && Cc == 32) return stats ? c2_launch_f(conv2_down_f32_kernel<16, 32, true>, a, grid, lds, st, m0) : c2_launch_f(conv2_down_f32_kernel<16, 32, false>, a, grid, lds, st, m1);
+        if (Cf == 32 && Cc == 64) return stats ? c2_launch_f(conv2_down_f32_kernel<32, 64, true>, a, grid, lds, st, m2) : c2_launch_f(conv2_down_f32_kernel<32, 64, false>, a, grid, lds, st, m3);
+        return VNET_E_UNSUPPORTED;
+    }
+    if (Cf == 16 && Cc == 32) return c2_launch_f(conv2_up_f32_kernel<16, 32>, a, grid, lds, st, m4);
+    if (Cf == 32 && Cc == 64) return c2_launch_f(conv2_up_f32_kernel<32, 64>, a, grid, lds, st, m5);
+    return VNET_E_UNSUPPORTED;
 }
 
 }  // extern "C"

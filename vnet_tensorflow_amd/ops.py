@@ -484,19 +484,29 @@ _DIRECT2 = {"on": _os.environ.get("VNET_CONV2_DIRECT", "1") != "0"}          # (
 
 
 def _conv2_b16(down, x, w, bias, y, dims_fine, dims_coarse, Cf, Cc, accum=False, stats=None):
-    """The 2^3 stride-2 pair on bf16 tensors.  down: coarse y = conv(fine x); else fine y (+)= transposed conv(coarse x).
+    """The 2^3 stride-2 pair (fp32 or bf16 tensors, by the dtype of x).  down: coarse y = conv(fine x); else fine y (+)= transposed conv(coarse x).
     w: the fp32 filter in TF layout -- [2,2,2,Cf,Cc] for BOTH layers2.down_convolution (Cin = Cf) and layers2.up_convolution
     (filter [k,k,k,Cout = Cf,Cin = Cc]).  Levels 1-2 of the V-Net (Cf 16 / 32) take the LDS-free direct kernels
     (csrc/conv2_b16.hip: one 16-byte load = one MFMA operand), other widths the generic fp32-MFMA kernels on packed weights."""
     L = _lib.lib()
     B = x.shape[0]
-    if _DIRECT2["on"] and L.vnet_conv2_direct_ok(Cf, Cc):
+    f32 = x.dtype == torch.float32
+    if _DIRECT2["on"] and L.vnet_conv2_direct_ok(Cf, Cc) and w.data_ptr() % 16 == 0:
         nf = B * dims_fine[0] * dims_fine[1] * dims_fine[2]
         nc = B * dims_coarse[0] * dims_coarse[1] * dims_coarse[2]
-        tag = "conv-b16 k2 s2%s %d^3x%d %d->%d" % ("" if down else " up", (dims_coarse if down else dims_fine)[2], B, Cf if down else Cc, Cc if down else Cf)
-        with _Timed(tag, 2.0 * nc * 8 * Cf * Cc, 2.0 * (nf * Cf + nc * Cc) + 4.0 * 8 * Cf * Cc):
-            check(L.vnet_conv2_direct_b16(int(bool(down)), _ptr(x), _ptr(y), _ptr(w), _ptr(bias), Cf, Cc, B, *dims_fine, *dims_coarse,
-                                          int(bool(accum)), _ptr(stats), _stream()), "vnet_conv2_direct_b16")
+        tag = "conv%s k2 s2%s %d^3x%d %d->%d" % ("" if f32 else "-b16", "" if down else " up", (dims_coarse if down else dims_fine)[2], B,
+                                                 Cf if down else Cc, Cc if down else Cf)
+        esz = 4.0 if f32 else 2.0
+        with _Timed(tag, 2.0 * nc * 8 * Cf * Cc, esz * (nf * Cf + nc * Cc) + 4.0 * 8 * Cf * Cc):
+            fn, what = (L.vnet_conv2_direct_f32, "vnet_conv2_direct_f32") if f32 else (L.vnet_conv2_direct_b16, "vnet_conv2_direct_b16")
+            check(fn(int(bool(down)), _ptr(x), _ptr(y), _ptr(w), _ptr(bias), Cf, Cc, B, *dims_fine, *dims_coarse,
+                     int(bool(accum)), _ptr(stats), _stream()), what)
+        return
+    if f32:             # the generic fp32 MFMA kernels on packed filters (any width)
+        if down:
+            _conv_call(2, 2, 0, x, None, packed_weights(w, PACK_FWD, 8, Cf, Cc), bias, y, None, dims_fine, dims_coarse, accum=accum, stats=stats)
+        else:
+            _conv_call(2, 2, 1, x, None, packed_weights(w, PACK_UP, 8, Cc, Cf), bias, y, None, dims_coarse, dims_fine, accum=accum)
         return
     if down:
         _conv2_b16_call(0, x, packed_weights(w, PACK_FWD | PACK_ROUND16, 8, Cf, Cc), bias, y, dims_fine, dims_coarse, accum=accum, stats=stats)
@@ -770,7 +780,7 @@ class _ConvFn(torch.autograd.Function):
         if up:
             O, I = w.shape[-2], w.shape[-1]
             dims_out = tuple(int(v) for v in out_spatial)
-            wp = packed_weights(w, PACK_UP, 8, I, O) if not _is16(x0) else None
+            wp = None
         else:
             I, O = w.shape[-2], w.shape[-1]
             dims_out = (_same_out(Di, stride), _same_out(Hi, stride), _same_out(Wi, stride))
@@ -795,9 +805,13 @@ class _ConvFn(torch.autograd.Function):
                 _conv5_b16_call(x0, x1, packed_weights(w, PACK_FWD_BF16, 125, I, O), b, y, None, dims_out, stats=stats, res=res)
         elif bf16:
             _conv_bf16_call(x0, x1, packed_weights(w, PACK_FWD_BF16, 125, I, O), b, y, None, dims_out, stats=stats, res=res)
+        elif up and x1 is None:
+            _conv2_b16(False, x0, w, b, y, dims_out, (Di, Hi, Wi), O, I)
+        elif ks == 2 and stride == 2 and x1 is None and res is None:
+            _conv2_b16(True, x0, w, b, y, (Di, Hi, Wi), dims_out, I, O, stats=stats)
         else:
             if wp is None:
-                wp = packed_weights(w, PACK_FWD, ks ** 3, I, O)
+                wp = packed_weights(w, PACK_UP, 8, I, O) if up else packed_weights(w, PACK_FWD, ks ** 3, I, O)
             _conv_call(ks, stride, 1 if up else 0, x0, x1, wp, b, y, None, (Di, Hi, Wi), dims_out, stats=stats, res=res)
         ctx.save_for_backward(x0, x1, w)
         ctx.params = (w, b)
@@ -903,11 +917,9 @@ class _ConvFn(torch.autograd.Function):
                 if oop is not None:
                     slot0.total = dx0
             elif up:        # backward-data of the transposed conv = the 2^3 stride-2 conv with the same filter
-                wp = packed_weights(w, PACK_FWD, 8, O, I)
-                _conv_call(2, 2, 0, dy, None, wp, None, dx0, None, dout, din, accum=accum)
+                _conv2_b16(True, dy, w, None, dx0, dout, din, O, I, accum=accum)
             elif stride == 2:   # backward-data of the down conv = the 2^3 transposed conv with the same filter
-                wp = packed_weights(w, PACK_UP, 8, O, I)
-                _conv_call(2, 2, 1, dy, None, wp, None, dx0, None, dout, din, accum=accum)
+                _conv2_b16(False, dy, w, None, dx0, din, dout, I, O, accum=accum)
             elif ctx.bf16:
                 _conv_bf16_call(dy, None, packed_weights(w, PACK_BWD_BF16, 125, I, O), None, dx0, dx1, din, accum=accum, acc_src=oop)
                 if oop is not None:
@@ -1050,9 +1062,13 @@ def _epilogue_stats_buffer(bf16, ks, kx, stride, x0, x1, O, dims_out):
         # fp32 MFMA kernels: measured (profiles/r02_epilogue_stats.txt) the STATS instantiations lose in their main loop most of
         # what the statistics pass costs (+1..3 % per launch, residual re-read on the input conv): the fused form is worth
         # 0.07 ms of a 25.7 ms step; VNET_BN_STATS_FP32=0 keeps it to the split-K launches (statistics from the reduce kernel)
-        if not _FUSE["bn_stats_fp32_direct"] and not L.vnet_conv_stats_from_reduce(ks, kx, stride, C0 + C1, O, B, *dims_out):
-            return None
-        rows = L.vnet_conv_stats_rows(ks, kx, stride, 0, C0 + C1, O, 0, B, *dims_out)
+        rows = 0
+        if ks == 2 and stride == 2 and x1 is None and _DIRECT2["on"]:
+            rows = L.vnet_conv2_direct_stats_rows(C0, O, B, *dims_out)        # the LDS-free direct kernel (levels 1-2): one row per workgroup
+        if rows <= 0:
+            if not _FUSE["bn_stats_fp32_direct"] and not L.vnet_conv_stats_from_reduce(ks, kx, stride, C0 + C1, O, B, *dims_out):
+                return None
+            rows = L.vnet_conv_stats_rows(ks, kx, stride, 0, C0 + C1, O, 0, B, *dims_out)
     if rows <= 0:
         return None
     return torch.empty((rows, 2 * O), dtype=torch.float32, device=x0.device)
