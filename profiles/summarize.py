@@ -11,6 +11,11 @@ import shutil
 import sys
 from collections import defaultdict
 
+# launches per step of the C5 network's 32-cout row-pair kernel without statistics / of the row-reuse filter gradient with TZ = 4
+# (checked against the per-step launch counts the script prints)
+FAM_BWD_PER_STEP = None
+FAM_WGRAD_PER_STEP = None
+
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
@@ -23,6 +28,7 @@ def main(src, tag):
     if os.path.exists(os.path.join(src, "serial_kernel_stats.csv")):      # VNET_PARAM_GRAD_STREAM=0: no kernels overlap
         shutil.copy(os.path.join(src, "serial_kernel_stats.csv"), os.path.join(here, tag + "_kernel_stats_serial.csv"))
     pmc = {}
+    ordered = {}
     for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         path = os.path.join(src, which + "_counter_collection.csv")
         if not os.path.exists(path):
@@ -37,6 +43,11 @@ def main(src, tag):
             key = r["Dispatch_Id"]
             per_dispatch[key] += float(r["Counter_Value"])
             meta[key] = (short(r["Kernel_Name"]), r["Grid_Size"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        seqs = defaultdict(list)
+        for key in sorted(per_dispatch, key=int):
+            name, grid, dur = meta[key]
+            seqs[(name, grid)].append((per_dispatch[key], dur))
+        ordered[counter] = seqs
         for key, val in per_dispatch.items():
             name, grid, dur = meta[key]
             a = agg[(name, grid)]
@@ -50,7 +61,8 @@ def main(src, tag):
         keys |= set(agg)
     for key in sorted(keys):
         name, grid = key
-        if not (name.startswith("conv_kernel<5") or name.startswith("wgrad_kernel<5") or name.startswith("conv5_bf16") or name.startswith("wgrad5_bf16")):
+        if not (name.startswith("conv_kernel<") or name.startswith("wgrad_kernel<") or name.startswith("conv5_bf16") or name.startswith("wgrad5_bf16")
+                or name.startswith("conv2_") or name.startswith("bn_") or name.startswith("input_")):
             continue
         e = {"grid_threads": int(grid)}
         if "FETCH_SIZE" in pmc and key in pmc["FETCH_SIZE"]:
@@ -64,23 +76,53 @@ def main(src, tag):
             e["hbm_write_bytes"] = 1024.0 * v / n
         e["hbm_bytes_per_launch"] = e.get("hbm_read_bytes", 0.0) + e.get("hbm_write_bytes", 0.0)
         out["kernels"]["%s grid=%s" % (name, grid)] = e
-    # the kernel family bench.py reports (decoder level 1 conv_1 at 128^3: forward 32->16, backward-data 16->32, filter
-    # gradient): launches on 8192 bricks x 256 threads (conv) / the one-slab filter-gradient kernels
-    fams = {"fp32": [k for k in out["kernels"] if (k.startswith("conv_kernel<5, 1, 4, 8, 8, 4, 4, 1, false, 5> grid=2097152")
-                                                     or k.startswith("conv_kernel<5, 1, 4, 8, 8, 4, 4, 2, false, 5> grid=2097152")
-                                                     or k.startswith("wgrad_kernel<5, 1, 4, 4, 16, 1, 16, 5>"))],
-            # bf16: the 128^3 launches cannot be told apart by grid -- all five conv (4->16, 16->16, 32->16 forward; 16->16,
-            # 16->32 backward-data) and three filter-gradient launches per step of the C5 network are averaged
-            "bf16": [k for k in out["kernels"] if (k.startswith("conv5_bf16_kernel<4, 8, 16, 1, 8> grid=2097152")
-                                                     or k.startswith("conv5_bf16_c16_kernel")
-                                                     or k.startswith("wgrad5_bf16_kernel<4, 4, 16, 1, 16>"))]}
+    # The kernel family bench.py reports = decoder level 1 conv_1 at 128^3: forward 32->16, backward-data 16->32, filter gradient.
+    # A member is (kernel-name regex, launches of that name+grid per training step, position among them in launch order):
+    # every step launches the same sequence, so dispatch i of a name+grid is position i mod per_step.
+    fams = {"fp32": [("fwd", r"conv_kernel<5, 1, 4, 8, 8, 4, 4, 1, false, 5, true", "2097152", 1, 0),
+                     ("bwd", r"conv_kernel<5, 1, 4, 8, 8, 4, 4, 2, false, 5, false", "2097152", 1, 0),
+                     ("wgrad", r"wgrad_kernel<5, 1, 4, 4, 16, 1, 16, 5", "131072", 1, 0)],
+            # C5, bf16 storage: persistent kernels (grid = CUs x 512 whatever the problem), so launch order tells them apart:
+            # forward 4->16, 16->16, 32->16 (the third c16 launch); backward starts at decoder level 1, so its backward-data
+            # 16->32 and its filter gradient are the first launches of their kernels in a step
+            "bf16": [("fwd", r"conv5_bf16_c16_kernel<4, 8, 16, true, true, true>", None, 3, 2),
+                     ("bwd", r"conv5_bf16_r32_kernel<false, true>", None, FAM_BWD_PER_STEP, 0),
+                     ("wgrad", r"wgrad5_bf16_rr_kernel<4>", None, FAM_WGRAD_PER_STEP, 0)]}
     out["families"] = {}
-    for name, keys in fams.items():
-        sel = [out["kernels"][k] for k in keys if out["kernels"][k].get("launches")]
-        if sel:
-            n = sum(e["launches"] for e in sel)
-            out["families"][name] = {"kernels": keys, "launches": n,
-                                     "hbm_bytes_per_launch": round(sum(e["launches"] * e["hbm_bytes_per_launch"] for e in sel) / n)}
+    for fam, members in fams.items():
+        per_kernel, used, nsteps = {}, [], 0
+        for tag, pat, grid, per_step, pos in members:
+            e = {}
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = ordered.get(counter, {})
+                keys = [k for k in d if k[0].startswith(pat) and (grid is None or k[1] == grid)]
+                if len(keys) != 1:
+                    continue
+                seq = d[keys[0]]
+                if per_step is None:        # derived from the family's first member (known launches per step)
+                    if not nsteps or len(seq) % nsteps:
+                        continue
+                    per_step = len(seq) // nsteps
+                elif not nsteps:
+                    nsteps = len(seq) // per_step
+                if len(seq) % per_step:
+                    print("WARNING: %s: %d launches is not a multiple of %d per step" % (keys[0], len(seq), per_step))
+                    continue
+                sel = seq[pos::per_step]
+                e[counter] = sum(v for v, _ in sel) / len(sel)
+                e["launches"] = len(sel)
+                e["avg_us_profiled"] = sum(t for _, t in sel) / len(sel) / 1e3
+                e["kernel"] = "%s grid=%s, launch %d of %d per step" % (keys[0][0], keys[0][1], pos + 1, per_step)
+            if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+                rd, wr = 2.0 * 1024.0 * e["FETCH_SIZE"], 1024.0 * e["WRITE_SIZE"]
+                per_kernel[tag] = {"kernel": e["kernel"], "launches": e["launches"], "hbm_read_bytes": round(rd), "hbm_write_bytes": round(wr),
+                                   "hbm_bytes_per_launch": round(rd + wr), "avg_us_profiled": round(e["avg_us_profiled"], 1)}
+                used.append(e["kernel"])
+        if len(per_kernel) == len(members):
+            out["families"][fam] = {"kernels": used, "per_kernel": per_kernel,
+                                    "hbm_bytes_per_launch": round(sum(v["hbm_bytes_per_launch"] for v in per_kernel.values()) / len(per_kernel))}
+        else:
+            print("WARNING: family %s incomplete: %s" % (fam, sorted(per_kernel)))
     json.dump(out, open(os.path.join(here, tag + "_pmc.json"), "w"), indent=1)
     for k, e in out["kernels"].items():
         print("%-70s n=%3d read %8.1f MB write %8.1f MB  %8.1f us" % (k, e.get("launches", 0), e.get("hbm_read_bytes", 0) / 1e6,
