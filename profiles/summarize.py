@@ -91,7 +91,7 @@ def main(src, tag):
     out["families"] = {}
     for fam, members in fams.items():
         per_kernel, used, nsteps = {}, [], 0
-        for tag, pat, grid, per_step, pos in members:
+        for which, pat, grid, per_step, pos in members:
             e = {}
             for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 d = ordered.get(counter, {})
@@ -115,7 +115,7 @@ def main(src, tag):
                 e["kernel"] = "%s grid=%s, launch %d of %d per step" % (keys[0][0], keys[0][1], pos + 1, per_step)
             if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
                 rd, wr = 2.0 * 1024.0 * e["FETCH_SIZE"], 1024.0 * e["WRITE_SIZE"]
-                per_kernel[tag] = {"kernel": e["kernel"], "launches": e["launches"], "hbm_read_bytes": round(rd), "hbm_write_bytes": round(wr),
+                per_kernel[which] = {"kernel": e["kernel"], "launches": e["launches"], "hbm_read_bytes": round(rd), "hbm_write_bytes": round(wr),
                                    "hbm_bytes_per_launch": round(rd + wr), "avg_us_profiled": round(e["avg_us_profiled"], 1)}
                 used.append(e["kernel"])
         if len(per_kernel) == len(members):
