@@ -210,3 +210,10 @@ int vnet_conv2_wgrad_b16(const void* x, int Cin, const void* dy, int Cout, float
 }
 
 }  // extern "C"
+
+#ifdef VNET_STAMPS
+// experiment build only: where the persistent bf16 kernels write their s_memtime stamps (4 steps x 8 waves x 12 int64)
+extern "C" int vnet_debug_set_stamps(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf));
+}
+#endif

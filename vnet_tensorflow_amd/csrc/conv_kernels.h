@@ -30,6 +30,39 @@ struct ConvArgs {
     float* stats; const float* res;
 };
 
+// Experiment build -DVNET_STAMPS (profiles/build_stamps.sh): s_memtime stamps around the phases of four consecutive brick steps of
+// one workgroup of the persistent bf16 kernels, written to the buffer set by vnet_debug_set_stamps (profiles/step_stamps.py).
+#ifdef VNET_STAMPS
+static __device__ long long* g_stamps = nullptr;
+#define VNET_STAMP_DECL long long ts[12]; bool stamp_on = false
+#define VNET_STAMP_STEP(step) stamp_on = blockIdx.x == 88 && (step) >= 4 && (step) < 8
+#define VNET_STAMP(k) do { if (stamp_on) ts[k] = __builtin_readcyclecounter(); } while (0)
+#define VNET_STAMP_FLUSH(step, wave, lane, n) do { if (stamp_on && (lane) == 0 && g_stamps) { \
+        for (int q_ = 0; q_ < (n); ++q_) g_stamps[(((step) - 4) * 8 + (wave)) * 12 + q_] = ts[q_]; } } while (0)
+#else
+#define VNET_STAMP_DECL
+#define VNET_STAMP_STEP(step)
+#define VNET_STAMP(k) do {} while (0)
+#define VNET_STAMP_FLUSH(step, wave, lane, n) do {} while (0)
+#endif
+
+// Sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15), every lane gets the sum: four v_add_f32_dpp (quad_perm [1,0,3,2],
+// [2,3,0,1], row_half_mirror, row_mirror).  __shfl_xor compiles to ds_bpermute_b32, which goes through the LDS pipe and queues
+// behind the other waves' fragment reads: the 16 dependent rounds of the statistics reduction were ~2.5 K cycles of the 16-cout
+// kernel's brick step (s_memtime stamps, round 3).
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    return v;
+}
+// ... over 32 lanes (lanes 32h .. 32h+31): the row sums, then one exchange between the two rows
+__device__ __forceinline__ float half32_sum(float v) {
+    v = row16_sum(v);
+    return v + __shfl_xor(v, 16, 64);
+}
+
 // cross-wave stage of the epilogue statistics: per-wave sums in red[wave][2 * CW] -> one row of the partial buffer
 template <int WAVES_, int CW>
 __device__ __forceinline__ void stats_row_write(const float* red, float* __restrict__ stats, size_t row, int co0, int Cout, int tid) {
@@ -68,6 +101,49 @@ __device__ __forceinline__ void epilogue4_b16(const ConvArgs& a, size_t ov, int 
         for (int k = 0; k < 4; ++k) { s1[k] += v[k]; s2[k] += v[k] * v[k]; }
     }
     *reinterpret_cast<uint2*>(y) = pk;
+}
+
+// The same for N units of one lane at once (round 3): every load of the batch -- the other gradient in accumulate mode, the
+// residual of the statistics -- is in flight before the first is used.  One unit at a time, each runtime `if` around a load costs
+// its own s_waitcnt vmcnt(0): s_memtime stamps showed 2.3 K (plain) to 5 K cycles (statistics + residual) per brick step of the
+// persistent kernels in an epilogue that stores 32 bytes per lane.  Units that must not be stored (ok = false) come with ov = 0 and
+// co = 0, a readable address.  e: in = accumulator + bias, out = what the batch-norm statistics see (rounded value + residual).
+template <bool STATS, int N>
+__device__ __forceinline__ void epilogue_b16_batch(const ConvArgs& a, const size_t (&ov)[N], const int (&co)[N], const bool (&ok)[N],
+                                                   float (&e)[N][4]) {
+    unsigned short* y[N];
+    uint2 old[N], rr[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u)
+        y[u] = (co[u] < a.Cy0) ? reinterpret_cast<unsigned short*>(a.y0) + ov[u] * a.Cy0 + co[u]
+                               : reinterpret_cast<unsigned short*>(a.y1) + ov[u] * a.Cy1 + (co[u] - a.Cy0);
+    if (a.accum) {
+        if (a.accsrc) {
+#pragma unroll
+            for (int u = 0; u < N; ++u)
+                old[u] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.accsrc) + ov[u] * a.Cy0 + co[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < N; ++u) old[u] = *reinterpret_cast<const uint2*>(y[u]);
+        }
+    }
+    if constexpr (STATS) {
+        if (a.res) {
+#pragma unroll
+            for (int u = 0; u < N; ++u)
+                rr[u] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.res) + ov[u] * a.Cout + co[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        if (a.accum) { e[u][0] += bf_lo(old[u].x); e[u][1] += bf_hi(old[u].x); e[u][2] += bf_lo(old[u].y); e[u][3] += bf_hi(old[u].y); }
+        const uint2 pk = make_uint2(pk_bf16(e[u][0], e[u][1]), pk_bf16(e[u][2], e[u][3]));
+        if constexpr (STATS) {
+            e[u][0] = bf_lo(pk.x); e[u][1] = bf_hi(pk.x); e[u][2] = bf_lo(pk.y); e[u][3] = bf_hi(pk.y);
+            if (a.res) { e[u][0] += bf_lo(rr[u].x); e[u][1] += bf_hi(rr[u].x); e[u][2] += bf_lo(rr[u].y); e[u][3] += bf_hi(rr[u].y); }
+        }
+        if (ok[u]) *reinterpret_cast<uint2*>(y[u]) = pk;
+    }
 }
 
 template <int KS, int STRIDE, int TZ, int TY, int TX, int KX = KS>
@@ -1115,7 +1191,13 @@ struct XTileH {
     __device__ static __forceinline__ void issue_part(u32x4 (&v)[KN], const unsigned short* __restrict__ x0, const unsigned short* __restrict__ x1,
                                                       int C0, int C1, int chunk, int b, int gz0, int gy0, int gx0,
                                                       int Di, int Hi, int Wi, int tid) {
-        const int r0 = tid / COLS, col = tid - r0 * COLS;
+        int r0 = tid / COLS;
+        const int col = tid - r0 * COLS;
+        // r0 is made opaque per call: everything below that depends only on the thread (the per-row offsets: 2 x PER registers as
+        // 64-bit values) would otherwise be hoisted out of the caller's brick loop and held for the whole kernel -- in the
+        // row-pair kernel that spilled, and the scratch reloads between the loads made the prefetch synchronous (round-3 stamps:
+        // 9-10 K cycles of tile issue per step instead of 2-3 K)
+        asm volatile("" : "+v"(r0));
         const int ix = col >> 1, hf = col & 1;
         const int c = chunk * 16 + hf * 8;
         const int gx = gx0 + ix;
@@ -1131,20 +1213,21 @@ struct XTileH {
         // to mask, so a load is an offset add.  The address arithmetic of the general path costs ~27 instructions per load
         // (s_memtime stamps: 2 K cycles per brick step for 8 loads in the 16-cout kernel) at a moment when the other wave of the
         // SIMD is doing exactly the same, i.e. with the matrix pipe idle.  (Wave-uniform branch: every lane sees the same brick.)
+        const int csu = (chunk * 16 < C0) ? C0 : C1;                                      // (uniform: a chunk never straddles the sources)
         const bool interior = gz0 >= 0 && gz0 + IZ <= Di && gy0 >= 0 && gy0 + IY <= Hi && gx0 >= 0 && gx0 + IX <= Wi &&
-                              (chunk + 1) * 16 <= C0 + C1 && (C0 & 15) == 0;
+                              (chunk + 1) * 16 <= C0 + C1 && (C0 & 15) == 0 && (long long)Di * Hi * Wi * csu < (1ll << 31);
         if (interior) {
-            const int cs = (chunk * 16 < C0) ? C0 : C1;                                   // (uniform: a chunk never straddles the sources)
-            const unsigned short* src = (chunk * 16 < C0) ? x0 + chunk * 16 : x1 + (chunk * 16 - C0);
-            const int rs = Wi * cs;
+            // one UNIFORM 64-bit base (source tensor, sample) + a 32-bit element offset per load (saddr form of global_load)
+            const unsigned short* src = ((chunk * 16 < C0) ? x0 + chunk * 16 : x1 + (chunk * 16 - C0)) + (size_t)b * Di * Hi * Wi * csu;
+            const int rs = Wi * csu;
             const int r0c = min(r0, RPI - 1);                                              // idle threads (r0 >= RPI) load a valid row, commit drops it
-            const unsigned short* tp = src + ((size_t)(b * Di + gz0) * Hi + gy0) * rs + (size_t)(gx0 + ix) * cs + hf * 8;
+            const int col0 = (gx0 + ix) * csu + hf * 8;
             int rowc = r0c + K0 * RPI;
             int jz = rowc / IY, jy = rowc - jz * IY;
 #pragma unroll
             for (int k = 0; k < KN; ++k) {
-                const int lin = min(jz, IZ - 1) * Hi + jy;                                   // rows past the tile (last iteration) stay inside it
-                v[k] = *(gvec16_t)(tp + lin * rs);
+                const unsigned off = (unsigned)(((gz0 + min(jz, IZ - 1)) * Hi + gy0 + jy) * rs + col0);   // rows past the tile (last iteration) stay inside it
+                v[k] = *(gvec16_t)(src + off);
                 jy += DIY; jz += DIZ;
                 if (jy >= IY) { jy -= IY; ++jz; }
             }
@@ -1383,8 +1466,52 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int k = 0; k < 4; ++k) s1[n][g][k] = s2[n][g][k] = 0.f;
+    if constexpr (O16) {
+        if (!a.part) {
+            // bf16 outputs, no split-K: the four channel groups of a voxel and cout block as one batch (epilogue_b16_batch)
+#pragma unroll
+            for (int n = 0; n < NSB; ++n) {
+                float bq[4][4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = co0 + n * 32 + g * 8 + half * 4;
+                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a.bias && co < a.Cout) bv = make_float4(a.bias[co], a.bias[co + 1], a.bias[co + 2], a.bias[co + 3]);
+                    bq[g][0] = bv.x; bq[g][1] = bv.y; bq[g][2] = bv.z; bq[g][3] = bv.w;
+                }
+#pragma unroll
+                for (int m = 0; m < MS; ++m) {
+                    const int v = (wave * MS + m) * 32 + q32;
+                    const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+                    const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
+                    const bool vok = oz < a.Do && oy < a.Ho && ox < a.Wo;
+                    const size_t ov = vok ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
+                    size_t ovs[4]; int cos[4]; bool oks[4]; float e[4][4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = co0 + n * 32 + g * 8 + half * 4;
+                        oks[g] = vok && co < a.Cout;
+                        ovs[g] = oks[g] ? ov : 0;
+                        cos[g] = oks[g] ? co : 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) e[g][k] = acc[m][n][g * 4 + k] + bq[g][k];
+                    }
+                    epilogue_b16_batch<STATS, 4>(a, ovs, cos, oks, e);
+                    if constexpr (STATS) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            if (oks[g]) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) { s1[n][g][k] += e[g][k]; s2[n][g][k] += e[g][k] * e[g][k]; }
+                            }
+                    }
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int m = 0; m < MS; ++m) {
+        if (O16 && !a.part) break;
         const int v = (wave * MS + m) * 32 + q32;
         const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
         const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
@@ -1443,11 +1570,8 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                    for (int off = 1; off < 32; off <<= 1) {
-                        s1[n][g][k] += __shfl_xor(s1[n][g][k], off, 64);
-                        s2[n][g][k] += __shfl_xor(s2[n][g][k], off, 64);
-                    }
+                    s1[n][g][k] = half32_sum(s1[n][g][k]);
+                    s2[n][g][k] = half32_sum(s2[n][g][k]);
                     if (p32 == 0) {
                         red[wave * 2 * CW + n * 32 + g * 8 + half * 4 + k] = s1[n][g][k];
                         red[wave * 2 * CW + CW + n * 32 + g * 8 + half * 4 + k] = s2[n][g][k];
@@ -1598,18 +1722,27 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     tile_commit();
     __syncthreads();
 
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};       // this lane's four output channels never change: the bias stays in registers
+    if (a.bias && 4 * g < a.Cout) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bias4[k] = a.bias[4 * g + k];
+    }
     f32x4 accA[4], accB[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) accB[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    VNET_STAMP_DECL;
     for (int step = 0; step < nsteps; ++step) {
         sched(step, bi, ch, first, last, swp);
         const bool more = step + 1 < nsteps;
         int nbi = 0, nchk = ch; bool nf, nl, ns;
+        VNET_STAMP_STEP(step);
+        VNET_STAMP(0);
         if (more) {
             sched(step + 1, nbi, nchk, nf, nl, ns);
             tile_issue(nbi, nchk);
             __builtin_amdgcn_sched_barrier(0);
         }
+        VNET_STAMP(1);
         if (swp) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) { const f32x4 t = accA[m]; accA[m] = accB[m]; accB[m] = t; }
@@ -1640,6 +1773,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                                                        // (0.155-0.172 vs 0.157-0.167 ms at 128^3 16->16): two waves per SIMD
                                                        // already cover the read latency
             }
+        VNET_STAMP(2);
         if (more) tile_pack();          // the prefetched tile has long arrived: convert now, 32 fewer live registers from here
                                         // (packing after the first dz pair and letting the second pair's reads hoist: measured 2 % slower)
         // ---- dz = 4: dy pairs (0,1), (2,3) and the single tap dy = 4 ----
@@ -1659,20 +1793,42 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 accA[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2], S[m], accA[m], 0, 0, 0);
             }
         }
+        VNET_STAMP(3);
         if (last) {
             // epilogue: lane holds cout 4g..4g+3 of voxel (vz, vy0 + m, x = j)
             int b, bz, by, bx;
             brick_origin(bi, b, bz, by, bx);
             const int oz = bz * TZ + vz, ox = bx * TX + j, co = 4 * g;
             float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (O16) {
+                const bool colok = oz < a.Do && ox < a.Wo && co < a.Cout;
+                size_t ovs[4]; int cos[4]; bool oks[4]; float e[4][4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < 4; ++m) {
+                    const int oy = by * TY + vy0 + m;
+                    oks[m] = colok && oy < a.Ho;
+                    ovs[m] = oks[m] ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
+                    cos[m] = oks[m] ? co : 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) e[m][k] = accA[m][k] + bias4[k];
+                }
+                epilogue_b16_batch<STATS, 4>(a, ovs, cos, oks, e);
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        if (oks[m]) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { s1[k] += e[m][k]; s2[k] += e[m][k] * e[m][k]; }
+                        }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < (O16 ? 0 : 4); ++m) {
                 const int oy = by * TY + vy0 + m;
                 if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo || co >= a.Cout) continue;
                 const size_t ov = ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
                 float e[4] = {accA[m][0], accA[m][1], accA[m][2], accA[m][3]};
-                if (a.bias) { e[0] += a.bias[co]; e[1] += a.bias[co + 1]; e[2] += a.bias[co + 2]; e[3] += a.bias[co + 3]; }
-                if constexpr (O16) { epilogue4_b16<STATS>(a, ov, co, e, s1, s2); continue; }
+                e[0] += bias4[0]; e[1] += bias4[1]; e[2] += bias4[2]; e[3] += bias4[3];
                 if constexpr (STATS) {
                     float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (a.res) rr = *reinterpret_cast<const float4*>(a.res + ov * a.Cout + co);
@@ -1690,13 +1846,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             if constexpr (STATS) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                    for (int off = 1; off < 16; off <<= 1) { s1[k] += __shfl_xor(s1[k], off, 64); s2[k] += __shfl_xor(s2[k], off, 64); }
+                    s1[k] = row16_sum(s1[k]); s2[k] = row16_sum(s2[k]);
                     if (j == 0) { red[wave * 32 + co + k] = s1[k]; red[wave * 32 + 16 + co + k] = s2[k]; }
                 }
             }
         }
+        VNET_STAMP(4);
         __syncthreads();                               // every wave is done reading the tile (and the filter chunk)
+        VNET_STAMP(5);
         if constexpr (STATS) if (last) stats_row_write<8, 16>(red, a.stats, (size_t)(b_lo + slot + bi * G8), 0, a.Cout, tid);
         if (more) {
             tile_commit();
@@ -1704,7 +1861,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             // register prefetch across the MFMA section does not fit next to the tile prefetch (it spilled)
             if (nchk != ch) { filter_issue(nchk); filter_commit(); }
         }
+        VNET_STAMP(6);
         __syncthreads();
+        VNET_STAMP(7);
+        VNET_STAMP_FLUSH(step, wave, lane, 8);
     }
 }
 
@@ -1781,15 +1941,19 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
     f32x16 acc[4];
     int cur = 0;                                   // plane buffer that holds the current dz plane
+    VNET_STAMP_DECL;
     for (int step = 0; step < nsteps; ++step) {
         step_of(step, brick, cob, ch);
         const bool more = step + 1 < nsteps;
         int nbrick_ = brick, ncob_ = cob, nch_ = ch;
+        VNET_STAMP_STEP(step);
+        VNET_STAMP(0);
         if (more) {
             step_of(step + 1, nbrick_, ncob_, nch_);
             tile_issue(nbrick_, nch_);
             __builtin_amdgcn_sched_barrier(0);
         }
+        VNET_STAMP(1);
         if (ch == 0) {
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -1821,6 +1985,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             if (wnext) bf16_w_commit<1, WPER, NT>(reinterpret_cast<u32x4*>(wbuf + (cur ^ 1) * WBUF), wreg, tid);
             if (dz < 4) __syncthreads();           // (the last plane's barrier follows the epilogue)
             cur ^= 1;
+            VNET_STAMP(2 + dz);
         }
         if (ch == nch - 1) {
             // epilogue: register r of lane = cout co0 + 8*(r/4) + 4*half + r%4 of voxel (subtile m, q32)
@@ -1833,8 +1998,44 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) s1[g][k] = s2[g][k] = 0.f;
+            if constexpr (O16) {
+                // bf16 outputs: the four channel groups of a voxel as one batch (loads of the batch in flight together)
+                float bq[4][4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+                for (int g = 0; g < 4; ++g) {
+                    const int co = co0 + g * 8 + half * 4;
+                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a.bias && co < a.Cout) bv = make_float4(a.bias[co], a.bias[co + 1], a.bias[co + 2], a.bias[co + 3]);
+                    bq[g][0] = bv.x; bq[g][1] = bv.y; bq[g][2] = bv.z; bq[g][3] = bv.w;
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int oy = by * TY + vy0 + 2 * m + (q32 >> 4);
+                    const bool vok = oz < a.Do && oy < a.Ho && ox < a.Wo;
+                    const size_t ov = vok ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
+                    size_t ovs[4]; int cos[4]; bool oks[4]; float e[4][4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = co0 + g * 8 + half * 4;
+                        oks[g] = vok && co < a.Cout;
+                        ovs[g] = oks[g] ? ov : 0;
+                        cos[g] = oks[g] ? co : 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) e[g][k] = acc[m][g * 4 + k] + bq[g][k];
+                    }
+                    epilogue_b16_batch<STATS, 4>(a, ovs, cos, oks, e);
+                    if constexpr (STATS) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            if (oks[g]) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) { s1[g][k] += e[g][k]; s2[g][k] += e[g][k] * e[g][k]; }
+                            }
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < (O16 ? 0 : 4); ++m) {
                 const int oy = by * TY + vy0 + 2 * m + (q32 >> 4);
                 if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
                 const size_t ov = ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
@@ -1844,7 +2045,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     if (co >= a.Cout) continue;
                     float e[4] = {acc[m][g * 4], acc[m][g * 4 + 1], acc[m][g * 4 + 2], acc[m][g * 4 + 3]};
                     if (a.bias) { e[0] += a.bias[co]; e[1] += a.bias[co + 1]; e[2] += a.bias[co + 2]; e[3] += a.bias[co + 3]; }
-                    if constexpr (O16) { epilogue4_b16<STATS>(a, ov, co, e, s1[g], s2[g]); continue; }
                     if constexpr (STATS) {
                         float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (a.res) rr = *reinterpret_cast<const float4*>(a.res + ov * a.Cout + co);
@@ -1865,11 +2065,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                        for (int off = 1; off < 32; off <<= 1) {
-                            s1[g][k] += __shfl_xor(s1[g][k], off, 64);
-                            s2[g][k] += __shfl_xor(s2[g][k], off, 64);
-                        }
+                        s1[g][k] = half32_sum(s1[g][k]);
+                        s2[g][k] = half32_sum(s2[g][k]);
                         if (p32 == 0) {
                             red[wave * 64 + g * 8 + half * 4 + k] = s1[g][k];
                             red[wave * 64 + 32 + g * 8 + half * 4 + k] = s2[g][k];
@@ -1877,10 +2074,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     }
             }
         }
+        VNET_STAMP(7);
         __syncthreads();                               // every wave is done with the tile (and the last filter plane; red is complete)
+        VNET_STAMP(8);
         if constexpr (STATS) if (ch == nch - 1) stats_row_write<8, 32>(red, a.stats, (size_t)brick, cob * 32, a.Cout, tid);
         if (more) bf16_tile_commit_h<G, XH, 0, XH::PER>(tile, dump, hv, tid);
+        VNET_STAMP(9);
         __syncthreads();
+        VNET_STAMP(10);
+        VNET_STAMP_FLUSH(step, wave, lane, 11);
     }
 }
 
