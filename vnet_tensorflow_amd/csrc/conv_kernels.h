@@ -1888,7 +1888,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     unsigned char* tile = smem;
     unsigned char* wbuf = smem + G::TILE_BYTES;                          // two plane buffers
     unsigned char* dump = smem + G::TILE_BYTES + 2 * WBUF + (threadIdx.x & 63) * 16;
-    float* red = reinterpret_cast<float*>(smem + G::TILE_BYTES + 2 * WBUF + 64 * 16);            // [8 waves][2 x 32] epilogue statistics
+    float* red = reinterpret_cast<float*>(smem + G::TILE_BYTES + 2 * WBUF + 64 * 16);            // [8 waves x 2 DPP rows][2 x 32] epilogue statistics
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1999,38 +1999,92 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                 for (int k = 0; k < 4; ++k) s1[g][k] = s2[g][k] = 0.f;
             if constexpr (O16) {
-                // bf16 outputs: the four channel groups of a voxel as one batch (loads of the batch in flight together)
+                // bf16 outputs (round 3).  (1) every load of the epilogue -- bias, the other gradient in accumulate mode, the
+                // residual of the statistics -- is in flight before the first use; (2) the packed results of channel groups
+                // (g, g+1) are exchanged between lanes L and L+32 (v_permlane32_swap), after which a lane holds 8 consecutive
+                // channels of its voxel: 16-byte stores, half as many, each half of a 64-byte run instead of a quarter.
+                // Stamps before: 6 K (plain) / 11 K (statistics + residual) cycles of a 53-57 K cycle step.
                 float bq[4][4];
+                int cg[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int co = co0 + g * 8 + half * 4;
+                    cg[g] = co0 + g * 8 + half * 4;                               // (a whole 32-cout block: always < Cout)
                     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (a.bias && co < a.Cout) bv = make_float4(a.bias[co], a.bias[co + 1], a.bias[co + 2], a.bias[co + 3]);
+                    if (a.bias) bv = make_float4(a.bias[cg[g]], a.bias[cg[g] + 1], a.bias[cg[g] + 2], a.bias[cg[g] + 3]);
                     bq[g][0] = bv.x; bq[g][1] = bv.y; bq[g][2] = bv.z; bq[g][3] = bv.w;
                 }
+                size_t ovm[4]; bool vok[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const int oy = by * TY + vy0 + 2 * m + (q32 >> 4);
-                    const bool vok = oz < a.Do && oy < a.Ho && ox < a.Wo;
-                    const size_t ov = vok ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
-                    size_t ovs[4]; int cos[4]; bool oks[4]; float e[4][4];
+                    vok[m] = oz < a.Do && oy < a.Ho && ox < a.Wo;
+                    ovm[m] = vok[m] ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
+                }
+                // per 16-channel pair of groups: the output tensor it lies in (uniform: y0 / y1 split at a multiple of 16)
+                unsigned short* yb[2]; int ycs[2];
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int c = co0 + pr * 16;
+                    const bool iny0 = c < a.Cy0;
+                    yb[pr] = iny0 ? reinterpret_cast<unsigned short*>(a.y0) + c : reinterpret_cast<unsigned short*>(a.y1) + (c - a.Cy0);
+                    ycs[pr] = iny0 ? a.Cy0 : a.Cy1;
+                }
+                // one register array for the batched loads: the other gradient (accumulate mode) or else the residual; a launch with
+                // both (none in the networks) loads its residual per voxel row below
+                uint2 ld[4][4];
+                const bool res_batched = STATS && a.res && !a.accum;
+                if (a.accum) {
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const unsigned short* sb = a.accsrc ? reinterpret_cast<const unsigned short*>(a.accsrc) + co0 + pr * 16 : yb[pr];
+                        const int scs = a.accsrc ? a.Cy0 : ycs[pr];
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+#pragma unroll
+                            for (int gg = 0; gg < 2; ++gg)
+                                ld[m][2 * pr + gg] = *reinterpret_cast<const uint2*>(sb + ovm[m] * scs + gg * 8 + half * 4);
+                    }
+                }
+                if constexpr (STATS) {
+                    if (res_batched) {
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+                                ld[m][g] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.res) + ovm[m] * a.Cout + cg[g]);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    uint2 pk[4];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int co = co0 + g * 8 + half * 4;
-                        oks[g] = vok && co < a.Cout;
-                        ovs[g] = oks[g] ? ov : 0;
-                        cos[g] = oks[g] ? co : 0;
+                        float e[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) e[g][k] = acc[m][g * 4 + k] + bq[g][k];
-                    }
-                    epilogue_b16_batch<STATS, 4>(a, ovs, cos, oks, e);
-                    if constexpr (STATS) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            if (oks[g]) {
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) { s1[g][k] += e[g][k]; s2[g][k] += e[g][k] * e[g][k]; }
+                        for (int k = 0; k < 4; ++k) e[k] = acc[m][g * 4 + k] + bq[g][k];
+                        if (a.accum) { e[0] += bf_lo(ld[m][g].x); e[1] += bf_hi(ld[m][g].x); e[2] += bf_lo(ld[m][g].y); e[3] += bf_hi(ld[m][g].y); }
+                        pk[g] = make_uint2(pk_bf16(e[0], e[1]), pk_bf16(e[2], e[3]));
+                        if constexpr (STATS) {
+                            float v[4] = {bf_lo(pk[g].x), bf_hi(pk[g].x), bf_lo(pk[g].y), bf_hi(pk[g].y)};
+                            if (a.res) {
+                                const uint2 r = res_batched ? ld[m][g]
+                                    : *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.res) + ovm[m] * a.Cout + cg[g]);
+                                v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
                             }
+                            if (vok[m]) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) { s1[g][k] += v[k]; s2[g][k] += v[k] * v[k]; }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        // lanes L < 32 keep group 2pr and receive lane L+32's part of it (channels +4..7); lanes L+32 receive
+                        // lane L's part of group 2pr+1 and keep their own: 8 consecutive channels each
+                        const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * pr].x, pk[2 * pr + 1].x, false, false);
+                        const auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * pr].y, pk[2 * pr + 1].y, false, false);
+                        const u32x4 o = {sx[0], sy[0], sx[1], sy[1]};
+                        if (vok[m]) *reinterpret_cast<u32x4*>(yb[pr] + ovm[m] * ycs[pr] + half * 8) = o;
                     }
                 }
             }
@@ -2065,11 +2119,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        s1[g][k] = half32_sum(s1[g][k]);
-                        s2[g][k] = half32_sum(s2[g][k]);
-                        if (p32 == 0) {
-                            red[wave * 64 + g * 8 + half * 4 + k] = s1[g][k];
-                            red[wave * 64 + 32 + g * 8 + half * 4 + k] = s2[g][k];
+                        s1[g][k] = row16_sum(s1[g][k]);                  // per DPP row (16 lanes); the two rows of a half meet in LDS
+                        s2[g][k] = row16_sum(s2[g][k]);
+                        if ((lane & 15) == 0) {
+                            red[(wave * 2 + (p32 >> 4)) * 64 + g * 8 + half * 4 + k] = s1[g][k];
+                            red[(wave * 2 + (p32 >> 4)) * 64 + 32 + g * 8 + half * 4 + k] = s2[g][k];
                         }
                     }
             }
@@ -2077,7 +2131,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         VNET_STAMP(7);
         __syncthreads();                               // every wave is done with the tile (and the last filter plane; red is complete)
         VNET_STAMP(8);
-        if constexpr (STATS) if (ch == nch - 1) stats_row_write<8, 32>(red, a.stats, (size_t)brick, cob * 32, a.Cout, tid);
+        if constexpr (STATS) if (ch == nch - 1) stats_row_write<16, 32>(red, a.stats, (size_t)brick, cob * 32, a.Cout, tid);
         if (more) bf16_tile_commit_h<G, XH, 0, XH::PER>(tile, dump, hv, tid);
         VNET_STAMP(9);
         __syncthreads();
@@ -2570,7 +2624,7 @@ bool conv_bf16_use_r32(int Cout, int Cy0, int Cy1, int B, int D, int H, int W) {
     static const int off = getenv("VNET_BF16_R32") ? (atoi(getenv("VNET_BF16_R32")) == 0) : 0;
     if (off) return false;
 #endif
-    if ((Cout & 31) || (Cy0 & 3) || (Cy1 & 3) || W < 16 || H < 16) return false;
+    if ((Cout & 31) || (Cy0 & 15) || (Cy1 & 15) || W < 16 || H < 16) return false;      // (16-channel pairs never straddle y0 / y1)
     return (long)B * ceil_div(D, 4) * ceil_div(H, 16) * ceil_div(W, 16) * (Cout / 32) >= 256;
 }
 
@@ -2667,7 +2721,7 @@ int conv_fwd_bf16_go(ConvArgs& a, const Bf16Plan& p, int nslab, int C0, int C1, 
             // 32-cout blocks, many bricks, bf16 shadows: the row-pair kernel (11 B + 5 A fragments per 20 MFMAs)
             using GR = Bf16Geom<4, 16, 16>;
             a.nbz = ceil_div(D, 4); a.nby = ceil_div(H, 16); a.nbx = ceil_div(W, 16);
-            const size_t lds = (size_t)GR::TILE_BYTES + 2 * (25 * 1024 + 16) + 64 * 16 + 8 * 64 * 4;
+            const size_t lds = (size_t)GR::TILE_BYTES + 2 * (25 * 1024 + 16) + 64 * 16 + 16 * 64 * 4;
             if (a.stats) {
                 auto k = conv5_bf16_r32_kernel<true, O16>;
                 static unsigned long long attr_done = 0;
