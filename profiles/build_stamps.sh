@@ -5,10 +5,10 @@ set -e
 cd "$(dirname "$0")/.."
 T=$(mktemp -d)
 for f in conv_mfma conv_b16 conv2_b16 elementwise input_block; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-result -DVNET_STAMPS $EXTRA \
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-result ${DEFS:--DVNET_STAMPS} $EXTRA \
       -Iinclude -c vnet_tensorflow_amd/csrc/$f.hip -o $T/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $T/*.o -o profiles/probes/libvnet_hip_stamps.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $T/*.o -o profiles/probes/${OUT:-libvnet_hip_stamps.so}
 rm -rf $T
-ls -la profiles/probes/libvnet_hip_stamps.so
+ls -la profiles/probes/${OUT:-libvnet_hip_stamps.so}

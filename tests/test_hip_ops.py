@@ -214,6 +214,32 @@ def test_bn_act_random_cases(dev):
     run()
 
 
+@pytest.mark.parametrize("C", [10, 37, 300, 1021])
+def test_bn_stats_generic_path_is_deterministic(dev, C):
+    """Channel counts that are neither a multiple of 4 nor <= 8 take the generic statistics kernel (thread = (row group, channel)
+    for C <= 256, one row per block pass above): right against fp64, and bit-identical from launch to launch (it used LDS float
+    atomics before round 3)."""
+    from vnet_tensorflow_amd import _lib, ops
+    L = _lib.lib()
+    rng = np.random.default_rng(C)
+    M = 5000
+    x = (rng.standard_normal((M, C)) * 2.0 + 0.5).astype(np.float32)
+    tx = torch.from_numpy(x).to(dev)
+    nb = L.vnet_bn_ws_bytes(C)
+    outs = []
+    for _ in range(3):
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        mean, invstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        rc = L.vnet_bn_stats(ops._ptr(tx), None, 0, M, C, 1e-3, 0.99, ops._ptr(mean), ops._ptr(invstd), None, None, ops._ptr(ws), nb, ops._stream())
+        assert rc == 0
+        outs.append((mean.cpu().numpy().copy(), invstd.cpu().numpy().copy()))
+    x64 = x.astype(np.float64)
+    np.testing.assert_allclose(outs[0][0], x64.mean(0), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(outs[0][1], 1.0 / np.sqrt(x64.var(0) + 1e-3), rtol=5e-6)
+    for m, i in outs[1:]:
+        assert np.array_equal(m, outs[0][0]) and np.array_equal(i, outs[0][1])
+
+
 def _bn_act_case(dev, C, act, res, tile, shp, seed):
     from vnet_tensorflow_amd import ops
     rng = np.random.default_rng(seed)

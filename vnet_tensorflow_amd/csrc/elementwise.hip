@@ -117,20 +117,54 @@ __global__ void __launch_bounds__(EW_BLOCK) bn_stats_row_kernel(const float* __r
     block_reduce_row<2, 8>(acc, C, partial + (size_t)blockIdx.x * 2 * C);
 }
 
+// any channel count up to MAXC (the V-Net widths never come here): thread = (row group, channel), coalesced along the channels,
+// the row groups of a block meet in LDS in a fixed order -- deterministic like the other statistics kernels (round 3; this
+// fallback used LDS float atomics before)
 __global__ void __launch_bounds__(EW_BLOCK) bn_stats_generic_kernel(const float* __restrict__ x, const float* __restrict__ r,
                                                                     size_t n, int C, float* __restrict__ partial) {
-    __shared__ float sh[2 * MAXC];
-    for (int c = threadIdx.x; c < 2 * C; c += EW_BLOCK) sh[c] = 0.f;
-    __syncthreads();
-    const size_t stride = (size_t)gridDim.x * EW_BLOCK;
-    for (size_t idx = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x; idx < n; idx += stride) {
-        float v = x[idx];
-        if (r) v += r[idx];
-        const int c = (int)(idx % C);
-        atomicAdd(&sh[c], v); atomicAdd(&sh[C + c], v * v);
+    __shared__ float sh[2][EW_BLOCK];
+    const size_t M = n / C;
+    if (C > EW_BLOCK) {                                      // wide rows: one row per block pass, up to MAXC / EW_BLOCK columns per thread
+        constexpr int NCOL = MAXC / EW_BLOCK;
+        float s[NCOL], q[NCOL];
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) s[j] = q[j] = 0.f;
+        for (size_t row = blockIdx.x; row < M; row += gridDim.x) {
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) {
+                const int c = threadIdx.x + j * EW_BLOCK;
+                if (c < C) {
+                    float v = x[row * C + c];
+                    if (r) v += r[row * C + c];
+                    s[j] += v; q[j] += v * v;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) {
+            const int c = threadIdx.x + j * EW_BLOCK;
+            if (c < C) { partial[(size_t)blockIdx.x * 2 * C + c] = s[j]; partial[(size_t)blockIdx.x * 2 * C + C + c] = q[j]; }
+        }
+        return;
     }
+    const int G = EW_BLOCK / C;                              // row groups per block
+    const int rg = threadIdx.x / C, c = threadIdx.x - rg * C;
+    float s = 0.f, q = 0.f;
+    if (rg < G) {
+        for (size_t row = (size_t)blockIdx.x * G + rg; row < M; row += (size_t)gridDim.x * G) {
+            float v = x[row * C + c];
+            if (r) v += r[row * C + c];
+            s += v; q += v * v;
+        }
+    }
+    sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = q;
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * C; c += EW_BLOCK) partial[(size_t)blockIdx.x * 2 * C + c] = sh[c];
+    if (threadIdx.x < C) {
+        float ts = 0.f, tq = 0.f;
+        for (int g = 0; g < G; ++g) { ts += sh[0][g * C + threadIdx.x]; tq += sh[1][g * C + threadIdx.x]; }
+        partial[(size_t)blockIdx.x * 2 * C + threadIdx.x] = ts;
+        partial[(size_t)blockIdx.x * 2 * C + C + threadIdx.x] = tq;
+    }
 }
 
 // ---- finalize kernels: one workgroup per output column sums <= EW_MAXBLK partial rows in float64 ----
