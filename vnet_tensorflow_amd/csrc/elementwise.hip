@@ -1283,32 +1283,76 @@ __global__ void __launch_bounds__(EW_BLOCK) head_bwd_b16_kernel(const u32x4* __r
     const int CO = C >> 3;
     const size_t n8 = M * CO, stride = (size_t)gridDim.x * EW_BLOCK, start = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x;
     const int co = (int)(start % CO), c0 = co * 8;
-    float aw[8][K], ab[K];
+    float aw[8][K], ab[K], wr[8][K];             // wr: this thread's 8 x K weights (its channel octet never changes) in registers
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         ab[k] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) aw[j][k] = 0.f;
+        for (int j = 0; j < 8; ++j) { aw[j][k] = 0.f; wr[j][k] = ws[(c0 + j) * K + k]; }
     }
-    for (size_t idx = start; idx < n8; idx += stride) {
-        const size_t row = idx / CO;
-        float v[8], g[K], o[8];
-        unpack8(x[idx], v);
+    // two rows per iteration, their loads issued together (one 16-byte + K 4-byte loads per row: with a single row in flight per
+    // thread the pass ran at 2.8 TB/s)
+    for (size_t idx = start; idx < n8; idx += 2 * stride) {
+        const size_t idx1 = idx + stride;
+        const bool ok1 = idx1 < n8;
+        const size_t i1 = ok1 ? idx1 : idx;
+        const size_t row0 = idx / CO, row1 = i1 / CO;
+        const u32x4 q0 = x[idx], q1 = x[i1];
+        float g[2][K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) g[k] = dy[row * K + k];
+        for (int k = 0; k < K; ++k) { g[0][k] = dy[row0 * K + k]; g[1][k] = dy[row1 * K + k]; }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            o[j] = 0.f;
+        for (int u = 0; u < 2; ++u) {
+            float v[8], o[8];
+            unpack8(u == 0 ? q0 : q1, v);
+            if (u == 1 && !ok1) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) { o[j] += g[k] * ws[(c0 + j) * K + k]; aw[j][k] += v[j] * g[k]; }
+                for (int k = 0; k < K; ++k) g[1][k] = 0.f;            // dy = 0 adds nothing to dw / db
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o[j] = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) { o[j] += g[u][k] * wr[j][k]; aw[j][k] += v[j] * g[u][k]; }
+            }
+            if (co == 0) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) ab[k] += g[u][k];
+            }
+            if (dx && (u == 0 || ok1)) dx[u == 0 ? idx : idx1] = pack8(o);
         }
-        if (co == 0) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) ab[k] += g[k];
-        }
-        if (dx) dx[idx] = pack8(o);
     }
     float* prow = partial + (size_t)blockIdx.x * (C * K + K);
+    if (CO <= 4) {
+        // 9K sums per thread, threads of one channel octet are tid = co (mod CO): DPP steps that keep lane mod CO (xor 1, xor 2,
+        // row_ror 4, row_ror 8) give the totals of each 16-lane row, the 16 rows of the block meet in LDS in a fixed order.
+        // (The tree below, one block-wide reduction with ~9 barriers per sum, was 405 barriers = ~18 us of tail in a 63 us kernel.)
+        __shared__ float rs[16][9 * K * 4];
+        const int lr = threadIdx.x & 15, rg = threadIdx.x >> 4;
+#pragma unroll
+        for (int s = 0; s < 9 * K; ++s) {
+            const int j = s / K, k = s % K;
+            float t = ab[k];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) if (j == jj) t = aw[jj][k];
+            if (CO <= 1) t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xf, 0xf, true));
+            if (CO <= 2) t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xf, 0xf, true));
+            t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x124, 0xf, 0xf, true));
+            t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x128, 0xf, 0xf, true));
+            if (lr < CO) rs[rg][s * CO + lr] = t;
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < 9 * K * CO; o += EW_BLOCK) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) t += rs[g][o];
+            const int sI = o / CO, c = o - sI * CO, j = sI / K, k = sI - j * K;
+            if (j < 8) prow[(c * 8 + j) * K + k] = t;
+            else if (c == 0) prow[C * K + k] = t;
+        }
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < 9 * K; ++s) {
         const int j = s / K, k = s % K;
