@@ -143,7 +143,14 @@ static std::map<std::string, Var> load_weights(const std::string& path) {
 }
 
 // ---- the network (forward only), wired on the C ABI ----------------------------------------------------------------
-struct Tensor { float* p; void* h /* bf16 shadow behind the fp32 data (bf16 mode, vnet_hip.h *_x16) or null */; int B, D, H, W, C; size_t numel() const { return (size_t)B * D * H * W * C; } int64_t rows() const { return (int64_t)B * D * H * W; } };
+struct Tensor {
+    float* p;        // fp32 data (null for a bf16-storage tensor)
+    void* h;         // bf16 shadow behind the fp32 data (--compute bf16_operands, vnet_hip.h *_x16) or null
+    int B, D, H, W, C;
+    void* q = nullptr;   // bf16 data (--compute bf16: bf16 tensors end to end, vnet_hip.h *_b16)
+    size_t numel() const { return (size_t)B * D * H * W * C; }
+    int64_t rows() const { return (int64_t)B * D * H * W; }
+};
 
 struct Config {
     int classes = 2, channels = 16, levels = 4, bottom = 3, batch = 1;
@@ -151,7 +158,8 @@ struct Config {
     int patch[3] = {64, 64, 64}, stride[3] = {64, 64, 64};
     std::string weights, image, label_out, prob_out;
     bool normalise = true;
-    bool bf16 = false;       // --compute bf16: bf16 operands / fp32 accumulation in the 5^3 convolutions (BASELINE config C5)
+    bool bf16 = false;       // --compute bf16_operands: bf16 operands / fp32 accumulation in the 5^3 convolutions, fp32 tensors + bf16 shadows
+    bool store16 = false;    // --compute bf16: every activation is a bf16 tensor (BASELINE config C5 as the Python path runs it)
 };
 
 class VNetForward {
@@ -168,7 +176,11 @@ public:
         Tensor x = images;
         scope_ = {"vnet/input_layer"};
         if (images.C == 1) x = bn(x, 0, nullptr, true);
-        else { x = conv(x, nullptr, 5, 1, cfg.channels); x = bn(x, VNET_ACT_PRELU, nullptr, false); }
+        else {
+            if (cfg.store16) x = cast16(x);       // bf16, channels zero-padded to the 16-byte unit (ops.cast_input)
+            x = conv(x, nullptr, 5, 1, cfg.channels, images.C);
+            x = bn(x, VNET_ACT_PRELU, nullptr, false);
+        }
         std::vector<Tensor> feats;
         for (int l = 0; l < cfg.levels; ++l) {
             scope_ = {"vnet/encoder/level_" + std::to_string(l + 1)};
@@ -219,6 +231,19 @@ private:
         if (shadow) t.h = (char*)t.p + t.numel() * 4;
         return t;
     }
+    Tensor alloc16(int B, int D, int H, int W, int C) {
+        Tensor t{nullptr, nullptr, B, D, H, W, C};
+        size_t bytes = (t.numel() * 2 + 255) / 256 * 256;
+        if (top_ + bytes > arena_bytes_) { std::fprintf(stderr, "activation arena too small\n"); std::exit(1); }
+        t.q = arena_ + top_; top_ += bytes;
+        return t;
+    }
+    Tensor cast16(const Tensor& x) {
+        const int Cp = (x.C + 7) / 8 * 8;
+        Tensor y = alloc16(x.B, x.D, x.H, x.W, Cp);
+        ABI_OK(vnet_cast_bf16(x.p, y.q, x.rows(), x.C, Cp, st_));
+        return y;
+    }
     float* pack(const std::string& wname, int mode, int taps, int I, int O) {
         const std::string key = wname + "#" + std::to_string(mode);
         auto it = packed_.find(key);
@@ -234,10 +259,20 @@ private:
         const std::string name = sc + "/batch_normalization" + (n ? "_" + std::to_string(n) : "");
         Var& g = var(name + "/gamma"); Var& b = var(name + "/beta");
         const int C = (int)g.n;
-        Tensor y = alloc(x.B, x.D, x.H, x.W, C, true);
         float* mean = stat_; float* invstd = stat_ + 1024;
-        ABI_OK(vnet_bn_stats(x.p, res ? res->p : nullptr, tile ? 1 : 0, x.rows(), C, 1e-3f, 0.99f, mean, invstd, nullptr, nullptr, ws_, ws_bytes_, st_));
         const float* alpha = act == VNET_ACT_PRELU ? var(sc + "/alpha").dev : nullptr;
+        if (cfg.store16 && (x.q || tile)) {
+            // bf16 storage: statistics of the bf16 tensor (+ bf16 residual) -- or of the fp32 1-channel image that is tiled -- in fp32,
+            // one rounding of the normalised / activated value
+            Tensor y = alloc16(x.B, x.D, x.H, x.W, C);
+            if (tile) ABI_OK(vnet_bn_stats(x.p, nullptr, 1, x.rows(), C, 1e-3f, 0.99f, mean, invstd, nullptr, nullptr, ws_, ws_bytes_, st_));
+            else ABI_OK(vnet_bn_stats_b16(x.q, res ? res->q : nullptr, x.rows(), C, 1e-3f, 0.99f, mean, invstd, nullptr, nullptr, ws_, ws_bytes_, st_));
+            ABI_OK(vnet_bn_act_fwd_b16(tile ? (const void*)x.p : x.q, res ? res->q : nullptr, tile ? 1 : 0, x.rows(), C, mean, invstd, g.dev, b.dev,
+                                       act, alpha, y.q, st_));
+            return y;
+        }
+        Tensor y = alloc(x.B, x.D, x.H, x.W, C, true);
+        ABI_OK(vnet_bn_stats(x.p, res ? res->p : nullptr, tile ? 1 : 0, x.rows(), C, 1e-3f, 0.99f, mean, invstd, nullptr, nullptr, ws_, ws_bytes_, st_));
         ABI_OK(vnet_bn_act_fwd_x16(x.p, res ? res->p : nullptr, tile ? 1 : 0, x.rows(), C, mean, invstd, g.dev, b.dev, act, alpha, y.p, y.h, st_));
         return y;
     }
@@ -254,18 +289,44 @@ private:
             Var& g = var(name + "/gamma"); Var& b = var(name + "/beta");
             gp[k] = g.dev; bp[k] = b.dev; C = (int)g.n;
         }
-        Tensor y = alloc(x.B, x.D, x.H, x.W, C, true);
         float* mean = stat_; float* invstd = stat_ + 1024; float* ceff = stat_ + 2048; float* deff = stat_ + 3072;
+        if (x.q) {
+            Tensor y = alloc16(x.B, x.D, x.H, x.W, C);
+            ABI_OK(vnet_bn_stats_b16(x.q, nullptr, x.rows(), C, 1e-3f, 0.99f, mean, invstd, nullptr, nullptr, ws_, ws_bytes_, st_));
+            ABI_OK(vnet_bn_chain_coef_fwd(kind, C, 1e-3f, 0.99f, mean, invstd, gp[0], bp[0], gp[1], bp[1], gp[2], bp[2], ceff, deff,
+                                          nullptr, nullptr, nullptr, nullptr, st_));
+            ABI_OK(vnet_bn_act_fwd_b16(x.q, nullptr, 0, x.rows(), C, mean, invstd, ceff, deff, VNET_ACT_PRELU, var(sc + "/alpha").dev, y.q, st_));
+            return y;
+        }
+        Tensor y = alloc(x.B, x.D, x.H, x.W, C, true);
         ABI_OK(vnet_bn_stats(x.p, nullptr, 0, x.rows(), C, 1e-3f, 0.99f, mean, invstd, nullptr, nullptr, ws_, ws_bytes_, st_));
         ABI_OK(vnet_bn_chain_coef_fwd(kind, C, 1e-3f, 0.99f, mean, invstd, gp[0], bp[0], gp[1], bp[1], gp[2], bp[2], ceff, deff,
                                       nullptr, nullptr, nullptr, nullptr, st_));
         ABI_OK(vnet_bn_act_fwd_x16(x.p, nullptr, 0, x.rows(), C, mean, invstd, ceff, deff, VNET_ACT_PRELU, var(sc + "/alpha").dev, y.p, y.h, st_));
         return y;
     }
-    Tensor conv(const Tensor& x0, const Tensor* x1, int ks, int stride, int Cout) {
+    // Cin_w: input channels of the FILTER when the tensor carries zero-padded channels (the cast 4-modality input), else 0
+    Tensor conv(const Tensor& x0, const Tensor* x1, int ks, int stride, int Cout, int Cin_w = 0) {
         const std::string sc = scope();
         const int Cin = x0.C + (x1 ? x1->C : 0);
         const int Do = (x0.D + stride - 1) / stride, Ho = (x0.H + stride - 1) / stride, Wo = (x0.W + stride - 1) / stride;
+        if (x0.q) {
+            Tensor y = alloc16(x0.B, Do, Ho, Wo, Cout);
+            if (ks == 5 && stride == 1) {
+                float* wpb = pack(sc + "/weights", VNET_PACK_FWD_BF16, 125, Cin_w ? Cin_w : Cin, Cout);
+                if (vnet_conv_bf16_ws_bytes(Cin, Cout, x0.B, Do, Ho, Wo) > ws_bytes_) { std::fprintf(stderr, "workspace too small\n"); std::exit(1); }
+                ABI_OK(vnet_conv_fwd_b16(x0.q, x0.C, x1 ? x1->q : nullptr, x1 ? x1->C : 0, wpb, var(sc + "/biases").dev, y.q, Cout, nullptr, 0,
+                                         x0.B, x0.D, x0.H, x0.W, nullptr, nullptr, nullptr, ws_, ws_bytes_, st_));
+            } else if (vnet_conv2_direct_ok(Cin, Cout)) {     // 2^3 stride-2 at levels 1-2: LDS-free kernel on the unpacked filter
+                ABI_OK(vnet_conv2_direct_b16(1, x0.q, y.q, var(sc + "/weights").dev, var(sc + "/biases").dev, Cin, Cout, x0.B, x0.D, x0.H, x0.W,
+                                             Do, Ho, Wo, 0, nullptr, st_));
+            } else {
+                float* wp = pack(sc + "/weights", VNET_PACK_FWD | VNET_PACK_ROUND_BF16, 8, Cin, Cout);
+                ABI_OK(vnet_conv2_fwd_b16(0, x0.q, Cin, wp, var(sc + "/biases").dev, y.q, Cout, x0.B, x0.D, x0.H, x0.W, Do, Ho, Wo, 0, nullptr,
+                                          ws_, ws_bytes_, st_));
+            }
+            return y;
+        }
         Tensor y = alloc(x0.B, Do, Ho, Wo, Cout);
         if (cfg.bf16 && ks == 5 && stride == 1) {
             float* wpb = pack(sc + "/weights", VNET_PACK_FWD_BF16, 125, Cin, Cout);
@@ -288,6 +349,18 @@ private:
     Tensor upconv(const Tensor& x, const Tensor& like) {
         const std::string sc = scope();
         const int Cout = x.C / 2;
+        if (x.q) {
+            Tensor y = alloc16(x.B, like.D, like.H, like.W, Cout);
+            if (vnet_conv2_direct_ok(Cout, x.C)) {
+                ABI_OK(vnet_conv2_direct_b16(0, x.q, y.q, var(sc + "/weights").dev, var(sc + "/biases").dev, Cout, x.C, x.B, like.D, like.H, like.W,
+                                             x.D, x.H, x.W, 0, nullptr, st_));
+            } else {
+                float* wp = pack(sc + "/weights", VNET_PACK_UP | VNET_PACK_ROUND_BF16, 8, x.C, Cout);
+                ABI_OK(vnet_conv2_fwd_b16(1, x.q, x.C, wp, var(sc + "/biases").dev, y.q, Cout, x.B, x.D, x.H, x.W, like.D, like.H, like.W, 0, nullptr,
+                                          ws_, ws_bytes_, st_));
+            }
+            return y;
+        }
         Tensor y = alloc(x.B, like.D, like.H, like.W, Cout);
         float* wp = pack(sc + "/weights", VNET_PACK_UP, 8, x.C, Cout);
         ABI_OK(vnet_conv_fwd(2, 0, 2, 1, x.p, x.C, nullptr, 0, wp, var(sc + "/biases").dev, y.p, Cout, nullptr, 0,
@@ -297,7 +370,8 @@ private:
     Tensor head(const Tensor& x) {
         const std::string sc = scope();
         Tensor y = alloc(x.B, x.D, x.H, x.W, cfg.classes);
-        ABI_OK(vnet_head_fwd(x.p, var(sc + "/weights").dev, var(sc + "/biases").dev, y.p, x.rows(), x.C, cfg.classes, st_));
+        if (x.q) ABI_OK(vnet_head_fwd_b16(x.q, var(sc + "/weights").dev, var(sc + "/biases").dev, y.p, x.rows(), x.C, cfg.classes, st_));
+        else ABI_OK(vnet_head_fwd(x.p, var(sc + "/weights").dev, var(sc + "/biases").dev, y.p, x.rows(), x.C, cfg.classes, st_));
         return y;
     }
     Tensor softmax(const Tensor& logits) {
@@ -364,12 +438,20 @@ static Config parse(int argc, char** argv) {
         else if (a == "--patch") { auto v = ints(next()); for (int k = 0; k < 3; ++k) c.patch[k] = v[k]; }
         else if (a == "--stride") { auto v = ints(next()); for (int k = 0; k < 3; ++k) c.stride[k] = v[k]; }
         else if (a == "--no-normalise") c.normalise = false;
-        else if (a == "--compute") { const std::string v = next(); if (v != "fp32" && v != "bf16") { std::fprintf(stderr, "--compute fp32|bf16\n"); std::exit(1); } c.bf16 = (v == "bf16"); }
+        else if (a == "--compute") {
+            const std::string v = next();
+            if (v != "fp32" && v != "bf16" && v != "bf16_operands") { std::fprintf(stderr, "--compute fp32|bf16|bf16_operands\n"); std::exit(1); }
+            c.bf16 = (v == "bf16_operands"); c.store16 = (v == "bf16");
+        }
         else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); std::exit(1); }
+    }
+    if (c.store16 && (c.channels < 8 || (c.channels & (c.channels - 1)))) {
+        std::fprintf(stderr, "--compute bf16 needs --channels 8 * 2^k (16-byte units of bf16 channels); use bf16_operands or fp32\n");
+        std::exit(1);
     }
     if (c.weights.empty() || c.image.empty() || c.label_out.empty() || (int)c.convs.size() != c.levels) {
         std::fprintf(stderr, "usage: vnet_infer --weights W --image I.npy --label-out L.npy [--prob-out P.npy] --classes K --channels C "
-                             "--levels L --convs a,b,.. --bottom n --patch x,y,z --stride x,y,z --batch b [--compute fp32|bf16]\n");
+                             "--levels L --convs a,b,.. --bottom n --patch x,y,z --stride x,y,z --batch b [--compute fp32|bf16|bf16_operands]\n");
         std::exit(1);
     }
     return c;
@@ -480,6 +562,6 @@ int main(int argc, char** argv) {
     std::printf("vnet_infer: %zu batches (%zu patches of %dx%dx%d), %dx%dx%d volume, %d classes -> %s\n", batches.size(), npatch,
                 P0, P1, P2, X, Y, Z, K, cfg.label_out.c_str());
     std::printf("vnet_infer: sliding window %.3f s = %.1f patches/s (crop + H2D + forward + accumulate, %s)\n", secs, npatch / secs,
-                cfg.bf16 ? "bf16 compute" : "fp32");
+                cfg.store16 ? "bf16 storage" : cfg.bf16 ? "bf16 operands" : "fp32");
     return 0;
 }
