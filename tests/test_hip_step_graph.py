@@ -161,12 +161,14 @@ def _dp_worker(rank, world, port, out, mode):
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     np.random.seed(7)
-    m = image2label(None, _cfg(), device=dev, verbose=False)
+    import json
+    kw = json.loads(os.environ.get("VNET_TEST_DP_CFG", "{}"))
+    m = image2label(None, _cfg(**kw), device=dev, verbose=False)
     m.read_config()
     m.build_model_graph()
     m._setup_training()
     assert m.sync is not None and m.sync.active and len(m.sync.buckets) >= 3
-    x, l = synthetic_batch(2, 16, 1, 2, seed=40)
+    x, l = synthetic_batch(2, 16, kw.get("cin", 1), kw.get("K", 2), seed=40)
     x, l = torch.from_numpy(x).to(dev), torch.from_numpy(l).to(dev)
     losses = [float(m.train_step(x, l)) for _ in range(5)]
     torch.cuda.synchronize()
@@ -207,6 +209,24 @@ def test_data_parallel_segmented_graph_rccl_group_of_one(tmp_path, dev):
         b = torch.load(tmp_path / ("dp_%s.pt" % md))
         assert a["losses"] == b["losses"], md
         assert torch.equal(a["data"], b["data"]), md
+
+
+def test_data_parallel_segmented_graph_bf16_storage(tmp_path, dev, monkeypatch):
+    """The same with bf16 tensors end to end (BASELINE config C5's per-GPU arithmetic): graph replay == eager enqueue and
+    segmented == serial bit for bit; the two-pass backward differs from the one-pass form only in where the second gradient of a
+    cut tensor is rounded (sum of two bf16 tensors instead of one rounding of bf16 + fp32 accumulator), i.e. by bf16 round-off."""
+    monkeypatch.setenv("VNET_TEST_DP_CFG", '{"opt": "SGD", "compute": "bf16", "cin": 4, "K": 5}')
+    modes = ("eager1p", "segmented1p", "eager", "segmented", "serial")
+    for md in modes:
+        mp.spawn(_dp_worker, args=(1, _free_port(), str(tmp_path), md), nprocs=1, join=True)
+    r = {md: torch.load(tmp_path / ("dp_%s.pt" % md)) for md in modes}
+    for a, b in (("eager1p", "segmented1p"), ("eager", "segmented"), ("segmented", "serial")):
+        assert r[a]["losses"] == r[b]["losses"], (a, b)
+        assert torch.equal(r[a]["data"], r[b]["data"]), (a, b)
+    l1, l2 = np.array(r["eager1p"]["losses"]), np.array(r["eager"]["losses"])
+    assert np.all(np.isfinite(l1)) and np.all(np.isfinite(l2)) and np.abs(l1 - l2).max() < 2e-2 * np.abs(l1).max(), (l1, l2)
+    d = (r["eager1p"]["data"] - r["eager"]["data"]).norm() / r["eager"]["data"].norm()
+    assert float(d) < 2e-2, float(d)
 
 
 def test_refused_capture_falls_back_to_eager_steps(dev, monkeypatch):
