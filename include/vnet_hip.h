@@ -427,6 +427,19 @@ int vnet_bn_act_bwd_apply_b16(const void* dy16, const void* x, const void* r16, 
                               const float* mean, const float* invstd, const float* gamma, const float* beta,
                               int act, const float* alpha, const float* sum_dz, const float* sum_dz_xhat, double M_total,
                               const float* xhat_coef, void* ds16, void* stream);
+/* Small tensors (M <= 8192 rows: the 16^3 / 8^3 levels): the whole batch-norm of a layer in ONE launch per direction -- one
+ * workgroup per channel octet reads its column twice, so no partial rows, no finalize launch (replaces, per layer,
+ * vnet_conv_*_stats rows + vnet_bn_finalize_partial + vnet_bn_act_fwd_b16, and vnet_bn_act_bwd_reduce_b16 + its finalize +
+ * vnet_bn_act_bwd_apply_b16; networks.py:316-321 and its autodiff at the deep levels).  Per-replica statistics only.
+ * fwd: statistics of x (+ r16), mean / invstd written (+ moving averages updated), y = act(BN(x + r)).
+ * bwd: dgamma / dbeta / dalpha written, ds16 (NULL to skip) = gradient w.r.t. s = x + r. */
+int vnet_bn_small_ok(int64_t M, int C);
+int vnet_bn_small_fwd_b16(const void* x16, const void* r16, int64_t M, int C, float eps, float momentum,
+                          const float* gamma, const float* beta, int act, const float* alpha,
+                          float* mean, float* invstd, float* moving_mean, float* moving_var, void* y16, void* stream);
+int vnet_bn_small_bwd_b16(const void* dy16, const void* x16, const void* r16, int64_t M, int C,
+                          const float* mean, const float* invstd, const float* gamma, const float* beta, int act, const float* alpha,
+                          float* dgamma, float* dbeta, float* dalpha, void* ds16, void* stream);
 /* 1x1x1 output head: bf16 activations in, fp32 logits out (K <= 8); backward: fp32 dy, bf16 dx (NULL to skip), fp32 dw / db */
 int vnet_head_fwd_b16(const void* x16, const float* w, const float* bias, float* y, int64_t M, int C, int K, void* stream);
 int vnet_head_bwd_b16(const void* x16, const float* w, const float* dy, void* dx16, float* dw, float* db,

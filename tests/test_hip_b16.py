@@ -224,9 +224,17 @@ def _bn_reference(x, r, gamma, beta, act, alpha, dy):
 
 @pytest.mark.parametrize("M,C,act,res", [((2, 6, 7, 9), 16, "prelu", True), ((1, 8, 8, 8), 32, "relu", False),
                                          ((1, 4, 4, 4), 256, "prelu", True), ((1, 5, 3, 7), 8, None, False),
-                                         ((1, 32, 32, 32), 16, "prelu", False)])
-def test_bn_act_b16(dev, M, C, act, res):
+                                         ((1, 32, 32, 32), 16, "prelu", False), ((1, 16, 16, 16), 128, "prelu", True),
+                                         ((2, 16, 16, 16), 64, "relu", False)])
+@pytest.mark.parametrize("small", [True, False])
+def test_bn_act_b16(dev, M, C, act, res, small, monkeypatch):
+    """small: tensors of <= 8192 rows take the one-launch-per-direction kernels (vnet_bn_small_*_b16); False: the streaming kernels
+    (statistics / finalize / normalise, reduce / finalize / apply) everywhere."""
     from vnet_tensorflow_amd import ops
+    monkeypatch.setitem(ops._SMALL_BN, "on", small)
+    monkeypatch.setitem(ops._SMALL_BN, "rows", 8192)          # (default 512: only where it measured faster)
+    if small and int(np.prod(M)) > 8192:
+        pytest.skip("more rows than the small-tensor kernels take")
     rng = np.random.default_rng(C + len(M))
     shape = M + (C,)
     x = rb(rng.standard_normal(shape) * 2 + 0.5)

@@ -106,6 +106,9 @@ SIGNATURES = {
     "vnet_bn_act_fwd_b16": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "vnet_bn_act_bwd_reduce_b16": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vnet_bn_act_bwd_apply_b16": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp, _vp]),
+    "vnet_bn_small_ok": (_i, [_i64, _i]),
+    "vnet_bn_small_fwd_b16": (_i, [_vp, _vp, _i64, _i, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vnet_bn_small_bwd_b16": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vnet_head_fwd_b16": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
     "vnet_head_bwd_b16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _sz, _vp]),
     "vnet_dropout_fwd_b16": (_i, [_vp, _vp, _vp, _i64, _f, _u64, _vp, _vp]),

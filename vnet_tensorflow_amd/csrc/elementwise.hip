@@ -1231,6 +1231,210 @@ __global__ void __launch_bounds__(EW_BLOCK) bn_act_bwd_apply_b16_kernel(BnP16 p)
     }
 }
 
+// ---- small tensors (deep levels: 16^3 x 128, 8^3 x 256 ...): the whole batch-norm of a layer in ONE launch per direction (round 3).
+// At <= 1 M elements the streaming kernels above are launch-bound -- conv-epilogue rows -> bn_finalize -> bn_act_fwd, and
+// bwd_reduce -> sum_finalize -> bwd_apply, are 5 launches of 4.5-6 us each with nothing to stream.  Here one workgroup owns one
+// channel OCTET (C / 8 workgroups): it reads its column twice (the second time from L2), so the statistics / gradient sums never
+// leave the workgroup: no partial rows, no finalize launch, no cross-workgroup dependency.
+__device__ __forceinline__ float dpp_row16_sum(float v) {          // sum over the 16 lanes of a DPP row, every lane gets it
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    return v;
+}
+// NV per-thread floats -> block totals in double (all 256 threads contribute; result valid in threads 0..NV-1)
+template <int NV>
+__device__ __forceinline__ double block_total_d(const float (&v)[NV], float (*rows)[NV]) {
+    const int lr = threadIdx.x & 15, rg = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float t = dpp_row16_sum(v[i]);
+        if (lr == 0) rows[rg][i] = t;
+    }
+    __syncthreads();
+    double tot = 0.0;
+    if (threadIdx.x < NV) {
+#pragma unroll
+        for (int g = 0; g < EW_BLOCK / 16; ++g) tot += (double)rows[g][threadIdx.x];
+    }
+    return tot;
+}
+
+struct BnSmall {
+    const u32x4* x; const u32x4* r; const u32x4* dy; u32x4* out;
+    const float* gamma; const float* beta; const float* alpha;
+    float* mean; float* invstd; float* mm; float* mv;            // forward: written; backward: read
+    float* dgamma; float* dbeta; float* dalpha;
+    int M, C, act; float eps, momentum;
+};
+
+template <bool HASR>
+__global__ void __launch_bounds__(EW_BLOCK) bn_small_fwd_b16_kernel(BnSmall p) {
+    __shared__ float rows[EW_BLOCK / 16][16];
+    __shared__ float coef[4][8];                                  // sc, sf, neg, zer of this octet
+    const int CO = p.C >> 3, co = blockIdx.x, c0 = co * 8, tid = threadIdx.x;
+    float a[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = 0.f;
+    for (int m = tid; m < p.M; m += 4 * EW_BLOCK) {
+        u32x4 qx[4], qr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int mm_ = m + u * EW_BLOCK;
+            const size_t j = (size_t)(mm_ < p.M ? mm_ : m) * CO + co;
+            qx[u] = p.x[j];
+            if (HASR) qr[u] = p.r[j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (m + u * EW_BLOCK >= p.M) break;
+            float v[8];
+            unpack8(qx[u], v);
+            if (HASR) { float t[8]; unpack8(qr[u], t);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += t[k]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { a[k] += v[k]; a[8 + k] += v[k] * v[k]; }
+        }
+    }
+    const double tot = block_total_d<16>(a, rows);
+    __shared__ double tots[16];
+    if (tid < 16) tots[tid] = tot;
+    __syncthreads();
+    if (tid < 8) {
+        const int c = c0 + tid;
+        const double mu = tots[tid] / (double)p.M;
+        double var = tots[8 + tid] / (double)p.M - mu * mu;
+        var = var > 0.0 ? var : 0.0;
+        const float is = (float)(1.0 / sqrt(var + (double)p.eps));
+        p.mean[c] = (float)mu; p.invstd[c] = is;
+        if (p.mm) p.mm[c] = p.mm[c] - (p.mm[c] - (float)mu) * (1.f - p.momentum);
+        if (p.mv) p.mv[c] = p.mv[c] - (p.mv[c] - (float)var) * (1.f - p.momentum);
+        const float sc = p.gamma[c] * is;
+        coef[0][tid] = sc; coef[1][tid] = p.beta[c] - (float)mu * sc;
+        const bool prelu = p.act == VNET_ACT_PRELU;
+        coef[2][tid] = prelu ? p.alpha[c] : (p.act == VNET_ACT_RELU ? 0.f : (p.act == VNET_ACT_LRELU ? 0.2f : 1.f));
+        coef[3][tid] = 0.f;
+    }
+    __syncthreads();
+    float sc[8], sf[8], neg[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = coef[0][k]; sf[k] = coef[1][k]; neg[k] = coef[2][k]; }
+    for (int m = tid; m < p.M; m += 4 * EW_BLOCK) {
+        u32x4 qx[4], qr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int mm_ = m + u * EW_BLOCK;
+            const size_t j = (size_t)(mm_ < p.M ? mm_ : m) * CO + co;
+            qx[u] = p.x[j];
+            if (HASR) qr[u] = p.r[j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int mm_ = m + u * EW_BLOCK;
+            if (mm_ >= p.M) break;
+            float v[8], o[8];
+            unpack8(qx[u], v);
+            if (HASR) { float t[8]; unpack8(qr[u], t);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += t[k]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = act8_fwd(v[k] * sc[k] + sf[k], neg[k]);
+            p.out[(size_t)mm_ * CO + co] = pack8(o);
+        }
+    }
+}
+
+template <bool HASR>
+__global__ void __launch_bounds__(EW_BLOCK) bn_small_bwd_b16_kernel(BnSmall p) {
+    __shared__ float rows[EW_BLOCK / 16][24];
+    __shared__ double tots[24];
+    const int CO = p.C >> 3, co = blockIdx.x, c0 = co * 8, tid = threadIdx.x;
+    float ga[8], is[8], be[8], mu[8], al[8], sc[8], sf[8], neg[8], zer[8];
+    const bool prelu = p.act == VNET_ACT_PRELU;
+    load8f(p.gamma, c0, ga); load8f(p.invstd, c0, is); load8f(p.beta, c0, be); load8f(p.mean, c0, mu);
+    load8f(prelu ? p.alpha : p.gamma, c0, al);
+    const float neg0 = p.act == VNET_ACT_RELU ? 0.f : (p.act == VNET_ACT_LRELU ? 0.2f : 1.f);
+    const float zer0 = p.act == VNET_ACT_LRELU ? 0.2f : (p.act == VNET_ACT_NONE ? 1.f : 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = ga[k] * is[k]; sf[k] = be[k] - mu[k] * sc[k]; neg[k] = prelu ? al[k] : neg0; zer[k] = zer0; }
+    float a[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) a[k] = 0.f;
+    for (int m = tid; m < p.M; m += 2 * EW_BLOCK) {
+        u32x4 qx[2], qr[2], qd[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int mm_ = m + u * EW_BLOCK;
+            const size_t j = (size_t)(mm_ < p.M ? mm_ : m) * CO + co;
+            qx[u] = p.x[j]; qd[u] = p.dy[j];
+            if (HASR) qr[u] = p.r[j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (m + u * EW_BLOCK >= p.M) break;
+            float v[8], g[8];
+            unpack8(qx[u], v); unpack8(qd[u], g);
+            if (HASR) { float t[8]; unpack8(qr[u], t);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += t[k]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float z = v[k] * sc[k] + sf[k];
+                const float dz = g[k] * act8_grad(z, neg[k], zer[k]);
+                const float xh = (v[k] - mu[k]) * is[k];
+                a[k] += dz; a[8 + k] += dz * xh; a[16 + k] += g[k] * fminf(z, 0.f);
+            }
+        }
+    }
+    const double tot = block_total_d<24>(a, rows);
+    if (tid < 24) tots[tid] = tot;
+    __syncthreads();
+    if (tid < 8) {
+        p.dbeta[c0 + tid] = (float)tots[tid];
+        p.dgamma[c0 + tid] = (float)tots[8 + tid];
+        if (prelu && p.dalpha) p.dalpha[c0 + tid] = (float)tots[16 + tid];
+    }
+    if (!p.out) return;
+    float k1[8], k2[8];
+    const float invM = 1.f / (float)p.M;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { k1[k] = (float)tots[k] * invM; k2[k] = (float)tots[8 + k] * invM; }
+    for (int m = tid; m < p.M; m += 2 * EW_BLOCK) {
+        u32x4 qx[2], qr[2], qd[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int mm_ = m + u * EW_BLOCK;
+            const size_t j = (size_t)(mm_ < p.M ? mm_ : m) * CO + co;
+            qx[u] = p.x[j]; qd[u] = p.dy[j];
+            if (HASR) qr[u] = p.r[j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int mm_ = m + u * EW_BLOCK;
+            if (mm_ >= p.M) break;
+            float v[8], g[8], o[8];
+            unpack8(qx[u], v); unpack8(qd[u], g);
+            if (HASR) { float t[8]; unpack8(qr[u], t);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += t[k]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float z = v[k] * sc[k] + sf[k];
+                const float dz = g[k] * act8_grad(z, neg[k], zer[k]);
+                const float xh = (v[k] - mu[k]) * is[k];
+                o[k] = sc[k] * (dz - k1[k] - xh * k2[k]);
+            }
+            p.out[(size_t)mm_ * CO + co] = pack8(o);
+        }
+    }
+}
+
 // fp32 [M][C] -> bf16 [M][Cpad] (zero-padded channels): the network input of a multi-modality net, padded to the 16-byte unit
 __global__ void __launch_bounds__(EW_BLOCK) cast_pad_bf16_kernel(const float* __restrict__ x, u32x4* __restrict__ y, size_t M, int C, int Cpad) {
     const int CO = Cpad >> 3;
@@ -1969,6 +2173,40 @@ int vnet_bn_act_bwd_apply_b16(const void* dy16, const void* x, const void* r16, 
     if (bcast) hipLaunchKernelGGL((bn_act_bwd_apply_b16_kernel<true, false>), dim3(nblk), dim3(EW_BLOCK), 0, (hipStream_t)stream, p);
     else if (p.r) hipLaunchKernelGGL((bn_act_bwd_apply_b16_kernel<false, true>), dim3(nblk), dim3(EW_BLOCK), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((bn_act_bwd_apply_b16_kernel<false, false>), dim3(nblk), dim3(EW_BLOCK), 0, (hipStream_t)stream, p);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+// ---- small tensors: one launch per direction (bn_small_*_b16_kernel) ---------------------------------------------------------------
+int vnet_bn_small_ok(int64_t M, int C) {
+    return (M > 0 && M <= 8192 && C >= 8 && C <= MAXC && (C & 7) == 0) ? 1 : 0;
+}
+int vnet_bn_small_fwd_b16(const void* x16, const void* r16, int64_t M, int C, float eps, float momentum,
+                          const float* gamma, const float* beta, int act, const float* alpha,
+                          float* mean, float* invstd, float* moving_mean, float* moving_var, void* y16, void* stream) {
+    if (!x16 || !gamma || !beta || !mean || !invstd || !y16) return VNET_E_BADARG;
+    if (act == VNET_ACT_PRELU && !alpha) return VNET_E_BADARG;
+    if (act < 0 || act > 3 || !vnet_bn_small_ok(M, C) || !al16(x16) || !al16(r16) || !al16(y16)) return VNET_E_UNSUPPORTED;
+    BnSmall p{};
+    p.x = (const u32x4*)x16; p.r = (const u32x4*)r16; p.out = (u32x4*)y16; p.gamma = gamma; p.beta = beta; p.alpha = alpha;
+    p.mean = mean; p.invstd = invstd; p.mm = moving_mean; p.mv = moving_var; p.M = (int)M; p.C = C; p.act = act; p.eps = eps; p.momentum = momentum;
+    if (r16) hipLaunchKernelGGL(bn_small_fwd_b16_kernel<true>, dim3(C / 8), dim3(EW_BLOCK), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(bn_small_fwd_b16_kernel<false>, dim3(C / 8), dim3(EW_BLOCK), 0, (hipStream_t)stream, p);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+int vnet_bn_small_bwd_b16(const void* dy16, const void* x16, const void* r16, int64_t M, int C,
+                          const float* mean, const float* invstd, const float* gamma, const float* beta, int act, const float* alpha,
+                          float* dgamma, float* dbeta, float* dalpha, void* ds16, void* stream) {
+    if (!dy16 || !x16 || !gamma || !beta || !mean || !invstd || !dgamma || !dbeta) return VNET_E_BADARG;
+    if (act == VNET_ACT_PRELU && (!alpha || !dalpha)) return VNET_E_BADARG;
+    if (act < 0 || act > 3 || !vnet_bn_small_ok(M, C) || !al16(x16) || !al16(r16) || !al16(dy16) || !al16(ds16)) return VNET_E_UNSUPPORTED;
+    BnSmall p{};
+    p.x = (const u32x4*)x16; p.r = (const u32x4*)r16; p.dy = (const u32x4*)dy16; p.out = (u32x4*)ds16; p.gamma = gamma; p.beta = beta; p.alpha = alpha;
+    p.mean = const_cast<float*>(mean); p.invstd = const_cast<float*>(invstd); p.dgamma = dgamma; p.dbeta = dbeta; p.dalpha = dalpha;
+    p.M = (int)M; p.C = C; p.act = act;
+    if (r16) hipLaunchKernelGGL(bn_small_bwd_b16_kernel<true>, dim3(C / 8), dim3(EW_BLOCK), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(bn_small_bwd_b16_kernel<false>, dim3(C / 8), dim3(EW_BLOCK), 0, (hipStream_t)stream, p);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
 }

@@ -1163,6 +1163,18 @@ def _bn_statistics(L, x, r, bcast, M, C, mean, invstd, mm, mv, ws, nb, pre=None,
     return float(M) * world
 
 
+# bf16 storage, tiny tensors (the 8^3 level: <= 512 rows): statistics + finalize + normalise in ONE launch, and reduce + finalize +
+# apply in one (vnet_bn_small_*_b16; VNET_BN_SMALL=0: the streaming kernels everywhere).  Measured (profiles/ab_env.sh, C5 step):
+# <= 512 rows -0.015 ms, <= 1024 the same, <= 8192 (the 16^3 level too) +0.13 ms -- one workgroup per channel octet uses 16 bytes
+# of every 256-byte row it touches, on 16-32 CUs; the five launch-bound streaming launches on 128+ workgroups are faster there.
+_SMALL_BN = {"on": _os.environ.get("VNET_BN_SMALL", "1") != "0", "rows": int(_os.environ.get("VNET_BN_SMALL_ROWS", "512"))}
+
+
+def _bn_small(M, C, *tensors):
+    return (_SMALL_BN["on"] and M <= _SMALL_BN["rows"] and _SYNC_BN is None and all(t is None or _is16(t) for t in tensors)
+            and bool(_lib.lib().vnet_bn_small_ok(int(M), int(C))))
+
+
 class _BnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, r, gamma, beta, alpha, act, bcast, mm, mv):
@@ -1177,6 +1189,18 @@ class _BnActFn(torch.autograd.Function):
         dev = x.device
         mean = torch.empty(C, dtype=torch.float32, device=dev)
         invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        ctx.small = small = (not bcast) and _is16(x) and _bn_small(M, C, x, r)
+        if small:
+            y = torch.empty(x.shape[:-1] + (C,), dtype=torch.bfloat16, device=dev)
+            check(L.vnet_bn_small_fwd_b16(_ptr(x), _ptr(r), M, C, BN_EPS, BN_MOMENTUM, _ptr(gamma), _ptr(beta), act, _ptr(alpha),
+                                          _ptr(mean), _ptr(invstd), _ptr(mm), _ptr(mv), _ptr(y), _stream()), "vnet_bn_small_fwd_b16")
+            ctx.m_total, ctx.sync, ctx.b16 = float(M), None, True
+            ctx.save_for_backward(x, r, gamma, beta, alpha, mean, invstd)
+            ctx.params = (gamma, beta, alpha)
+            ctx.cfg = (act, bcast, M, C)
+            ctx.mark_non_differentiable(mean, invstd)
+            ctx.set_materialize_grads(False)
+            return y, mean, invstd
         nb = L.vnet_bn_ws_bytes(C)
         ws = workspace(nb, dev)
         ctx.m_total = _bn_statistics(L, x, r, bcast, M, C, mean, invstd, mm, mv, ws, nb, pre, r_orig)
@@ -1225,7 +1249,12 @@ class _BnActFn(torch.autograd.Function):
             ds = torch.empty(dy.shape, dtype=torch.float32, device=dev) if need_ds else None
         nb = L.vnet_bn_ws_bytes(C)
         ws = workspace(nb, dev)
-        if ctx.b16:
+        if ctx.small:
+            if not _is16(dy):
+                raise VnetHipError("bn_act backward: expected a bfloat16 gradient")
+            check(L.vnet_bn_small_bwd_b16(_ptr(dy), _ptr(x), _ptr(r), M, C, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), act,
+                                          _ptr(alpha), _ptr(dgamma), _ptr(dbeta), _ptr(dalpha), _ptr(ds), _stream()), "vnet_bn_small_bwd_b16")
+        elif ctx.b16:
             if not _is16(dy):
                 raise VnetHipError("bn_act backward: expected a bfloat16 gradient")
             check(L.vnet_bn_act_bwd_reduce_b16(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd),
