@@ -1,10 +1,10 @@
 #!/bin/bash
-# where the product loop loses time against the replayed step alone: kernel + memory-copy trace of profiles/train_loop_bench.py,
+# where the product loop loses time against the replayed step alone: kernel trace of profiles/train_loop_bench.py,
 # idle time between consecutive steps (a step = the kernels between two adam_kernel launches)
 MODE=${1:-bf16}; CIN=${2:-4}; K=${3:-5}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/tlg
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/tlg -o t -- python profiles/train_loop_bench.py 128 $MODE $CIN $K > gpurun_out/tlg/log.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tlg -o t -- python profiles/train_loop_bench.py 128 $MODE $CIN $K > gpurun_out/tlg/log.txt 2>&1
 tail -1 gpurun_out/tlg/log.txt
 python - <<'PY'
 import csv
@@ -35,10 +35,7 @@ for g, n in biggest:
         d[n][0] += 1; d[n][1] += g
 for n, (c, t) in sorted(d.items(), key=lambda kv: -kv[1][1])[:12]:
     print("  idle before %-52s n=%4d  %.3f ms per step" % (n, c, t / (len(ends) - 1) / 1e6))
-try:
-    m = list(csv.DictReader(open('gpurun_out/tlg/t_memory_copy_trace.csv')))
-    print("memory copies:", len(m), "columns", list(m[0].keys())[:8])
-except Exception as e:
-    print("no memory copy trace", e)
+blit = [(s, e) for s, e, n in k[ends[0]:ends[-1]] if 'copyBuffer' in n]
+print("blit kernels (__amd_rocclr_copyBuffer): %.1f per step, %.3f ms per step summed" % (len(blit) / (len(ends) - 1), sum(e - s for s, e in blit) / (len(ends) - 1) / 1e6))
 PY
-rm -f gpurun_out/tlg/t_kernel_trace.csv gpurun_out/tlg/t_memory_copy_trace.csv
+rm -f gpurun_out/tlg/t_kernel_trace.csv
