@@ -109,6 +109,44 @@ def test_conv5_b16_against_oracle_and_fp32_output_kernels(dev, shape, monkeypatc
         ops.set_compute_dtype("fp32")
 
 
+@pytest.mark.parametrize("cin,dims,stats", [(4, (32, 64, 64), False), (3, (33, 64, 70), True), (1, (32, 64, 64), False)])
+def test_conv5_b16_zero_padded_input_x_im2col(dev, cin, dims, stats, monkeypatch):
+    """The network input of a multi-modality net: cin <= 4 real channels zero-padded to 8.  With >= 256 bricks the 16-cout kernel
+    takes its x-im2col form (K-channels = 4 x shifts x 4 modalities, vnet_conv_fwd_b16_padded): forward against the oracle, against the
+    plain kernel (other summation order: equal up to a rounding flip here and there), epilogue statistics, and the filter gradient
+    [125][cin][16]."""
+    from vnet_tensorflow_amd import ops
+    D, H, W = dims
+    rng = np.random.default_rng(cin + D)
+    x = rb(rng.standard_normal((1, D, H, W, cin)))
+    w = rng.standard_normal((5, 5, 5, cin, 16)) * 0.2
+    b = rng.standard_normal(16)
+    y_ex = O.conv_nd_fwd(x, rb(w), 1) + b
+    tx = ops.cast_input(g(x, dev))
+    assert tx.shape[-1] == 8 and tx.dtype == BF
+    tw, tb = g(w, dev).requires_grad_(True), g(b, dev).requires_grad_(True)
+    outs = {}
+    for on in (True, False):
+        monkeypatch.setitem(ops._IN4, "on", on)
+        y = ops.conv(tx, tw, tb, 5, 1, bn_stats=stats)
+        check_bf16("in4=%s fwd" % on, y, y_ex)
+        outs[on] = y.detach()
+        if stats:
+            st = getattr(y, "_vnet_stats", None)
+            assert st is not None
+            part = st.partial.double().sum(0).cpu().numpy()
+            v = y.detach().float().cpu().numpy().astype(np.float64).reshape(-1, 16)
+            np.testing.assert_allclose(part[:16], v.sum(0), rtol=1e-5, atol=1e-3)
+            np.testing.assert_allclose(part[16:], (v * v).sum(0), rtol=1e-5)
+    assert (outs[True] == outs[False]).float().mean() > 0.995
+    dy = rb(rng.standard_normal((1, D, H, W, 16)))
+    monkeypatch.setitem(ops._IN4, "on", True)
+    y = ops.conv(tx, tw, tb, 5, 1)
+    y.backward(g16(dy, dev))
+    _, dw_ex = O.conv_nd_bwd(x, rb(w), dy, 1)
+    check_close("in4 dw", tw.grad, dw_ex, 2e-6)
+
+
 @pytest.mark.parametrize("shape", [(1, 16, 32, 64, 16, 0, 16), (1, 16, 64, 64, 32, 0, 32), (1, 8, 16, 32, 64, 0, 64), (1, 8, 8, 8, 32, 0, 32)])
 def test_conv5_b16_epilogue_statistics_and_accumulation(dev, shape):
     """Statistics of the ROUNDED output (+ bf16 residual) from the epilogue == a separate statistics pass over the stored tensor;

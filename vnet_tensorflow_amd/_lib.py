@@ -94,6 +94,7 @@ SIGNATURES = {
     # bf16-storage mode
     "vnet_cast_bf16": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "vnet_conv_fwd_b16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vnet_conv_fwd_b16_padded": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "vnet_conv_wgrad_b16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "vnet_conv2_fwd_b16": (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "vnet_conv2_wgrad_b16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),

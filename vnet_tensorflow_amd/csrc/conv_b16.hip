@@ -20,9 +20,25 @@ inline bool al8p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) ==
 
 extern "C" {
 
+static int conv_fwd_b16_impl(const void* x0, int C0, const void* x1, int C1, const void* wp, const float* bias,
+                             void* y0, int Cy0, void* y1, int Cy1, int B, int D, int H, int W,
+                             const void* acc16, const void* res16, float* stats, void* ws, size_t ws_bytes, void* stream, int cin_real);
+
 int vnet_conv_fwd_b16(const void* x0, int C0, const void* x1, int C1, const void* wp, const float* bias,
                       void* y0, int Cy0, void* y1, int Cy1, int B, int D, int H, int W,
                       const void* acc16, const void* res16, float* stats, void* ws, size_t ws_bytes, void* stream) {
+    return conv_fwd_b16_impl(x0, C0, x1, C1, wp, bias, y0, Cy0, y1, Cy1, B, D, H, W, acc16, res16, stats, ws, ws_bytes, stream, 0);
+}
+
+int vnet_conv_fwd_b16_padded(const void* x16, int Cpad, int Cin, const void* wp, const float* bias, void* y16, int Cout,
+                             int B, int D, int H, int W, const void* res16, float* stats, void* ws, size_t ws_bytes, void* stream) {
+    if (Cin <= 0 || Cin > Cpad) return VNET_E_BADARG;
+    return conv_fwd_b16_impl(x16, Cpad, nullptr, 0, wp, bias, y16, Cout, nullptr, 0, B, D, H, W, nullptr, res16, stats, ws, ws_bytes, stream, Cin);
+}
+
+static int conv_fwd_b16_impl(const void* x0, int C0, const void* x1, int C1, const void* wp, const float* bias,
+                             void* y0, int Cy0, void* y1, int Cy1, int B, int D, int H, int W,
+                             const void* acc16, const void* res16, float* stats, void* ws, size_t ws_bytes, void* stream, int cin_real) {
     if (!x0 || !wp || !y0 || C0 <= 0 || Cy0 <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return VNET_E_BADARG;
     if ((C1 > 0 && !x1) || (Cy1 > 0 && !y1) || C1 < 0 || Cy1 < 0) return VNET_E_BADARG;
     if (stats && Cy1 > 0) return VNET_E_BADARG;
@@ -43,6 +59,8 @@ int vnet_conv_fwd_b16(const void* x0, int C0, const void* x1, int C1, const void
         a.accsrc = reinterpret_cast<const float*>(acc16);
     }
     if (stats && vnet_conv_bf16_stats_rows_x16(a.Cin, Cy0, Cy1, C0, C1, B, D, H, W) == 0) return VNET_E_UNSUPPORTED;
+    // the caller vouches that channels cin_real .. C0-1 of x0 are zero (the cast network input): x-im2col form of the 16-cout kernel
+    a.in4 = (cin_real > 0 && cin_real <= 4 && C0 == 8 && C1 == 0) ? 1 : 0;
     Bf16Plan p = plan_conv_bf16(a.Cin, a.Cout, B, D, H, W);
     a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.cps = p.cps; a.nz = p.nz;
     const int nslab = p.nsplit * p.nz;

@@ -28,6 +28,7 @@ struct ConvArgs {
     // channel, row [2][Cout] per brick (or per reduce block for split-K launches); the batch-norm that consumes y then
     // only runs its finalize.  res: optional residual that is added in front of that batch-norm (networks.py:318).
     float* stats; const float* res;
+    int in4;           // bf16 storage, 16-cout kernel: the single source is the network input, 4 real channels zero-padded to 8 (IN4)
 };
 
 // Experiment build -DVNET_STAMPS (profiles/build_stamps.sh): s_memtime stamps around the phases of four consecutive brick steps of
@@ -1596,11 +1597,18 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
 //   * persistent workgroups (one per CU) walk their bricks; the next tile (and filter chunk) is prefetched global ->
 //     registers during the MFMAs and committed between two barriers.
 // ------------------------------------------------------------------------------------------
-template <int TZ, int TY, int TX, bool STATS = false, bool H = false, bool O16 = false>
+// IN4 (round 3): the network input of a multi-modality net -- 4 real channels zero-padded to 8.  With K = 2 taps x 16 zero-padded
+// channels three quarters of every MFMA multiply zeros; here the 16 K-channels of a tap pair are j = (sx, c): x-SHIFT sx = 0..3
+// times modality c = 0..3 (an x-im2col done while the tile is committed to LDS: every loaded voxel's 8 bytes go to the four
+// units (x - sx, slot sx)), so one MFMA covers the taps dx = 0..3 of a (dz pair, dy) and a second one, at x offset 4, the tap
+// dx = 4 (its other twelve K-channels meet zero weights): 26 filter fragments and 104 MFMAs per 4 rows instead of 65 and 260.
+template <int TZ, int TY, int TX, bool STATS = false, bool H = false, bool O16 = false, bool IN4 = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv5_bf16_c16_kernel(ConvArgs a) {
     using G = Bf16Geom<TZ, TY, TX>;
     static_assert(TZ == 4 && TY == 8 && TX == 16, "8 waves x 4 rows of 16 voxels");
-    constexpr int NT = 512, NFRAG = 65, FUNITS = NFRAG * 64, FPER = (FUNITS + NT - 1) / NT;
+    static_assert(!IN4 || H, "IN4 stages bf16 sources");
+    constexpr int NDX = IN4 ? 2 : 5, XSTEP = IN4 ? 4 : 1;                 // x groups of a (dz pair, dy) and their tile offset
+    constexpr int NT = 512, NFRAG = IN4 ? 26 : 65, FUNITS = NFRAG * 64, FPER = (FUNITS + NT - 1) / NT;
     constexpr int ROWB = G::IX * 16, PLANEB = G::IY * G::IX * 16;       // bytes per tile row / per tile z-plane (one cin half)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* tile = smem;
@@ -1650,11 +1658,28 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     auto filter_issue = [&](int chunk) {
 #pragma unroll
         for (int k = 0; k < FPER; ++k) {
-            bool valid;
-            const u32x4* src = fsrc(min(tid + k * NT, FUNITS - 1), chunk, valid);
-            const u32x4 t = *src;
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            freg[k] = valid ? t : z;
+            if constexpr (IN4) {
+                // unit (fragment f, lane l): 8 K-channels j = 8 hf .. 8 hf + 7 = x shifts 2 hf, 2 hf + 1 x 4 modalities of cout co:
+                // the first 8 bytes (cin 0..3) of the generic image's units of the taps dx = 4 dxg + 2 hf and dx + 1
+                const int u = min(tid + k * NT, FUNITS - 1);
+                const int f = u >> 6, l = u & 63;
+                const int co = l & 15, gg = l >> 4, hf = gg & 1, up = gg >> 1;
+                int dz, dy, dxg;
+                bool valid = tid + k * NT < FUNITS;
+                if (f < 20) { const int zp = f / 10, r = f - zp * 10; dxg = r / 5; dy = r - dxg * 5; dz = 2 * zp + up; }
+                else { const int r = f - 20; dxg = r / 3; const int q = r - dxg * 3; dz = 4; dy = 2 * q + up; if (q == 2 && up) valid = false; }
+                const int dxa = 4 * dxg + 2 * hf;
+                const bool va = valid && dxa < 5, vb = valid && dxa + 1 < 5;
+                const u32x4 ta = *(wg + ((size_t)((dz * 5 + dy) * 5 + (va ? dxa : 0)) * 2) * 32 + co);
+                const u32x4 tb = *(wg + ((size_t)((dz * 5 + dy) * 5 + (vb ? dxa + 1 : 0)) * 2) * 32 + co);
+                freg[k] = u32x4{va ? ta[0] : 0u, va ? ta[1] : 0u, vb ? tb[0] : 0u, vb ? tb[1] : 0u};
+            } else {
+                bool valid;
+                const u32x4* src = fsrc(min(tid + k * NT, FUNITS - 1), chunk, valid);
+                const u32x4 t = *src;
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                freg[k] = valid ? t : z;
+            }
         }
     };
     auto filter_commit = [&]() {
@@ -1698,7 +1723,24 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
     };
     auto tile_commit = [&]() {
-        if constexpr (H) {
+        if constexpr (IN4) {
+            // x-im2col: the 8 bytes (4 modalities) of source voxel ix -> unit (x' = ix - s, plane s >> 1, slot s & 1), s = 0..3
+            const int r0 = tid / XH::COLS, col = tid - r0 * XH::COLS;
+            const int ix = col >> 1;
+            const bool src = (col & 1) == 0 && r0 < XH::RPI;
+#pragma unroll
+            for (int k = 0; k < XH::PER; ++k) {
+                const int row = r0 + k * XH::RPI;
+                const bool ok = src && row < XH::ROWS;
+                const uint2 v8 = make_uint2(hv[k][0], hv[k][1]);
+#pragma unroll
+                for (int sft = 0; sft < 4; ++sft) {
+                    const int xp = ix - sft;
+                    unsigned char* dst = tile + (sft >> 1) * G::PLANE + (row * G::IX + xp) * 16 + (sft & 1) * 8;
+                    *reinterpret_cast<uint2*>(ok && xp >= 0 ? dst : dump) = v8;
+                }
+            }
+        } else if constexpr (H) {
             bf16_tile_commit_h<G, XH, 0, XH::PER>(tile, dump, hv, tid);
         } else {
             const int r0 = tid / XT::COLS, col = tid - r0 * XT::COLS;
@@ -1713,6 +1755,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
     };
 
+    if constexpr (IN4) {
+        // units whose source voxel lies beyond the tile are never written (they only ever meet zero weights): make them finite once
+        for (int u = tid; u < G::TILE_BYTES / 16; u += NT) reinterpret_cast<u32x4*>(tile)[u] = u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+    }
     int bi, ch; bool first, last, swp;
     sched(0, bi, ch, first, last, swp);
     filter_issue(ch);
@@ -1755,12 +1802,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int zp = 0; zp < 2; ++zp)
 #pragma unroll
-            for (int dx = 0; dx < 5; ++dx) {
+            for (int dx = 0; dx < NDX; ++dx) {
                 bf16x8 R[8], A[5];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) R[k] = *reinterpret_cast<const bf16x8*>(bZ + ((2 * zp * G::IY + k) * G::IX + dx) * 16);
+                for (int k = 0; k < 8; ++k) R[k] = *reinterpret_cast<const bf16x8*>(bZ + ((2 * zp * G::IY + k) * G::IX + dx * XSTEP) * 16);
 #pragma unroll
-                for (int dy = 0; dy < 5; ++dy) A[dy] = *reinterpret_cast<const bf16x8*>(fa + ((zp * 5 + dx) * 5 + dy) * 1024);
+                for (int dy = 0; dy < 5; ++dy) A[dy] = *reinterpret_cast<const bf16x8*>(fa + ((zp * NDX + dx) * 5 + dy) * 1024);
 #pragma unroll
                 for (int dy = 0; dy < 5; ++dy)
 #pragma unroll
@@ -1778,14 +1825,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                                         // (packing after the first dz pair and letting the second pair's reads hoist: measured 2 % slower)
         // ---- dz = 4: dy pairs (0,1), (2,3) and the single tap dy = 4 ----
 #pragma unroll
-        for (int dx = 0; dx < 5; ++dx) {
+        for (int dx = 0; dx < NDX; ++dx) {
             bf16x8 P[6], S[4], A[3];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) P[k] = *reinterpret_cast<const bf16x8*>(bY + ((4 * G::IY + k) * G::IX + dx) * 16);
+            for (int k = 0; k < 6; ++k) P[k] = *reinterpret_cast<const bf16x8*>(bY + ((4 * G::IY + k) * G::IX + dx * XSTEP) * 16);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) S[m] = *reinterpret_cast<const bf16x8*>(b0 + ((4 * G::IY + 4 + m) * G::IX + dx) * 16);
+            for (int m = 0; m < 4; ++m) S[m] = *reinterpret_cast<const bf16x8*>(b0 + ((4 * G::IY + 4 + m) * G::IX + dx * XSTEP) * 16);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) A[q] = *reinterpret_cast<const bf16x8*>(fa + (50 + dx * 3 + q) * 1024);
+            for (int q = 0; q < 3; ++q) A[q] = *reinterpret_cast<const bf16x8*>(fa + (2 * NDX * 5 + dx * 3 + q) * 1024);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 accA[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], P[m], accA[m], 0, 0, 0);
@@ -2702,6 +2749,23 @@ int conv_fwd_bf16_go(ConvArgs& a, const Bf16Plan& p, int nslab, int C0, int C1, 
         using GC = Bf16Geom<4, 8, 16>;
         a.nbz = ceil_div(D, 4); a.nby = ceil_div(H, 8); a.nbx = ceil_div(W, 16);
         const size_t lds = (size_t)GC::TILE_BYTES + 65 * 1024 + 64 * 16 + 8 * 32 * 4;
+        if constexpr (HS && O16) {
+            if (a.in4) {              // the multi-modality network input: x-im2col in LDS, 2.5x fewer MFMAs
+                if (a.stats) {
+                    auto k = conv5_bf16_c16_kernel<4, 8, 16, true, true, true, true>;
+                    static unsigned long long attr_done = 0;
+                    if (int ae = ensure_lds(k, lds, attr_done)) return ae;
+                    hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, st, a);
+                } else {
+                    auto k = conv5_bf16_c16_kernel<4, 8, 16, false, true, true, true>;
+                    static unsigned long long attr_done = 0;
+                    if (int ae = ensure_lds(k, lds, attr_done)) return ae;
+                    hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, st, a);
+                }
+                VNET_LAUNCH_CHECK();
+                return -1;
+            }
+        }
         if (a.stats) {
             auto k = conv5_bf16_c16_kernel<4, 8, 16, true, HS, O16>;
             static unsigned long long attr_done = 0;

@@ -433,7 +433,11 @@ def _conv_bf16_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res
 
 
 # ---- bf16-storage convolution calls (include/vnet_hip.h: vnet_conv_fwd_b16, vnet_conv2_fwd_b16, ...) ----------------------------
-def _conv5_b16_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res=None, acc_src=None):
+_IN4 = {"on": _os.environ.get("VNET_CONV_IN4", "1") != "0"}
+
+
+def _conv5_b16_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res=None, acc_src=None, cin_real=0):
+    """cin_real: the input channels of the FILTER when x0 carries zero-padded channels behind them (the cast network input)."""
     L = _lib.lib()
     B = x0.shape[0]
     C0, C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
@@ -446,6 +450,10 @@ def _conv5_b16_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res
     tag = "conv-bf16 k5 s1 %d^3x%d %d->%d" % (dims[2], B, C0 + C1, Cy0 + Cy1)
     acc = _ptr(acc_src) if acc_src is not None else (_ptr(y0) if accum else None)
     with _Timed(tag, flops, nbytes):
+        if cin_real and _IN4["on"] and x1 is None and y1 is None and not accum and acc_src is None:
+            check(L.vnet_conv_fwd_b16_padded(_ptr(x0), C0, int(cin_real), _ptr(wp), _ptr(bias), _ptr(y0), Cy0, B, *dims,
+                                             _ptr(res), _ptr(stats), _ptr(ws), nb, _stream()), "vnet_conv_fwd_b16_padded")
+            return
         check(L.vnet_conv_fwd_b16(_ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias), _ptr(y0), Cy0, _ptr(y1), Cy1, B, *dims,
                                   acc, _ptr(res), _ptr(stats), _ptr(ws), nb, _stream()), "vnet_conv_fwd_b16")
 
@@ -802,7 +810,8 @@ class _ConvFn(torch.autograd.Function):
             elif ks == 2:   # w [2,2,2,I,O]: fine channels I, coarse channels O
                 _conv2_b16(True, x0, w, b, y, (Di, Hi, Wi), dims_out, I, O, stats=stats)
             else:
-                _conv5_b16_call(x0, x1, packed_weights(w, PACK_FWD_BF16, 125, I, O), b, y, None, dims_out, stats=stats, res=res)
+                _conv5_b16_call(x0, x1, packed_weights(w, PACK_FWD_BF16, 125, I, O), b, y, None, dims_out, stats=stats, res=res,
+                                cin_real=(I if x1 is None and I < x0.shape[-1] else 0))
         elif bf16:
             _conv_bf16_call(x0, x1, packed_weights(w, PACK_FWD_BF16, 125, I, O), b, y, None, dims_out, stats=stats, res=res)
         elif up and x1 is None:
