@@ -115,7 +115,10 @@ int vnet_conv_wgrad_b16(const void* x0, int C0, const void* x1, int C1, const vo
         a.nbrick = rr_nbrick; a.nsplit = rr_nsplit;
         direct = rr_nsplit == 1 && a.CinP == Cin_dw && a.CoutP == Cout;
         a.part = direct ? dw : reinterpret_cast<float*>(ws);
-        e = launch_wgrad_bf16_rr<4>(a, rr_nsplit, a.ncob, st);
+        // the zero-padded network input (Cin_dw <= 4 real channels of 8): x-im2col form, 10 instead of 25 tap pairs per k-step
+        const char* in4_env = getenv("VNET_CONV_IN4");
+        const bool in4 = Cin_dw <= 4 && C0 == 8 && C1 == 0 && !(in4_env && atoi(in4_env) == 0);
+        e = in4 ? launch_wgrad_bf16_rr<4, true>(a, rr_nsplit, a.ncob, st) : launch_wgrad_bf16_rr<4>(a, rr_nsplit, a.ncob, st);
         if (e) return e;
         if (direct) return VNET_OK;
         launch_wgrad_reduce(a.part, rr_nsplit, 125, a.CinP, a.CoutP, Cin_dw, Cout, dw, st);

@@ -2445,7 +2445,12 @@ __global__ void __launch_bounds__(512) wgrad5_bf16_kernel(WgradArgs a) {
 //   * D[cout][cin] per tap, one 16-cin chunk x one 16-cout block per workgroup, bricks split over nsplit workgroups, next brick's
 //     tiles prefetched global -> registers during the MFMAs; partial slabs + the usual reduce.
 // ------------------------------------------------------------------------------------------
-template <int TZ>
+// IN4 (round 3): the filter gradient of the network-input conv of a multi-modality net (4 real channels zero-padded to 8, x in
+// source 0).  The 16 "input channels" of the tile become j = (x shift sx = 0..3, modality c = 0..3) -- an x-im2col done while the tile
+// is committed: a voxel's 8 bytes go to the rows x - sx, bytes 8 sx -- so D[cout][j] of a (dz, dy) holds the taps dx = sx (tile
+// offset 0) resp. dx = 4 (offset 4, sx = 0 only): 10 (dz, x offset) pairs instead of 25 (dz, dx) pairs; waves 0-7 own pair w,
+// waves 0-1 also pair 8 + w.
+template <int TZ, bool IN4 = false>
 __global__ void __launch_bounds__(512) wgrad5_bf16_rr_kernel(WgradArgs a) {
     constexpr int TY = 8, TX = 32, IZ = TZ + 4, IY = TY + 4, IX = TX + 4;
     constexpr int XROWS = IZ * IY, XCOLS = IX * 2, XRPI = 512 / XCOLS, XPER = (XROWS + XRPI - 1) / XRPI;    // x tile: 16-byte units
@@ -2465,13 +2470,19 @@ __global__ void __launch_bounds__(512) wgrad5_bf16_rr_kernel(WgradArgs a) {
     // this wave's three (dz, dx) pairs: pair index q = 3 * wave + c  (q = dz * 5 + dx, 0..23); pair 24 = (4, 4) is shared: its tap
     // dy = wave goes to waves 0..4
     const int lane_off = (4 * g + (i >> 2)) * 32 + (i & 3) * 8;
+    constexpr int NPAIR = IN4 ? 2 : 3;
     const unsigned char* pb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const int q = 3 * wave + c, dz = q / 5, dx = q - dz * 5;
-        pb[c] = xt + ((dz * IY) * IX + dx) * 32 + lane_off;
+        if constexpr (IN4) {
+            const int q = (c == 0) ? wave : (wave < 2 ? 8 + wave : 0), dxg = q / 5, dz = q - dxg * 5;
+            pb[c] = xt + ((dz * IY) * IX + 4 * dxg) * 32 + lane_off;
+        } else {
+            const int q = 3 * wave + c, dz = q / 5, dx = q - dz * 5;
+            pb[c] = xt + ((dz * IY) * IX + dx) * 32 + lane_off;
+        }
     }
-    const bool extra = wave < 5;
+    const bool extra = !IN4 && wave < 5;
     const unsigned char* pe = xt + ((4 * IY + (extra ? wave : 0)) * IX + 4) * 32 + lane_off;
     const unsigned char* pa = dyt + lane_off;
 
@@ -2541,7 +2552,14 @@ __global__ void __launch_bounds__(512) wgrad5_bf16_rr_kernel(WgradArgs a) {
 #pragma unroll
             for (int k = 0; k < XPER; ++k) {
                 const int row = r0 + k * XRPI;
-                if (r0 < XRPI && row < XROWS)
+                if constexpr (IN4) {
+                    if (r0 < XRPI && row < XROWS && (col & 1) == 0) {
+                        const uint2 v8 = make_uint2(hx[k][0], hx[k][1]);
+#pragma unroll
+                        for (int sft = 0; sft < 4; ++sft)
+                            if ((col >> 1) - sft >= 0) *reinterpret_cast<uint2*>(xt + (row * IX + (col >> 1) - sft) * 32 + sft * 8) = v8;
+                    }
+                } else if (r0 < XRPI && row < XROWS)
                     *reinterpret_cast<u32x4*>(xt + (row * IX + (col >> 1)) * 32 + (col & 1) * 16) = hx[k];
             }
 #pragma unroll
@@ -2558,7 +2576,8 @@ __global__ void __launch_bounds__(512) wgrad5_bf16_rr_kernel(WgradArgs a) {
             // one (dz, dx) pair at a time: the window of five row fragments of ONE pair is live (20 registers; all three pairs in
             // lockstep -- A read once per row -- needed 60 and spilled next to the prefetch registers); A is re-read per pair
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
+            for (int c = 0; c < NPAIR; ++c) {
+                if (IN4 && c == 1 && wave >= 2) continue;                          // (wave-uniform)
                 bf16x8 F[5];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) F[r] = frag(pb[c], zx + r * (IX * 32));
@@ -2585,6 +2604,22 @@ __global__ void __launch_bounds__(512) wgrad5_bf16_rr_kernel(WgradArgs a) {
             }
         }
     }
+    if constexpr (IN4) {
+        // lane holds D[(dz, dy), x offset 4 dxg][j = i = (sx, c)][co]: the tap dx = 4 dxg + sx of modality c (dx <= 4)
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            const int c = t / 5;
+            if (c == 1 && wave >= 2) continue;
+            const int q = (c == 0) ? wave : 8 + wave, dxg = q / 5, dz = q - dxg * 5;
+            const int dx = 4 * dxg + (i >> 2);
+            if (dx > 4) continue;
+            const int tap = (dz * 5 + t % 5) * 5 + dx;
+            float* dst = a.part + ((size_t)(split * 125 + tap) * a.CinP + (i & 3)) * a.CoutP + co0 + g * 4;
+            const f32x4 r = acc[t];
+            *reinterpret_cast<float4*>(dst) = make_float4(r.x, r.y, r.z, r.w);
+        }
+        return;
+    }
     // lane holds dW[tap][ci = chunk*16 + i][co = co0 + 4*g + {0..3}]
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -2597,11 +2632,11 @@ __global__ void __launch_bounds__(512) wgrad5_bf16_rr_kernel(WgradArgs a) {
     }
 }
 
-template <int TZ>
+template <int TZ, bool IN4 = false>
 int launch_wgrad_bf16_rr(const WgradArgs& a, int nsplit, int ncob, hipStream_t st) {
     constexpr int IZ = TZ + 4, IY = 12, IX = 36;
     const size_t lds = (size_t)IZ * IY * IX * 32 + (size_t)TZ * 8 * 32 * 32;
-    auto k = wgrad5_bf16_rr_kernel<TZ>;
+    auto k = wgrad5_bf16_rr_kernel<TZ, IN4>;
     static unsigned long long attr_done = 0;
     if (int ae = ensure_lds(k, lds, attr_done)) return ae;
     dim3 grid(nsplit, (a.CinP / 16) * ncob, 1);
