@@ -265,6 +265,11 @@ private:
             // bf16 storage: statistics of the bf16 tensor (+ bf16 residual) -- or of the fp32 1-channel image that is tiled -- in fp32,
             // one rounding of the normalised / activated value
             Tensor y = alloc16(x.B, x.D, x.H, x.W, C);
+            if (!tile && x.rows() <= 512 && vnet_bn_small_ok(x.rows(), C)) {      // tiny tensors: one launch (the Python path's rule, ops._bn_small)
+                ABI_OK(vnet_bn_small_fwd_b16(x.q, res ? res->q : nullptr, x.rows(), C, 1e-3f, 0.99f, g.dev, b.dev, act, alpha, mean, invstd,
+                                             nullptr, nullptr, y.q, st_));
+                return y;
+            }
             if (tile) ABI_OK(vnet_bn_stats(x.p, nullptr, 1, x.rows(), C, 1e-3f, 0.99f, mean, invstd, nullptr, nullptr, ws_, ws_bytes_, st_));
             else ABI_OK(vnet_bn_stats_b16(x.q, res ? res->q : nullptr, x.rows(), C, 1e-3f, 0.99f, mean, invstd, nullptr, nullptr, ws_, ws_bytes_, st_));
             ABI_OK(vnet_bn_act_fwd_b16(tile ? (const void*)x.p : x.q, res ? res->q : nullptr, tile ? 1 : 0, x.rows(), C, mean, invstd, g.dev, b.dev,
