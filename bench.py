@@ -299,7 +299,7 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
                 tper = ent.get("per_kernel")                      # forward / backward-data / filter gradient, each per launch
                 tsrc = "profiles/%s: rocprofv3 --pmc passes of this command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), not this run" % os.path.basename(pmc)
         peak = PEAK_BF16_TFLOPS if bf16 else PEAK_FP32_TFLOPS
-        kname = ("conv5_bf16_c16_kernel (fwd 32->16) + conv5_bf16_r32_kernel (bwd-data 16->32) + wgrad5_bf16_kernel, bf16 tensors in and out" if bf16
+        kname = ("conv5_bf16_c16_kernel (fwd 32->16) + conv5_bf16_r32_kernel (bwd-data 16->32) + wgrad5_bf16_rr_kernel (row-reuse filter gradient), bf16 tensors in and out" if bf16
                  else "conv_kernel<5,1,4,8,8,4,4,{1,2}> (fwd 32->16, bwd-data 16->32) + wgrad_kernel<5,1,4,4,16,1,16>")
         res["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),

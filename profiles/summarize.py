@@ -83,11 +83,12 @@ def main(src, tag):
                      ("bwd", r"conv_kernel<5, 1, 4, 8, 8, 4, 4, 2, false, 5, false", "2097152", 1, 0),
                      ("wgrad", r"wgrad_kernel<5, 1, 4, 4, 16, 1, 16, 5", "131072", 1, 0)],
             # C5, bf16 storage: persistent kernels (grid = CUs x 512 whatever the problem), so launch order tells them apart:
-            # forward 4->16, 16->16, 32->16 (the third c16 launch); backward starts at decoder level 1, so its backward-data
-            # 16->32 and its filter gradient are the first launches of their kernels in a step
-            "bf16": [("fwd", r"conv5_bf16_c16_kernel<4, 8, 16, true, true, true>", None, 3, 2),
+            # forward with statistics 16->16, 32->16 (the second launch of the plain 16-cout kernel; the 4->16 input conv is the
+            # x-im2col instantiation); backward starts at decoder level 1, so its backward-data 16->32 and its filter gradient
+            # are the first launches of their kernels in a step
+            "bf16": [("fwd", r"conv5_bf16_c16_kernel<4, 8, 16, true, true, true, false>", None, 2, 1),
                      ("bwd", r"conv5_bf16_r32_kernel<false, true>", None, FAM_BWD_PER_STEP, 0),
-                     ("wgrad", r"wgrad5_bf16_rr_kernel<4>", None, FAM_WGRAD_PER_STEP, 0)]}
+                     ("wgrad", r"wgrad5_bf16_rr_kernel<4, false>", None, FAM_WGRAD_PER_STEP, 0)]}
     out["families"] = {}
     for fam, members in fams.items():
         per_kernel, used, nsteps = {}, [], 0
