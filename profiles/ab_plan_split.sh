@@ -1,3 +1,6 @@
+#!/bin/bash
+# split-K of the bf16-storage conv at exactly 256 workgroups (the 32^3 level); needs the -DVNET_PLAN_ENV build:
+#   DEFS=-DVNET_PLAN_ENV OUT=libvnet_hip_env.so bash profiles/build_stamps.sh
 export VNET_HIP_LIB=$PWD/profiles/probes/libvnet_hip_env.so
 for cfg in "255 512" "256 512" "256 1024" "512 1024" "512 2048"; do
   set -- $cfg

@@ -2687,7 +2687,13 @@ Bf16Plan plan_conv_bf16(int Cin, int Cout, int B, int Do, int Ho, int Wo) {
 #else
     constexpr int tgt = 512, nzmin = 64;
 #endif
-    if (nwg < 256 && nchunks > 1) p.nsplit = (int)min((long)nchunks, (long)ceil_div(tgt, (int)nwg));
+    // (nwg == 256, the 32^3 level, stays unsplit: profiles/ab_plan_split.sh -- two workgroups per CU + the reduce pass: 50 vs 42 us)
+#ifdef VNET_PLAN_ENV
+    static const int splitmax = getenv("VNET_BF16_SPLIT_NWG_MAX") ? atoi(getenv("VNET_BF16_SPLIT_NWG_MAX")) : 255;
+#else
+    constexpr int splitmax = 255;
+#endif
+    if (nwg <= splitmax && nchunks > 1) p.nsplit = (int)min((long)nchunks, (long)ceil_div(tgt, (int)nwg));
     p.cps = ceil_div(nchunks, p.nsplit);
     p.nsplit = ceil_div(nchunks, p.cps);
     p.nz = (nwg * p.nsplit < nzmin) ? 5 : 1;
