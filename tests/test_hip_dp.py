@@ -41,9 +41,11 @@ def _free_port():
 
 
 def _build(dev, seed):
-    from vnet_tensorflow_amd import networks
+    from vnet_tensorflow_amd import networks, ops
     np.random.seed(seed)
-    net = networks.VNet(NET["K"], 0.0, NET["C0"], NET["levels"], NET["ncv"], NET["nb"], True, "prelu", device=dev)
+    compute = os.environ.get("VNET_TEST_COMPUTE", "fp32")      # "bf16": bf16 tensors end to end (needs 8 * 2^k channels)
+    ops.set_compute_dtype(compute)
+    net = networks.VNet(NET["K"], 0.0, 8 if compute == "bf16" else NET["C0"], NET["levels"], NET["ncv"], NET["nb"], True, "prelu", device=dev)
     net.build((1, NET["P"], NET["P"], NET["P"], 1))
     return net
 
@@ -143,8 +145,20 @@ def _worker(rank, world, port, out, backend="gloo"):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
 @pytest.mark.parametrize("backend", BACKENDS)
-def test_two_ranks(tmp_path, dev, backend):
+def test_two_ranks(tmp_path, dev, backend, compute, monkeypatch):
+    from vnet_tensorflow_amd import ops, optim
+    monkeypatch.setenv("VNET_TEST_COMPUTE", compute)       # (bf16: bf16 storage -- the per-GPU arithmetic of BASELINE config C5)
+    if compute == "bf16":
+        monkeypatch.setenv("VNET_TEST_PG", "0")            # as the product step: no side stream, gradients accumulate in the epilogues
+    try:
+        _two_ranks(tmp_path, dev, backend, tol=(1e-5, 1e-4, 1e-5) if compute == "fp32" else (2e-4, 2e-3, 2e-4))
+    finally:
+        ops.set_compute_dtype("fp32")
+
+
+def _two_ranks(tmp_path, dev, backend, tol):
     from vnet_tensorflow_amd import ops, optim
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), backend), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
@@ -162,14 +176,14 @@ def test_two_ranks(tmp_path, dev, backend):
             loss, _, _, _ = ops.softmax_loss(net.GetNetwork(x), lab, "sorensen")
             loss.backward()
             if step == 1:
-                assert abs(float(loss.detach()) - (r0, r1)[rank]["loss"]) < 1e-5      # per-replica BN: same loss as B=1 alone
+                assert abs(float(loss.detach()) - (r0, r1)[rank]["loss"]) < tol[0]      # per-replica BN: same loss as B=1 alone
             tot += flat.grad
         flat.grad.copy_(tot)
         opt.apply(1e-2)               # single-process TF-Adam on the mean gradient
     ref = tot.cpu()
     err = float((r0["gsum"] - ref).norm() / ref.norm())
-    assert err < 1e-4, err
-    assert float((flat.data.cpu() - r0["data"]).abs().max()) < 1e-5
+    assert err < tol[1], err
+    assert float((flat.data.cpu() - r0["data"]).abs().max()) < tol[2]
 
 
 def _rccl_worker(rank, world, port, out):
