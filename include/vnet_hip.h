@@ -375,8 +375,13 @@ int vnet_cast_bf16(const float* x, void* y16, int64_t M, int C, int Cpad, void* 
 
 /* 5^3 stride-1 convolution, bf16 in / bf16 out; forward (VNET_PACK_FWD_BF16) and backward-data (VNET_PACK_BWD_BF16).
  * acc16: NULL, or a bf16 tensor of y0's shape that is added before the rounding (== y0: in place; else out of place, Cy1 = 0);
- * res16 / stats: batch-norm statistics of the ROUNDED output (+ res16) in the epilogue, rows = vnet_conv_bf16_stats_rows_x16;
- * ws >= vnet_conv_bf16_ws_bytes.  Result == RNE(what vnet_conv_fwd_bf16_x16 writes in fp32), bit for bit. */
+ * res16 / stats: batch-norm statistics of the ROUNDED output (+ res16) in the epilogue, rows = vnet_conv_b16_stats_rows;
+ * ws >= vnet_conv_b16_ws_bytes.  Result == RNE(what vnet_conv_fwd_bf16_x16 writes in fp32), bit for bit, wherever the two take
+ * the same kernels.  Round 4: few bricks and whole 32-cout blocks / 16-cin chunks (the deep levels: 32^3 64->64, 16^3 128->128,
+ * 8^3 256->256 and their two-source / backward-data relatives) take the K-split-over-waves kernel of csrc/conv_deep.h, which sums
+ * in another (fixed) order; environment VNET_BF16_DEEP=0 keeps the generic kernels. */
+size_t vnet_conv_b16_ws_bytes(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W);
+int vnet_conv_b16_stats_rows(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W);
 int vnet_conv_fwd_b16(const void* x0, int C0, const void* x1, int C1, const void* wp, const float* bias,
                       void* y0, int Cy0, void* y1, int Cy1, int B, int D, int H, int W,
                       const void* acc16, const void* res16, float* stats, void* ws, size_t ws_bytes, void* stream);

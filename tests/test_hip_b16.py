@@ -74,6 +74,9 @@ def test_conv5_b16_against_oracle_and_fp32_output_kernels(dev, shape, monkeypatc
     from vnet_tensorflow_amd import ops
     monkeypatch.setenv("VNET_WGRAD_RR", "0")        # the bit-exact link below is to the generic filter-gradient kernel (the row-reuse
                                                     # kernel sums in another order: test_row_reuse_filter_gradient)
+    monkeypatch.setenv("VNET_BF16_DEEP", "0")       # ... and to the generic forward kernels (round 4: shapes with few bricks and whole
+                                                    # 32-cout blocks take the deep-level kernel, which splits K over the waves --
+                                                    # against the oracle and against these kernels in tests/test_hip_deep.py)
     B, D, H, W, C0, C1, Co = shape
     x0, x1, w, b, dy = _conv5_inputs(shape, sum(shape) + 3)
     xcat = x0 if x1 is None else np.concatenate((x0, x1), -1)

@@ -36,6 +36,8 @@ SIGNATURES = {
     "vnet_conv_fwd_bf16_stats": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "vnet_bn_finalize_partial": (_i, [_vp, _i, _i, _d, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "vnet_conv_bf16_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "vnet_conv_b16_ws_bytes": (_sz, [_i] * 8),
+    "vnet_conv_b16_stats_rows": (_i, [_i] * 8),
     "vnet_conv_fwd_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "vnet_wgrad_bf16_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "vnet_conv_wgrad_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
@@ -150,19 +152,22 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
-            if name.endswith("_ws_bytes") or name.endswith("_stats_rows") or name.endswith("_stats_rows_x16") or name == "vnet_conv_stats_from_reduce" or name == "vnet_packed_weight_floats":
+            if name == "vnet_conv_b16_stats_rows":
+                setattr(L, name, _memo(fn, ("VNET_BF16_DEEP", "VNET_BF16_DEEP_TARGET")))     # (the kernel choice follows these switches)
+            elif name.endswith("_ws_bytes") or name.endswith("_stats_rows") or name.endswith("_stats_rows_x16") or name == "vnet_conv_stats_from_reduce" or name == "vnet_packed_weight_floats":
                 setattr(L, name, _memo(fn))    # pure size queries, asked before every launch: answer repeats from a dict
         _lib = L
     return _lib
 
 
-def _memo(fn):
+def _memo(fn, env=None):
     cache = {}
 
     def cached(*args):
-        r = cache.get(args)
+        key = args if env is None else args + tuple(os.environ.get(e) for e in env)
+        r = cache.get(key)
         if r is None:
-            r = cache[args] = fn(*args)
+            r = cache[key] = fn(*args)
         return r
     return cached
 

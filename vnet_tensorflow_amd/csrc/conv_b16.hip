@@ -11,6 +11,7 @@
 //     HBM-bound, what matters is that they move 2-byte elements.
 // Reference call sites replaced: layers2.py:59-63, 65-74, 78-94 (forward), model.py:660 (their gradients).
 #include "conv_kernels.h"
+#include "conv_deep.h"
 #include <cstdlib>
 
 namespace {
@@ -19,6 +20,27 @@ inline bool al8p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) ==
 }  // namespace
 
 extern "C" {
+
+// workspace bytes / epilogue-statistics rows of vnet_conv_fwd_b16 for one problem (the kernel choice is a function of the shape)
+size_t vnet_conv_b16_ws_bytes(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W) {
+    // (the larger of the two plans: the zero-padded network input takes the x-im2col kernel whatever the deep plan says)
+    const size_t g = vnet_conv_bf16_ws_bytes(C0 + C1, Cy0 + Cy1, B, D, H, W);
+    const DeepPlan dp = plan_conv_deep(C0, C1, Cy0, Cy1, B, D, H, W, true);      // (whatever VNET_BF16_DEEP says: callers cache this)
+    const size_t d = (dp.use && dp.nsplit > 1) ? (size_t)dp.nsplit * B * D * H * W * round_up(Cy0 + Cy1, 32) * sizeof(float) : 0;
+    return d > g ? d : g;
+}
+
+int vnet_conv_b16_stats_rows(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W) {
+    if (Cy1 != 0 || Cy0 <= 0 || (Cy0 & 3) || C0 <= 0 || B <= 0) return 0;
+    const DeepPlan dp = plan_conv_deep(C0, C1, Cy0, Cy1, B, D, H, W);
+    if (!dp.use) return vnet_conv_bf16_stats_rows_x16(C0 + C1, Cy0, Cy1, C0, C1, B, D, H, W);
+    if (dp.nsplit > 1) {                              // statistics from the split-K reduce kernel: one row per reduce block
+        if (Cy0 > 256 || 256 % Cy0) return 0;
+        const size_t total = (size_t)B * D * H * W * Cy0;
+        return (int)min((size_t)2048, (total + 255) / 256);
+    }
+    return B * dp.nbz * dp.nby * dp.nbx;              // one row per 4x8x8 brick
+}
 
 static int conv_fwd_b16_impl(const void* x0, int C0, const void* x1, int C1, const void* wp, const float* bias,
                              void* y0, int Cy0, void* y1, int Cy1, int B, int D, int H, int W,
@@ -58,19 +80,22 @@ static int conv_fwd_b16_impl(const void* x0, int C0, const void* x1, int C1, con
         if (Cy1 > 0) return VNET_E_BADARG;
         a.accsrc = reinterpret_cast<const float*>(acc16);
     }
-    if (stats && vnet_conv_bf16_stats_rows_x16(a.Cin, Cy0, Cy1, C0, C1, B, D, H, W) == 0) return VNET_E_UNSUPPORTED;
+    if (stats && vnet_conv_b16_stats_rows(C0, C1, Cy0, Cy1, B, D, H, W) == 0) return VNET_E_UNSUPPORTED;
     // the caller vouches that channels cin_real .. C0-1 of x0 are zero (the cast network input): x-im2col form of the 16-cout kernel
     a.in4 = (cin_real > 0 && cin_real <= 4 && C0 == 8 && C1 == 0) ? 1 : 0;
     Bf16Plan p = plan_conv_bf16(a.Cin, a.Cout, B, D, H, W);
-    a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.cps = p.cps; a.nz = p.nz;
-    const int nslab = p.nsplit * p.nz;
+    // deep levels (few bricks, wide channels): the K-split-over-waves kernel of conv_deep.h
+    const DeepPlan dp = a.in4 ? DeepPlan{} : plan_conv_deep(C0, C1, Cy0, Cy1, B, D, H, W);
+    if (dp.use) { a.nbz = dp.nbz; a.nby = dp.nby; a.nbx = dp.nbx; a.cps = dp.cps; a.nz = 1; }
+    else { a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.cps = p.cps; a.nz = p.nz; }
+    const int nslab = dp.use ? dp.nsplit : p.nsplit * p.nz;
     const size_t nvox = (size_t)B * D * H * W;
     if (nslab > 1) {
         const size_t need = (size_t)nslab * nvox * a.CoutP * sizeof(float);
         if (!ws || ws_bytes < need) return VNET_E_WORKSPACE;
         a.part = reinterpret_cast<float*>(ws); a.part_stride = nvox * a.CoutP;
     }
-    const int e = conv_fwd_bf16_go<true, true>(a, p, nslab, C0, C1, Cy0, Cy1, B, D, H, W, st);
+    const int e = dp.use ? launch_conv_deep(a, dp, st) : conv_fwd_bf16_go<true, true>(a, p, nslab, C0, C1, Cy0, Cy1, B, D, H, W, st);
     if (e == -1) return VNET_OK;
     if (e) return e;
     if (nslab > 1) {

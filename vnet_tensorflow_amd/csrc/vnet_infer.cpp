@@ -319,7 +319,7 @@ private:
             Tensor y = alloc16(x0.B, Do, Ho, Wo, Cout);
             if (ks == 5 && stride == 1) {
                 float* wpb = pack(sc + "/weights", VNET_PACK_FWD_BF16, 125, Cin_w ? Cin_w : Cin, Cout);
-                if (vnet_conv_bf16_ws_bytes(Cin, Cout, x0.B, Do, Ho, Wo) > ws_bytes_) { std::fprintf(stderr, "workspace too small\n"); std::exit(1); }
+                if (vnet_conv_b16_ws_bytes(x0.C, x1 ? x1->C : 0, Cout, 0, x0.B, Do, Ho, Wo) > ws_bytes_) { std::fprintf(stderr, "workspace too small\n"); std::exit(1); }
                 if (Cin_w && !x1)       // the zero-padded network input: x-im2col form where the shape allows (as ops._conv5_b16_call)
                     ABI_OK(vnet_conv_fwd_b16_padded(x0.q, x0.C, Cin_w, wpb, var(sc + "/biases").dev, y.q, Cout, x0.B, x0.D, x0.H, x0.W,
                                                     nullptr, nullptr, ws_, ws_bytes_, st_));

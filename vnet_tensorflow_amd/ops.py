@@ -442,7 +442,7 @@ def _conv5_b16_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res
     B = x0.shape[0]
     C0, C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
     Cy0, Cy1 = y0.shape[-1], (y1.shape[-1] if y1 is not None else 0)
-    nb = L.vnet_conv_bf16_ws_bytes(C0 + C1, Cy0 + Cy1, B, *dims)
+    nb = L.vnet_conv_b16_ws_bytes(C0, C1, Cy0, Cy1, B, *dims)
     ws = workspace(nb, x0.device) if nb else None
     nvox = B * dims[0] * dims[1] * dims[2]
     flops = 2.0 * nvox * 125 * (C0 + C1) * (Cy0 + Cy1)
@@ -1065,8 +1065,11 @@ def _epilogue_stats_buffer(bf16, ks, kx, stride, x0, x1, O, dims_out):
             rows = L.vnet_conv_stats_rows(ks, kx, stride, 0, C0 + C1, O, 0, B, *dims_out)
     elif bf16:
         # (the kernels that stage bf16 sources have their own brick shapes: one partial row per brick)
-        x16 = _is16(x0) or (_shadow_ptr(x0) is not None and (x1 is None or _shadow_ptr(x1) is not None) and C0 % 8 == 0 and C1 % 8 == 0)
-        rows = (L.vnet_conv_bf16_stats_rows_x16 if x16 else L.vnet_conv_bf16_stats_rows)(C0 + C1, O, 0, C0, C1, B, *dims_out)
+        if _is16(x0):                         # bf16 storage: the deep-level kernel has its own bricks (csrc/conv_deep.h)
+            rows = L.vnet_conv_b16_stats_rows(C0, C1, O, 0, B, *dims_out)
+        else:
+            x16 = _shadow_ptr(x0) is not None and (x1 is None or _shadow_ptr(x1) is not None) and C0 % 8 == 0 and C1 % 8 == 0
+            rows = (L.vnet_conv_bf16_stats_rows_x16 if x16 else L.vnet_conv_bf16_stats_rows)(C0 + C1, O, 0, C0, C1, B, *dims_out)
     else:
         # fp32 MFMA kernels: measured (profiles/r02_epilogue_stats.txt) the STATS instantiations lose in their main loop most of
         # what the statistics pass costs (+1..3 % per launch, residual re-read on the input conv): the fused form is worth
