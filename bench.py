@@ -4,6 +4,7 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...            (no launcher: starts the N ranks itself as a child torch.distributed.run, see self_launch)
 
 One "step" = one pass of the hot path over one batch of synthetic patches already resident in HBM:
 forward (networks.VNet, batch-statistics BN) + softmax/Sorensen-Dice + backward + gradient all-reduce
@@ -324,8 +325,33 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
     return res
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks ourselves.  The parent never touches
+    the GPU (device_count() does not initialise it on this image; nothing is exec'ed): it starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same arguments>` as a CHILD process, relays the
+    child's output -- rank 0's single JSON line -- and exits with its code.  Fewer than N visible devices: refused, unless the
+    gloo test hook (VNET_DIST_BACKEND=gloo: several ranks share one device) is set."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and os.environ.get("VNET_DIST_BACKEND") != "gloo":
+        sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible\n" % (args.gpus, ndev))
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode       # stdout / stderr inherited: the JSON line passes through
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
     if args.pin_core >= 0:
         os.sched_setaffinity(0, {args.pin_core})     # before anything touches the GPU; no wrapper / launcher hop
     import torch

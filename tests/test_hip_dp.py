@@ -260,3 +260,27 @@ def test_bench_contract_two_ranks(tmp_path, backend):
     assert abs(out["value"] - 2 * 1 * 1000.0 / out["ms_per_step"]) < 1e-2 * out["value"]
     assert out["roofline"] is None or out["roofline"]["frac"] > 0
     assert "cpu_baseline" not in out                     # rank 0 at N=1 only
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher (the way the driver runs the N = 1 bench): the parent must start two ranks itself
+    (a child torch.distributed.run; it never touches the GPU and execs nothing) and relay rank 0's single JSON line.  Two ranks
+    share the device over gloo here; with fewer devices than ranks and no test hook it must refuse."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["VNET_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "2", "--patch", "32"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["config"]["backend"] == "gloo"
+    assert out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 2
+    if torch.cuda.device_count() < 2:
+        env.pop("VNET_DIST_BACKEND")
+        r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "device(s) visible" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -248,3 +248,18 @@ def test_make_batch_into_caller_buffers_equals_stacked_batches():
     got = ds.make_batch(cases, seeds, out=(oi, ol))
     assert got[0] is oi and got[1] is ol
     assert np.array_equal(oi, ref_i) and np.array_equal(ol, ref_l) and ol.dtype == np.int32
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus N` without a launcher starts its own ranks (tests/test_hip_dp.py on the GPU); with fewer visible
+    devices than ranks it must refuse with a non-zero code and print no JSON line -- never measure one GPU and call it N."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this host has the devices")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "VNET_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "device(s) visible" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
