@@ -4,13 +4,10 @@ cd "$(dirname "$0")"
 F="--offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-function -Wno-unused-result"
 hipcc $F deep_probe.hip -o deep_probe &
 hipcc $F -DDEEP_STAMPS deep_probe.hip -o deep_probe_stamps &
-hipcc $F -DDEEP_NO_A deep_probe.hip -o deep_probe_noa &
-hipcc $F -DDEEP_NO_B deep_probe.hip -o deep_probe_nob &
+hipcc $F -DDEEP_STAMPS -DDEEP_NO_A deep_probe.hip -o deep_probe_stamps_noa &
+hipcc $F -DDEEP_STAMPS -DDEEP_NO_B deep_probe.hip -o deep_probe_stamps_nob &
 wait
-hipcc $F -DDEEP_NO_MFMA deep_probe.hip -o deep_probe_nomfma &
-hipcc $F -DDEEP_NO_A -DDEEP_NO_B deep_probe.hip -o deep_probe_noab &
-hipcc $F -DDEEP_A1 deep_probe.hip -o deep_probe_a1 &
-hipcc $F -DDEEP_TILE_ZERO deep_probe.hip -o deep_probe_tz &
-hipcc $F -DDEEP_STAMPS -DDEEP_STAMP_CHUNK=1 deep_probe.hip -o deep_probe_stamps_c1 &
+hipcc $F -DDEEP_STAMPS -DDEEP_NO_MFMA deep_probe.hip -o deep_probe_stamps_nomfma &
+hipcc $F -DDEEP_STAMPS -DDEEP_A1 deep_probe.hip -o deep_probe_stamps_a1 &
 wait
-ls -la deep_probe*
+ls deep_probe*

@@ -85,7 +85,8 @@ static int conv_fwd_b16_impl(const void* x0, int C0, const void* x1, int C1, con
     a.in4 = (cin_real > 0 && cin_real <= 4 && C0 == 8 && C1 == 0) ? 1 : 0;
     Bf16Plan p = plan_conv_bf16(a.Cin, a.Cout, B, D, H, W);
     // deep levels (few bricks, wide channels): the K-split-over-waves kernel of conv_deep.h
-    const DeepPlan dp = a.in4 ? DeepPlan{} : plan_conv_deep(C0, C1, Cy0, Cy1, B, D, H, W);
+    const bool al16_all = al16p(y0) && al16p(y1) && al16p(acc16) && al16p(res16);          // (its epilogue moves 16 bytes per lane)
+    const DeepPlan dp = (a.in4 || !al16_all) ? DeepPlan{} : plan_conv_deep(C0, C1, Cy0, Cy1, B, D, H, W);
     if (dp.use) { a.nbz = dp.nbz; a.nby = dp.nby; a.nbx = dp.nbx; a.cps = dp.cps; a.nz = 1; }
     else { a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.cps = p.cps; a.nz = p.nz; }
     const int nslab = dp.use ? dp.nsplit : p.nsplit * p.nz;

@@ -15,11 +15,14 @@
 //     No filter planes, no per-plane barriers, no ds_write of weights;
 //   * z-sliding B reuse: tile plane p of the brick + halo feeds output plane z = p - dz for every dz, so a unit reads
 //     8 planes x 2 y-halves = 16 B fragments for 40 MFMAs: 0.4 KB of LDS per MFMA (generic: 1.5, row-pair kernel: 0.8);
-//   * the tile (brick + halo of one chunk: 36 KB) is staged through registers into two buffers; per chunk every wave does
-//     three units (dy, dx) = wave, 8 + wave, 16 + wave and one fifth (one dz) of the 25th, so the single barrier per chunk
-//     finds the waves together; straight-line code per chunk, every prefetch issued unconditionally (see the kernel);
+//   * the tiles (brick + halo, 36 KB per chunk) of up to four chunks = 64 input channels = one 128-byte line per voxel are
+//     resident in LDS for a whole phase and loaded in whole lines; inside a phase there is no barrier and no staging at
+//     all: per chunk every wave does three units (dy, dx) = wave, 8 + wave, 16 + wave and one dz of the 25th (which five
+//     waves, rotates), straight-line code, filter prefetch two units ahead, every issue unconditional (see the kernel);
 //   * at the end the eight partial bricks meet in LDS (two rounds of 4 tiles x 8 waves x 4 KB = 128 KB), every wave sums half
-//     a tile per round in a fixed order (deterministic) and runs the ordinary epilogue on it: bias, accumulate, one RNE rounding, statistics,
+//     a tile per round in a fixed order (deterministic) and runs the ordinary epilogue on it (four rounds of 64 KB through two
+//     alternating buffers were measured and are SLOWER, 8.8 K against 7.2 K cycles: the LDS serves one access at a time and
+//     every extra barrier costs more than the overlap gains): bias, accumulate, one RNE rounding, statistics,
 //     or the fp32 split-K slab when the chunk range is split over workgroups.
 #pragma once
 #include "conv_kernels.h"
@@ -53,7 +56,7 @@ inline DeepPlan plan_conv_deep(int C0, int C1, int Cy0, int Cy1, int B, int D, i
     const int Cin = C0 + C1, Cout = Cy0 + Cy1;
     const char* env = getenv("VNET_BF16_DEEP");          // 0: off (the generic kernels; read per call: tests and A/B runs flip it)
     if (!ignore_env && env && atoi(env) == 0) return p;
-    if ((Cout & 31) || (C0 & 15) || (C1 & 15) || (Cy0 & 3) || (Cy1 & 3) || Cin < 16) return p;
+    if ((Cout & 31) || (C0 & 15) || (C1 & 15) || (Cy0 & 7) || (Cy1 & 7) || Cin < 16) return p;     // (16-byte epilogue accesses)
     if (conv_bf16_use_c16(Cin, Cout, C0, C1, Cy0, Cy1, B, D, H, W)) return p;
     const int nchunks = Cin / 16;
     p.nbz = ceil_div(D, 4); p.nby = ceil_div(H, 8); p.nbx = ceil_div(W, 8);
@@ -76,12 +79,15 @@ inline DeepPlan plan_conv_deep(int C0, int C1, int Cy0, int Cy1, int B, int D, i
 template <bool STATS>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv5_bf16_deep_kernel(ConvArgs a) {
     using G = Bf16Geom<4, 8, 8>;
-    constexpr int NT = 512, NW = 8, NBUF = 2;
+    constexpr int NW = 8, NSLOT = 4;
+    // a (chunk, cin half) plane is padded by one 16-byte unit: the eight planes of a phase then start 16 bytes apart modulo the
+    // 256-byte bank row, so the eight lanes of a ds_write_b128 cycle -- eight pieces of ONE voxel, see load_pass -- hit
+    // eight different bank quads (unpadded: the same one, 8-way conflict)
+    constexpr int PLANE = G::PLANE + 16, TILE = 2 * PLANE;
     constexpr int SCRATCH = 4 * NW * 4096;                              // one reduction round: 4 tiles x 8 waves x 4 KB
-    constexpr int MAIN = (NBUF * G::TILE_BYTES > SCRATCH) ? NBUF * G::TILE_BYTES : SCRATCH;
+    constexpr int MAIN = (NSLOT * TILE > SCRATCH) ? NSLOT * TILE : SCRATCH;
     constexpr int PSTRIDE = G::IY * G::IX * 16;                         // bytes between two z planes of a cin-half plane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using XH = XTileH<G::IZ, G::IY, G::IX, NT>;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -109,21 +115,20 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     unsigned char* dump = smem + MAIN + lane * 16;
 
     // B fragment base of (y half 0, plane 0, tap (0,0)): lane -> (cin half, row, x)
-    const int boff0 = half * G::PLANE + ((q32 >> 3) * G::IX + (q32 & 7)) * 16;
+    const int boff0 = half * PLANE + ((q32 >> 3) * G::IX + (q32 & 7)) * 16;
     constexpr int YH = 4 * G::IX * 16;                                  // second y half: four tile rows further
     const u32x4* wg = reinterpret_cast<const u32x4*>(a.wp) + (size_t)cob * 64 + lane;
     const size_t wtap = (size_t)ncob * 64;                              // u32x4 units between two taps
 
     f32x16 acc[8];
-    u32x4 tv[XH::PER];                                                  // tile prefetch: the next chunk, global -> registers
-    u32x4 afx[5], afy[5], am;                                           // filter fragments: this unit / the next one / the tail unit
+    u32x4 afx[5], afy[5], afz[5], am;                                   // filter fragments: a ring of three units + the tail unit's
 
-    // Every load of the main loop is issued UNCONDITIONALLY (past the end: the last chunk's filter again, the zero line for
-    // the tile): a branch around an issue makes hipcc merge two counter states at the join and wait for the YOUNGER one,
-    // i.e. s_waitcnt vmcnt(4..0) instead of (9..5) in front of the MFMAs -- the prefetch of the next unit then has to land
-    // inside the first planes of this one (round-4 stamps: 72 % of the MFMA rate; without the filter loads 100 %).
-    auto a_issue5 = [&](u32x4 (&f)[5], int c, int r) {                  // r = dy * 5 + dx
-        const u32x4* src = wg + ((size_t)(c_begin + c) * 125 + r) * wtap;
+    // Every load of the main loop is issued UNCONDITIONALLY (past the end: the last chunk's filter again): a branch around an
+    // issue makes hipcc merge two counter states at the join and wait for the YOUNGER one, i.e. s_waitcnt vmcnt(4..0) instead
+    // of the exact count in front of the MFMAs -- the prefetch then has to land inside the first planes of the unit that
+    // issued it (round-4 stamps: 72 % of the MFMA rate; without the filter loads 100 %).
+    auto a_issue5 = [&](u32x4 (&f)[5], int c, int r) {                  // c: chunk of this workgroup, r = dy * 5 + dx
+        const u32x4* src = wg + ((size_t)(c_begin + min(c, ncl - 1)) * 125 + r) * wtap;
 #ifdef DEEP_A1
         f[0] = *(const __attribute__((address_space(1))) u32x4*)(src);
 #elif !defined(DEEP_NO_A)
@@ -131,67 +136,98 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int dz = 0; dz < 5; ++dz) f[dz] = *(const __attribute__((address_space(1))) u32x4*)(src + (size_t)dz * 25 * wtap);
 #endif
     };
-    // Tile staging, one 16-byte piece k = 0..4 of this thread at a time (thread = (tile row r0 of 21, x, cin half) column as in
-    // XTileH; piece k = tile row r0 + 21 k).  Branch-free -- masked lanes load the zero line, masked stores go to a dump slot --
-    // so that the pieces can sit between the MFMAs of a unit (round-4 stamps: the XTileH call + commit + the waits hipcc put
-    // behind its interior / boundary branch cost 3.5 K cycles per chunk, a third of the main loop).
-    const int t_r0 = tid / XH::COLS, t_col = tid - t_r0 * XH::COLS;
-    const int t_ix = t_col >> 1, t_hf = t_col & 1;
-    const int t_gx = gx0 + t_ix;
-    const bool t_colok = t_r0 < XH::RPI && (unsigned)t_gx < (unsigned)a.Wi;
-    const int t_lds0 = t_hf * G::PLANE + (t_r0 * G::IX + t_ix) * 16;     // + k * RPI * IX * 16
-    auto t_issue_k = [&](int c, int k) {
-        const int cg = c_begin + c;
-        const bool live = c < ncl;                                      // (uniform) past the last chunk: the zero line
-        const bool s0 = cg * 16 < a.C0;                                 // (uniform) which source the chunk lies in
-        const unsigned short* src = s0 ? x0h + cg * 16 : x1h + (cg * 16 - a.C0);
-        const int Cs = s0 ? a.C0 : a.C1;
-        const int row = t_r0 + k * XH::RPI;
-        const int iz = (row * 5462) >> 16, iy = row - iz * G::IY;      // row / 12 for row < 192
-        const int gz = gz0 + iz, gy = gy0 + iy;
-#ifdef DEEP_TILE_ZERO
-        const bool ok = live && t_colok && row < XH::ROWS && (unsigned)gz < (unsigned)a.Di && (unsigned)gy < (unsigned)a.Hi && c < 1;
-#else
-        const bool ok = live && t_colok && row < XH::ROWS && (unsigned)gz < (unsigned)a.Di && (unsigned)gy < (unsigned)a.Hi;
-#endif
-        const long long vox = ((long long)(b * a.Di + gz) * a.Hi + gy) * a.Wi + t_gx;
-        tv[k] = load16_or_zero(src + (ok ? vox * Cs + t_hf * 8 : 0), ok);
-    };
-    auto t_commit_k = [&](int c, int k) {
-        const int row = t_r0 + k * XH::RPI;
-        const bool ok = t_r0 < XH::RPI && row < XH::ROWS;
-        unsigned char* dst = ok ? smem + (c & 1) * G::TILE_BYTES + t_lds0 + k * (XH::RPI * G::IX * 16) : dump;
-        *reinterpret_cast<u32x4*>(dst) = tv[k];
-    };
-    // one unit = one (dy, dx) with all five dz: 16 B fragments (8 planes x 2 y halves) feed 40 MFMAs.  Fragment ring two planes
-    // deep (the outer planes carry only 2 MFMAs = 64 cycles, less than an LDS round trip), issue points pinned: hipcc
-    // otherwise sinks every read next to its first use (read -> lgkmcnt(0) -> MFMA)
-    auto unit = [&](const u32x4 (&f)[5], int c, int r) {
-        const int dy = r / 5, dx = r - dy * 5;
-        const unsigned char* tp = smem + (c & 1) * G::TILE_BYTES + boff0 + (dy * G::IX + dx) * 16;
-        bf16x8 bb[3][2];
-#ifdef DEEP_NO_B
+
+    // ---- tile staging.  A PHASE = up to four chunks (64 input channels = one 128-byte line per voxel), all resident in LDS for
+    // the whole phase.  The generic kernels (and this one until its third version) staged one chunk at a time: 32 bytes of
+    // every voxel's line per pass, i.e. every line of the brick + halo crossed the L2 -> L1 path once per chunk; those loads,
+    // queued in order in front of the filter prefetch, held the main loop at 70 % of the MFMA rate (round-4 stamps: 47 K cycles
+    // for 32.8 K of MFMAs at 32^3 64->64; 38.8 K now).  Here a pass moves 2^LG 16-byte pieces per voxel -- whole lines when a
+    // phase has four chunks -- lanes in (voxel, piece) order: 16 lanes read two whole lines (with the lanes in (piece, voxel)
+    // order the texture path saw 8 lines per 16 lanes and the pass took 11 K instead of 5 K cycles), and the piece goes to
+    // its (chunk, cin half) plane.  Staged through two register batches of six; nothing else runs meanwhile.
+    // FIRST (the first phase: the accumulators are not live yet): every load of the pass in flight at once; later phases: two
+    // register batches of six.
+    auto load_pass = [&](auto lgc, auto firstc, const unsigned short* src, int Cs, int slot0) {
+        constexpr int LG = decltype(lgc)::value, NP = 1 << LG, VPI = 64 >> LG;      // pieces per voxel, voxels per instruction
+        constexpr int NINST = (G::NV * NP + 63) / 64, NI = (NINST + NW - 1) / NW;   // wave instructions of the pass, per wave
+        constexpr int NB = decltype(firstc)::value ? NI : 6;
+        int vsub = lane >> LG;
+        // (opaque per call: what follows depends only on the thread, and hipcc would otherwise hoist the address arithmetic of all
+        // eighteen pieces out of the phase loop and keep it in registers for the whole kernel)
+        asm volatile("" : "+v"(vsub));
+        const int piece = lane & (NP - 1);
+        const int ldsp = (slot0 + (piece >> 1)) * TILE + (piece & 1) * PLANE;
+        auto issue = [&](u32x4 (&t)[NB], int k0) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) { bb[p][0] = __builtin_bit_cast(bf16x8, f[p]); bb[p][1] = __builtin_bit_cast(bf16x8, f[p + 1]); }
-        asm volatile("" :: "v"(tp));
-#else
+            for (int k = 0; k < NB; ++k) {
+                if (k0 + k >= NI) break;
+                const int v = (wave + NW * (k0 + k)) * VPI + vsub;
+                const int iz = v / (G::IY * G::IX), rem = v - iz * (G::IY * G::IX), iy = rem / G::IX, ix = rem - iy * G::IX;
+                const int gz = gz0 + iz, gy = gy0 + iy, gx = gx0 + ix;
+                const bool ok = v < G::NV && (unsigned)gz < (unsigned)a.Di && (unsigned)gy < (unsigned)a.Hi && (unsigned)gx < (unsigned)a.Wi;
+                const long long vox = ((long long)(b * a.Di + gz) * a.Hi + gy) * a.Wi + gx;
+                t[k] = load16_or_zero(src + (ok ? vox * Cs + piece * 8 : 0), ok);
+            }
+        };
+        auto commit = [&](const u32x4 (&t)[NB], int k0) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            bb[p][0] = *reinterpret_cast<const bf16x8*>(tp + p * PSTRIDE);
-            bb[p][1] = *reinterpret_cast<const bf16x8*>(tp + p * PSTRIDE + YH);
+            for (int k = 0; k < NB; ++k) {
+                if (k0 + k >= NI) break;
+                const int v = (wave + NW * (k0 + k)) * VPI + vsub;
+                *reinterpret_cast<u32x4*>(v < G::NV ? smem + ldsp + v * 16 : dump) = t[k];
+            }
+        };
+        u32x4 ta[NB], tb[NB];
+        issue(ta, 0);
+#pragma unroll
+        for (int k0 = 0; k0 < NI; k0 += 2 * NB) {
+            if (k0 + NB < NI) issue(tb, k0 + NB);
+            commit(ta, k0);
+            if (k0 + 2 * NB < NI) issue(ta, k0 + 2 * NB);
+            if (k0 + NB < NI) commit(tb, k0 + NB);
         }
-#endif
+    };
+    // chunks [c0, c1) of this workgroup -> slots 0 .. c1 - c0 - 1, in groups of 4 / 2 / 1 chunks that stay inside one source tensor
+    auto load_phase = [&](auto firstc, int c0, int c1) {
+        int c = c0;
+        while (c < c1) {
+            const int cg = c_begin + c;
+            const bool s0 = cg * 16 < a.C0;
+            const unsigned short* src = s0 ? x0h + cg * 16 : x1h + (cg * 16 - a.C0);
+            const int Cs = s0 ? a.C0 : a.C1;
+            const int room = min(c1 - c, ((s0 ? a.C0 : a.C0 + a.C1) - cg * 16) / 16);     // chunks left in this phase and in this source
+            if (room >= 4) { load_pass(std::integral_constant<int, 3>{}, firstc, src, Cs, c - c0); c += 4; }
+            else if (room >= 2) { load_pass(std::integral_constant<int, 2>{}, firstc, src, Cs, c - c0); c += 2; }
+            else { load_pass(std::integral_constant<int, 1>{}, firstc, src, Cs, c - c0); c += 1; }
+        }
+    };
+
+    // one unit = one (dy, dx) with all five dz: 16 B fragments (8 planes x 2 y halves) feed 40 MFMAs.  The fragment ring is
+    // two planes deep (the outer planes carry only 2 MFMAs = 64 cycles, less than an LDS round trip) and runs THROUGH the
+    // units: planes 6 and 7 of a unit issue planes 0 and 1 of the next one (a unit that starts by reading its first fragments
+    // waits an LDS round trip with the matrix pipe idle, twelve times per phase).  24 planes per chunk = 0 mod 3, so the ring
+    // position of a unit's first plane is a compile-time constant (0, 2, 1).  Issue points pinned: hipcc otherwise sinks every
+    // read next to its first use (read -> lgkmcnt(0) -> MFMA).
+    bf16x8 bb[3][2];
+    auto tile_ptr = [&](int slot, int r) {
+        const int dy = r / 5, dx = r - dy * 5;
+        return smem + slot * TILE + boff0 + (dy * G::IX + dx) * 16;
+    };
+    auto b_read = [&](bf16x8 (&dst)[2], const unsigned char* tp, int p) {
+        dst[0] = *reinterpret_cast<const bf16x8*>(tp + p * PSTRIDE);
+        dst[1] = *reinterpret_cast<const bf16x8*>(tp + p * PSTRIDE + YH);
+    };
+    auto unit = [&](auto basec, const u32x4 (&f)[5], const unsigned char* tp, const unsigned char* tp_next) {
+        constexpr int BASE = decltype(basec)::value;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
 #ifndef DEEP_NO_B
-            if (p + 2 < 8) {
-                bb[(p + 2) % 3][0] = *reinterpret_cast<const bf16x8*>(tp + (p + 2) * PSTRIDE);
-                bb[(p + 2) % 3][1] = *reinterpret_cast<const bf16x8*>(tp + (p + 2) * PSTRIDE + YH);
-            }
+            if (p + 2 < 8) b_read(bb[(BASE + p + 2) % 3], tp, p + 2);
+            else b_read(bb[(BASE + p + 2) % 3], tp_next, p + 2 - 8);
 #endif
             __builtin_amdgcn_sched_barrier(0);
 #ifdef DEEP_NO_MFMA
-            asm volatile("" :: "v"(bb[p % 3][0]), "v"(bb[p % 3][1]), "v"(f[p < 5 ? p : 4]));
+            asm volatile("" :: "v"(bb[(BASE + p) % 3][0]), "v"(bb[(BASE + p) % 3][1]), "v"(f[p < 5 ? p : 4]));
 #else
 #pragma unroll
             for (int dz = 0; dz < 5; ++dz) {
@@ -202,111 +238,92 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #else
                 const bf16x8 av = __builtin_bit_cast(bf16x8, f[dz]);
 #endif
-                acc[2 * z] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bb[p % 3][0], acc[2 * z], 0, 0, 0);
-                acc[2 * z + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bb[p % 3][1], acc[2 * z + 1], 0, 0, 0);
+                acc[2 * z] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bb[(BASE + p) % 3][0], acc[2 * z], 0, 0, 0);
+                acc[2 * z + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bb[(BASE + p) % 3][1], acc[2 * z + 1], 0, 0, 0);
             }
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // the 25th (dy, dx) = (4, 4) of a chunk, split by dz over waves 0..4: 8 B fragments, 8 MFMAs each (25 units do not divide
-    // by 8 waves: with it every wave does 3 units + this per chunk, and the per-chunk barrier finds them together)
-    const int dzm = min(wave, 4);
+    // the 25th (dy, dx) = (4, 4) of a chunk is split by dz over five waves (8 B fragments, 8 MFMAs each); which five rotates with
+    // the chunk, and there is no barrier inside a phase, so the uneven share evens out over the chunks
+    auto tail_dz = [&](int c) { return (wave - (c_begin + c)) & 7; };
     auto tail_issue = [&](int c) {
 #ifndef DEEP_NO_A
-        am = *(const __attribute__((address_space(1))) u32x4*)(wg + ((size_t)(c_begin + c) * 125 + dzm * 25 + 24) * wtap);
+        am = *(const __attribute__((address_space(1))) u32x4*)(wg + ((size_t)(c_begin + min(c, ncl - 1)) * 125 + min(tail_dz(c), 4) * 25 + 24) * wtap);
 #endif
     };
-    auto tail = [&](int c) {
-        if (wave < 5) {
-            const unsigned char* tp = smem + (c & 1) * G::TILE_BYTES + boff0 + (4 * G::IX + 4) * 16 + wave * PSTRIDE;
-            bf16x8 bt[4][2];
-#pragma unroll
-            for (int z = 0; z < 4; ++z) {
-                bt[z][0] = *reinterpret_cast<const bf16x8*>(tp + z * PSTRIDE);
-                bt[z][1] = *reinterpret_cast<const bf16x8*>(tp + z * PSTRIDE + YH);
-            }
+    auto tail = [&](int slot, int c) {
+        const int dz = tail_dz(c);
+        if (dz < 5) {
+            const unsigned char* tp = smem + slot * TILE + boff0 + (4 * G::IX + 4) * 16 + dz * PSTRIDE;
+            bf16x8 bt[2][2];
+            bt[0][0] = *reinterpret_cast<const bf16x8*>(tp);
+            bt[0][1] = *reinterpret_cast<const bf16x8*>(tp + YH);
             const bf16x8 av = __builtin_bit_cast(bf16x8, am);
 #pragma unroll
             for (int z = 0; z < 4; ++z) {
-                acc[2 * z] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bt[z][0], acc[2 * z], 0, 0, 0);
-                acc[2 * z + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bt[z][1], acc[2 * z + 1], 0, 0, 0);
+                if (z + 1 < 4) {
+                    bt[(z + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(tp + (z + 1) * PSTRIDE);
+                    bt[(z + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(tp + (z + 1) * PSTRIDE + YH);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[2 * z] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bt[z & 1][0], acc[2 * z], 0, 0, 0);
+                acc[2 * z + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bt[z & 1][1], acc[2 * z + 1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
-    // chunk c: its tile is visible in buffer c & 1, its first unit's fragments are in flight in fx; leaves the next chunk's first
-    // unit in fy (the buffers swap roles every chunk: three units each)
-    // Staging of the tiles under the chunk: pieces {0,1}, {2,3}, {4} at the head of the three units, each right BEHIND that unit's
-    // filter prefetch.  s_waitcnt vmcnt counts in order, so a tile load in flight holds up every wait for a filter fragment
-    // issued after it; issued behind the prefetch of unit u + 1 the first wait that covers it is the one for unit u + 2, two
-    // units (5-6 K cycles) later -- a tile piece takes 3-4 K cycles when every workgroup of the launch asks for its own at the
-    // same moment (round-4 stamps), and spreading the pieces over the units thins that burst.  A piece is committed one chunk
-    // after its issue (its buffer is free since the barrier that opened this chunk), then its registers take the next piece.
-    auto stage = [&](int c, int k0, int k1) {
-        if (c + 1 < ncl) {                                              // (uniform branch around stores: no load inside, the counters stay exact)
-            for (int k = k0; k < k1; ++k) t_commit_k(c + 1, k);
-        }
-        for (int k = k0; k < k1; ++k) t_issue_k(c + 2, k);
-    };
-    auto chunk = [&](int c, u32x4 (&fx)[5], u32x4 (&fy)[5]) {
-        const int cn = min(c + 1, ncl - 1);
-        a_issue5(fy, c, 8 + wave);
-        stage(c, 0, 2);
+    // chunk c (tile in `slot`): its units (dy, dx) = wave, 8 + wave, 16 + wave; fragments of the first two are in flight in
+    // afx / afy on entry, the prefetch runs two units ahead (three buffers = the three units of a chunk: no role swapping)
+    // (slot_next: where the next chunk's tile lies -- the last chunk of a phase points at its own slot: those reads are dropped)
+    auto chunk = [&](int slot, int c, int slot_next) {
+        const unsigned char* t0 = tile_ptr(slot, wave);
+        const unsigned char* t1 = tile_ptr(slot, 8 + wave);
+        const unsigned char* t2 = tile_ptr(slot, 16 + wave);
+        a_issue5(afz, c, 16 + wave);
         __builtin_amdgcn_sched_barrier(0);
-        unit(fx, c, wave);
-        if (c == DEEP_STAMP_CHUNK) DEEP_STAMP(8);
-        a_issue5(fx, c, 16 + wave);
-        stage(c, 2, 4);
-        __builtin_amdgcn_sched_barrier(0);
-        unit(fy, c, 8 + wave);
-        if (c == DEEP_STAMP_CHUNK) DEEP_STAMP(9);
+        unit(std::integral_constant<int, 0>{}, afx, t0, t1);
+        a_issue5(afx, c + 1, wave);
         tail_issue(c);
-        a_issue5(fy, cn, wave);
-        stage(c, 4, 5);
         __builtin_amdgcn_sched_barrier(0);
-        unit(fx, c, 16 + wave);
-        if (c == DEEP_STAMP_CHUNK) DEEP_STAMP(10);
-        tail(c);
-        if (c == DEEP_STAMP_CHUNK) DEEP_STAMP(11);
-        __syncthreads();                                                // chunk c + 1's tile (committed during this chunk) is visible
-        if (c == DEEP_STAMP_CHUNK) DEEP_STAMP(13);
+        unit(std::integral_constant<int, 2>{}, afy, t1, t2);
+        a_issue5(afy, c + 1, 8 + wave);
+        __builtin_amdgcn_sched_barrier(0);
+        unit(std::integral_constant<int, 1>{}, afz, t2, tile_ptr(slot_next, wave));
+        tail(slot, c);
+    };
+    auto phase = [&](int c0, int c1) {
+        b_read(bb[0], tile_ptr(0, wave), 0);
+        b_read(bb[1], tile_ptr(0, wave), 1);
+        for (int c = c0; c < c1; ++c) chunk(c - c0, c, c + 1 < c1 ? c - c0 + 1 : c - c0);
     };
 
-    // prologue: chunk 0 into buffer 0 (its loads go out before anything else), chunk 1 on its way in registers, the first unit's
-    // filter fragments in flight.  The loads that stay in flight into the loop are issued in the order the loop itself leaves
-    // them at a chunk boundary -- tile pieces 0..3, filter fragments of the first unit, tile piece 4 -- because hipcc merges the
-    // counter state of the loop entry with that of the back edge and waits for the younger of the two: with the pieces issued
-    // last, every commit of the loop waited vmcnt(9), i.e. for loads issued one unit earlier.
     __builtin_amdgcn_sched_barrier(0);
     DEEP_STAMP(1);
-    u32x4 tv0[XH::PER];
-#pragma unroll
-    for (int k = 0; k < XH::PER; ++k) { t_issue_k(0, k); tv0[k] = tv[k]; }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) t_issue_k(1, k);
+    // first phase: the filter fragments of the first two units go out first, then the whole tile; the accumulators are cleared
+    // while the loads fly
     a_issue5(afx, 0, wave);
-    t_issue_k(1, 4);
-    __builtin_amdgcn_sched_barrier(0);
+    a_issue5(afy, 0, 8 + wave);
     DEEP_STAMP(2);
+    load_phase(std::true_type{}, 0, min(ncl, NSLOT));
 #pragma unroll
     for (int n = 0; n < 8; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-    {
-        u32x4 keep[XH::PER];
-#pragma unroll
-        for (int k = 0; k < XH::PER; ++k) { keep[k] = tv[k]; tv[k] = tv0[k]; t_commit_k(0, k); tv[k] = keep[k]; }
-    }
     __syncthreads();
     DEEP_STAMP(3);
-    {
-        int c = 0;
-        for (; c + 1 < ncl; c += 2) {
-            chunk(c, afx, afy);
-            chunk(c + 1, afy, afx);
-        }
-        if (c < ncl) chunk(c, afx, afy);
+    phase(0, min(ncl, NSLOT));
+    for (int c0 = NSLOT; c0 < ncl; c0 += NSLOT) {
+        const int c1 = min(ncl, c0 + NSLOT);
+        __syncthreads();                                                // every wave is done with the previous phase's tiles
+        load_phase(std::false_type{}, c0, c1);
+        a_issue5(afx, c0, wave);                                        // (behind the staging: its register batches need the room)
+        a_issue5(afy, c0, 8 + wave);
+        __syncthreads();
+        phase(c0, c1);
     }
+    __syncthreads();                                                    // the tiles are dead: the reduction scratch may overwrite them
 
     // ---- the eight partial bricks meet in LDS.  Two rounds of four tiles (128 KB); in round rd wave w sums HALF a tile: registers
     // 8h .. 8h+7 (h = w & 1: cout groups 2h, 2h+1) of tile 4 rd + (w >> 1), in a fixed order (deterministic) ----
@@ -360,51 +377,93 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     DEEP_STAMP(6);
 
-    // ---- epilogue: this wave holds, for rd = 0, 1: voxel (tile 4 rd + tsel, q32), channels co0 + (2 hsel + gg) * 8 + 4 half + k ----
-    size_t ovs[4]; int cos[4]; bool oks[4]; float e[4][4];
+    // ---- epilogue: this wave holds, for rd = 0, 1: voxel (tile 4 rd + tsel, q32), channels co0 + (2 hsel + gg) * 8 + 4 half + k.
+    // Lanes L and L + 32 hold the same voxel: they exchange (v_permlane32_swap) so that lane L keeps cout group 2 hsel and
+    // lane L + 32 group 2 hsel + 1 -- EIGHT consecutive channels each: one 16-byte load / store per lane and voxel instead of
+    // two 8-byte ones (the store path is issue-bound: round-4 stamps had 2.5-3.9 K cycles here for 32 bytes per lane) ----
+    const int cb = co0 + (2 * hsel + half) * 8;                         // first of this lane's eight channels
+    float e8[2][8]; size_t ov2[2]; bool ok2[2];
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) {
         const int tile = rd * 4 + tsel;
         const int oz = bz * 4 + (tile >> 1), oy = by * 8 + (tile & 1) * 4 + (q32 >> 3), ox = bx * 8 + (q32 & 7);
-        const bool vok = oz < a.Do && oy < a.Ho && ox < a.Wo;
-        const size_t ov = vok ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
+        ok2[rd] = oz < a.Do && oy < a.Ho && ox < a.Wo;
+        ov2[rd] = ok2[rd] ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
 #pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
-            const int u = rd * 2 + gg;
-            oks[u] = vok; ovs[u] = ov; cos[u] = co0 + (2 * hsel + gg) * 8 + half * 4;
-            e[u][0] = fin[rd][4 * gg] + bv[gg].x; e[u][1] = fin[rd][4 * gg + 1] + bv[gg].y;
-            e[u][2] = fin[rd][4 * gg + 2] + bv[gg].z; e[u][3] = fin[rd][4 * gg + 3] + bv[gg].w;
+        for (int k = 0; k < 4; ++k) {
+            const float bk0 = k == 0 ? bv[0].x : k == 1 ? bv[0].y : k == 2 ? bv[0].z : bv[0].w;
+            const float bk1 = k == 0 ? bv[1].x : k == 1 ? bv[1].y : k == 2 ? bv[1].z : bv[1].w;
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(fin[rd][k] + bk0), __float_as_uint(fin[rd][4 + k] + bk1), false, false);
+            e8[rd][k] = __uint_as_float(sw[0]);                         // lower half: own group 2 hsel; upper half: partner's group 2 hsel + 1
+            e8[rd][4 + k] = __uint_as_float(sw[1]);                     // lower half: partner's part of group 2 hsel (+4..7); upper half: own
         }
     }
     if (a.part) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (oks[u]) *reinterpret_cast<float4*>(a.part + blockIdx.z * a.part_stride + ovs[u] * a.CoutP + cos[u]) = make_float4(e[u][0], e[u][1], e[u][2], e[u][3]);
+        for (int rd = 0; rd < 2; ++rd)
+            if (ok2[rd]) {
+                float* dst = a.part + blockIdx.z * a.part_stride + ov2[rd] * a.CoutP + cb;
+                *reinterpret_cast<float4*>(dst) = make_float4(e8[rd][0], e8[rd][1], e8[rd][2], e8[rd][3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(e8[rd][4], e8[rd][5], e8[rd][6], e8[rd][7]);
+            }
         DEEP_STAMP(7);
         return;
     }
+    {
+        const bool iny0 = cb < a.Cy0;                                   // (Cy0 % 8 == 0: eight channels never straddle y0 / y1)
+        unsigned short* yb = iny0 ? reinterpret_cast<unsigned short*>(a.y0) + cb : reinterpret_cast<unsigned short*>(a.y1) + (cb - a.Cy0);
+        const int ycs = iny0 ? a.Cy0 : a.Cy1;
+        u32x4 old[2], rr[2];
+        if (a.accum) {                                                  // every load of the epilogue in flight before the first use
+            const unsigned short* sb = a.accsrc ? reinterpret_cast<const unsigned short*>(a.accsrc) + cb : yb;
+            const int scs = a.accsrc ? a.Cy0 : ycs;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) if (!oks[u]) cos[u] = 0;
-    epilogue_b16_batch<STATS, 4>(a, ovs, cos, oks, e);
+            for (int rd = 0; rd < 2; ++rd) old[rd] = *reinterpret_cast<const u32x4*>(sb + ov2[rd] * scs);
+        }
+        if constexpr (STATS) {
+            if (a.res) {
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd) rr[rd] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(a.res) + ov2[rd] * a.Cout + cb);
+            }
+        }
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            if (a.accum) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { e8[rd][2 * k] += bf_lo(old[rd][k]); e8[rd][2 * k + 1] += bf_hi(old[rd][k]); }
+            }
+            u32x4 pk;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pk[k] = pk_bf16(e8[rd][2 * k], e8[rd][2 * k + 1]);
+            if constexpr (STATS) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { e8[rd][2 * k] = bf_lo(pk[k]); e8[rd][2 * k + 1] = bf_hi(pk[k]); }
+                if (a.res) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { e8[rd][2 * k] += bf_lo(rr[rd][k]); e8[rd][2 * k + 1] += bf_hi(rr[rd][k]); }
+                }
+            }
+            if (ok2[rd]) *reinterpret_cast<u32x4*>(yb + ov2[rd] * ycs) = pk;
+        }
+    }
     DEEP_STAMP(7);
     if constexpr (STATS) {
-        // e now holds what the batch-norm behind sees (rounded value + residual): per channel over this wave's 2 x 32 voxels, then
-        // over the waves; a wave owns 16 of the block's 32 channels and writes zeros for the others
+        // e8 now holds what the batch-norm behind sees (rounded value + residual): per channel over this wave's 2 x 32 voxels (the 32
+        // lanes of a half hold the same eight channels), then over the waves; a wave owns 16 of the block's 32 channels and
+        // writes zeros for the others
         __syncthreads();                                                // the reduction scratch is free again
         float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
-        for (int gg = 0; gg < 2; ++gg)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float v1 = (oks[gg] ? e[gg][k] : 0.f) + (oks[2 + gg] ? e[2 + gg][k] : 0.f);
-                float v2 = (oks[gg] ? e[gg][k] * e[gg][k] : 0.f) + (oks[2 + gg] ? e[2 + gg][k] * e[2 + gg][k] : 0.f);
-                v1 = half32_sum(v1); v2 = half32_sum(v2);
-                if (p32 == 0) {
-                    const int ch = (2 * hsel + gg) * 8 + half * 4 + k, other = ch ^ 16;
-                    red[wave * 64 + ch] = v1; red[wave * 64 + 32 + ch] = v2;
-                    red[wave * 64 + other] = 0.f; red[wave * 64 + 32 + other] = 0.f;
-                }
+        for (int k = 0; k < 8; ++k) {
+            float v1 = (ok2[0] ? e8[0][k] : 0.f) + (ok2[1] ? e8[1][k] : 0.f);
+            float v2 = (ok2[0] ? e8[0][k] * e8[0][k] : 0.f) + (ok2[1] ? e8[1][k] * e8[1][k] : 0.f);
+            v1 = half32_sum(v1); v2 = half32_sum(v2);
+            if (p32 == 0) {
+                const int ch = (2 * hsel + half) * 8 + k, other = ch ^ 16;
+                red[wave * 64 + ch] = v1; red[wave * 64 + 32 + ch] = v2;
+                red[wave * 64 + other] = 0.f; red[wave * 64 + 32 + other] = 0.f;
             }
+        }
         __syncthreads();
         stats_row_write<NW, 32>(red, a.stats, (size_t)brick_id, co0, a.Cout, tid);
     }
@@ -412,7 +471,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
 int launch_conv_deep(const ConvArgs& a, const DeepPlan& p, hipStream_t st) {
     using G = Bf16Geom<4, 8, 8>;
-    constexpr size_t main_bytes = (2 * G::TILE_BYTES > 4 * 8 * 4096) ? 2 * G::TILE_BYTES : 4 * 8 * 4096;
+    constexpr size_t main_bytes = 4 * (G::TILE_BYTES + 32);          // four padded tiles (> the 128 KB of a reduction round)
     const size_t lds = main_bytes + 64 * 16;
     dim3 grid(a.B * p.nbz * p.nby * p.nbx, p.ncob, p.nsplit);
     if (a.stats && p.nsplit == 1) {
