@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="skip the bf16 / 4-modality / 5-class sub-measurement (N=1)")
+    ap.add_argument("--no-c2", action="store_true", help="skip the 64^3 batch-2 fp32 sub-measurement (BASELINE configs[1], N=1)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 400 extra replays after the timed region (N=1)")
     ap.add_argument("--cpu-patch", type=int, default=0, help="CPU baseline patch edge (0 = the benchmarked patch itself)")
     ap.add_argument("--pin-core", type=int, default=-1,
@@ -176,6 +177,93 @@ def sustained_run(m, images, labels, ms_per_step):
     return {"steps": n, "ms_per_step": round(dt / n * 1e3, 3), "seconds": round(dt, 2),
             "sclk_mhz": smi.get("sclk_mhz"), "power_w": smi.get("power_w"),
             "note": "graph replays after the timed region (not part of `value`)"}
+
+
+def hbm_kernel_table(dev, bf16, classes, iters=50):
+    """The HBM-bound kernels of the step ("report both for every kernel"), one kernel at a time at the shapes of the
+    128^3 network's level 1: `iters` back-to-back launches between two HIP events on the launch stream (the C ABI called as ops.py
+    calls it), over the ALGORITHMIC bytes of the pass -- what it must read and write once.  Replaces, per the
+    reference: networks.py:259,319 (batch-norm + PReLU), layers2.py:78-94 (2^3 stride-2 / transposed convolutions),
+    model.py:447,60-83 (softmax + Dice) and model.py:649-662 (Adam)."""
+    import torch
+    from vnet_tensorflow_amd import _lib, ops
+    L = _lib.lib()
+    P_ = ops._ptr
+    st = ops._stream()
+    dt = torch.bfloat16 if bf16 else torch.float32
+    esz = 2 if bf16 else 4
+    out = {}
+
+    def timed(name, nbytes, fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / iters * 1e3
+        gbps = nbytes / us / 1e3
+        out[name] = {"us": round(us, 2), "algorithmic_bytes": int(nbytes), "GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / PEAK_HBM_GBS, 4)}
+
+    M, C = 128 ** 3, 16
+    x = torch.randn(M, C, device=dev).to(dt)
+    r = torch.randn(M, C, device=dev).to(dt)
+    dy = torch.randn(M, C, device=dev).to(dt)
+    y, ds = torch.empty_like(x), torch.empty_like(x)
+    mean, invstd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    gamma, beta, alpha = torch.ones(C, device=dev), torch.zeros(C, device=dev), torch.full((C,), 0.25, device=dev)
+    dg, db, da = (torch.zeros(C, device=dev) for _ in range(3))
+    mm, mv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    nb = L.vnet_bn_ws_bytes(C)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    if bf16:
+        timed("bn_stats 128^3x16", M * C * esz, lambda: L.vnet_bn_stats_b16(P_(x), None, M, C, 1e-3, 0.99, P_(mean), P_(invstd), P_(mm), P_(mv), P_(ws), nb, st))
+        timed("bn_act_fwd 128^3x16 +res", 3 * M * C * esz, lambda: L.vnet_bn_act_fwd_b16(P_(x), P_(r), 0, M, C, P_(mean), P_(invstd), P_(gamma), P_(beta), 2, P_(alpha), P_(y), st))
+        timed("bn_act_bwd_reduce 128^3x16 +res", 3 * M * C * esz, lambda: L.vnet_bn_act_bwd_reduce_b16(P_(dy), P_(x), P_(r), 0, M, C, P_(mean), P_(invstd), P_(gamma), P_(beta), 2, P_(alpha), P_(dg), P_(db), P_(da), P_(ws), nb, st))
+        timed("bn_act_bwd_apply 128^3x16 +res", 4 * M * C * esz, lambda: L.vnet_bn_act_bwd_apply_b16(P_(dy), P_(x), P_(r), 0, M, C, P_(mean), P_(invstd), P_(gamma), P_(beta), 2, P_(alpha), P_(db), P_(dg), float(M), None, P_(ds), st))
+    else:
+        timed("bn_stats 128^3x16", M * C * esz, lambda: L.vnet_bn_stats(P_(x), None, 0, M, C, 1e-3, 0.99, P_(mean), P_(invstd), P_(mm), P_(mv), P_(ws), nb, st))
+        timed("bn_act_fwd 128^3x16 +res", 3 * M * C * esz, lambda: L.vnet_bn_act_fwd(P_(x), P_(r), 0, M, C, P_(mean), P_(invstd), P_(gamma), P_(beta), 2, P_(alpha), P_(y), st))
+        timed("bn_act_bwd_reduce 128^3x16 +res", 3 * M * C * esz, lambda: L.vnet_bn_act_bwd_reduce(P_(dy), P_(x), P_(r), 0, M, C, P_(mean), P_(invstd), P_(gamma), P_(beta), 2, P_(alpha), P_(dg), P_(db), P_(da), P_(ws), nb, st))
+        timed("bn_act_bwd_apply 128^3x16 +res", 4 * M * C * esz, lambda: L.vnet_bn_act_bwd_apply(P_(dy), P_(x), P_(r), 0, M, C, P_(mean), P_(invstd), P_(gamma), P_(beta), 2, P_(alpha), P_(db), P_(dg), float(M), None, P_(ds), st))
+    del r, dy, y, ds
+    # level-1 down convolution 16 -> 32 (128^3 -> 64^3) and transposed convolution 32 -> 16 (64^3 -> 128^3)
+    x5 = x.view(1, 128, 128, 128, 16)
+    wd = torch.randn(2, 2, 2, 16, 32, device=dev) * 0.1
+    bd = torch.zeros(32, device=dev)
+    xc = torch.randn(1, 64, 64, 64, 32, device=dev).to(dt)
+    wu = torch.randn(2, 2, 2, 16, 32, device=dev) * 0.1
+    bu = torch.zeros(16, device=dev)
+    with torch.no_grad():
+        timed("down_conv 2^3 s2 16->32 @128^3", (M * 16 + M // 8 * 32) * esz, lambda: ops.conv(x5, wd, bd, 2, 2))
+        timed("up_conv 2^3 s2 32->16 @64^3", (M // 8 * 32 + M * 16) * esz, lambda: ops.conv_transpose2(xc, wu, bu, (128, 128, 128)))
+    del x, x5, xc
+    # softmax + Dice at 128^3 (fp32 logits in both modes), forward and backward
+    K = classes
+    logits = torch.randn(1, 128, 128, 128, K, device=dev)
+    labels = torch.randint(0, K, (1, 128, 128, 128, 1), device=dev, dtype=torch.int32)
+    kind = ops.parse_loss("sorensen")
+    loss = torch.empty((), device=dev); dice = torch.empty((), device=dev)
+    coef = torch.empty(2 * K + 1, device=dev)
+    nbl = L.vnet_loss_ws_bytes(1, K)
+    wsl = torch.empty(max(nbl, 16), dtype=torch.uint8, device=dev)
+    g1 = torch.ones((), device=dev)
+    dl = torch.empty_like(logits)
+    timed("softmax_dice_fwd 128^3 K=%d" % K, M * K * 4 + M * 4,
+          lambda: L.vnet_softmax_dice_fwd(P_(logits), P_(labels), 1, M, K, kind, None, 1.0, 1e-5, None, None, P_(loss), P_(dice), P_(coef), P_(wsl), nbl, st))
+    timed("softmax_dice_bwd 128^3 K=%d" % K, 2 * M * K * 4 + M * 4,
+          lambda: L.vnet_softmax_dice_bwd(P_(logits), P_(labels), 1, M, K, kind, None, 1.0, P_(coef), P_(g1), P_(dl), st))
+    del logits, labels, dl
+    # Adam over the whole flat parameter vector (43 940 486 floats): reads p, g, m, v, writes p, m, v
+    n = 43940486
+    p_ = torch.zeros(n, device=dev); g_ = torch.full((n,), 1e-3, device=dev); m_ = torch.zeros(n, device=dev); v_ = torch.zeros(n, device=dev)
+    timed("adam 43.9M parameters", 7 * n * 4, lambda: L.vnet_adam_apply(P_(p_), P_(g_), P_(m_), P_(v_), n, 1e-3, 0.9, 0.999, 1e-8, 1.0, st))
+    del p_, g_, m_, v_
+    torch.cuda.empty_cache()
+    return out
 
 
 def family_tags(P, B, bf16):
@@ -314,6 +402,13 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
             "measured": ("HIP events on the launch stream in %d eager steps that follow the timed region (same process, same "
                          "kernels and arguments; events cannot be timed inside a replayed hipGraph on this runtime)" % nroof)
             if graph else "HIP events on the launch stream inside the timed region"}
+    if world == 1 and patch == 128 and not os.environ.get("BENCH_NO_HBM_TABLE"):
+        del m
+        gc.collect()
+        res["hbm_kernels"] = hbm_kernel_table(dev, bf16, classes)
+        res["hbm_kernels_note"] = ("one kernel at a time after the timed region: 50 back-to-back launches between HIP events on the launch "
+                                   "stream, GB/s over the algorithmic bytes of the pass, fraction of the 8 TB/s HBM3E peak "
+                                   "(a float4 copy reaches 6.3 TB/s = 0.79 on this part)")
     if full_table:
         tot_ms = sum(v[3] for v in per.values())
         res["conv_ms_per_step"] = round(tot_ms / (nroof if graph else args.steps), 3)
@@ -381,7 +476,8 @@ def main():
                           "ranks": world, "backend": (dist.get_backend() if world > 1 else None)},
                "final_loss": r["final_loss"], "host_enqueue_ms_per_step": r["host_enqueue_ms_per_step"],
                "step_enqueue": r["step_enqueue"], "dp_autotune_ms": r.get("dp_autotune_ms"), "pinned_to_core": args.pin_core if args.pin_core >= 0 else None,
-               "roofline": r["roofline"], "sustained": r.get("sustained")}
+               "roofline": r["roofline"], "hbm_kernels": r.get("hbm_kernels"), "hbm_kernels_note": r.get("hbm_kernels_note"),
+               "sustained": r.get("sustained")}
         for k in ("conv_ms_per_step", "conv_tflops"):
             if k in r:
                 out[k] = r[k]
@@ -393,6 +489,12 @@ def main():
         c5["dtype"] = "bf16"
         c5["steps"], c5["warmup"] = args.steps, args.warmup
         out["c5_bf16"] = c5
+    if world == 1 and not bf16 and not args.no_c2 and args.patch == 128 and args.channels == 1:
+        # BASELINE configs[1]: 64^3 patch, 1 modality, 2 classes, batch 2, fp32 -- the same measurement on a second model
+        c2 = measure(args, 64, 2, 1, 2, "fp32", rank, local, world)
+        out["c2_64cube_b2"] = {"metric": "training patches/sec (64^3x1ch fp32, batch 2), 1 GPU (BASELINE configs[1])", "value": c2["value"], "unit": "patches/s",
+                               "ms_per_step": c2["ms_per_step"], "batch": 2, "patch": 64, "dtype": "f32", "steps": args.steps, "warmup": args.warmup,
+                               "final_loss": c2["final_loss"], "step_enqueue": c2["step_enqueue"]}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
