@@ -7,6 +7,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // two fp32 -> packed bf16 pair, round-to-nearest-even (the rounding of every bf16 operand in this library)
 __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
     uint32_t r;

@@ -1369,20 +1369,22 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
             __builtin_amdgcn_sched_barrier(0);
             bf16_tile_commit_h<G, XH, 0, XH::PER>(tile, dump, v, tid);
         } else if (a.vec_in) {
-            constexpr int H0 = XT::PER / 2, H1 = XT::PER - H0;       // two batches: half the staging registers
-            {
-                float4 v[H0];
-                XT::template issue_part<0, H0>(v, a.x0, a.x1, a.C0, a.C1, chunk, b, gz0, gy0, gx0, a.Di, a.Hi, a.Wi, tid);
-                __builtin_amdgcn_sched_barrier(0);
-                bf16_tile_commit<G, XT, 0, H0>(tile, dump, v, tid);
+            // four batches: a quarter of the staging registers (round 4: with two, the fp32-source instantiations of this
+            // legacy bf16_operands path spilled up to 78 VGPRs -- profiles/check_isa.sh; the staging here is synchronous anyway)
+            constexpr int Q0 = XT::PER / 4, Q1 = XT::PER / 2, Q2 = (3 * XT::PER) / 4;
+#define VNET_STAGE_BATCH(K0, K1)                                                                                        \
+            if constexpr ((K1) > (K0)) {                                                                                \
+                float4 v[(K1) - (K0)];                                                                                  \
+                XT::template issue_part<(K0), (K1) - (K0)>(v, a.x0, a.x1, a.C0, a.C1, chunk, b, gz0, gy0, gx0, a.Di, a.Hi, a.Wi, tid); \
+                __builtin_amdgcn_sched_barrier(0);                                                                      \
+                bf16_tile_commit<G, XT, (K0), (K1) - (K0)>(tile, dump, v, tid);                                         \
+                __builtin_amdgcn_sched_barrier(0);                                                                      \
             }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                float4 v[H1];
-                XT::template issue_part<H0, H1>(v, a.x0, a.x1, a.C0, a.C1, chunk, b, gz0, gy0, gx0, a.Di, a.Hi, a.Wi, tid);
-                __builtin_amdgcn_sched_barrier(0);
-                bf16_tile_commit<G, XT, H0, H1>(tile, dump, v, tid);
-            }
+            VNET_STAGE_BATCH(0, Q0)
+            VNET_STAGE_BATCH(Q0, Q1)
+            VNET_STAGE_BATCH(Q1, Q2)
+            VNET_STAGE_BATCH(Q2, XT::PER)
+#undef VNET_STAGE_BATCH
         } else {
             const int Cin = a.C0 + a.C1;
             for (int q = tid; q < G::NV * 4; q += NT) {       // channel counts that are not multiples of 4
@@ -1703,23 +1705,40 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         bi = 2 * q + (second ? 1 : 0); ch = r < 2 ? cf : 1 - cf; first = r < 2; last = r >= 2; swap = (r == 1 || r == 3);
     };
     using XH = XTileH<G::IZ, G::IY, G::IX, NT>;
-    float4 v[H ? 1 : XT::PER];
-    uint2 pk[H ? 1 : XT::PER];
+    // fp32 sources (the round-2 bf16_operands path without shadows): the prefetch goes in two halves through ONE half-sized
+    // register set -- first half at the head of the step, packed to bf16 half-way, when the second half is issued into the same
+    // registers; that one is packed at the commit.  (Round 4: with the whole fp32 tile in flight, 64 + 32 registers, these two
+    // instantiations spilled 7 / 19 VGPRs: profiles/check_isa.sh.)
+    constexpr int HP = H ? 1 : (XT::PER + 1) / 2, HQ = H ? 1 : XT::PER - HP;
+    float4 v[HP];
+    u32x2 pk[H ? 1 : XT::PER];          // (native vector type: arrays of HIP's uint2 struct are not scalarised)
     u32x4 hv[H ? XH::PER : 1];           // H: the prefetched tile as it will sit in LDS
+    int p_b = 0, p_z = 0, p_y = 0, p_x = 0, p_ch = 0;      // (fp32 sources) origin of the tile in flight, for its second half
     auto tile_issue = [&](int bi, int ch) {
         int b, bz, by, bx;
         brick_origin(bi, b, bz, by, bx);
         if constexpr (H)
             XH::template issue_part<0, XH::PER>(hv, reinterpret_cast<const unsigned short*>(a.x0), reinterpret_cast<const unsigned short*>(a.x1),
                                                 a.C0, a.C1, ch, b, bz * TZ - 2, by * TY - 2, bx * TX - 2, a.Di, a.Hi, a.Wi, tid);
-        else
-            XT::template issue_part<0, XT::PER>(v, a.x0, a.x1, a.C0, a.C1, ch, b, bz * TZ - 2, by * TY - 2, bx * TX - 2,
-                                                a.Di, a.Hi, a.Wi, tid);
+        else {
+            p_b = b; p_z = bz * TZ - 2; p_y = by * TY - 2; p_x = bx * TX - 2; p_ch = ch;
+            XT::template issue_part<0, HP>(v, a.x0, a.x1, a.C0, a.C1, ch, b, p_z, p_y, p_x, a.Di, a.Hi, a.Wi, tid);
+        }
     };
-    auto tile_pack = [&]() {            // fp32 -> bf16 (RNE) in registers; halves the registers the prefetch holds
+    auto tile_pack = [&]() {            // fp32 -> bf16 (RNE) in registers; then the second half of the tile takes the registers
         if constexpr (!H) {
 #pragma unroll
-            for (int k = 0; k < XT::PER; ++k) pk[k] = make_uint2(pk_bf16(v[k].x, v[k].y), pk_bf16(v[k].z, v[k].w));
+            for (int k = 0; k < HP; ++k) pk[k] = u32x2{pk_bf16(v[k].x, v[k].y), pk_bf16(v[k].z, v[k].w)};
+            if constexpr (HQ > 0) {
+                float4 (&v2)[HQ] = *reinterpret_cast<float4 (*)[HQ]>(&v[0]);
+                XT::template issue_part<HP, HQ>(v2, a.x0, a.x1, a.C0, a.C1, p_ch, p_b, p_z, p_y, p_x, a.Di, a.Hi, a.Wi, tid);
+            }
+        }
+    };
+    auto tile_pack2 = [&]() {
+        if constexpr (!H) {
+#pragma unroll
+            for (int k = 0; k < HQ; ++k) pk[HP + k] = u32x2{pk_bf16(v[k].x, v[k].y), pk_bf16(v[k].z, v[k].w)};
         }
     };
     auto tile_commit = [&]() {
@@ -1743,6 +1762,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         } else if constexpr (H) {
             bf16_tile_commit_h<G, XH, 0, XH::PER>(tile, dump, hv, tid);
         } else {
+            tile_pack2();
             const int r0 = tid / XT::COLS, col = tid - r0 * XT::COLS;
             const int ix = col >> 2, cq = col & 3;
             unsigned char* base = tile + (cq >> 1) * G::PLANE + ix * 16 + (cq & 1) * 8;
@@ -1750,7 +1770,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             for (int k = 0; k < XT::PER; ++k) {
                 const int row = r0 + k * XT::RPI;
                 const bool ok = r0 < XT::RPI && row < XT::ROWS;
-                *reinterpret_cast<uint2*>(ok ? base + row * (G::IX * 16) : dump) = pk[k];
+                *reinterpret_cast<u32x2*>(ok ? base + row * (G::IX * 16) : dump) = pk[k];
             }
         }
     };
@@ -2077,61 +2097,69 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     ycs[pr] = iny0 ? a.Cy0 : a.Cy1;
                 }
                 // one register array for the batched loads: the other gradient (accumulate mode) or else the residual; a launch with
-                // both (none in the networks) loads its residual per voxel row below
-                uint2 ld[4][4];
+                // both (none in the networks) loads its residual per voxel row below.
+                // (a NATIVE vector type: arrays of HIP's uint2 struct are not scalarised -- with two conditional writers this one
+                // stayed in scratch in the statistics variant: 32 scratch instructions per brick step, profiles/check_isa.sh; in
+                // registers it has to be half as large there, or the statistics variant spills: two voxel rows per batch)
+                constexpr int MB = STATS ? 2 : 4;
                 const bool res_batched = STATS && a.res && !a.accum;
-                if (a.accum) {
 #pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        const unsigned short* sb = a.accsrc ? reinterpret_cast<const unsigned short*>(a.accsrc) + co0 + pr * 16 : yb[pr];
-                        const int scs = a.accsrc ? a.Cy0 : ycs[pr];
+                for (int m0 = 0; m0 < 4; m0 += MB) {
+                    u32x2 ld[MB][4];
+                    if (a.accum) {
 #pragma unroll
-                        for (int m = 0; m < 4; ++m)
+                        for (int pr = 0; pr < 2; ++pr) {
+                            const unsigned short* sb = a.accsrc ? reinterpret_cast<const unsigned short*>(a.accsrc) + co0 + pr * 16 : yb[pr];
+                            const int scs = a.accsrc ? a.Cy0 : ycs[pr];
 #pragma unroll
-                            for (int gg = 0; gg < 2; ++gg)
-                                ld[m][2 * pr + gg] = *reinterpret_cast<const uint2*>(sb + ovm[m] * scs + gg * 8 + half * 4);
+                            for (int mm = 0; mm < MB; ++mm)
+#pragma unroll
+                                for (int gg = 0; gg < 2; ++gg)
+                                    ld[mm][2 * pr + gg] = *reinterpret_cast<const u32x2*>(sb + ovm[m0 + mm] * scs + gg * 8 + half * 4);
+                        }
                     }
-                }
-                if constexpr (STATS) {
-                    if (res_batched) {
+                    if constexpr (STATS) {
+                        if (res_batched) {
 #pragma unroll
-                        for (int m = 0; m < 4; ++m)
+                            for (int mm = 0; mm < MB; ++mm)
 #pragma unroll
-                            for (int g = 0; g < 4; ++g)
-                                ld[m][g] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.res) + ovm[m] * a.Cout + cg[g]);
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    uint2 pk[4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float e[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) e[k] = acc[m][g * 4 + k] + bq[g][k];
-                        if (a.accum) { e[0] += bf_lo(ld[m][g].x); e[1] += bf_hi(ld[m][g].x); e[2] += bf_lo(ld[m][g].y); e[3] += bf_hi(ld[m][g].y); }
-                        pk[g] = make_uint2(pk_bf16(e[0], e[1]), pk_bf16(e[2], e[3]));
-                        if constexpr (STATS) {
-                            float v[4] = {bf_lo(pk[g].x), bf_hi(pk[g].x), bf_lo(pk[g].y), bf_hi(pk[g].y)};
-                            if (a.res) {
-                                const uint2 r = res_batched ? ld[m][g]
-                                    : *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.res) + ovm[m] * a.Cout + cg[g]);
-                                v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
-                            }
-                            if (vok[m]) {
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) { s1[g][k] += v[k]; s2[g][k] += v[k] * v[k]; }
-                            }
+                                for (int g = 0; g < 4; ++g)
+                                    ld[mm][g] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(a.res) + ovm[m0 + mm] * a.Cout + cg[g]);
                         }
                     }
 #pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        // lanes L < 32 keep group 2pr and receive lane L+32's part of it (channels +4..7); lanes L+32 receive
-                        // lane L's part of group 2pr+1 and keep their own: 8 consecutive channels each
-                        const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * pr].x, pk[2 * pr + 1].x, false, false);
-                        const auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * pr].y, pk[2 * pr + 1].y, false, false);
-                        const u32x4 o = {sx[0], sy[0], sx[1], sy[1]};
-                        if (vok[m]) *reinterpret_cast<u32x4*>(yb[pr] + ovm[m] * ycs[pr] + half * 8) = o;
+                    for (int mm = 0; mm < MB; ++mm) {
+                        const int m = m0 + mm;
+                        uint2 pk[4];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float e[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) e[k] = acc[m][g * 4 + k] + bq[g][k];
+                            if (a.accum) { e[0] += bf_lo(ld[mm][g].x); e[1] += bf_hi(ld[mm][g].x); e[2] += bf_lo(ld[mm][g].y); e[3] += bf_hi(ld[mm][g].y); }
+                            pk[g] = make_uint2(pk_bf16(e[0], e[1]), pk_bf16(e[2], e[3]));
+                            if constexpr (STATS) {
+                                float v[4] = {bf_lo(pk[g].x), bf_hi(pk[g].x), bf_lo(pk[g].y), bf_hi(pk[g].y)};
+                                if (a.res) {
+                                    const u32x2 r = res_batched ? ld[mm][g]
+                                        : *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(a.res) + ovm[m] * a.Cout + cg[g]);
+                                    v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
+                                }
+                                if (vok[m]) {
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) { s1[g][k] += v[k]; s2[g][k] += v[k] * v[k]; }
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            // lanes L < 32 keep group 2pr and receive lane L+32's part of it (channels +4..7); lanes L+32 receive
+                            // lane L's part of group 2pr+1 and keep their own: 8 consecutive channels each
+                            const auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * pr].x, pk[2 * pr + 1].x, false, false);
+                            const auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * pr].y, pk[2 * pr + 1].y, false, false);
+                            const u32x4 o = {sx[0], sy[0], sx[1], sy[1]};
+                            if (vok[m]) *reinterpret_cast<u32x4*>(yb[pr] + ovm[m] * ycs[pr] + half * 8) = o;
+                        }
                     }
                 }
             }
@@ -2728,7 +2756,15 @@ int launch_conv_bf16(const ConvArgs& a, const Bf16Plan& p, hipStream_t st) {
         if (int ae = ensure_lds(k, lds, attr_done)) return ae;                                    \
         hipLaunchKernelGGL(k, grid, block, lds, st, a);                                           \
     }
-    if (p.nsb == 2) VNET_GO(2) else VNET_GO(1)
+    if constexpr (!H) {
+        // fp32 sources (the round-2 bf16_operands path without shadows): one cout block per workgroup only -- the two-block
+        // instantiations spilled 2..78 VGPRs next to the fp32 staging registers (profiles/check_isa.sh).  Every output still sums
+        // its products in the same order, so the results do not change.
+        grid.y = p.ncobg * p.nsb;
+        VNET_GO(1)
+    } else {
+        if (p.nsb == 2) VNET_GO(2) else VNET_GO(1)
+    }
 #undef VNET_GO
     return (int)hipGetLastError();
 }

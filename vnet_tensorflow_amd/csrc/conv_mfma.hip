@@ -432,8 +432,10 @@ static int conv_wgrad_bf16_impl(const float* x0, int C0, const float* x1, int C1
         e = p.ns == 2 ? launch_wgrad_bf16<4, 8, 8, 2, 8>(a, p.nsplit, p.ncob, p.ntg, st)
                       : launch_wgrad_bf16<4, 8, 8, 1, 16>(a, p.nsplit, p.ncob, p.ntg, st);
     } else {
-        e = p.ns == 2 ? launch_wgrad_bf16<4, 4, 16, 2, 8>(a, p.nsplit, p.ncob, p.ntg, st)
-                      : launch_wgrad_bf16<4, 4, 16, 1, 16>(a, p.nsplit, p.ncob, p.ntg, st);
+        // fp32 sources on wide bricks: always one cout block per workgroup (the two-block instantiation spilled VGPRs next to
+        // its fp32 prefetch registers, profiles/check_isa.sh): twice the cout blocks, one tap group, the same slabs
+        if (p.ns == 2) { a.ncob = p.ncob * 2; e = launch_wgrad_bf16<4, 4, 16, 1, 16>(a, p.nsplit, a.ncob, 1, st); }
+        else e = launch_wgrad_bf16<4, 4, 16, 1, 16>(a, p.nsplit, p.ncob, p.ntg, st);
     }
     if (e) return e;
     if (direct) return VNET_OK;
