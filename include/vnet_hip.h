@@ -373,6 +373,11 @@ int vnet_accumulate_patch(const float* patch, float* vol, float* count, int K,
  * the 16-byte unit the convolution kernels stage (the filter's packed image is zero-padded to 16 input channels anyway) */
 int vnet_cast_bf16(const float* x, void* y16, int64_t M, int C, int Cpad, void* stream);
 
+/* per-channel sum of a bf16 [M][C] tensor in fp32 (the bias gradient sum(dy) of layers2.py:63 / :73 in bf16 storage, outside the
+ * networks' closed form); C % 8 == 0, deterministic; ws >= vnet_colsum_b16_ws_bytes(C) */
+size_t vnet_colsum_b16_ws_bytes(int C);
+int vnet_colsum_b16(const void* x16, float* out, int64_t M, int C, void* ws, size_t ws_bytes, void* stream);
+
 /* 5^3 stride-1 convolution, bf16 in / bf16 out; forward (VNET_PACK_FWD_BF16) and backward-data (VNET_PACK_BWD_BF16).
  * acc16: NULL, or a bf16 tensor of y0's shape that is added before the rounding (== y0: in place; else out of place, Cy1 = 0);
  * res16 / stats: batch-norm statistics of the ROUNDED output (+ res16) in the epilogue, rows = vnet_conv_b16_stats_rows;

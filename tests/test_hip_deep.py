@@ -48,7 +48,7 @@ def test_deep_conv_forward_backward_against_oracle(dev, shape, target, monkeypat
         monkeypatch.setenv("VNET_BF16_DEEP", deep)
         tx0 = g16(x0, dev).requires_grad_(True)
         tx1 = g16(x1, dev).requires_grad_(True) if C1 else None
-        tw, tb = g(w, dev).requires_grad_(True), g(b, dev)        # (the bias gradient is a column sum of dy: not under test here)
+        tw, tb = g(w, dev).requires_grad_(True), g(b, dev).requires_grad_(True)
         y = ops.conv(tx0, tw, tb, 5, 1, x1=tx1)
         tag = "deep=%s %s" % (deep, shape)
         check_bf16(tag + " fwd", y, y_ex)
@@ -57,6 +57,8 @@ def test_deep_conv_forward_backward_against_oracle(dev, shape, target, monkeypat
         if C1:
             check_bf16(tag + " dx1", tx1.grad, dx_ex[..., C0:])
         check_close(tag + " dw", tw.grad, dw_ex, 2e-6)
+        # the bias gradient: a column sum of dy (vnet_colsum_b16: any channel count that is a multiple of 8, e.g. 96)
+        check_close(tag + " db", tb.grad, dy.reshape(-1, Co).sum(0), 2e-6, atol=1e-6 * float(np.abs(dy).reshape(-1, Co).sum(0).max()))
         outs[deep] = (y.detach().clone(), tx0.grad.clone())
     # the two kernels sum in different orders: equal up to a rounding flip here and there, and NOT equal everywhere (else the
     # deep kernel did not run)

@@ -112,6 +112,17 @@ def test_read_config_contract(tmp_path):
     m3.read_config()
     with pytest.raises(SystemExit):
         m3.build_model_graph()
+    # ComputeDtype 'bf16' (bf16 storage) needs NumChannel = 8 * 2^k: refused when the config is read, not at the first forward
+    cfg4 = _config(tmp_path)
+    cfg4["TrainingSetting"]["ComputeDtype"] = "bf16"
+    cfg4["TrainingSetting"]["Networks"]["NumChannel"] = 12
+    with pytest.raises(SystemExit, match="NumChannel"):
+        image2label(None, cfg4, device="cpu", verbose=False).read_config()
+    cfg4["TrainingSetting"]["ComputeDtype"] = "bf16_operands"
+    image2label(None, cfg4, device="cpu", verbose=False).read_config()
+    cfg4["TrainingSetting"]["ComputeDtype"] = "fp16"
+    with pytest.raises(SystemExit, match="ComputeDtype"):
+        image2label(None, cfg4, device="cpu", verbose=False).read_config()
 
 
 def test_shipped_reference_style_config_parses(tmp_path):

@@ -36,6 +36,8 @@ SIGNATURES = {
     "vnet_conv_fwd_bf16_stats": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "vnet_bn_finalize_partial": (_i, [_vp, _i, _i, _d, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "vnet_conv_bf16_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "vnet_colsum_b16_ws_bytes": (_sz, [_i]),
+    "vnet_colsum_b16": (_i, [_vp, _vp, _i64, _i, _vp, _sz, _vp]),
     "vnet_conv_b16_ws_bytes": (_sz, [_i] * 8),
     "vnet_conv_b16_stats_rows": (_i, [_i] * 8),
     "vnet_conv_fwd_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),

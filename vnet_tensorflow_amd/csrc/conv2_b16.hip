@@ -446,16 +446,17 @@ int c2_launch_f(K kernel, const C2ArgsF& a, int grid, size_t lds, hipStream_t st
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
     const unsigned long long bit = 1ull << (dev & 63);
-    if (!(done_mask & bit)) {        // the level-2 filter image (64 KB) + statistics scratch exceeds the default dynamic-LDS limit
+    if (!(__atomic_load_n(&done_mask, __ATOMIC_ACQUIRE) & bit)) {        // the level-2 filter image (64 KB) + statistics scratch exceeds the default dynamic-LDS limit
         const int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e) return e;
-        done_mask |= bit;
+        __atomic_fetch_or(&done_mask, bit, __ATOMIC_RELEASE);
     }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(C2_THREADS), lds, st, a);
     return (int)hipGetLastError();
 }
 
-inline bool c2_widths_ok(int Cf, int Cc) { return (Cf == 16 || Cf == 32) && (Cc == 32 || Cc == 64) && (size_t)8 * Cf * Cc * 2 <= (64u << 10); }
+// exactly the instantiated pairs (levels 1 and 2 of the V-Net: Cc = 2 Cf); other widths take the generic kernels
+inline bool c2_widths_ok(int Cf, int Cc) { return (Cf == 16 && Cc == 32) || (Cf == 32 && Cc == 64); }
 
 inline int c2_grid(int nseg) {
     // >= 2 segments per wave where the problem allows, at most 2048 workgroups (8 per CU, 32 waves: full occupancy)

@@ -1056,9 +1056,11 @@ int ensure_lds(K kernel, size_t bytes, unsigned long long& done_mask) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
     const unsigned long long bit = 1ull << (dev & 63);
-    if (done_mask & bit) return 0;
+    // (atomic: launches may come from several host threads -- vnet_infer's workers, torch's autograd thread; setting the
+    // attribute twice is harmless, losing another device's bit to a torn read-modify-write would only repeat it)
+    if (__atomic_load_n(&done_mask, __ATOMIC_ACQUIRE) & bit) return 0;
     const int e = set_lds(kernel, bytes);
-    if (e == 0) done_mask |= bit;
+    if (e == 0) __atomic_fetch_or(&done_mask, bit, __ATOMIC_RELEASE);
     return e;
 }
 

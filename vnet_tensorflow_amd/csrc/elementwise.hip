@@ -2096,6 +2096,54 @@ int vnet_bn_stats_b16(const void* x16, const void* r16, int64_t M, int C, float 
     return VNET_OK;
 }
 
+// per-channel sum of a bf16 [M][C] tensor into fp32 (the bias gradient of a bf16-storage convolution outside the networks' closed
+// form): any C % 8 == 0.  A thread owns one 8-channel unit column and every (256 / CO)-th row of its block's share; the rows of a
+// block meet in LDS in a fixed order, the blocks in sum_finalize_kernel: deterministic.
+__global__ void __launch_bounds__(256) colsum_b16_kernel(const u32x4* __restrict__ x, size_t M, int CO, float* __restrict__ partial) {
+    const int RB = 256 / CO, tid = threadIdx.x;
+    const int u = tid % CO, r = tid / CO;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    if (r < RB) {
+        for (size_t row = (size_t)blockIdx.x * RB + r; row < M; row += (size_t)gridDim.x * RB) {
+            const u32x4 q = x[row * CO + u];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc[2 * k] += __uint_as_float(q[k] << 16); acc[2 * k + 1] += __uint_as_float(q[k] & 0xffff0000u); }
+        }
+    }
+    __shared__ float sh[256][9];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sh[tid][k] = acc[k];
+    __syncthreads();
+    if (tid < CO) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = 0.f;
+        for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] += sh[rr * CO + tid][k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) partial[(size_t)blockIdx.x * CO * 8 + tid * 8 + k] = t[k];
+    }
+}
+
+size_t vnet_colsum_b16_ws_bytes(int C) { return (size_t)1024 * (C > 0 ? C : 1) * sizeof(float); }
+
+int vnet_colsum_b16(const void* x16, float* out, int64_t M, int C, void* ws, size_t ws_bytes, void* stream) {
+    if (!x16 || !out || M <= 0 || C <= 0) return VNET_E_BADARG;
+    if ((C & 7) || C > 2048 || !al16(x16)) return VNET_E_UNSUPPORTED;
+    if (!ws || ws_bytes < vnet_colsum_b16_ws_bytes(C)) return VNET_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int CO = C / 8, RB = 256 / CO;
+    const int nblk = (int)min((int64_t)1024, (M + RB - 1) / RB);
+    hipLaunchKernelGGL(colsum_b16_kernel, dim3(nblk), dim3(256), 0, st, reinterpret_cast<const u32x4*>(x16), (size_t)M, CO, (float*)ws);
+    VNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_finalize_kernel<float>, dim3(C), dim3(256), 0, st, (const float*)ws, nblk, 1, C, out, (float*)nullptr, (float*)nullptr);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
 int vnet_bn_moments_b16(const void* x16, const void* r16, int64_t M, int C, double* sums, void* ws, size_t ws_bytes, void* stream) {
     if (!x16 || !sums || M <= 0 || C <= 0) return VNET_E_BADARG;
     if (!ws || ws_bytes < vnet_bn_ws_bytes(C)) return VNET_E_WORKSPACE;

@@ -265,7 +265,11 @@ private:
             // bf16 storage: statistics of the bf16 tensor (+ bf16 residual) -- or of the fp32 1-channel image that is tiled -- in fp32,
             // one rounding of the normalised / activated value
             Tensor y = alloc16(x.B, x.D, x.H, x.W, C);
-            if (!tile && x.rows() <= 512 && vnet_bn_small_ok(x.rows(), C)) {      // tiny tensors: one launch (the Python path's rule, ops._bn_small)
+            // tiny tensors: one launch -- the Python path's rule INCLUDING its switches (ops._SMALL_BN reads the same two variables:
+            // an A/B run that sets them must flip both drivers, or the native-vs-Python comparison compares different kernels)
+            static const bool small_on = !(std::getenv("VNET_BN_SMALL") && std::string(std::getenv("VNET_BN_SMALL")) == "0");
+            static const long small_rows = std::getenv("VNET_BN_SMALL_ROWS") ? std::atol(std::getenv("VNET_BN_SMALL_ROWS")) : 512;
+            if (!tile && small_on && (long)x.rows() <= small_rows && vnet_bn_small_ok(x.rows(), C)) {
                 ABI_OK(vnet_bn_small_fwd_b16(x.q, res ? res->q : nullptr, x.rows(), C, 1e-3f, 0.99f, g.dev, b.dev, act, alpha, mean, invstd,
                                              nullptr, nullptr, y.q, st_));
                 return y;

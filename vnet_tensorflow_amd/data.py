@@ -56,9 +56,14 @@ def write_nifti(path, arr, pixdim=(1.0, 1.0, 1.0)):
 
 
 def volume_spacing(path):
-    """Voxel spacing (pixdim) of a volume file; (1, 1, 1) for .npy arrays, which carry none."""
+    """Voxel spacing (pixdim) of a volume file -- from the 348-byte NIfTI-1 header alone, the voxel array is not read;
+    (1, 1, 1) for .npy arrays, which carry none."""
     if path.endswith(".nii"):
-        return tuple(float(v) for v in read_nifti(path)[1]["pixdim"])
+        with open(path, "rb") as f:
+            hdr = f.read(348)
+        if len(hdr) < 348 or struct.unpack("<i", hdr[:4])[0] != 348:
+            raise ValueError("%s: not a little-endian NIfTI-1 file (Git-LFS pointer?)" % path)
+        return tuple(float(v) for v in struct.unpack("<8f", hdr[76:108])[1:4])
     return (1.0, 1.0, 1.0)
 
 

@@ -227,6 +227,15 @@ class image2label(object):
         self.label_filename = T['Data']['LabelFilename']
         self.synthetic = T['Data'].get('Synthetic')            # extension: synthetic generator (no NIfTI shipped)
         self.compute_dtype = T.get('ComputeDtype', 'fp32')            # extension: 'bf16' = BASELINE config C5 arithmetic
+        if self.compute_dtype not in ('fp32', 'bf16', 'bf16_operands'):
+            raise SystemExit("Invalid ComputeDtype %r (fp32 | bf16 | bf16_operands)" % (self.compute_dtype,))
+        if self.compute_dtype == 'bf16':
+            # since round 3 'bf16' means bf16 STORAGE (every activation a bf16 tensor; the operand-rounding form of round 2 is
+            # 'bf16_operands'); its kernels move 8-channel units whose count is a power of two: fail HERE, not at the first forward
+            nch = int(T.get('Networks', {}).get('NumChannel', 16))
+            if nch < 8 or nch & (nch - 1):
+                raise SystemExit("ComputeDtype 'bf16' (bf16 storage) needs Networks.NumChannel = 8 * 2^k, got %d; "
+                                 "'bf16_operands' (fp32 tensors, bf16 operands in the 5^3 convolutions) takes any width" % nch)
         self.sync_batch_norm = bool(T.get('SyncBatchNorm', False))   # extension: cross-replica BN statistics
         if 'AllReduceHoldFraction' in T:                               # extension: when the gradient buckets are launched (parallel.py)
             self.allreduce_hold_fraction = float(T['AllReduceHoldFraction'])

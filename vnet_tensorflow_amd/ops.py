@@ -549,27 +549,16 @@ def cast_input(img):
 
 
 def colsum16(x16, C, out):
-    """Per-channel sum of a bf16 channels-last tensor (bias gradients outside the networks' closed form), via the float64
-    moments of vnet_bn_moments_b16."""
+    """Per-channel fp32 sum of a bf16 channels-last tensor (bias gradients outside the networks' closed form): written by a kernel
+    on the launch stream straight into `out` (a raw-pointer write like colsum(): no copy_ on torch's current stream, no version
+    bump of a gradient-sink view)."""
     L = _lib.lib()
     M = x16.numel() // C
-    sums = torch.empty(2 * C, dtype=torch.float64, device=x16.device)
-    nb = L.vnet_bn_ws_bytes(C)
+    nb = L.vnet_colsum_b16_ws_bytes(C)
     ws = workspace(nb, x16.device)
-    check(L.vnet_bn_moments_b16(_ptr(x16), None, M, C, _ptr(sums), _ptr(ws), nb, _stream()), "vnet_bn_moments_b16")
-    out.copy_(sums[:C])
-    return out
+    check(L.vnet_colsum_b16(_ptr(x16), _ptr(out), M, C, _ptr(ws), nb, _stream()), "vnet_colsum_b16")
 
 
-# ---- deferred reduces of the filter-gradient slabs (include/vnet_hip.h: vnet_wgrad_defer / vnet_wgrad_flush) ------------------
-# Inside `deferred_wgrad_reduce()` the filter-gradient launches leave their partial slabs in a per-layer buffer and ONE batched
-# launch reduces all of them when the context ends (26 reduce launches of ~7 us per V-Net step otherwise).  Only for a backward
-# pass whose filter gradients nobody reads before it ends (model.image2label: not the eager data-parallel step, whose bucket
-# all-reduces start from the gradient hooks).
-_DEFER = {"on": False}
-
-
-@contextlib.contextmanager
 def deferred_wgrad_reduce(on=True):
     if not on or _DEFER["on"]:
         yield
