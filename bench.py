@@ -283,8 +283,7 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
 
     import gc
     gc.collect()                             # a previous measurement's model (graph memory pool, packed filters) is gone
-    ops.clear_pack_registry()
-    torch.cuda.empty_cache()
+    torch.cuda.empty_cache()                 # (compute dtype and pack registry are per-model state: nothing to reset by hand)
     dev = torch.device("cuda", local)
     np.random.seed(42)                       # the reference's unseeded global-NumPy Xavier init, made repeatable
     m = M.image2label(None, config(patch, batch, channels, classes, compute), device=dev, verbose=False)
@@ -484,7 +483,6 @@ def main():
     if world == 1 and not bf16 and not args.no_c5 and args.patch == 128 and args.channels == 1:
         # BASELINE configs[4] per-GPU workload on the same record (outside the headline's timed region)
         c5 = measure(args, args.patch, args.batch, 4, 5, "bf16", rank, local, world)
-        ops.set_compute_dtype("fp32")
         c5["metric"] = "training patches/sec (128^3x4ch, 5 classes, bf16 storage + bf16 conv operands / fp32 accumulate, fp32 BN statistics and Dice sums), 1 GPU"
         c5["dtype"] = "bf16"
         c5["steps"], c5["warmup"] = args.steps, args.warmup

@@ -516,7 +516,10 @@ def L_up_convolution(ps, x, out_spatial, factor, kernel_size):
     c = x.v.shape[-1]
     filt = list(kernel_size) + [c // factor, c]
     w, b = _conv_vars(ps, filt, filt[-2])
-    return deconvolution(x, w, b, out_spatial, factor)
+    y = deconvolution(x, w, b, out_spatial, factor)
+    if CAPTURE is not None:
+        CAPTURE[w.name] = (x, y)
+    return y
 
 
 def L_batch_norm(ps, x, dead=False):

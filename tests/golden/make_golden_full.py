@@ -5,7 +5,7 @@
     c2_64cube_b2.npz     configs[1]:     64^3,  B=2, 1 modality, 2 classes, full-width net
     c5_128cube_bf16.npz  configs[4]:     128^3, B=1, 4 modalities, 5 classes, bf16 conv operands / wide accumulate (round-2 mode)
     c5_128cube_b16.npz   configs[4] as SURVEY 8(d) words it: bf16 STORAGE of activations and their gradients (oracle.ACT_STORAGE);
-                         also holds, for six 5^3 layers, a crop of the layer's actual input and of the gradient that arrived
+                         also holds, for eight 5^3 layers and the level-2 2^3 pair, a crop of the layer's actual input and of the gradient that arrived
                          at its output (bf16 bit patterns) -- the teacher-forcing data of tests/test_hip_golden_full.py
 
 The reference itself (TF 1.15) cannot run here, so these are ORACLE outputs, not reference outputs
@@ -47,8 +47,18 @@ TF_LAYERS = {
     "vnet/encoder/level_2/conv_2/weights": (28, 30, 40),            # 32 -> 32 @64^3
     "vnet/encoder/level_3/conv_3/weights": (12, 24, 16),            # 64 -> 64 @32^3
     "vnet/bottom_level/conv_2/weights": (0, 0, 0),                  # 256 -> 256 @8^3: the whole volume
+    # round 4: the shapes the deep-level kernel (csrc/conv_deep.h) takes and a two-source decoder conv
+    "vnet/encoder/level_4/conv_2/weights": (4, 8, 0),               # 128 -> 128 @16^3, touches the y high and both x faces
+    "vnet/decoder/level_3/conv_1/weights": (12, 8, 16),             # 128 -> 64 @32^3: concat(up-convolved, skip), 64 + 64 channels
 }
 TF_BOX = (8, 8, 16)
+# the 2^3 pair (stride 2: no halo).  layer -> origin of a TF_BOX of COARSE voxels; the fine crop is the 2x box at 2x the origin.
+#   down convolution: x = fine crop (input), dy = coarse crop (gradient at its output)
+#   transposed convolution: x = coarse crop (input), dy = fine crop
+TF_LAYERS2 = {
+    "vnet/encoder/level_2/down_convolution/weights": ("down", (8, 16, 16)),      # 32 -> 64, 64^3 -> 32^3
+    "vnet/decoder/level_2/up_convolution/weights": ("up", (8, 16, 16)),          # 64 -> 32, 32^3 -> 64^3
+}
 
 
 def bf16_bits(a):
@@ -98,6 +108,13 @@ def make(case):
                 tf["tf:%s:x" % name] = bf16_bits(cx)
                 tf["tf:%s:dy" % name] = bf16_bits(cg)
                 tf["tf:%s:lo" % name] = np.asarray(lo, dtype=np.int32)
+            for name, (kind, origin) in TF_LAYERS2.items():
+                xin, yout = O.CAPTURE[name]
+                co = tuple(slice(origin[a], origin[a] + TF_BOX[a]) for a in range(3))
+                fi = tuple(slice(2 * origin[a], 2 * (origin[a] + TF_BOX[a])) for a in range(3))
+                sx, sg = (fi, co) if kind == "down" else (co, fi)
+                tf["tf:%s:x" % name] = bf16_bits(xin.v[(slice(None),) + sx])
+                tf["tf:%s:dy" % name] = bf16_bits(yout.g[(slice(None),) + sg])
     finally:
         O.CONV5_OPERAND_ROUNDING = None
         O.ACT_STORAGE = None

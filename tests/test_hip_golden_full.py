@@ -103,7 +103,7 @@ def test_full_size_network_fp32(dev, case):
     assert len(errs) > 100
     worst = sorted(errs, key=lambda e: -e[1])[:5]
     for n, e_sample, e_norm, e_head, e_sum in errs:
-        assert e_sample < 1.5e-2 and e_norm < 5e-3 and e_head < 5e-3, (n, e_sample, e_norm, e_head, worst)
+        assert e_sample < 1.2e-2 and e_norm < 5e-3 and e_head < 5e-3, (n, e_sample, e_norm, e_head, worst)      # measured worst 9.6e-3 (C2), profiles/r04_golden_full_errors.txt
     assert np.median([e[1] for e in errs]) < 6e-3, np.median([e[1] for e in errs])
     names = list(map(str, z["names"]))
     num = sum((e[1] * float(z["grad_norm"][names.index(e[0])])) ** 2 for e in errs)
@@ -157,9 +157,10 @@ def test_full_size_network_c5_b16_storage(dev):
 
 
 def test_teacher_forced_layers_c5_b16(dev):
-    """per-layer parity of the bf16 kernels WITHOUT chaotic amplification.  The fixture holds, for six 5^3
-    layers of the 128^3 C5 oracle run (input conv 4->16, 16->16 and 32->16 at 128^3, 32->32 at 64^3, 64->64 at 32^3, 256->256 at
-    8^3), a crop of the bf16 tensor the layer actually read and of the bf16 gradient that actually arrived at its output.  Each
+    """VERDICT r2 next #3(b), widened in round 4: per-layer parity of the bf16 kernels WITHOUT chaotic
+    amplification.  The fixture holds, for eight 5^3 layers of the 128^3 C5 oracle run (input conv 4->16, 16->16 and 32->16 at 128^3,
+    32->32 at 64^3, 64->64 at 32^3, 128->128 at 16^3, 256->256 at 8^3 -- the last three take the deep-level kernel -- and the two-source
+    decoder conv 64+64->64 at 32^3) and for the level-2 pair of 2^3 convolutions (down 32->64, transposed 64->32), a crop of the bf16 tensor the layer actually read and of the bf16 gradient that actually arrived at its output.  Each
     layer is run alone on that data -- forward, backward-data and filter gradient -- and compared per tensor with the oracle's
     convolution of the same operands: stored outputs must be correct roundings (half a bf16 ulp), the fp32 filter gradient 2e-6."""
     from tests.golden.make_golden_full import TF_LAYERS, from_bf16_bits
@@ -177,14 +178,43 @@ def test_teacher_forced_layers_c5_b16(dev):
         assert float(np.abs(x).max()) > 0 and float(np.abs(dy).max()) > 0
         y_ex = O.conv_nd_fwd(x, rb(w), 1) + b
         dx_ex, dw_ex = O.conv_nd_bwd(x, rb(w), dy, 1)
+        # the first convolution of a decoder level reads concat(up-convolved, skip) (networks.py:325): two sources, never materialised
+        two = name.startswith("vnet/decoder") and name.endswith("conv_1/weights") and x.shape[-1] == 2 * w.shape[-1]
+        C0 = x.shape[-1] // 2 if two else x.shape[-1]
+        tx1 = None
         if x.shape[-1] % 8:                      # the network input: fp32 image -> bf16, zero-padded to 8 channels
             tx = ops.cast_input(g(x, dev))
         else:
-            tx = g16(x, dev).requires_grad_(True)
+            tx = g16(x[..., :C0], dev).requires_grad_(True)
+            if two:
+                tx1 = g16(x[..., C0:], dev).requires_grad_(True)
         tw, tb = g(w, dev).requires_grad_(True), g(b, dev).requires_grad_(True)
-        y = ops.conv(tx, tw, tb, 5, 1)
+        y = ops.conv(tx, tw, tb, 5, 1, x1=tx1)
         check_bf16("teacher-forced %s fwd" % name, y, y_ex)
         y.backward(g16(dy, dev))
         if tx.requires_grad:
-            check_bf16("teacher-forced %s dx" % name, tx.grad, dx_ex, noise=1e-5)
+            check_bf16("teacher-forced %s dx" % name, tx.grad, dx_ex[..., :C0], noise=1e-5)
+        if two:
+            check_bf16("teacher-forced %s dx (skip source)" % name, tx1.grad, dx_ex[..., C0:], noise=1e-5)
+        check_close("teacher-forced %s dw" % name, tw.grad, dw_ex, 2e-6, atol=2e-6 * float(np.abs(dw_ex).max()))
+    # the level-2 pair of 2^3 convolutions on the same run's data (stride 2: the crops carry no halo)
+    from tests.golden.make_golden_full import TF_LAYERS2
+    for name, (kind, origin) in TF_LAYERS2.items():
+        x, dy = from_bf16_bits(z["tf:%s:x" % name]), from_bf16_bits(z["tf:%s:dy" % name])
+        w, b = store.vars[name].v, store.vars[name[:-len("weights")] + "biases"].v
+        assert float(np.abs(x).max()) > 0 and float(np.abs(dy).max()) > 0
+        tx, tw, tb = g16(x, dev).requires_grad_(True), g(w, dev).requires_grad_(True), g(b, dev).requires_grad_(True)
+        if kind == "down":                       # layers2.py:78-84
+            y_ex = O.conv_nd_fwd(x, rb(w), 2) + b
+            dx_ex, dw_ex = O.conv_nd_bwd(x, rb(w), dy, 2)
+            y = ops.conv(tx, tw, tb, 2, 2)
+        else:                                    # layers2.py:65-74, 88-94
+            y_ex = O.conv_nd_transpose_fwd(x, rb(w), dy.shape[1:4], 2) + b
+            dx_ex = O.conv_nd_fwd(dy, rb(w), 2)
+            _, dw_ex = O.conv_nd_bwd(dy, w, x, 2, need_dx=False)
+            y = ops.conv_transpose2(tx, tw, tb, dy.shape[1:4])
+        assert tuple(y.shape) == tuple(y_ex.shape) == tuple(dy.shape)
+        check_bf16("teacher-forced %s fwd" % name, y, y_ex)
+        y.backward(g16(dy, dev))
+        check_bf16("teacher-forced %s dx" % name, tx.grad, dx_ex, noise=1e-5)
         check_close("teacher-forced %s dw" % name, tw.grad, dw_ex, 2e-6, atol=2e-6 * float(np.abs(dw_ex).max()))

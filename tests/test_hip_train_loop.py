@@ -84,7 +84,7 @@ def test_loss_decreases_on_fixed_batch(dev, compute, cin, K):
     try:
         m.read_config()
         m.build_model_graph()
-        assert ops.get_compute_dtype() == compute
+        assert m.ctx.compute["name"] == compute and ops.get_compute_dtype() == "fp32"      # per-model state (round 4), not a process global
         m._setup_training()
         x, lab = synthetic_batch(2, 16, cin, K, seed=11)
         xt, lt = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
@@ -116,7 +116,7 @@ def test_param_grad_stream_is_bit_identical(dev, P, monkeypatch):
         m.read_config()
         m.build_model_graph()
         m._setup_training()
-        assert ops._PG["on"] == (on == "1")
+        assert m.ctx.pg["on"] == (on == "1") and not ops._PG["on"]      # per-model state (round 4): the default context is untouched
         # the side stream is held back ~0.2 ms per layer: anything the main stream does to a tensor the filter gradient still
         # needs (recycling it, accumulating into it in place) now lands BEFORE the filter gradient runs
         monkeypatch.setitem(ops._PG, "test_delay", 400000 if on == "1" else 0)
@@ -137,3 +137,43 @@ def test_main_cli(tmp_path):
                          capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "Segmentation training loss" in out.stdout and os.path.exists(tmp_path / "ckpt" / "checkpoint-latest")
+
+
+def test_fp32_and_bf16_models_coexist_and_interleave(dev):
+    """ComputeDtype, the parameter-gradient stream and the packed-filter registry are per-model state (an
+    ops.OpsContext owned by image2label), not process globals.  A fp32 and a bf16-storage model are built in ONE process and their
+    training steps interleaved (eager steps, the capture of each step graph and graph replays all fall between the other model's
+    steps); each must produce, bit for bit, the losses and parameters of the same model trained alone."""
+    from vnet_tensorflow_amd import ops
+    from vnet_tensorflow_amd.model import image2label
+    from oracle.vnet_oracle import synthetic_batch
+    import pathlib
+    P, NSTEP = 16, 6
+    x, lab = synthetic_batch(2, P, 1, 2, seed=33)
+    xt, lt = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
+
+    def build(compute):
+        np.random.seed(5)
+        cfg = _cfg(pathlib.Path("/tmp"), PatchShape=[P] * 3)
+        cfg["TrainingSetting"]["Networks"].update(NumChannel=8, NumLevels=3, NumConvolutions=[1, 2, 2])
+        cfg["TrainingSetting"]["ComputeDtype"] = compute
+        m = image2label(None, cfg, device=dev, verbose=False)
+        m.read_config(); m.build_model_graph(); m._setup_training()
+        return m
+
+    alone = {}
+    for compute in ("fp32", "bf16"):
+        m = build(compute)
+        alone[compute] = ([float(m.train_step(xt, lt, dropout=0.0)) for _ in range(NSTEP)], m.flat.data.clone())
+        del m
+    a, b = build("fp32"), build("bf16")
+    assert a.ctx is not b.ctx and ops.get_compute_dtype() == "fp32"
+    la, lb = [], []
+    for _ in range(NSTEP):
+        la.append(float(a.train_step(xt, lt, dropout=0.0)))
+        lb.append(float(b.train_step(xt, lt, dropout=0.0)))
+    torch.cuda.synchronize()
+    assert a.ctx.compute["name"] == "fp32" and b.ctx.compute["name"] == "bf16" and ops.get_compute_dtype() == "fp32"
+    assert la == alone["fp32"][0] and torch.equal(a.flat.data, alone["fp32"][1])
+    assert lb == alone["bf16"][0] and torch.equal(b.flat.data, alone["bf16"][1])
+    assert alone["fp32"][0] != alone["bf16"][0]                    # (the two really compute differently)

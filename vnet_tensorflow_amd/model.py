@@ -190,8 +190,21 @@ class _DeviceFeeder(object):
 # ------------------------------------------------------------------------------------------------
 # image2label -- reference model.py:169-1242
 # ------------------------------------------------------------------------------------------------
+def in_context(fn):
+    """The method runs inside the model's own OpsContext (compute dtype, parameter-gradient stream, packed-filter registry): what
+    used to be process-wide switches is per-model state, so models of different ComputeDtype coexist and interleave their steps."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        with ops.context(self.ctx):
+            return fn(self, *a, **kw)
+    return wrapped
+
+
 class image2label(object):
     def __init__(self, sess, config, device=None, verbose=True):
+        self.ctx = ops.OpsContext()
         """Args: sess: ignored (kept for signature parity, model.py:170); config: parsed config.json"""
         self.sess = sess
         self.config = config
@@ -288,6 +301,7 @@ class image2label(object):
         self._print("{}: Reading configuration file complete".format(_now()))
 
     # -- reference model.py:297-630 (network + loss head; summaries/metrics not carried) ---------------
+    @in_context
     def build_model_graph(self):
         self._print("{}: Start to build model graph...".format(_now()))
         self._validate_loss()
@@ -328,6 +342,7 @@ class image2label(object):
         if self.loss_name == "xent" and not self.config['TrainingSetting']['Loss'].get('AllowPlainXent', False):
             sys.exit("Invalid loss function")
 
+    @in_context
     def forward(self, images, labels=None, dropout=0.0, want_softmax=False, want_pred=False):
         """One pass of the graph of model.py:444-568.  images float32 [B,*P,Cin]; labels int32 [B,*P,1]."""
         self.dropout_placeholder = dropout
@@ -339,6 +354,7 @@ class image2label(object):
                                                 want_softmax=want_softmax, want_pred=want_pred)
         return logits, loss, sm, pred
 
+    @in_context
     def run(self, fetches, feed_dict):
         """sess.run shim keyed by the reference's graph tensor names (model.py:914-917)."""
         img = feed_dict['images_placeholder:0']
@@ -352,6 +368,7 @@ class image2label(object):
         return [table[f].cpu().numpy() for f in fetches]
 
     # -- distributed / optimiser set-up -------------------------------------------------------------
+    @in_context
     def _setup_training(self):
         self.flat = optim.FlatParams(self.network.named_parameters())
         self.optimizer = optim.make_optimizer(self.optimizer_name, self.flat, self.momentum)
@@ -508,7 +525,7 @@ class image2label(object):
         # much host time as the eager enqueue (measured 18.8 ms vs 0.11 ms per replay, 128^3 step) and runs 0.9 ms slower
         # on the GPU (the runtime schedules the branch worse than the eager two-stream order), while the side stream
         # itself is worth 0.06 ms -- profiles/r02_step_modes.txt.
-        pg_on = ops._PG["on"]
+        pg_on = self.ctx.pg["on"]
         ops.set_param_grad_stream(False)
         ops.settle_pack_registry()
         try:
@@ -536,6 +553,7 @@ class image2label(object):
             self._graphs = [ga, gb] if gr is None else [ga, gr, gb]
         return loss
 
+    @in_context
     def train_step(self, images, labels, dropout=None):
         """reference model.py:743-748: one fwd + loss + bwd + optimiser step; returns the loss tensor (device scalar; in
         graph mode it is a static buffer that the next step overwrites -- read or clone it before the next call)."""
@@ -566,6 +584,7 @@ class image2label(object):
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
         return bool(int(flag.item()))
 
+    @in_context
     def step_mode(self):
         """How train_step currently enqueues the step: 'off' (eager) | 'whole' | 'segmented'."""
         t = getattr(self, "_tuner", None)
@@ -642,6 +661,7 @@ class image2label(object):
     def _ckpt_prefix(self):
         return os.path.join(self.ckpt_dir, "checkpoint")
 
+    @in_context
     def save_checkpoint(self):
         if self.rank != 0:
             return
@@ -654,6 +674,7 @@ class image2label(object):
         with open(self._ckpt_prefix() + "-latest", "w") as f:
             f.write('model_checkpoint_path: "%s"\n' % os.path.basename(path))
 
+    @in_context
     def load_checkpoint(self, path=None, with_optimizer=True):
         if path is None:
             with open(self._ckpt_prefix() + "-latest") as f:
@@ -684,6 +705,7 @@ class image2label(object):
                                    rank=self.rank, world=self.world, transforms=tf)
 
     # -- reference model.py:632-815 ---------------------------------------------------------------------------
+    @in_context
     def train(self):
         self._print("{}: VNet training start...".format(_now()))
         self.rank, self.local_rank, self.world = parallel.init_from_env()
@@ -789,6 +811,7 @@ class image2label(object):
             self._print("{}: Saving checkpoint of epoch {} at {}...".format(_now(), epoch + 1, self.ckpt_dir))
             self.save_checkpoint()
 
+    @in_context
     def _infer(self, batch):
         """softmax of one evaluation batch (model.py:914-917: dropout 0, batch statistics of THIS batch).  Enqueued kernel by
         kernel: a replayed hipGraph of the forward pass was built and measured 5-8 % SLOWER end to end here
@@ -798,6 +821,7 @@ class image2label(object):
             return self.forward(batch, None, 0.0)[2]
 
     # -- reference model.py:817-977 (array in / arrays out; SimpleITK resampling not carried) -----------------
+    @in_context
     def evaluate_single_3D(self, images_np):
         """images_np float32 [X,Y,Z,Cin] -> (label int64 [X,Y,Z], softmax float32 [K,X,Y,Z]).
         Patch enumeration, the duplicated last batch and argmax-of-summed-softmax follow
@@ -863,6 +887,7 @@ class image2label(object):
         return label_np[sl], softmax_np[(slice(None),) + sl]
 
     # -- reference model.py:1131-1242 ------------------------------------------------------------------------------
+    @in_context
     def evaluate(self):
         self.read_config()
         self.rank, self.local_rank, self.world = 0, 0, 1

@@ -30,7 +30,69 @@ PACK_FWD, PACK_BWD, PACK_UP, PACK_FWD_BF16, PACK_BWD_BF16 = 0, 1, 2, 3, 4
 #                   `*_b16`); 5^3 AND 2^3 convolutions take bf16 operands; statistics, parameter gradients, logits and loss fp32.
 #                   The ops below dispatch on the tensor dtype, so the mode only decides what the network input is turned into.
 #   "bf16_operands" (round 2): fp32 tensors (+ bf16 shadows), only the 5^3 convolutions round their operands.
-_COMPUTE = {"dtype": "fp32", "store16": False, "name": "fp32"}
+# ---- per-model state (round 4) ---------------------------------------------------------------------------------------------
+# What used to be process globals -- the compute dtype, the parameter-gradient stream and the registry of packed filters -- lives
+# in an OpsContext.  image2label owns one and enters it around everything it runs (model.in_context), so a fp32 and a bf16 model
+# can coexist in one process and interleave their steps; code that calls the ops directly (tests, tools) works on the default
+# context exactly as before.  The switch is per process, not per thread: models take turns, they do not run concurrently.
+class OpsContext(object):
+    def __init__(self):
+        self.compute = {"dtype": "fp32", "store16": False, "name": "fp32"}
+        self.pg = {"on": False, "streams": {}, "used": set(), "keep": []}
+        self.pack_epoch = [0]
+        self.pack_reg = {"entries": [], "descs": None, "device": None}     # every (filter, mode) ever packed: repacked in one launch
+
+
+_DEFAULT_CTX = OpsContext()
+_CTX = [_DEFAULT_CTX]
+_TEST = {"test_delay": 0}          # (tests) cycles the parameter-gradient stream is held back per layer; shared by every context
+
+
+class context(object):
+    """with ops.context(ctx): ... -- the ops inside use ctx's compute dtype, parameter-gradient stream and pack registry."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        self.prev = _CTX[0]
+        _CTX[0] = self.ctx
+        return self.ctx
+
+    def __exit__(self, *a):
+        _CTX[0] = self.prev
+
+
+def current_context():
+    return _CTX[0]
+
+
+class _CtxDict(object):
+    """dict-like view of one attribute of the CURRENT context (keeps the module-level names the ops were written with)."""
+
+    def __init__(self, attr, shared=()):
+        self._attr, self._shared = attr, shared
+
+    def _d(self, k=None):
+        return _TEST if k in self._shared else getattr(_CTX[0], self._attr)
+
+    def __getitem__(self, k):
+        return self._d(k)[k]
+
+    def __setitem__(self, k, v):
+        self._d(k)[k] = v
+
+    def __delitem__(self, k):
+        del self._d(k)[k]
+
+    def __contains__(self, k):
+        return k in self._d(k)
+
+    def get(self, k, default=None):
+        return self._d(k).get(k, default)
+
+
+_COMPUTE = _CtxDict("compute")
 PACK_ROUND16 = 16
 
 
@@ -138,7 +200,7 @@ def workspace(nbytes, device):
 # only feed the optimiser / the gradient all-reduce.  With this switch on they are enqueued on a second HIP stream,
 # so their MFMA work fills the chip while the critical path sits in its short HBM- and latency-bound kernels.
 # Only gradients that go straight into the flat gradient buffer (GradSink) take this route.
-_PG = {"on": False, "streams": {}, "used": set(), "keep": [], "test_delay": 0}
+_PG = _CtxDict("pg", shared=("test_delay",))
 
 
 def set_param_grad_stream(on):
@@ -166,8 +228,8 @@ def join_param_grad_stream(device=None):
 
 
 # ---- packed-weight cache -------------------------------------------------------------------------
-_PACK_EPOCH = [0]
-_PACK_REG = {"entries": [], "descs": None, "device": None}     # every (filter, mode) ever packed: repacked in one launch
+_PACK_EPOCH = _CtxDict("pack_epoch")
+_PACK_REG = _CtxDict("pack_reg")
 
 
 def invalidate_packed():
@@ -557,8 +619,18 @@ def colsum16(x16, C, out):
     nb = L.vnet_colsum_b16_ws_bytes(C)
     ws = workspace(nb, x16.device)
     check(L.vnet_colsum_b16(_ptr(x16), _ptr(out), M, C, _ptr(ws), nb, _stream()), "vnet_colsum_b16")
+    return out
 
 
+# ---- deferred reduces of the filter-gradient slabs (include/vnet_hip.h: vnet_wgrad_defer / vnet_wgrad_flush) ------------------
+# Inside `deferred_wgrad_reduce()` the filter-gradient launches leave their partial slabs in a per-layer buffer and ONE batched
+# launch reduces all of them when the context ends (26 reduce launches of ~7 us per V-Net step otherwise).  Only for a backward
+# pass whose filter gradients nobody reads before it ends (model.image2label: not the eager data-parallel step, whose bucket
+# all-reduces start from the gradient hooks).
+_DEFER = {"on": False}
+
+
+@contextlib.contextmanager
 def deferred_wgrad_reduce(on=True):
     if not on or _DEFER["on"]:
         yield
