@@ -40,7 +40,7 @@ namespace {
 #define DEEP_STAMP_CHUNK 0
 #endif
 static __device__ long long* g_deep_stamps = nullptr;
-#define DEEP_STAMP(k) do { if (blockIdx.x == DEEP_STAMP_BLOCK && lane == 0 && g_deep_stamps) \
+#define DEEP_STAMP(k) do { if (blockIdx.x == DEEP_STAMP_BLOCK && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && g_deep_stamps) \
         g_deep_stamps[wave * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define DEEP_STAMP(k) do {} while (0)
@@ -98,32 +98,17 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int jq = ga ? (p32 < 4 ? p32 : p32 < 16 ? p32 - 8 : p32 - 12) : (p32 < 12 ? p32 - 4 : p32 < 20 ? p32 - 8 : p32 - 16);
     const int q32 = ((jq >> 3) * 2 + (ga ? 0 : 1)) * 8 + (jq & 7);
 
-    // Workgroup -> (brick, cout block, K split).  One 1-D grid; block i runs on XCD i % 8 (observed, speed only).  The workgroups
-    // that read the same filter SLICE (cout block, K split) are put on one XCD where the counts allow: in the step the filter
-    // comes from HBM (nothing has touched it since the repack a whole step ago), and with the bricks spread over the XCDs
-    // every XCD pulled every slice through the fabric -- 8 x 4 MB at 16^3 128->128, 2 x 16 MB at 8^3 (round-4 kernel trace:
-    // in the step the first versions of this kernel were no faster than the generic one, against +12..19 % warm).
-    //   nslice % 8 == 0: XCD x takes slices x, x + 8, ...; a slice's bricks are consecutive on it;
-    //   8 % nslice == 0 and nbrick % (8 / nslice) == 0: a slice spans 8 / nslice XCDs, each a contiguous range of bricks;
-    //   otherwise: plain order (correct anywhere: placement never matters for the result).
+    // (grid: bricks x cout blocks x K splits.  Putting all workgroups of one filter slice on one XCD -- a 1-D grid decoded per XCD --
+    // was measured: no gain in the step, +1 K cycles of index arithmetic in every prologue; dropped.)
     const int nbrick = a.B * a.nbz * a.nby * a.nbx;
     const int ncob = a.CoutP / 32;
-    const int nsplit_g = (a.nchunks + a.cps - 1) / a.cps, nslice = ncob * nsplit_g;
-    int brick, slice;
-    {
-        const int id = blockIdx.x, xcd = id & 7, k = id >> 3;
-        if ((nslice & 7) == 0) { slice = xcd + 8 * (k / nbrick); brick = k % nbrick; }
-        else if (nslice < 8 && (8 % nslice) == 0 && nbrick % (8 / nslice) == 0) {
-            const int per = nbrick / (8 / nslice);
-            slice = xcd % nslice; brick = (xcd / nslice) * per + k;
-        } else { slice = id % nslice; brick = id / nslice; }
-    }
-    const int bsplit = slice / ncob;
+    int brick = xcd_remap(blockIdx.x, nbrick);
+    const int bsplit = blockIdx.z;
     const int brick_id = brick;
     const int bx = brick % a.nbx; brick /= a.nbx;
     const int by = brick % a.nby; brick /= a.nby;
     const int bz = brick % a.nbz; const int b = brick / a.nbz;
-    const int cob = slice - bsplit * ncob, co0 = cob * 32;
+    const int cob = blockIdx.y, co0 = cob * 32;
     const int c_begin = bsplit * a.cps;
     const int ncl = min(a.nchunks, c_begin + a.cps) - c_begin;          // chunks of this workgroup
 
@@ -491,7 +476,7 @@ int launch_conv_deep(const ConvArgs& a, const DeepPlan& p, hipStream_t st) {
     using G = Bf16Geom<4, 8, 8>;
     constexpr size_t main_bytes = 4 * (G::TILE_BYTES + 32);          // four padded tiles (> the 128 KB of a reduction round)
     const size_t lds = main_bytes + 64 * 16;
-    dim3 grid(a.B * p.nbz * p.nby * p.nbx * p.ncob * p.nsplit);
+    dim3 grid(a.B * p.nbz * p.nby * p.nbx, p.ncob, p.nsplit);
     if (a.stats && p.nsplit == 1) {
         auto k = conv5_bf16_deep_kernel<true>;
         static unsigned long long attr_done = 0;
