@@ -63,6 +63,7 @@ inline DeepPlan plan_conv_deep(int C0, int C1, int Cy0, int Cy1, int B, int D, i
     p.ncob = Cout / 32;
     const long nwg0 = (long)B * p.nbz * p.nby * p.nbx * p.ncob;
     if (nwg0 > 512) return p;                        // enough bricks for the persistent row-pair / generic kernels
+    if ((long long)B * D * H * W * max(C0, C1) >= (1ll << 31)) return p;       // (32-bit element offsets in its tile loads)
     if (conv_bf16_use_r32(Cout, Cy0, Cy1, B, D, H, W) && nwg0 >= 256) {
         Bf16Plan g = plan_conv_bf16(Cin, Cout, B, D, H, W);
         if (g.nsplit * g.nz == 1) return p;          // the row-pair kernel takes it
@@ -120,8 +121,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     // B fragment base of (y half 0, plane 0, tap (0,0)): lane -> (cin half, row, x)
     const int boff0 = half * PLANE + ((q32 >> 3) * G::IX + (q32 & 7)) * 16;
     constexpr int YH = 4 * G::IX * 16;                                  // second y half: four tile rows further
-    const u32x4* wg = reinterpret_cast<const u32x4*>(a.wp) + (size_t)cob * 64 + lane;
-    const size_t wtap = (size_t)ncob * 64;                              // u32x4 units between two taps
+    // filter fragments: a UNIFORM base (this cout block) + a uniform 32-bit unit offset per (chunk, tap) + the lane -- the
+    // saddr form of global_load; with the lane folded into a 64-bit vector pointer every fragment address was a 64-bit vector
+    // multiply-add (1.5 K cycles for the ten loads of the prologue: round-4 stamps)
+    const u32x4* wbase = reinterpret_cast<const u32x4*>(a.wp) + (size_t)cob * 64;
+    const unsigned wtap = (unsigned)ncob * 64u;                         // u32x4 units between two taps (whole filter < 2^32 units)
 
     f32x16 acc[8];
     u32x4 afx[5], afy[5], afz[5], am;                                   // filter fragments: a ring of three units + the tail unit's
@@ -131,12 +135,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     // of the exact count in front of the MFMAs -- the prefetch then has to land inside the first planes of the unit that
     // issued it (round-4 stamps: 72 % of the MFMA rate; without the filter loads 100 %).
     auto a_issue5 = [&](u32x4 (&f)[5], int c, int r) {                  // c: chunk of this workgroup, r = dy * 5 + dx
-        const u32x4* src = wg + ((size_t)(c_begin + min(c, ncl - 1)) * 125 + r) * wtap;
+        const unsigned u0 = ((unsigned)(c_begin + min(c, ncl - 1)) * 125u + (unsigned)r) * wtap;
 #ifdef DEEP_A1
-        f[0] = *(const __attribute__((address_space(1))) u32x4*)(src);
+        f[0] = *(const __attribute__((address_space(1))) u32x4*)(wbase + u0 + lane);
 #elif !defined(DEEP_NO_A)
 #pragma unroll
-        for (int dz = 0; dz < 5; ++dz) f[dz] = *(const __attribute__((address_space(1))) u32x4*)(src + (size_t)dz * 25 * wtap);
+        for (int dz = 0; dz < 5; ++dz) f[dz] = *(const __attribute__((address_space(1))) u32x4*)(wbase + (u0 + (unsigned)dz * 25u * wtap) + lane);
 #endif
     };
 
@@ -160,23 +164,33 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         asm volatile("" : "+v"(vsub));
         const int piece = lane & (NP - 1);
         const int ldsp = (slot0 + (piece >> 1)) * TILE + (piece & 1) * PLANE;
+        // tile coordinates of this thread's first voxel (v0 < 64 * ... : one small division), then compile-time steps of VPI * NW
+        // voxels with at most one carry per axis; 32-bit element offsets (the launcher vouches for < 2^31 elements per source):
+        // ~20 VALU per load.  (The first version recomputed v / 144, v / 12 and a 64-bit offset per load, ~50 VALU: the
+        // address arithmetic of the 18 loads, not the memory, was most of the 9.9 K cycles of the tile load.)
+        const int v0 = wave * VPI + vsub;                               // < NW * VPI <= 256
+        const int iz0 = v0 / (G::IY * G::IX), r0 = v0 - iz0 * (G::IY * G::IX), iy0 = (r0 * 171) >> 11, ix0 = r0 - iy0 * G::IX;   // r0 < 144: r0 / 12
+        const unsigned sbase = (unsigned)b * (unsigned)(a.Di * a.Hi * a.Wi);
         auto issue = [&](u32x4 (&t)[NB], int k0) {
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 if (k0 + k >= NI) break;
-                const int v = (wave + NW * (k0 + k)) * VPI + vsub;
-                const int iz = v / (G::IY * G::IX), rem = v - iz * (G::IY * G::IX), iy = rem / G::IX, ix = rem - iy * G::IX;
+                const int dv = (k0 + k) * VPI * NW;                     // compile-time after unrolling
+                const int dzk = dv / (G::IY * G::IX), drk = dv - dzk * (G::IY * G::IX), dyk = drk / G::IX, dxk = drk - dyk * G::IX;
+                int ix = ix0 + dxk, iy = iy0 + dyk, iz = iz0 + dzk;
+                const int cx = ix >= G::IX; ix -= cx * G::IX; iy += cx;
+                const int cy = iy >= G::IY; iy -= cy * G::IY; iz += cy;
                 const int gz = gz0 + iz, gy = gy0 + iy, gx = gx0 + ix;
-                const bool ok = v < G::NV && (unsigned)gz < (unsigned)a.Di && (unsigned)gy < (unsigned)a.Hi && (unsigned)gx < (unsigned)a.Wi;
-                const long long vox = ((long long)(b * a.Di + gz) * a.Hi + gy) * a.Wi + gx;
-                t[k] = load16_or_zero(src + (ok ? vox * Cs + piece * 8 : 0), ok);
+                const bool ok = iz < G::IZ && (unsigned)gz < (unsigned)a.Di && (unsigned)gy < (unsigned)a.Hi && (unsigned)gx < (unsigned)a.Wi;
+                const unsigned vox = sbase + (unsigned)((gz * a.Hi + gy) * a.Wi + gx);
+                t[k] = load16_or_zero(src + (ok ? vox * (unsigned)Cs + (unsigned)(piece * 8) : 0u), ok);
             }
         };
         auto commit = [&](const u32x4 (&t)[NB], int k0) {
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 if (k0 + k >= NI) break;
-                const int v = (wave + NW * (k0 + k)) * VPI + vsub;
+                const int v = v0 + (k0 + k) * VPI * NW;
                 *reinterpret_cast<u32x4*>(v < G::NV ? smem + ldsp + v * 16 : dump) = t[k];
             }
         };
@@ -253,7 +267,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     auto tail_dz = [&](int c) { return (wave - (c_begin + c)) & 7; };
     auto tail_issue = [&](int c) {
 #ifndef DEEP_NO_A
-        am = *(const __attribute__((address_space(1))) u32x4*)(wg + ((size_t)(c_begin + min(c, ncl - 1)) * 125 + min(tail_dz(c), 4) * 25 + 24) * wtap);
+        am = *(const __attribute__((address_space(1))) u32x4*)(wbase + ((unsigned)(c_begin + min(c, ncl - 1)) * 125u + (unsigned)(min(tail_dz(c), 4) * 25 + 24)) * wtap + lane);
 #endif
     };
     auto tail = [&](int slot, int c) {
