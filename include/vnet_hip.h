@@ -399,6 +399,19 @@ int vnet_conv_fwd_b16_padded(const void* x16, int Cpad, int Cin, const void* wp,
  * zero-padded network input); ws >= vnet_wgrad_bf16_ws_bytes(C0 + C1, ...) */
 int vnet_conv_wgrad_b16(const void* x0, int C0, const void* x1, int C1, const void* dy, int Cout, float* dw, int Cin_dw,
                         int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream);
+/* Round 4: the filter gradients of SEVERAL layers in one launch (reference: the gradient ops tf.gradients creates for every
+ * layers2.py:59-63 convolution, model.py:660 -- TF runs them as independent nodes; here the deep-level ones of a backward pass are
+ * collected and share the 256 CUs according to their work: each workgroup walks many bricks with the next tile in flight and the
+ * split-K slabs shrink with the split).  jobs[i] are the arguments of vnet_conv_wgrad_b16 for layer i; the tensors must stay
+ * valid until the launch has run; a job whose shape the grouped kernels do not take runs as its own vnet_conv_wgrad_b16.
+ * Honours vnet_wgrad_defer (the slabs' reduces join the batched flush).  A layer's result depends on how the group splits it
+ * (summation order over bricks), never on the data of other layers.  VNET_WGRAD_GROUP_ROUNDS (default 2): workgroups per CU the
+ * plan aims at; 0 = every job on its own. */
+typedef struct vnet_wgrad_job {
+    const void* x0; const void* x1; const void* dy; float* dw; void* ws; size_t ws_bytes;
+    int C0, C1, Cout, Cin_dw, B, D, H, W;
+} vnet_wgrad_job;
+int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream);
 /* 2^3 stride-2 convolution (up = 0) / 2^3 transposed convolution (up = 1), bf16 in / bf16 out.  wp: the fp32 packed image of
  * the bf16-ROUNDED filter, vnet_pack_weights(VNET_PACK_FWD | VNET_PACK_ROUND_BF16, 8, Cin, Cout) resp. VNET_PACK_UP | ...;
  * accum: y += result (one rounding of the sum); stats (up = 0 only): rows = vnet_conv_stats_rows(2, 0, 2, 0, ...);

@@ -100,6 +100,7 @@ SIGNATURES = {
     "vnet_conv_fwd_b16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vnet_conv_fwd_b16_padded": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "vnet_conv_wgrad_b16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "vnet_conv_wgrad_b16_group": (_i, [_vp, _i, _vp]),
     "vnet_conv2_fwd_b16": (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "vnet_conv2_wgrad_b16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "vnet_conv2_direct_ok": (_i, [_i, _i]),
@@ -119,6 +120,14 @@ SIGNATURES = {
     "vnet_dropout_fwd_b16": (_i, [_vp, _vp, _vp, _i64, _f, _u64, _vp, _vp]),
     "vnet_dropout_bwd_b16": (_i, [_vp, _vp, _vp, _i64, _f, _vp]),
 }
+
+class WgradJob(ctypes.Structure):
+    """include/vnet_hip.h: vnet_wgrad_job (one layer of vnet_conv_wgrad_b16_group)."""
+    _fields_ = [("x0", ctypes.c_void_p), ("x1", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dw", ctypes.c_void_p),
+                ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_size_t),
+                ("C0", ctypes.c_int), ("C1", ctypes.c_int), ("Cout", ctypes.c_int), ("Cin_dw", ctypes.c_int),
+                ("B", ctypes.c_int), ("D", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int)]
+
 
 ERRORS = {-1: "VNET_E_BADARG", -2: "VNET_E_UNSUPPORTED", -3: "VNET_E_WORKSPACE"}
 

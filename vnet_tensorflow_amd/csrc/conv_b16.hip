@@ -13,6 +13,9 @@
 #include "conv_kernels.h"
 #include "conv_deep.h"
 #include <cstdlib>
+#include <algorithm>
+#include <cmath>
+#include <vector>
 
 namespace {
 inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -162,6 +165,126 @@ int vnet_conv_wgrad_b16(const void* x0, int C0, const void* x1, int C1, const vo
     if (direct) return VNET_OK;
     // (Cin_dw < C0 + C1: the leading input channels only -- a network input that was zero-padded to the 16-byte unit)
     launch_wgrad_reduce(a.part, p.nsplit, 125, a.CinP, a.CoutP, Cin_dw, Cout, dw, st);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+}  // extern "C"
+
+// ---- grouped filter gradients (round 4) ---------------------------------------------------------------------------------------
+// One layer's filter gradient at the deep levels (32^3 and below) is a launch of 256 workgroups with ONE or TWO bricks each: the
+// first tile load is exposed, nothing is prefetched under the MFMAs, and every workgroup writes its whole accumulator block as a
+// split-K slab (256 x 128 KB = 32 MB per layer whatever the filter's size: 390 MB per C5 step, written once and read once by the
+// reduce).  The layers of a backward pass whose filter gradients nobody reads before the pass ends are therefore collected and
+// launched TOGETHER: each layer gets as many workgroups as its share of the work, a workgroup walks 6-16 bricks with the next
+// brick's tiles in flight, and the slabs shrink with the split (nsplit 16 -> 2-5 at 32^3, 4 -> 1 at 16^3: a slab-less layer writes
+// dw directly and has nothing to reduce).  Same kernels bodies, same per-workgroup summation order over ascending bricks: a
+// layer's result depends on its nsplit only (tests compare against the oracle, not against the ungrouped launch, bit for bit).
+namespace {
+constexpr int WG_MAXJ = 24;
+enum { WG_RR = 0, WG_S16 = 1, WG_S8 = 2 };
+struct WgradGroup { int n; unsigned blk0[WG_MAXJ + 1]; unsigned char fam[WG_MAXJ]; WgradArgs job[WG_MAXJ]; };
+
+__global__ void __launch_bounds__(512) wgrad5_b16_group_kernel(WgradGroup g) {
+    int j = 0;
+#pragma unroll 1
+    for (int k = 1; k < g.n; ++k) if (blockIdx.x >= g.blk0[k]) j = k;
+    const WgradArgs& a = g.job[j];
+    const unsigned local = blockIdx.x - g.blk0[j];
+    const int split = (int)(local % (unsigned)a.nsplit);
+    const int rest = (int)(local / (unsigned)a.nsplit);
+    const int ny = (a.CinP / 16) * a.ncob;
+    switch (g.fam[j]) {
+        case WG_RR: wgrad5_bf16_rr_body<4, false>(a, split, rest); break;
+        case WG_S16: wgrad5_bf16_body<4, 4, 16, 2, 8, true>(a, split, rest % ny, rest / ny); break;
+        default: wgrad5_bf16_body<4, 8, 8, 2, 8, true>(a, split, rest % ny, rest / ny); break;
+    }
+}
+
+struct GroupItem { WgradArgs a; int fam, nblock, nbrick, Cin_dw; double unit; float* dw; void* ws; size_t ws_bytes; };
+}  // namespace
+
+extern "C" {
+
+int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream) {
+    if (n < 0 || (n > 0 && !jobs)) return VNET_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<GroupItem> items;
+    const char* genv = getenv("VNET_WGRAD_GROUP_ROUNDS");
+    const double rounds = genv ? atof(genv) : 2.0;
+    for (int q = 0; q < n; ++q) {
+        const vnet_wgrad_job& J = jobs[q];
+        if (!J.x0 || !J.dy || !J.dw || J.C0 <= 0 || J.Cout <= 0 || J.B <= 0 || J.C1 < 0 || (J.C1 > 0 && !J.x1)) return VNET_E_BADARG;
+        if (J.D <= 0 || J.H <= 0 || J.W <= 0 || J.Cin_dw <= 0 || J.Cin_dw > J.C0 + J.C1) return VNET_E_BADARG;
+        const int Cin = J.C0 + J.C1, CinP = round_up(Cin, 16), CoutP = round_up(J.Cout, 16);
+        const bool in4 = J.Cin_dw <= 4 && J.C0 == 8 && J.C1 == 0;
+        const bool ok = !(J.C0 & 15) && !(J.C1 & 15) && !(J.Cout & 7) && al16p(J.x0) && al16p(J.x1) && al16p(J.dy) && !in4;
+        int fam = -1;
+        if (ok && J.W >= 32 && J.H >= 8) fam = WG_RR;
+        else if (ok && (CoutP % 32) == 0) fam = J.W >= 16 ? WG_S16 : WG_S8;
+        if (fam < 0 || rounds <= 0.0) {           // not a shape of the grouped kernels: the layer's own launch
+            const int e = vnet_conv_wgrad_b16(J.x0, J.C0, J.x1, J.C1, J.dy, J.Cout, J.dw, J.Cin_dw, J.B, J.D, J.H, J.W, J.ws, J.ws_bytes, stream);
+            if (e) return e;
+            continue;
+        }
+        GroupItem it{};
+        WgradArgs& a = it.a;
+        a.x0 = reinterpret_cast<const float*>(J.x0); a.x1 = reinterpret_cast<const float*>(J.x1); a.C0 = J.C0; a.C1 = J.C1; a.Cin = Cin;
+        a.dy = reinterpret_cast<const float*>(J.dy); a.Cout = J.Cout;
+        a.B = J.B; a.Di = J.D; a.Hi = J.H; a.Wi = J.W; a.Do = J.D; a.Ho = J.H; a.Wo = J.W;
+        a.CinP = CinP; a.CoutP = CoutP; a.pad = 2; a.padx = 2; a.vec_in = 1; a.vec_dy = 1;
+        if (fam == WG_RR) {
+            a.ncob = CoutP / 16; a.nbz = ceil_div(J.D, 4); a.nby = ceil_div(J.H, 8); a.nbx = ceil_div(J.W, 32);
+            it.nblock = (CinP / 16) * a.ncob; it.unit = 1.0;
+        } else {
+            a.ncob = CoutP / 32; a.nbz = ceil_div(J.D, 4);
+            if (fam == WG_S16) { a.nby = ceil_div(J.H, 4); a.nbx = ceil_div(J.W, 16); }
+            else { a.nby = ceil_div(J.H, 8); a.nbx = ceil_div(J.W, 8); }
+            it.nblock = (CinP / 16) * a.ncob * 2; it.unit = 0.5;          // two tap groups of 64; a brick is 256 voxels and tile-bound
+        }
+        a.nbrick = J.B * a.nbz * a.nby * a.nbx;
+        it.fam = fam; it.nbrick = a.nbrick; it.Cin_dw = J.Cin_dw; it.dw = J.dw; it.ws = J.ws; it.ws_bytes = J.ws_bytes;
+        items.push_back(it);
+    }
+    if (items.empty()) return VNET_OK;
+    // work shares: a workgroup should carry total / (256 CUs x rounds); a layer block of `nbrick` bricks is split accordingly
+    double total = 0.0;
+    for (const GroupItem& it : items) total += it.unit * it.nblock * it.nbrick;
+    const double target = total / (256.0 * rounds);
+    for (GroupItem& it : items) {
+        const size_t slab = (size_t)125 * it.a.CinP * it.a.CoutP * sizeof(float);
+        int ns = (int)ceil(it.unit * it.nbrick / target - 1e-9);
+        ns = max(1, min(ns, it.nbrick));
+        const bool padded = !(it.a.CinP == it.Cin_dw && it.a.CoutP == it.a.Cout);
+        if (ns > 1 || padded) {
+            const size_t cap = it.ws ? it.ws_bytes / slab : 0;
+            if (cap < 1) return VNET_E_WORKSPACE;
+            ns = (int)min((size_t)ns, cap);
+            it.a.part = reinterpret_cast<float*>(it.ws);
+        } else it.a.part = it.dw;
+        it.a.nsplit = ns;
+    }
+    std::stable_sort(items.begin(), items.end(), [](const GroupItem& p, const GroupItem& q) {
+        return p.unit * ceil_div(p.nbrick, p.a.nsplit) > q.unit * ceil_div(q.nbrick, q.a.nsplit); });
+    constexpr size_t LDS_RR = (size_t)8 * 12 * 36 * 32 + (size_t)4 * 8 * 32 * 32;
+    auto k = wgrad5_b16_group_kernel;
+    static unsigned long long attr_done = 0;
+    if (int ae = ensure_lds(k, LDS_RR, attr_done)) return ae;
+    for (size_t i0 = 0; i0 < items.size(); i0 += WG_MAXJ) {
+        WgradGroup g{};
+        g.n = (int)min((size_t)WG_MAXJ, items.size() - i0);
+        unsigned blk = 0;
+        for (int q = 0; q < g.n; ++q) {
+            const GroupItem& it = items[i0 + q];
+            g.job[q] = it.a; g.fam[q] = (unsigned char)it.fam; g.blk0[q] = blk;
+            blk += (unsigned)(it.nblock * it.a.nsplit);
+        }
+        g.blk0[g.n] = blk;
+        hipLaunchKernelGGL(k, dim3(blk), dim3(512), LDS_RR, st, g);
+        VNET_LAUNCH_CHECK();
+    }
+    for (const GroupItem& it : items)
+        if (it.a.part != it.dw) launch_wgrad_reduce(it.a.part, it.a.nsplit, 125, it.a.CinP, it.a.CoutP, it.Cin_dw, it.a.Cout, it.dw, st);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
 }

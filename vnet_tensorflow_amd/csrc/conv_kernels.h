@@ -2251,7 +2251,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p, int off) {
 }
 
 template <int TZ, int TY, int TX, int NS, int TW, bool H = false>
-__global__ void __launch_bounds__(512) wgrad5_bf16_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad5_bf16_body(const WgradArgs& a, const int bid_x, const int bid_y, const int bid_z) {
     using G = TileGeom<5, 1, TZ, TY, TX, 5>;
     using XT = XTile<G::IZ, G::IY, G::IX, 512>;
     using XH = XTileH<G::IZ, G::IY, G::IX, 512>;
@@ -2268,10 +2268,10 @@ __global__ void __launch_bounds__(512) wgrad5_bf16_kernel(WgradArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
-    const int split = blockIdx.x;
-    const int chunk = blockIdx.y / a.ncob, cob = blockIdx.y - chunk * a.ncob;
+    const int split = bid_x;
+    const int chunk = bid_y / a.ncob, cob = bid_y - chunk * a.ncob;
     const int co0 = cob * NS * 16;
-    const int tap0 = (blockIdx.z * 8 + wave) * TW;
+    const int tap0 = (bid_z * 8 + wave) * TW;
 
     // lane part of every transpose read: voxel row (group's first voxel + i/4), 8-byte column quad i%4
     const int gx = (TX == 16) ? ((g & 1) * G::IX + (g >> 1) * 8) : g * G::IX;
@@ -2461,6 +2461,11 @@ __global__ void __launch_bounds__(512) wgrad5_bf16_kernel(WgradArgs a) {
     }
 }
 
+template <int TZ, int TY, int TX, int NS, int TW, bool H = false>
+__global__ void __launch_bounds__(512) wgrad5_bf16_kernel(WgradArgs a) {
+    wgrad5_bf16_body<TZ, TY, TX, NS, TW, H>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
 // ------------------------------------------------------------------------------------------
 // Row-reuse filter gradient (round 3; bf16 tensors only).  The kernel above reads one 1 KB B fragment (x, tap-shifted) from LDS per
 // MFMA -- with 16 output channels there is a single cout block to share it with -- and on this part fragment delivery and MFMA issue
@@ -2481,7 +2486,7 @@ __global__ void __launch_bounds__(512) wgrad5_bf16_kernel(WgradArgs a) {
 // offset 0) resp. dx = 4 (offset 4, sx = 0 only): 10 (dz, x offset) pairs instead of 25 (dz, dx) pairs; waves 0-7 own pair w,
 // waves 0-1 also pair 8 + w.
 template <int TZ, bool IN4 = false>
-__global__ void __launch_bounds__(512) wgrad5_bf16_rr_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad5_bf16_rr_body(const WgradArgs& a, const int bid_x, const int bid_y) {
     constexpr int TY = 8, TX = 32, IZ = TZ + 4, IY = TY + 4, IX = TX + 4;
     constexpr int XROWS = IZ * IY, XCOLS = IX * 2, XRPI = 512 / XCOLS, XPER = (XROWS + XRPI - 1) / XRPI;    // x tile: 16-byte units
     constexpr int XBYTES = XROWS * IX * 32;
@@ -2493,8 +2498,8 @@ __global__ void __launch_bounds__(512) wgrad5_bf16_rr_kernel(WgradArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
-    const int split = blockIdx.x;
-    const int chunk = blockIdx.y / a.ncob, cob = blockIdx.y - chunk * a.ncob;
+    const int split = bid_x;
+    const int chunk = bid_y / a.ncob, cob = bid_y - chunk * a.ncob;
     const int co0 = cob * 16;
 
     // this wave's three (dz, dx) pairs: pair index q = 3 * wave + c  (q = dz * 5 + dx, 0..23); pair 24 = (4, 4) is shared: its tap
@@ -2660,6 +2665,11 @@ __global__ void __launch_bounds__(512) wgrad5_bf16_rr_kernel(WgradArgs a) {
         const f32x4 r = acc[t];
         *reinterpret_cast<float4*>(dst) = make_float4(r.x, r.y, r.z, r.w);
     }
+}
+
+template <int TZ, bool IN4 = false>
+__global__ void __launch_bounds__(512) wgrad5_bf16_rr_kernel(WgradArgs a) {
+    wgrad5_bf16_rr_body<TZ, IN4>(a, blockIdx.x, blockIdx.y);
 }
 
 template <int TZ, bool IN4 = false>

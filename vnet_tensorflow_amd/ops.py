@@ -531,6 +531,13 @@ def _wgrad5_b16_call(x0, x1, dy, dw, dims, cin_dw, owner=None):
     flops = 2.0 * nvox * 125 * (C0 + C1) * Co
     nbytes = 2.0 * nvox * (C0 + C1 + Co) + 4.0 * 125 * (C0 + C1) * Co
     tag = _wgrad_tag(True, 5, 0, 1, dims[2], B, C0 + C1, Co)
+    if (_DEFER["on"] and owner is not None and _GROUP["on"] and not _PROFILE["on"] and _LAUNCH_ON[0] is None
+            and dims[0] * dims[1] * dims[2] <= _GROUP["max_voxels"]):
+        # a deep-level layer of a pass whose filter gradients nobody reads before it ends: launched together with the others when the
+        # pass ends (vnet_conv_wgrad_b16_group); the tensors stay alive -- and unmodified, see _ConvFn.backward -- until then
+        _DEFER["jobs"].append((x0, x1, dy, dw, ws, nb, int(cin_dw), B, tuple(dims)))
+        _DEFER["dy_ptrs"].add(dy.data_ptr())
+        return
     with _Timed(tag, flops, nbytes), _immediate_reduce(owner is None):
         check(L.vnet_conv_wgrad_b16(_ptr(x0), C0, _ptr(x1), C1, _ptr(dy), Co, _ptr(dw), int(cin_dw), B, *dims, _ptr(ws), nb, _stream()),
               "vnet_conv_wgrad_b16")
@@ -627,7 +634,30 @@ def colsum16(x16, C, out):
 # launch reduces all of them when the context ends (26 reduce launches of ~7 us per V-Net step otherwise).  Only for a backward
 # pass whose filter gradients nobody reads before it ends (model.image2label: not the eager data-parallel step, whose bucket
 # all-reduces start from the gradient hooks).
-_DEFER = {"on": False}
+_DEFER = {"on": False, "jobs": [], "dy_ptrs": set()}
+# grouped launch of the deep-level 5^3 filter gradients of a deferring pass (bf16 storage; include/vnet_hip.h:
+# vnet_conv_wgrad_b16_group).  VNET_WGRAD_GROUP=0: every layer launches its own kernel as it did through round 3.
+_GROUP = {"on": _os.environ.get("VNET_WGRAD_GROUP", "1") != "0", "max_voxels": int(_os.environ.get("VNET_WGRAD_GROUP_MAXVOX", 32 ** 3))}
+
+
+def set_wgrad_group(on):
+    _GROUP["on"] = bool(on)
+
+
+def _flush_wgrad_group(launch=True):
+    """Launch the collected filter gradients (the reduces of their slabs join the deferred queue) and let go of their tensors."""
+    jobs, _DEFER["jobs"] = _DEFER["jobs"], []
+    _DEFER["dy_ptrs"] = set()
+    if not jobs or not launch:
+        return
+    L = _lib.lib()
+    arr = (_lib.WgradJob * len(jobs))()
+    for k, (x0, x1, dy, dw, ws, nb, cin_dw, B, dims) in enumerate(jobs):
+        j = arr[k]
+        j.x0, j.x1, j.dy, j.dw, j.ws, j.ws_bytes = _ptr(x0), _ptr(x1), _ptr(dy), _ptr(dw), _ptr(ws), int(nb)
+        j.C0, j.C1, j.Cout, j.Cin_dw = int(x0.shape[-1]), (int(x1.shape[-1]) if x1 is not None else 0), int(dy.shape[-1]), cin_dw
+        j.B, j.D, j.H, j.W = int(B), int(dims[0]), int(dims[1]), int(dims[2])
+    check(L.vnet_conv_wgrad_b16_group(ctypes.addressof(arr), len(jobs), _stream()), "vnet_conv_wgrad_b16_group")
 
 
 @contextlib.contextmanager
@@ -644,12 +674,16 @@ def deferred_wgrad_reduce(on=True):
         # the pass failed (e.g. an invalidated stream capture): drain the queue without raising a SECOND error from here, so that
         # the caller sees the original one (model._train_step_graph turns a refused capture into eager steps)
         _DEFER["on"] = False
+        _flush_wgrad_group(launch=False)
         L.vnet_wgrad_defer(0)
         L.vnet_wgrad_flush(_stream())
         raise
     else:
-        _DEFER["on"] = False
-        L.vnet_wgrad_defer(0)
+        try:
+            _flush_wgrad_group()                  # (still deferring: the reduces of its slabs join the one batched launch below)
+        finally:
+            _DEFER["on"] = False
+            L.vnet_wgrad_defer(0)
         check(L.vnet_wgrad_flush(_stream()), "vnet_wgrad_flush")
 
 
@@ -975,6 +1009,11 @@ class _ConvFn(torch.autograd.Function):
                     and slot0.first.data_ptr() == dy.data_ptr() and tuple(dy.shape) == tuple(x0.shape)
                     and (b16 or _shadow_ptr(dy) is not None) and C0 % 8 == 0):
                 oop = dy
+            if acc is not None and b16 and ks == 5 and stride == 1 and not up and acc.data_ptr() in _DEFER["dy_ptrs"]:
+                # the other gradient of x0 is ALSO the dy of a filter gradient that waits for the grouped launch (a residual block's
+                # ds serves its last convolution and the block input): add it on the way out into a fresh tensor instead of in place
+                # -- the same arithmetic, RNE(accumulator + stored gradient), so the bits do not change
+                oop, acc = acc, None
             dx0 = acc if acc is not None else torch.empty_like(x0)
             dx1 = torch.empty_like(x1) if x1 is not None else None
             accum = acc is not None
