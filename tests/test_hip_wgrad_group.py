@@ -80,6 +80,45 @@ def test_group_is_deterministic_and_independent_of_company(dev, monkeypatch):
         check_close("reordered group %s" % (GROUP[k],), q, dw_ex, 2e-6)
 
 
+ZS_SHAPES = [
+    (1, 8, 16, 32, 32, 0, 32),      # 32-wide columns, ring of eight planes wraps once
+    (1, 20, 9, 37, 16, 16, 64),     # ... ragged, two sources, two cout blocks, 20 z steps: the ring wraps five times
+    (1, 16, 16, 16, 32, 0, 64),     # 16-wide columns: two planes per step
+    (2, 7, 9, 17, 16, 0, 32),       # ... ragged (odd depth: a half-empty plane pair), batch 2
+    (1, 8, 8, 8, 64, 0, 64),        # 8-wide columns: four planes per step, the whole column resident
+    (1, 6, 7, 5, 32, 32, 96),       # ... ragged, two sources, three cout blocks
+    (1, 12, 4, 4, 16, 0, 32),       # the deepest column the 8-wide form takes
+]
+
+
+@pytest.mark.parametrize("shape", ZS_SHAPES)
+def test_z_streaming_kernel_against_oracle(dev, shape, monkeypatch):
+    """csrc/wgrad_zs.h on its own (VNET_WGRAD_ZS=1 routes the per-layer entry point to it): column steps split over workgroups,
+    slabs + reduce; and with a workspace of ONE slab (no split: every step of a (chunk, cout block) in one workgroup)."""
+    from vnet_tensorflow_amd import ops, _lib
+    monkeypatch.setenv("VNET_WGRAD_ZS", "1")
+    B, D, H, W, C0, C1, Co = shape
+    x0, x1, w, b, dy = _conv5_inputs(shape, sum(shape) + 17)
+    xcat = x0 if x1 is None else np.concatenate((x0, x1), -1)
+    _, dw_ex = O.conv_nd_bwd(xcat, np.zeros((5, 5, 5, C0 + C1, Co)), dy, 1)
+    tx0, tx1, tdy = g16(x0, dev), (g16(x1, dev) if C1 else None), g16(dy, dev)
+    dw = torch.full((5, 5, 5, C0 + C1, Co), float("nan"), dtype=torch.float32, device=dev)
+    ops._wgrad5_b16_call(tx0, tx1, tdy, dw, (D, H, W), C0 + C1)
+    check_close("z-streaming %s dw" % (shape,), dw, dw_ex, 2e-6)
+    dw2 = torch.full_like(dw, float("nan"))
+    ops._wgrad5_b16_call(tx0, tx1, tdy, dw2, (D, H, W), C0 + C1)
+    assert torch.equal(dw, dw2)
+    # one slab of workspace: nsplit = 1
+    L = _lib.lib()
+    slab = 125 * (-(-(C0 + C1) // 16) * 16) * (-(-Co // 16) * 16) * 4
+    ws = torch.empty(slab, dtype=torch.uint8, device=dev)
+    dw3 = torch.full_like(dw, float("nan"))
+    _lib.check(L.vnet_conv_wgrad_b16(ops._ptr(tx0), C0, ops._ptr(tx1), C1, ops._ptr(tdy), Co, ops._ptr(dw3), C0 + C1, B, D, H, W,
+                                     ops._ptr(ws), slab, None), "vnet_conv_wgrad_b16")
+    torch.cuda.synchronize()
+    check_close("z-streaming unsplit %s dw" % (shape,), dw3, dw_ex, 2e-6)
+
+
 def test_c_abi_rejects_bad_jobs(dev):
     from vnet_tensorflow_amd import _lib
     L = _lib.lib()

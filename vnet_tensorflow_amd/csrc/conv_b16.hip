@@ -12,6 +12,7 @@
 // Reference call sites replaced: layers2.py:59-63, 65-74, 78-94 (forward), model.py:660 (their gradients).
 #include "conv_kernels.h"
 #include "conv_deep.h"
+#include "wgrad_zs.h"
 #include <cstdlib>
 #include <algorithm>
 #include <cmath>
@@ -125,6 +126,28 @@ int vnet_conv_wgrad_b16(const void* x0, int C0, const void* x1, int C1, const vo
     a.B = B; a.Di = D; a.Hi = H; a.Wi = W; a.Do = D; a.Ho = H; a.Wo = W;
     a.CinP = round_up(a.Cin, 16); a.CoutP = round_up(Cout, 16);
     a.pad = 2; a.padx = 2; a.vec_in = 1; a.vec_dy = 1;
+    // z-streaming kernel (wgrad_zs.h; VNET_WGRAD_ZS=1): 16 cin x 32 cout per workgroup, column steps split over workgroups
+    {
+        const char* zs_env = getenv("VNET_WGRAD_ZS");
+        const bool in4z = Cin_dw <= 4 && C0 == 8 && C1 == 0;
+        if (zs_env && atoi(zs_env) == 1 && zs_shape_ok(C0, C1, Cout) && zs_depth_ok(D, W) && !in4z && (size_t)D * H * W * max(max(C0, C1), Cout) < ((size_t)1 << 31)) {
+            const int nitems = zs_geometry(a);
+            const int nblock = (a.CinP / 16) * a.ncob;
+            const size_t slab = (size_t)125 * a.CinP * a.CoutP * sizeof(float);
+            int ns = max(1, min(nitems, ceil_div(256, nblock)));
+            const bool padded = !(a.CinP == Cin_dw && a.CoutP == Cout);
+            if (ns > 1 || padded) {
+                if (!ws || ws_bytes < slab) return VNET_E_WORKSPACE;
+                ns = (int)min((size_t)ns, ws_bytes / slab);
+                a.part = reinterpret_cast<float*>(ws);
+            } else a.part = dw;
+            a.nsplit = ns;
+            if (int e = launch_wgrad_zs(a, st)) return e;
+            if (a.part != dw) launch_wgrad_reduce(a.part, ns, 125, a.CinP, a.CoutP, Cin_dw, Cout, dw, st);
+            VNET_LAUNCH_CHECK();
+            return VNET_OK;
+        }
+    }
     WgradPlan p = plan_wgrad(5, 5, 1, a.Cin, Cout, B, D, H, W, true);
     a.ncob = p.ncob; a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.nbrick = p.nbrick; a.nsplit = p.nsplit;
     const size_t need = (size_t)p.nsplit * 125 * a.CinP * a.CoutP * sizeof(float);
@@ -182,7 +205,7 @@ int vnet_conv_wgrad_b16(const void* x0, int C0, const void* x1, int C1, const vo
 // layer's result depends on its nsplit only (tests compare against the oracle, not against the ungrouped launch, bit for bit).
 namespace {
 constexpr int WG_MAXJ = 24;
-enum { WG_RR = 0, WG_S16 = 1, WG_S8 = 2 };
+enum { WG_RR = 0, WG_S16 = 1, WG_S8 = 2, WG_ZS32 = 3, WG_ZS16 = 4, WG_ZS8 = 5 };
 struct WgradGroup { int n; unsigned blk0[WG_MAXJ + 1]; unsigned char fam[WG_MAXJ]; WgradArgs job[WG_MAXJ]; };
 
 __global__ void __launch_bounds__(512) wgrad5_b16_group_kernel(WgradGroup g) {
@@ -197,6 +220,9 @@ __global__ void __launch_bounds__(512) wgrad5_b16_group_kernel(WgradGroup g) {
     switch (g.fam[j]) {
         case WG_RR: wgrad5_bf16_rr_body<4, false>(a, split, rest); break;
         case WG_S16: wgrad5_bf16_body<4, 4, 16, 2, 8, true>(a, split, rest % ny, rest / ny); break;
+        case WG_ZS32: wgrad5_b16_zs_body<32>(a, split, rest); break;
+        case WG_ZS16: wgrad5_b16_zs_body<16>(a, split, rest); break;
+        case WG_ZS8: wgrad5_b16_zs_body<8>(a, split, rest); break;
         default: wgrad5_bf16_body<4, 8, 8, 2, 8, true>(a, split, rest % ny, rest / ny); break;
     }
 }
@@ -212,6 +238,12 @@ int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream) {
     std::vector<GroupItem> items;
     const char* genv = getenv("VNET_WGRAD_GROUP_ROUNDS");
     const double rounds = genv ? atof(genv) : 2.0;
+    const char* zenv = getenv("VNET_WGRAD_ZS");
+    // VNET_WGRAD_ZS: 0 = round-3 kernel bodies only, 1 = the z-streaming kernel wherever it applies, 2 (default) = below 32 voxels
+    // per row only: at 32^3 the row-reuse body with many bricks per workgroup measures faster (profiles/r04_wgrad_group.txt)
+    const int zs_mode = zenv ? atoi(zenv) : 2;
+    const bool zs_on = zs_mode != 0;
+    const int zs_maxw = zs_mode == 2 ? 31 : (1 << 30);
     for (int q = 0; q < n; ++q) {
         const vnet_wgrad_job& J = jobs[q];
         if (!J.x0 || !J.dy || !J.dw || J.C0 <= 0 || J.Cout <= 0 || J.B <= 0 || J.C1 < 0 || (J.C1 > 0 && !J.x1)) return VNET_E_BADARG;
@@ -220,7 +252,9 @@ int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream) {
         const bool in4 = J.Cin_dw <= 4 && J.C0 == 8 && J.C1 == 0;
         const bool ok = !(J.C0 & 15) && !(J.C1 & 15) && !(J.Cout & 7) && al16p(J.x0) && al16p(J.x1) && al16p(J.dy) && !in4;
         int fam = -1;
-        if (ok && J.W >= 32 && J.H >= 8) fam = WG_RR;
+        if (ok && zs_on && J.W <= zs_maxw && zs_shape_ok(J.C0, J.C1, J.Cout) && zs_depth_ok(J.D, J.W) && (size_t)J.D * J.H * J.W * max(max(J.C0, J.C1), J.Cout) < ((size_t)1 << 31))
+            fam = J.W >= 32 ? WG_ZS32 : (J.W >= 16 ? WG_ZS16 : WG_ZS8);
+        else if (ok && J.W >= 32 && J.H >= 8) fam = WG_RR;
         else if (ok && (CoutP % 32) == 0) fam = J.W >= 16 ? WG_S16 : WG_S8;
         if (fam < 0 || rounds <= 0.0) {           // not a shape of the grouped kernels: the layer's own launch
             const int e = vnet_conv_wgrad_b16(J.x0, J.C0, J.x1, J.C1, J.dy, J.Cout, J.dw, J.Cin_dw, J.B, J.D, J.H, J.W, J.ws, J.ws_bytes, stream);
@@ -233,7 +267,12 @@ int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream) {
         a.dy = reinterpret_cast<const float*>(J.dy); a.Cout = J.Cout;
         a.B = J.B; a.Di = J.D; a.Hi = J.H; a.Wi = J.W; a.Do = J.D; a.Ho = J.H; a.Wo = J.W;
         a.CinP = CinP; a.CoutP = CoutP; a.pad = 2; a.padx = 2; a.vec_in = 1; a.vec_dy = 1;
-        if (fam == WG_RR) {
+        if (fam >= WG_ZS32) {
+            a.Do = J.D; a.Ho = J.H; a.Wo = J.W;
+            const int nitems = zs_geometry(a);
+            (void)nitems;
+            it.nblock = (CinP / 16) * a.ncob; it.unit = 0.4;                 // a column step: 256 voxels x 16 cin x 32 cout x 125 taps
+        } else if (fam == WG_RR) {
             a.ncob = CoutP / 16; a.nbz = ceil_div(J.D, 4); a.nby = ceil_div(J.H, 8); a.nbx = ceil_div(J.W, 32);
             it.nblock = (CinP / 16) * a.ncob; it.unit = 1.0;
         } else {
@@ -242,7 +281,7 @@ int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream) {
             else { a.nby = ceil_div(J.H, 8); a.nbx = ceil_div(J.W, 8); }
             it.nblock = (CinP / 16) * a.ncob * 2; it.unit = 0.5;          // two tap groups of 64; a brick is 256 voxels and tile-bound
         }
-        a.nbrick = J.B * a.nbz * a.nby * a.nbx;
+        if (fam < WG_ZS32) a.nbrick = J.B * a.nbz * a.nby * a.nbx;
         it.fam = fam; it.nbrick = a.nbrick; it.Cin_dw = J.Cin_dw; it.dw = J.dw; it.ws = J.ws; it.ws_bytes = J.ws_bytes;
         items.push_back(it);
     }
