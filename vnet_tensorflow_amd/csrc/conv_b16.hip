@@ -204,20 +204,31 @@ int vnet_conv_wgrad_b16(const void* x0, int C0, const void* x1, int C1, const vo
 // dw directly and has nothing to reduce).  Same kernels bodies, same per-workgroup summation order over ascending bricks: a
 // layer's result depends on its nsplit only (tests compare against the oracle, not against the ungrouped launch, bit for bit).
 namespace {
-constexpr int WG_MAXJ = 24;
+constexpr int WG_MAXJ = 32;          // (a V-Net of 5 levels has 29 5^3 convolutions; the table travels in the 4 KB of kernel arguments)
 enum { WG_RR = 0, WG_S16 = 1, WG_S8 = 2, WG_ZS32 = 3, WG_ZS16 = 4, WG_ZS8 = 5 };
-struct WgradGroup { int n; unsigned blk0[WG_MAXJ + 1]; unsigned char fam[WG_MAXJ]; WgradArgs job[WG_MAXJ]; };
+struct WgradGroupJob {                // what the kernel bodies read of WgradArgs, 96 bytes
+    const void* x0; const void* x1; const void* dy; float* part;
+    int C0, C1, Cout, B, D, H, W, CinP, CoutP, ncob, nbz, nby, nbx, nbrick, nsplit, fam;
+};
+struct WgradGroup { int n; unsigned blk0[WG_MAXJ + 1]; WgradGroupJob job[WG_MAXJ]; };
+static_assert(sizeof(WgradGroup) <= 4096, "the job table is a kernel argument");
 
 __global__ void __launch_bounds__(512) wgrad5_b16_group_kernel(WgradGroup g) {
     int j = 0;
 #pragma unroll 1
     for (int k = 1; k < g.n; ++k) if (blockIdx.x >= g.blk0[k]) j = k;
-    const WgradArgs& a = g.job[j];
+    const WgradGroupJob& q = g.job[j];
+    WgradArgs a;
+    a.x0 = reinterpret_cast<const float*>(q.x0); a.x1 = reinterpret_cast<const float*>(q.x1); a.dy = reinterpret_cast<const float*>(q.dy);
+    a.part = q.part; a.C0 = q.C0; a.C1 = q.C1; a.Cin = q.C0 + q.C1; a.Cout = q.Cout; a.B = q.B;
+    a.Di = a.Do = q.D; a.Hi = a.Ho = q.H; a.Wi = a.Wo = q.W; a.CinP = q.CinP; a.CoutP = q.CoutP; a.ncob = q.ncob;
+    a.nbz = q.nbz; a.nby = q.nby; a.nbx = q.nbx; a.nbrick = q.nbrick; a.nsplit = q.nsplit;
+    a.pad = 2; a.padx = 2; a.vec_in = 1; a.vec_dy = 1;
     const unsigned local = blockIdx.x - g.blk0[j];
     const int split = (int)(local % (unsigned)a.nsplit);
     const int rest = (int)(local / (unsigned)a.nsplit);
     const int ny = (a.CinP / 16) * a.ncob;
-    switch (g.fam[j]) {
+    switch (q.fam) {
         case WG_RR: wgrad5_bf16_rr_body<4, false>(a, split, rest); break;
         case WG_S16: wgrad5_bf16_body<4, 4, 16, 2, 8, true>(a, split, rest % ny, rest / ny); break;
         case WG_ZS32: wgrad5_b16_zs_body<32>(a, split, rest); break;
@@ -315,7 +326,10 @@ int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream) {
         unsigned blk = 0;
         for (int q = 0; q < g.n; ++q) {
             const GroupItem& it = items[i0 + q];
-            g.job[q] = it.a; g.fam[q] = (unsigned char)it.fam; g.blk0[q] = blk;
+            const WgradArgs& w = it.a;
+            g.job[q] = WgradGroupJob{w.x0, w.x1, w.dy, w.part, w.C0, w.C1, w.Cout, w.B, w.Do, w.Ho, w.Wo, w.CinP, w.CoutP, w.ncob,
+                                     w.nbz, w.nby, w.nbx, w.nbrick, w.nsplit, it.fam};
+            g.blk0[q] = blk;
             blk += (unsigned)(it.nblock * it.a.nsplit);
         }
         g.blk0[g.n] = blk;
