@@ -266,6 +266,10 @@ def hbm_kernel_table(dev, bf16, classes, iters=50):
     return out
 
 
+def peak_for(bf16):
+    return PEAK_BF16_TFLOPS if bf16 else PEAK_FP32_TFLOPS
+
+
 def family_tags(P, B, bf16):
     """Launch tags (ops._Timed) of decoder level 1 / conv_1: forward 32->16, backward-data 16->32, filter gradient."""
     c, w = ("conv-bf16", "wgrad-bf16") if bf16 else ("conv", "wgrad")
@@ -308,6 +312,7 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
 
     bf16 = compute == "bf16"
     fam = family_tags(patch, batch, bf16)
+    timed = set(fam) | {ops.WGRAD_GROUP_TAG}     # + the grouped launch of the other 5^3 filter gradients (bf16 storage)
     full_table = bool(os.environ.get("BENCH_KERNEL_TABLE"))
     graph = m._graph_mode() != "off"
     mode = m._graph_mode()
@@ -316,7 +321,7 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
     # steps right after the timed region
     loss = None
     if not graph:
-        ops.profile_start(None if full_table else fam)
+        ops.profile_start(None if full_table else timed)
     nprep = 3 if graph else 0                # prepare: 2 eager steps + the capture (and first replay) of the step graph
     if mode == "segmented":
         tn = m._dp_tuner()                   # + the data-parallel start-up autotune: 3 rounds x 5 steps each of segmented / serial / eager
@@ -330,7 +335,7 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
         ops.profile_stop()                   # (synchronises; the warm-up records are dropped)
     barrier()
     if not graph:
-        ops.profile_start(None if full_table else fam)
+        ops.profile_start(None if full_table else timed)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = m.train_step(images, labels)
@@ -347,7 +352,7 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
         m.force_eager = True                     # same kernels, enqueued one by one so that events can bracket them
         m.train_step(images, labels)
         barrier()
-        ops.profile_start(None if full_table else fam)
+        ops.profile_start(None if full_table else timed)
         for _ in range(nroof):
             m.train_step(images, labels)
     recs = ops.profile_stop()
@@ -400,7 +405,17 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
             "hbm_GBps_algorithmic": round(by / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
             "measured": ("HIP events on the launch stream in %d eager steps that follow the timed region (same process, same "
                          "kernels and arguments; events cannot be timed inside a replayed hipGraph on this runtime)" % nroof)
+            + ("; the filter-gradient launch is timed on its own here -- in the replayed step it is one of the layers of the grouped "
+               "launch (`filter_gradient_group`)" if bf16 else "")
             if graph else "HIP events on the launch stream inside the timed region"}
+    if ops.WGRAD_GROUP_TAG in per and per[ops.WGRAD_GROUP_TAG][3] > 0:
+        v = per[ops.WGRAD_GROUP_TAG]
+        res["filter_gradient_group"] = {
+            "kernel": "wgrad5_b16_group_kernel: the 5^3 filter gradients of the backward pass in one launch (csrc/conv_b16.hip; the layer timed "
+                      "on its own for `roofline` and the zero-padded network input are not in it here)",
+            "avg_ms": round(v[3] / v[0], 4), "tflops": round(v[1] / (v[3] * 1e-3) / 1e12, 1),
+            "frac_of_peak": round(v[1] / (v[3] * 1e-3) / 1e12 / peak_for(bf16), 4), "launches_timed": v[0],
+            "note": "incl. its split-K slab writes; the slabs' one batched reduce is a separate launch"}
     if world == 1 and patch == 128 and not os.environ.get("BENCH_NO_HBM_TABLE"):
         del m
         gc.collect()

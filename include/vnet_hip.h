@@ -410,6 +410,9 @@ int vnet_conv_wgrad_b16(const void* x0, int C0, const void* x1, int C1, const vo
 typedef struct vnet_wgrad_job {
     const void* x0; const void* x1; const void* dy; float* dw; void* ws; size_t ws_bytes;
     int C0, C1, Cout, Cin_dw, B, D, H, W;
+    int ks;     /* 0 or 5: the 5^3 stride-1 convolution (arguments of vnet_conv_wgrad_b16); 2: the 2^3 stride-2 convolution -- x0 = the
+                 * FINE tensor [B,D,H,W,C0], dy = the COARSE tensor [B,ceil(D/2),ceil(H/2),ceil(W/2),Cout], dw [8][C0][Cout]
+                 * (arguments of vnet_conv2_wgrad_b16; C1 = 0, Cin_dw = C0) */
 } vnet_wgrad_job;
 int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream);
 /* 2^3 stride-2 convolution (up = 0) / 2^3 transposed convolution (up = 1), bf16 in / bf16 out.  wp: the fp32 packed image of

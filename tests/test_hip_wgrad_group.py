@@ -30,6 +30,47 @@ GROUP = [
 ]
 
 
+def test_group_with_2cube_layers_and_the_padded_input_layer(dev, monkeypatch):
+    """The other members of a V-Net pass: the 2^3 stride-2 filter gradients (ks = 2 jobs: x = the fine tensor, dy = the coarse one;
+    their dw is the filter gradient of the down conv and, with the roles of the tensors swapped by the caller, of the transposed conv)
+    and the zero-padded network input (4 real channels of 8: the x-im2col form of the row-reuse body), next to 5^3 layers."""
+    from vnet_tensorflow_amd import ops
+    monkeypatch.setitem(ops._GROUP, "in4", True)      # (off by default: inside the C5 group that layer measured slower than on its own)
+    rng = np.random.default_rng(77)
+    five = [(1, 8, 16, 32, 32, 0, 32), (1, 8, 8, 8, 64, 0, 64)]
+    two = [(1, 16, 16, 32, 16, 32), (2, 9, 10, 12, 32, 64), (1, 8, 8, 8, 64, 128), (1, 16, 16, 16, 8, 16)]     # B, D, H, W (fine), Cin, Cout
+    jobs = []
+    with ops.deferred_wgrad_reduce():
+        for k, shape in enumerate(five):
+            B, D, H, W, C0, C1, Co = shape
+            x0, x1, w, b, dy = _conv5_inputs(shape, 300 + k)
+            dw = torch.full((5, 5, 5, C0, Co), float("nan"), dtype=torch.float32, device=dev)
+            sink = ops.GradSink(dw)
+            ops._wgrad5_b16_call(g16(x0, dev), None, g16(dy, dev), dw, (D, H, W), C0, owner=sink)
+            jobs.append(("5^3 %s" % (shape,), dw, sink, O.conv_nd_bwd(x0, np.zeros((5, 5, 5, C0, Co)), dy, 1, need_dx=False)[1]))
+        for (B, D, H, W, Ci, Co) in two:
+            xf = rb(rng.standard_normal((B, D, H, W, Ci)))
+            dc = tuple((d + 1) // 2 for d in (D, H, W))
+            dyc = rb(rng.standard_normal((B,) + dc + (Co,)))
+            dw = torch.full((2, 2, 2, Ci, Co), float("nan"), dtype=torch.float32, device=dev)
+            sink = ops.GradSink(dw)
+            ops._wgrad2_b16_call(g16(xf, dev), g16(dyc, dev), dw, (D, H, W), dc, owner=sink)
+            jobs.append(("2^3 %s" % ((B, D, H, W, Ci, Co),), dw, sink, O.conv_nd_bwd(xf, np.zeros((2, 2, 2, Ci, Co)), dyc, 2, need_dx=False)[1]))
+        # the network input: 3 modalities zero-padded to 8 channels, dw has the 3 real input channels
+        B, D, H, W, Co = 1, 8, 16, 32, 16
+        xin = np.zeros((B, D, H, W, 8))
+        xin[..., :3] = rb(rng.standard_normal((B, D, H, W, 3)))
+        dyi = rb(rng.standard_normal((B, D, H, W, Co)))
+        dw = torch.full((5, 5, 5, 3, Co), float("nan"), dtype=torch.float32, device=dev)
+        sink = ops.GradSink(dw)
+        ops._wgrad5_b16_call(g16(xin, dev), None, g16(dyi, dev), dw, (D, H, W), 3, owner=sink)
+        jobs.append(("padded input", dw, sink, O.conv_nd_bwd(xin[..., :3], np.zeros((5, 5, 5, 3, Co)), dyi, 1, need_dx=False)[1]))
+        assert len(ops._DEFER["jobs"]) == len(jobs)
+    torch.cuda.synchronize()
+    for name, dw, _, ex in jobs:
+        check_close("group member " + name, dw, ex, 2e-6)
+
+
 def _run_group(dev, shapes, rounds=None, monkeypatch=None):
     from vnet_tensorflow_amd import ops
     if rounds is not None:

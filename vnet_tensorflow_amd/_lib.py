@@ -126,7 +126,7 @@ class WgradJob(ctypes.Structure):
     _fields_ = [("x0", ctypes.c_void_p), ("x1", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dw", ctypes.c_void_p),
                 ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_size_t),
                 ("C0", ctypes.c_int), ("C1", ctypes.c_int), ("Cout", ctypes.c_int), ("Cin_dw", ctypes.c_int),
-                ("B", ctypes.c_int), ("D", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int)]
+                ("B", ctypes.c_int), ("D", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("ks", ctypes.c_int)]
 
 
 ERRORS = {-1: "VNET_E_BADARG", -2: "VNET_E_UNSUPPORTED", -3: "VNET_E_WORKSPACE"}

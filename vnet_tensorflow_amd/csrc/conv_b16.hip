@@ -14,6 +14,7 @@
 #include "conv_deep.h"
 #include "wgrad_zs.h"
 #include <cstdlib>
+#include <cstdio>
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -204,8 +205,9 @@ int vnet_conv_wgrad_b16(const void* x0, int C0, const void* x1, int C1, const vo
 // dw directly and has nothing to reduce).  Same kernels bodies, same per-workgroup summation order over ascending bricks: a
 // layer's result depends on its nsplit only (tests compare against the oracle, not against the ungrouped launch, bit for bit).
 namespace {
-constexpr int WG_MAXJ = 32;          // (a V-Net of 5 levels has 29 5^3 convolutions; the table travels in the 4 KB of kernel arguments)
-enum { WG_RR = 0, WG_S16 = 1, WG_S8 = 2, WG_ZS32 = 3, WG_ZS16 = 4, WG_ZS8 = 5 };
+constexpr int WG_MAXJ = 32;          // (a V-Net of 5 levels: 22 5^3 + 8 2^3 convolutions; the table travels in the 4 KB of kernel arguments)
+enum { WG_RR = 0, WG_S16 = 1, WG_S8 = 2, WG_ZS32 = 3, WG_ZS16 = 4, WG_ZS8 = 5, WG_RR_IN4 = 6,
+       WG_K2_W2 = 7, WG_K2_W4 = 8, WG_K2_S2 = 9, WG_K2_S4 = 10 };     // 2^3 stride 2: wide / small bricks x 2 / 4 cout blocks
 struct WgradGroupJob {                // what the kernel bodies read of WgradArgs, 96 bytes
     const void* x0; const void* x1; const void* dy; float* part;
     int C0, C1, Cout, B, D, H, W, CinP, CoutP, ncob, nbz, nby, nbx, nbrick, nsplit, fam;
@@ -224,21 +226,29 @@ __global__ void __launch_bounds__(512) wgrad5_b16_group_kernel(WgradGroup g) {
     a.Di = a.Do = q.D; a.Hi = a.Ho = q.H; a.Wi = a.Wo = q.W; a.CinP = q.CinP; a.CoutP = q.CoutP; a.ncob = q.ncob;
     a.nbz = q.nbz; a.nby = q.nby; a.nbx = q.nbx; a.nbrick = q.nbrick; a.nsplit = q.nsplit;
     a.pad = 2; a.padx = 2; a.vec_in = 1; a.vec_dy = 1;
+    if (q.fam >= WG_K2_W2) {             // 2^3 stride 2: x0 is the fine tensor, dy the coarse one
+        a.Do = (q.D + 1) >> 1; a.Ho = (q.H + 1) >> 1; a.Wo = (q.W + 1) >> 1; a.pad = 0; a.padx = 0;
+    }
     const unsigned local = blockIdx.x - g.blk0[j];
     const int split = (int)(local % (unsigned)a.nsplit);
     const int rest = (int)(local / (unsigned)a.nsplit);
     const int ny = (a.CinP / 16) * a.ncob;
     switch (q.fam) {
         case WG_RR: wgrad5_bf16_rr_body<4, false>(a, split, rest); break;
+        case WG_RR_IN4: wgrad5_bf16_rr_body<4, true>(a, split, rest); break;
         case WG_S16: wgrad5_bf16_body<4, 4, 16, 2, 8, true>(a, split, rest % ny, rest / ny); break;
         case WG_ZS32: wgrad5_b16_zs_body<32>(a, split, rest); break;
         case WG_ZS16: wgrad5_b16_zs_body<16>(a, split, rest); break;
         case WG_ZS8: wgrad5_b16_zs_body<8>(a, split, rest); break;
+        case WG_K2_W2: wgrad_body<2, 2, 2, 4, 16, 2, 1, 2, true>(a, split, rest, 0); break;
+        case WG_K2_W4: wgrad_body<2, 2, 2, 4, 16, 4, 1, 2, true>(a, split, rest, 0); break;
+        case WG_K2_S2: wgrad_body<2, 2, 2, 8, 8, 2, 1, 2, true>(a, split, rest, 0); break;
+        case WG_K2_S4: wgrad_body<2, 2, 2, 8, 8, 4, 1, 2, true>(a, split, rest, 0); break;
         default: wgrad5_bf16_body<4, 8, 8, 2, 8, true>(a, split, rest % ny, rest / ny); break;
     }
 }
 
-struct GroupItem { WgradArgs a; int fam, nblock, nbrick, Cin_dw; double unit; float* dw; void* ws; size_t ws_bytes; };
+struct GroupItem { WgradArgs a; int fam, nblock, nbrick, Cin_dw, T3; double unit; float* dw; void* ws; size_t ws_bytes; };
 }  // namespace
 
 extern "C" {
@@ -260,10 +270,40 @@ int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream) {
         if (!J.x0 || !J.dy || !J.dw || J.C0 <= 0 || J.Cout <= 0 || J.B <= 0 || J.C1 < 0 || (J.C1 > 0 && !J.x1)) return VNET_E_BADARG;
         if (J.D <= 0 || J.H <= 0 || J.W <= 0 || J.Cin_dw <= 0 || J.Cin_dw > J.C0 + J.C1) return VNET_E_BADARG;
         const int Cin = J.C0 + J.C1, CinP = round_up(Cin, 16), CoutP = round_up(J.Cout, 16);
+        if (J.ks != 0 && J.ks != 5 && J.ks != 2) return VNET_E_BADARG;
+        if (J.ks == 2) {
+            if (J.C1 != 0 || J.Cin_dw != J.C0) return VNET_E_BADARG;
+            const int Do = (J.D + 1) / 2, Ho = (J.H + 1) / 2, Wo = (J.W + 1) / 2;
+            WgradPlan p = plan_wgrad(2, 2, 2, J.C0, J.Cout, J.B, Do, Ho, Wo);
+            const bool k2ok = !(J.C0 & 3) && !(J.Cout & 3) && al8p(J.x0) && al8p(J.dy) && (p.ns == 2 || p.ns == 4) && rounds > 0.0;
+            if (!k2ok) {
+                const int e = vnet_conv2_wgrad_b16(J.x0, J.C0, J.dy, J.Cout, J.dw, J.B, J.D, J.H, J.W, Do, Ho, Wo, J.ws, J.ws_bytes, stream);
+                if (e) return e;
+                continue;
+            }
+            GroupItem it{};
+            WgradArgs& a = it.a;
+            a.x0 = reinterpret_cast<const float*>(J.x0); a.C0 = J.C0; a.Cin = J.C0; a.dy = reinterpret_cast<const float*>(J.dy); a.Cout = J.Cout;
+            a.B = J.B; a.Di = J.D; a.Hi = J.H; a.Wi = J.W; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
+            a.CinP = CinP; a.CoutP = CoutP; a.vec_in = 1; a.vec_dy = 1;
+            a.ncob = p.ncob; a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.nbrick = p.nbrick;
+            it.fam = p.small ? (p.ns == 4 ? WG_K2_S4 : WG_K2_S2) : (p.ns == 4 ? WG_K2_W4 : WG_K2_W2);
+            it.nblock = (CinP / 16) * p.ncob; it.nbrick = p.nbrick; it.Cin_dw = J.C0; it.T3 = 8;
+            // a brick = 128 coarse voxels: 32 KB of the fine tensor + 4-16 KB of dy, next to no MFMA work to hide the loads behind: the
+            // stand-alone launches measure ~4.3 us per brick (latency-bound), a third of a row-reuse brick -- an underestimate leaves
+            // a layer to a handful of workgroups (0.02 x ns here cost +1.8 ms of tail in the C5 step)
+            it.unit = 0.35;
+            it.dw = J.dw; it.ws = J.ws; it.ws_bytes = J.ws_bytes;
+            items.push_back(it);
+            continue;
+        }
         const bool in4 = J.Cin_dw <= 4 && J.C0 == 8 && J.C1 == 0;
         const bool ok = !(J.C0 & 15) && !(J.C1 & 15) && !(J.Cout & 7) && al16p(J.x0) && al16p(J.x1) && al16p(J.dy) && !in4;
         int fam = -1;
-        if (ok && zs_on && J.W <= zs_maxw && zs_shape_ok(J.C0, J.C1, J.Cout) && zs_depth_ok(J.D, J.W) && (size_t)J.D * J.H * J.W * max(max(J.C0, J.C1), J.Cout) < ((size_t)1 << 31))
+        const char* in4_env = getenv("VNET_CONV_IN4");
+        if (in4 && !(in4_env && atoi(in4_env) == 0) && J.W >= 32 && J.H >= 8 && !(J.Cout & 7) && al16p(J.x0) && al16p(J.dy))
+            fam = WG_RR_IN4;          // the zero-padded network input: x-im2col form of the row-reuse body, 10 instead of 25 tap pairs
+        else if (ok && zs_on && J.W <= zs_maxw && zs_shape_ok(J.C0, J.C1, J.Cout) && zs_depth_ok(J.D, J.W) && (size_t)J.D * J.H * J.W * max(max(J.C0, J.C1), J.Cout) < ((size_t)1 << 31))
             fam = J.W >= 32 ? WG_ZS32 : (J.W >= 16 ? WG_ZS16 : WG_ZS8);
         else if (ok && J.W >= 32 && J.H >= 8) fam = WG_RR;
         else if (ok && (CoutP % 32) == 0) fam = J.W >= 16 ? WG_S16 : WG_S8;
@@ -278,22 +318,23 @@ int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream) {
         a.dy = reinterpret_cast<const float*>(J.dy); a.Cout = J.Cout;
         a.B = J.B; a.Di = J.D; a.Hi = J.H; a.Wi = J.W; a.Do = J.D; a.Ho = J.H; a.Wo = J.W;
         a.CinP = CinP; a.CoutP = CoutP; a.pad = 2; a.padx = 2; a.vec_in = 1; a.vec_dy = 1;
-        if (fam >= WG_ZS32) {
+        const bool zs_fam = fam >= WG_ZS32 && fam <= WG_ZS8;
+        if (zs_fam) {
             a.Do = J.D; a.Ho = J.H; a.Wo = J.W;
             const int nitems = zs_geometry(a);
             (void)nitems;
             it.nblock = (CinP / 16) * a.ncob; it.unit = 0.4;                 // a column step: 256 voxels x 16 cin x 32 cout x 125 taps
-        } else if (fam == WG_RR) {
+        } else if (fam == WG_RR || fam == WG_RR_IN4) {
             a.ncob = CoutP / 16; a.nbz = ceil_div(J.D, 4); a.nby = ceil_div(J.H, 8); a.nbx = ceil_div(J.W, 32);
-            it.nblock = (CinP / 16) * a.ncob; it.unit = 1.0;
+            it.nblock = (CinP / 16) * a.ncob; it.unit = fam == WG_RR ? 1.0 : 0.6;          // (x-im2col form: 10 of 25 tap pairs, the same tiles)
         } else {
             a.ncob = CoutP / 32; a.nbz = ceil_div(J.D, 4);
             if (fam == WG_S16) { a.nby = ceil_div(J.H, 4); a.nbx = ceil_div(J.W, 16); }
             else { a.nby = ceil_div(J.H, 8); a.nbx = ceil_div(J.W, 8); }
             it.nblock = (CinP / 16) * a.ncob * 2; it.unit = 0.5;          // two tap groups of 64; a brick is 256 voxels and tile-bound
         }
-        if (fam < WG_ZS32) a.nbrick = J.B * a.nbz * a.nby * a.nbx;
-        it.fam = fam; it.nbrick = a.nbrick; it.Cin_dw = J.Cin_dw; it.dw = J.dw; it.ws = J.ws; it.ws_bytes = J.ws_bytes;
+        if (!zs_fam) a.nbrick = J.B * a.nbz * a.nby * a.nbx;
+        it.fam = fam; it.nbrick = a.nbrick; it.Cin_dw = J.Cin_dw; it.T3 = 125; it.dw = J.dw; it.ws = J.ws; it.ws_bytes = J.ws_bytes;
         items.push_back(it);
     }
     if (items.empty()) return VNET_OK;
@@ -302,7 +343,7 @@ int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream) {
     for (const GroupItem& it : items) total += it.unit * it.nblock * it.nbrick;
     const double target = total / (256.0 * rounds);
     for (GroupItem& it : items) {
-        const size_t slab = (size_t)125 * it.a.CinP * it.a.CoutP * sizeof(float);
+        const size_t slab = (size_t)it.T3 * it.a.CinP * it.a.CoutP * sizeof(float);
         int ns = (int)ceil(it.unit * it.nbrick / target - 1e-9);
         ns = max(1, min(ns, it.nbrick));
         const bool padded = !(it.a.CinP == it.Cin_dw && it.a.CoutP == it.a.Cout);
@@ -316,6 +357,13 @@ int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream) {
     }
     std::stable_sort(items.begin(), items.end(), [](const GroupItem& p, const GroupItem& q) {
         return p.unit * ceil_div(p.nbrick, p.a.nsplit) > q.unit * ceil_div(q.nbrick, q.a.nsplit); });
+    if (getenv("VNET_WGRAD_GROUP_DEBUG")) {
+        fprintf(stderr, "[wgrad group] %zu layers, total %.0f units, target %.1f units per workgroup\n", items.size(), total, target);
+        for (const GroupItem& it : items)
+            fprintf(stderr, "  fam %2d  %3d^3 (D %d) %3d->%3d  blocks %3d  bricks %5d  unit %.3f  nsplit %3d  -> %4d workgroups of %.1f units\n",
+                    it.fam, it.a.Wi, it.a.Di, it.a.Cin, it.a.Cout, it.nblock, it.nbrick, it.unit, it.a.nsplit, it.nblock * it.a.nsplit,
+                    it.unit * ceil_div(it.nbrick, it.a.nsplit));
+    }
     constexpr size_t LDS_RR = (size_t)8 * 12 * 36 * 32 + (size_t)4 * 8 * 32 * 32;
     auto k = wgrad5_b16_group_kernel;
     static unsigned long long attr_done = 0;
@@ -327,7 +375,7 @@ int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream) {
         for (int q = 0; q < g.n; ++q) {
             const GroupItem& it = items[i0 + q];
             const WgradArgs& w = it.a;
-            g.job[q] = WgradGroupJob{w.x0, w.x1, w.dy, w.part, w.C0, w.C1, w.Cout, w.B, w.Do, w.Ho, w.Wo, w.CinP, w.CoutP, w.ncob,
+            g.job[q] = WgradGroupJob{w.x0, w.x1, w.dy, w.part, w.C0, w.C1, w.Cout, w.B, w.Di, w.Hi, w.Wi, w.CinP, w.CoutP, w.ncob,
                                      w.nbz, w.nby, w.nbx, w.nbrick, w.nsplit, it.fam};
             g.blk0[q] = blk;
             blk += (unsigned)(it.nblock * it.a.nsplit);
@@ -337,7 +385,7 @@ int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream) {
         VNET_LAUNCH_CHECK();
     }
     for (const GroupItem& it : items)
-        if (it.a.part != it.dw) launch_wgrad_reduce(it.a.part, it.a.nsplit, 125, it.a.CinP, it.a.CoutP, it.Cin_dw, it.a.Cout, it.dw, st);
+        if (it.a.part != it.dw) launch_wgrad_reduce(it.a.part, it.a.nsplit, it.T3, it.a.CinP, it.a.CoutP, it.Cin_dw, it.a.Cout, it.dw, st);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
 }

@@ -619,160 +619,25 @@ struct WgradArgs {
 // IO16: x and dy are bf16 tensors (bf16-storage mode of the 2^3 convolutions), converted to fp32 on their way into LDS
 template <int KS, int STRIDE, int TZ, int TY, int TX, int NS, int TW, int KX = KS, bool IO16 = false>
 __global__ void __launch_bounds__(512) wgrad_kernel(WgradArgs a) {
-    using G = TileGeom<KS, STRIDE, TZ, TY, TX, KX>;
-    using XT = XTile<G::IZ, G::IY, G::IX, 512, IO16>;
-    using DV = typename XT::V;
-    constexpr int NV = TZ * TY * TX;
-    constexpr int T3 = KS * KS * KX;
-    constexpr int NQD = NV * NS * 4, PERD = (NQD + 511) / 512;
-    static_assert(TX % 4 == 0, "voxel groups are 4 consecutive x");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* xt = lds;
-    float* dyt = lds + G::LDS_FLOATS;
-    const int tid = threadIdx.x;
-    // 8 waves = 2 per SIMD; wave w owns TW taps for the workgroup's NS*16 cout x 16 cin
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // static priority for the second-dispatched half of the workgroup (it loses the issue arbitration on every segment
-    // otherwise; MI355X_MICROARCH.md "two waves per SIMD" item 4): -0.04 ms per step, measured in an interleaved A/B
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-    const int i = lane & 15, kk = lane >> 4;
-    const int split = blockIdx.x;
-    const int chunk = blockIdx.y / a.ncob, cob = blockIdx.y - chunk * a.ncob;
-    const int co0 = cob * NS * 16;
-    const int tap0 = (blockIdx.z * 8 + wave) * TW;
+#define VNET_WG_BID_X blockIdx.x
+#define VNET_WG_BID_Y blockIdx.y
+#define VNET_WG_BID_Z blockIdx.z
+#include "wgrad_body.inc"
+#undef VNET_WG_BID_X
+#undef VNET_WG_BID_Y
+#undef VNET_WG_BID_Z
+}
 
-    int toff[TW];
-#pragma unroll
-    for (int t = 0; t < TW; ++t) {
-        int tap = tap0 + t;
-        tap = tap < T3 ? tap : 0;
-        const int dx = tap % KX, dy = (tap / KX) % KS, dz = tap / (KX * KS);
-        toff[t] = ((dz * G::IY + dy) * G::IX + dx) * 16;
-    }
-
-    // loop-invariant LDS read pointers: lane part (voxel kk of a group, channel i) + this wave's tap offsets
-    const float* pt[TW];
-#pragma unroll
-    for (int t = 0; t < TW; ++t) pt[t] = xt + kk * STRIDE * 16 + i + toff[t];
-    const float* pa = dyt + kk * (NS * 16) + i;
-
-    f32x4 acc[TW][NS];
-#pragma unroll
-    for (int t = 0; t < TW; ++t)
-#pragma unroll
-        for (int n = 0; n < NS; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const bool pre = IO16 || (a.vec_in && a.vec_dy);       // uniform: register-prefetch path needs vector accesses
-    DV px[XT::PER];
-    DV pd[PERD];
-
-    auto brick_coords = [&](int brick, int& b, int& bz, int& by, int& bx) {
-        bx = brick % a.nbx; brick /= a.nbx;
-        by = brick % a.nby; brick /= a.nby;
-        bz = brick % a.nbz; b = brick / a.nbz;
-    };
-    auto issue = [&](int brick) {
-        int b, bz, by, bx;
-        brick_coords(brick, b, bz, by, bx);
-        XT::issue(px, a.x0, a.x1, a.C0, a.C1, chunk, b, bz * TZ * STRIDE - a.pad, by * TY * STRIDE - a.pad,
-                  bx * TX * STRIDE - a.padx, a.Di, a.Hi, a.Wi, tid);
-#pragma unroll
-        for (int k = 0; k < PERD; ++k) {
-            const int q = tid + k * 512;
-            const int v = q / (NS * 4), cq = q - v * (NS * 4);
-            const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
-            const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
-            const int c = co0 + cq * 4;
-            const bool ok = q < NQD && oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout;
-            const size_t ov = ok ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
-            const DV t = *reinterpret_cast<const DV*>(reinterpret_cast<const typename XT::E*>(a.dy) + ov * a.Cout + (ok ? c : 0));
-            pd[k] = ok ? t : XT::vzero();
-        }
-    };
-
-    if (pre && split < a.nbrick) issue(split);
-    for (int brick = split; brick < a.nbrick; brick += a.nsplit) {
-        __syncthreads();                         // every wave is done reading the previous tiles
-        if (pre) {
-            XT::commit(xt, px, tid);
-#pragma unroll
-            for (int k = 0; k < PERD; ++k) {
-                const int q = tid + k * 512;
-                if (q < NQD) *reinterpret_cast<float4*>(dyt + (size_t)q * 4) = XT::to_f4(pd[k]);
-            }
-        } else if constexpr (!IO16) {
-            int b, bz, by, bx;
-            brick_coords(brick, b, bz, by, bx);
-            load_tile<G::IZ, G::IY, G::IX, 512>(xt, a.x0, a.x1, a.C0, a.C1, a.vec_in, chunk, b,
-                                                bz * TZ * STRIDE - a.pad, by * TY * STRIDE - a.pad, bx * TX * STRIDE - a.padx,
-                                                a.Di, a.Hi, a.Wi, tid);
-            for (int q = tid; q < NQD; q += 512) {
-                const int v = q / (NS * 4), cq = q - v * (NS * 4);
-                const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
-                const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
-                const int c = co0 + cq * 4;
-                float e[4] = {0.f, 0.f, 0.f, 0.f};
-                if (oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout) {
-                    const float* p = a.dy + (((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.Cout + c;
-#pragma unroll
-                    for (int kk2 = 0; kk2 < 4; ++kk2) if (c + kk2 < a.Cout) e[kk2] = p[kk2];
-                }
-                *reinterpret_cast<float4*>(dyt + (size_t)q * 4) = make_float4(e[0], e[1], e[2], e[3]);
-            }
-        }
-        __syncthreads();
-        if (pre && brick + a.nsplit < a.nbrick) {
-            issue(brick + a.nsplit);             // next brick's loads fly while this brick's MFMAs run
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // Inner loop, fully unrolled over the brick's voxel groups so that every LDS read is
-        //   ds_read_b32 v, <per-tap address register> offset:<compile-time group offset>
-        // with NO address VALU (on CDNA4 every non-MFMA VALU instruction of a wave costs MFMA issue time;
-        // 1.6 VALU per MFMA measured 16 % -- SQ_INSTS_VALU / SQ_INSTS_MFMA).  Two register sets in ping-pong:
-        // the next group's reads are issued (pinned by sched_barrier) before the current group's MFMAs.
-        constexpr int NG = NV / 4;
-        static_assert(NG % 2 == 0, "voxel groups are processed in pairs");
-        auto fetch = [&](int g, float (&av)[NS], float (&bv)[TW]) {      // g is a literal after unrolling
-            const int v0 = g * 4;
-            const int vx0 = v0 % TX, vy = (v0 / TX) % TY, vz = v0 / (TX * TY);
-            const int go = ((vz * STRIDE * G::IY + vy * STRIDE) * G::IX + vx0 * STRIDE) * 16;
-#pragma unroll
-            for (int n = 0; n < NS; ++n) av[n] = pa[v0 * (NS * 16) + n * 16];
-#pragma unroll
-            for (int t = 0; t < TW; ++t) bv[t] = pt[t][go];
-        };
-        float avA[NS], bvA[TW], avB[NS], bvB[TW];
-        fetch(0, avA, bvA);
-#pragma unroll
-        for (int g = 0; g < NG; g += 2) {
-            fetch(g + 1, avB, bvB);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < TW; ++t)
-#pragma unroll
-                for (int n = 0; n < NS; ++n)
-                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(avA[n], bvA[t], acc[t][n], 0, 0, 0);
-            if (g + 2 < NG) fetch(g + 2, avA, bvA);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < TW; ++t)
-#pragma unroll
-                for (int n = 0; n < NS; ++n)
-                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(avB[n], bvB[t], acc[t][n], 0, 0, 0);
-        }
-    }
-    // lane holds dW[tap][ci = chunk*16 + i][co = co0 + n*16 + 4*kk + {0..3}]
-#pragma unroll
-    for (int t = 0; t < TW; ++t) {
-        const int tap = tap0 + t;
-        if (tap >= T3) continue;
-        float* dst = a.part + ((size_t)(split * T3 + tap) * a.CinP + chunk * 16 + i) * a.CoutP + co0 + kk * 4;
-#pragma unroll
-        for (int n = 0; n < NS; ++n) {
-            const f32x4 r = acc[t][n];
-            *reinterpret_cast<float4*>(dst + n * 16) = make_float4(r.x, r.y, r.z, r.w);
-        }
-    }
+// the same body for a kernel that decodes (split, block, tap group) itself (conv_b16.hip: the grouped launch)
+template <int KS, int STRIDE, int TZ, int TY, int TX, int NS, int TW, int KX = KS, bool IO16 = false>
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int gid_x, const int gid_y, const int gid_z) {
+#define VNET_WG_BID_X gid_x
+#define VNET_WG_BID_Y gid_y
+#define VNET_WG_BID_Z gid_z
+#include "wgrad_body.inc"
+#undef VNET_WG_BID_X
+#undef VNET_WG_BID_Y
+#undef VNET_WG_BID_Z
 }
 
 // dw = sum over splits of the partial filter gradients; 64 output groups x 4 split-lanes per workgroup.  VEC: a group is

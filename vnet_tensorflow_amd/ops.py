@@ -531,11 +531,11 @@ def _wgrad5_b16_call(x0, x1, dy, dw, dims, cin_dw, owner=None):
     flops = 2.0 * nvox * 125 * (C0 + C1) * Co
     nbytes = 2.0 * nvox * (C0 + C1 + Co) + 4.0 * 125 * (C0 + C1) * Co
     tag = _wgrad_tag(True, 5, 0, 1, dims[2], B, C0 + C1, Co)
-    if (_DEFER["on"] and owner is not None and _GROUP["on"] and not _PROFILE["on"] and _LAUNCH_ON[0] is None
-            and dims[0] * dims[1] * dims[2] <= _GROUP["max_voxels"]):
+    if (_DEFER["on"] and owner is not None and _GROUP["on"] and not _timed_tag(tag) and _LAUNCH_ON[0] is None
+            and dims[0] * dims[1] * dims[2] <= _GROUP["max_voxels"] and (_GROUP["in4"] or not (cin_dw <= 4 and C0 == 8 and C1 == 0))):
         # a deep-level layer of a pass whose filter gradients nobody reads before it ends: launched together with the others when the
         # pass ends (vnet_conv_wgrad_b16_group); the tensors stay alive -- and unmodified, see _ConvFn.backward -- until then
-        _DEFER["jobs"].append((x0, x1, dy, dw, ws, nb, int(cin_dw), B, tuple(dims)))
+        _DEFER["jobs"].append((x0, x1, dy, dw, ws, nb, int(cin_dw), B, tuple(dims), flops, nbytes, 5))
         _DEFER["dy_ptrs"].add(dy.data_ptr())
         return
     with _Timed(tag, flops, nbytes), _immediate_reduce(owner is None):
@@ -599,6 +599,14 @@ def _wgrad2_b16_call(xfine, dycoarse, dw, dims_fine, dims_coarse, owner=None):
     ws = _wgrad_workspace(dw, nb, immediate, owner)
     nout = B * dims_coarse[0] * dims_coarse[1] * dims_coarse[2]
     tag = "wgrad-b16 k2 s2 %d^3x%d %d->%d" % (dims_coarse[2], B, Cin, Co)
+    if (_DEFER["on"] and not immediate and _GROUP["on"] and _GROUP["k2"] and not _timed_tag(tag) and _LAUNCH_ON[0] is None
+            and tuple(dims_coarse) == tuple((d + 1) // 2 for d in dims_fine)
+            and dims_fine[0] * dims_fine[1] * dims_fine[2] <= _GROUP["max_voxels"]):
+        # joins the grouped launch of the pass's filter gradients (ks = 2: x = the fine tensor, dy = the coarse one)
+        _DEFER["jobs"].append((xfine, None, dycoarse, dw, ws, nb, int(Cin), B, tuple(dims_fine),
+                               2.0 * nout * 8 * Cin * Co, 2.0 * nout * (8 * Cin + Co) + 4.0 * 8 * Cin * Co, 2))
+        _DEFER["dy_ptrs"].add(dycoarse.data_ptr())
+        return
     with _Timed(tag, 2.0 * nout * 8 * Cin * Co, 2.0 * nout * (8 * Cin + Co) + 4.0 * 8 * Cin * Co), _immediate_reduce(immediate):
         check(L.vnet_conv2_wgrad_b16(_ptr(xfine), Cin, _ptr(dycoarse), Co, _ptr(dw), B, *dims_fine, *dims_coarse, _ptr(ws), nb, _stream()),
               "vnet_conv2_wgrad_b16")
@@ -638,7 +646,13 @@ _DEFER = {"on": False, "jobs": [], "dy_ptrs": set()}
 # grouped launch of the 5^3 filter gradients of a deferring pass (layers up to 128^3 voxels; measured: 32^3 and below -0.23 ms,
 # all levels -0.33 ms per C5 step) (bf16 storage; include/vnet_hip.h:
 # vnet_conv_wgrad_b16_group).  VNET_WGRAD_GROUP=0: every layer launches its own kernel as it did through round 3.
-_GROUP = {"on": _os.environ.get("VNET_WGRAD_GROUP", "1") != "0", "max_voxels": int(_os.environ.get("VNET_WGRAD_GROUP_MAXVOX", 128 ** 3))}
+_GROUP = {"on": _os.environ.get("VNET_WGRAD_GROUP", "1") != "0", "max_voxels": int(_os.environ.get("VNET_WGRAD_GROUP_MAXVOX", 128 ** 3)),
+          "k2": _os.environ.get("VNET_WGRAD_GROUP_K2", "1") != "0", "in4": _os.environ.get("VNET_WGRAD_GROUP_IN4", "0") != "0"}
+# (k2: the 2^3 stride-2 filter gradients join too -- -0.05 ms per C5 step; in4: the zero-padded network input's x-im2col filter
+#  gradient can join but measures +0.07 ms inside the group, so it keeps its own launch)
+
+
+WGRAD_GROUP_TAG = "wgrad-group"
 
 
 def set_wgrad_group(on):
@@ -653,12 +667,14 @@ def _flush_wgrad_group(launch=True):
         return
     L = _lib.lib()
     arr = (_lib.WgradJob * len(jobs))()
-    for k, (x0, x1, dy, dw, ws, nb, cin_dw, B, dims) in enumerate(jobs):
+    for k, (x0, x1, dy, dw, ws, nb, cin_dw, B, dims, _fl, _by, ks) in enumerate(jobs):
         j = arr[k]
         j.x0, j.x1, j.dy, j.dw, j.ws, j.ws_bytes = _ptr(x0), _ptr(x1), _ptr(dy), _ptr(dw), _ptr(ws), int(nb)
         j.C0, j.C1, j.Cout, j.Cin_dw = int(x0.shape[-1]), (int(x1.shape[-1]) if x1 is not None else 0), int(dy.shape[-1]), cin_dw
-        j.B, j.D, j.H, j.W = int(B), int(dims[0]), int(dims[1]), int(dims[2])
-    check(L.vnet_conv_wgrad_b16_group(ctypes.addressof(arr), len(jobs), _stream()), "vnet_conv_wgrad_b16_group")
+        j.B, j.D, j.H, j.W, j.ks = int(B), int(dims[0]), int(dims[1]), int(dims[2]), ks
+    # (a layer that is being timed on its own -- profile_start(only=...) with its tag -- has not joined; "wgrad-group" times this launch)
+    with _Timed(WGRAD_GROUP_TAG, sum(j[9] for j in jobs), sum(j[10] for j in jobs)):
+        check(L.vnet_conv_wgrad_b16_group(ctypes.addressof(arr), len(jobs), _stream()), "vnet_conv_wgrad_b16_group")
 
 
 @contextlib.contextmanager
