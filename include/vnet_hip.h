@@ -415,6 +415,9 @@ typedef struct vnet_wgrad_job {
                  * (arguments of vnet_conv2_wgrad_b16; C1 = 0, Cin_dw = C0) */
 } vnet_wgrad_job;
 int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream);
+/* the same for fp32 tensors (x0, x1, dy float; ks = 0 or 5; Cin_dw = C0 + C1): jobs[i] are the arguments of
+ * vnet_conv_wgrad(5, 5, 1, ...) for layer i */
+int vnet_conv_wgrad_group(const vnet_wgrad_job* jobs, int n, void* stream);
 /* 2^3 stride-2 convolution (up = 0) / 2^3 transposed convolution (up = 1), bf16 in / bf16 out.  wp: the fp32 packed image of
  * the bf16-ROUNDED filter, vnet_pack_weights(VNET_PACK_FWD | VNET_PACK_ROUND_BF16, 8, Cin, Cout) resp. VNET_PACK_UP | ...;
  * accum: y += result (one rounding of the sum); stats (up = 0 only): rows = vnet_conv_stats_rows(2, 0, 2, 0, ...);

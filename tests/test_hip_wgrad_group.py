@@ -207,3 +207,79 @@ def test_training_step_gradients_do_not_depend_on_the_grouping(dev, P, monkeypat
     scale = float(gb.abs().max())
     assert float((ga - gb).abs().max()) <= 2e-5 * scale, (float((ga - gb).abs().max()), scale)
     assert max(grouped) >= 10 and min(grouped) == 0, grouped     # one pass collected the 5^3 layers, the other none
+
+
+F32_GROUP = [
+    (1, 8, 16, 16, 32, 0, 16),      # wide bricks (4 x 4 x 16), one cout block per workgroup
+    (1, 8, 8, 32, 16, 16, 32),      # ... two sources, two cout blocks, two tap groups
+    (1, 8, 8, 8, 32, 0, 64),        # small bricks (4 x 8 x 8), two cout blocks
+    (2, 5, 9, 7, 16, 0, 16),        # ... ragged, batch 2, one cout block
+    (1, 4, 4, 16, 6, 0, 16),        # 6 input channels: not a shape of the grouped kernels -> the layer's own launch
+]
+
+
+@pytest.mark.parametrize("rounds", [None, "8", "0.25"])
+def test_fp32_group_members_against_oracle(dev, rounds, monkeypatch):
+    """vnet_conv_wgrad_group: the fp32 tensors' 5^3 filter gradients of a pass in one launch (off by default in the product path:
+    VNET_WGRAD_GROUP_F32) -- every member against the fp64 oracle at fp32 accuracy, two runs bit-identical."""
+    from vnet_tensorflow_amd import ops
+    monkeypatch.setitem(ops._GROUP, "f32", True)
+    if rounds is not None:
+        monkeypatch.setenv("VNET_WGRAD_GROUP_ROUNDS", rounds)
+    outs = []
+    for rep in range(2):
+        res = []
+        with ops.deferred_wgrad_reduce():
+            for k, shape in enumerate(F32_GROUP):
+                B, D, H, W, C0, C1, Co = shape
+                rng = np.random.default_rng(500 + k)
+                x0 = rng.standard_normal((B, D, H, W, C0)).astype(np.float32)
+                x1 = rng.standard_normal((B, D, H, W, C1)).astype(np.float32) if C1 else None
+                dy = rng.standard_normal((B, D, H, W, Co)).astype(np.float32)
+                dw = torch.full((5, 5, 5, C0 + C1, Co), float("nan"), dtype=torch.float32, device=dev)
+                sink = ops.GradSink(dw)
+                ops._wgrad_call(5, 1, g(x0, dev), g(x1, dev) if C1 else None, g(dy, dev), dw, (D, H, W), (D, H, W), owner=sink)
+                res.append((shape, x0, x1, dy, dw, sink))
+            assert len(ops._DEFER["jobs32"]) == len(F32_GROUP)
+        torch.cuda.synchronize()
+        outs.append(res)
+    for (shape, x0, x1, dy, dw, _), (_, _, _, _, dw2, _) in zip(*outs):
+        xcat = x0 if x1 is None else np.concatenate((x0, x1), -1)
+        _, dw_ex = O.conv_nd_bwd(xcat.astype(np.float64), np.zeros((5, 5, 5, xcat.shape[-1], dy.shape[-1])), dy.astype(np.float64), 1, need_dx=False)
+        check_close("fp32 group rounds=%s %s" % (rounds, shape), dw, dw_ex, 2e-6)
+        assert torch.equal(dw, dw2)
+
+
+def test_fp32_training_step_with_the_group(dev, monkeypatch):
+    """fp32 V-Net, one fwd + bwd, grouped vs every layer on its own.  The fp32 backward-data kernels accumulate a residual block's
+    second gradient IN PLACE into the batch-norm's ds -- which is also the dy of the block's last filter gradient: that layer must
+    not wait for the group (ops._DEFER["acc_targets"]).  Data gradients and every ungrouped layer: bit-identical; grouped layers:
+    summation order."""
+    from vnet_tensorflow_amd import ops
+    from vnet_tensorflow_amd.model import image2label
+    from oracle.vnet_oracle import synthetic_batch
+    from tests.test_hip_train_loop import _cfg
+    import pathlib
+    monkeypatch.setenv("VNET_STEP_GRAPH", "0")
+    monkeypatch.setenv("VNET_PARAM_GRAD_STREAM", "0")      # one stream, as in the replayed step graph (a side stream's launches never wait)
+    x, lab = synthetic_batch(1, 32, 1, 2, seed=6)
+    xt, lt = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
+    res, counts = {}, []
+    launch = ops._launch_wgrad_group
+    monkeypatch.setattr(ops, "_launch_wgrad_group", lambda jobs, entry: (counts.append((entry, len(jobs))), launch(jobs, entry))[1])
+    for on in (True, False):
+        monkeypatch.setitem(ops._GROUP, "f32", on)
+        np.random.seed(9)
+        cfg = _cfg(pathlib.Path("/tmp"), PatchShape=[32] * 3, BatchSize=1)
+        cfg["TrainingSetting"]["Networks"].update(NumChannel=16, NumLevels=3, NumConvolutions=[1, 2, 3], BottomConvolutions=2)
+        m = image2label(None, cfg, device=dev, verbose=False)
+        m.read_config(); m.build_model_graph(); m._setup_training()
+        with ops.context(m.ctx):
+            loss = m._compute_gradients(xt, lt, 0.0)
+        torch.cuda.synchronize()
+        res[on] = (float(loss.detach()), m.flat.grad.clone())
+    assert res[True][0] == res[False][0]
+    ga, gb = res[True][1], res[False][1]
+    scale = float(gb.abs().max())
+    assert torch.isfinite(ga).all() and float((ga - gb).abs().max()) <= 2e-6 * scale, (float((ga - gb).abs().max()), scale)
+    assert counts and counts[0][0] == "vnet_conv_wgrad_group" and 3 <= counts[0][1] <= 12, counts     # some layers joined; the multi-convolution blocks' last ones (4 here) did not

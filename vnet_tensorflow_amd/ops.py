@@ -642,12 +642,14 @@ def colsum16(x16, C, out):
 # launch reduces all of them when the context ends (26 reduce launches of ~7 us per V-Net step otherwise).  Only for a backward
 # pass whose filter gradients nobody reads before it ends (model.image2label: not the eager data-parallel step, whose bucket
 # all-reduces start from the gradient hooks).
-_DEFER = {"on": False, "jobs": [], "dy_ptrs": set()}
+_DEFER = {"on": False, "jobs": [], "dy_ptrs": set(), "jobs32": [], "acc_targets": set()}
 # grouped launch of the 5^3 filter gradients of a deferring pass (layers up to 128^3 voxels; measured: 32^3 and below -0.23 ms,
 # all levels -0.33 ms per C5 step) (bf16 storage; include/vnet_hip.h:
 # vnet_conv_wgrad_b16_group).  VNET_WGRAD_GROUP=0: every layer launches its own kernel as it did through round 3.
 _GROUP = {"on": _os.environ.get("VNET_WGRAD_GROUP", "1") != "0", "max_voxels": int(_os.environ.get("VNET_WGRAD_GROUP_MAXVOX", 128 ** 3)),
-          "k2": _os.environ.get("VNET_WGRAD_GROUP_K2", "1") != "0", "in4": _os.environ.get("VNET_WGRAD_GROUP_IN4", "0") != "0"}
+          "k2": _os.environ.get("VNET_WGRAD_GROUP_K2", "1") != "0", "in4": _os.environ.get("VNET_WGRAD_GROUP_IN4", "0") != "0", "f32": _os.environ.get("VNET_WGRAD_GROUP_F32", "0") != "0"}
+# (f32: the fp32 tensors' 5^3 filter gradients as a group, vnet_conv_wgrad_group: built and tested, OFF by default -- those launches
+#  are 0.2-2 ms each and already at 0.83 of the fp32 peak: -0.07 ms of 25.3 with 8 rounds, +0.1 ms with 2)
 # (k2: the 2^3 stride-2 filter gradients join too -- -0.05 ms per C5 step; in4: the zero-padded network input's x-im2col filter
 #  gradient can join but measures +0.07 ms inside the group, so it keeps its own launch)
 
@@ -662,9 +664,17 @@ def set_wgrad_group(on):
 def _flush_wgrad_group(launch=True):
     """Launch the collected filter gradients (the reduces of their slabs join the deferred queue) and let go of their tensors."""
     jobs, _DEFER["jobs"] = _DEFER["jobs"], []
+    jobs32, _DEFER["jobs32"] = _DEFER["jobs32"], []
     _DEFER["dy_ptrs"] = set()
+    _DEFER["acc_targets"] = set()
+    if launch and jobs32:
+        _launch_wgrad_group(jobs32, "vnet_conv_wgrad_group")
     if not jobs or not launch:
         return
+    _launch_wgrad_group(jobs, "vnet_conv_wgrad_b16_group")
+
+
+def _launch_wgrad_group(jobs, entry):
     L = _lib.lib()
     arr = (_lib.WgradJob * len(jobs))()
     for k, (x0, x1, dy, dw, ws, nb, cin_dw, B, dims, _fl, _by, ks) in enumerate(jobs):
@@ -674,7 +684,7 @@ def _flush_wgrad_group(launch=True):
         j.B, j.D, j.H, j.W, j.ks = int(B), int(dims[0]), int(dims[1]), int(dims[2]), ks
     # (a layer that is being timed on its own -- profile_start(only=...) with its tag -- has not joined; "wgrad-group" times this launch)
     with _Timed(WGRAD_GROUP_TAG, sum(j[9] for j in jobs), sum(j[10] for j in jobs)):
-        check(L.vnet_conv_wgrad_b16_group(ctypes.addressof(arr), len(jobs), _stream()), "vnet_conv_wgrad_b16_group")
+        check(getattr(L, entry)(ctypes.addressof(arr), len(jobs), _stream()), entry)
 
 
 @contextlib.contextmanager
@@ -765,6 +775,14 @@ def _wgrad_call(ks, stride, x0, x1, dy, dw, dims_in, dims_out, kx=0, immediate=F
     flops = 2.0 * nout * taps * (C0 + C1) * Co
     nbytes = 4.0 * (nin * (C0 + C1) + nout * Co + taps * (C0 + C1) * Co)
     tag = _wgrad_tag(False, ks, kx, stride, dims_out[2], B, C0 + C1, Co)
+    if (_DEFER["on"] and not immediate and _GROUP["on"] and _GROUP["f32"] and ks == 5 and stride == 1 and kx in (0, 5)
+            and not _timed_tag(tag) and _LAUNCH_ON[0] is None and x0.dtype == torch.float32 and dy.dtype == torch.float32
+            and dims_out[0] * dims_out[1] * dims_out[2] <= _GROUP["max_voxels"] and dy.data_ptr() not in _DEFER["acc_targets"]):
+        # fp32 tensors: joins the pass's grouped launch (vnet_conv_wgrad_group) -- unless its dy is a tensor another convolution's
+        # backward-data will add its gradient INTO in place (a residual block's ds, registered by the batch-norm's backward): the
+        # fp32 kernels have no out-of-place accumulate, so that layer's filter gradient runs now, as it always did
+        _DEFER["jobs32"].append((x0, x1, dy, dw, ws, nb, C0 + C1, B, tuple(dims_out), flops, nbytes, 5))
+        return
     with _Timed(tag, flops, nbytes), _immediate_reduce(immediate):
         check(L.vnet_conv_wgrad(ks, kx, stride, _ptr(x0), C0, _ptr(x1), C1, _ptr(dy), Co, _ptr(dw),
                                 B, *dims_in, *dims_out, _ptr(ws), nb, _stream()), "vnet_conv_wgrad")
@@ -1431,6 +1449,8 @@ class _BnActFn(torch.autograd.Function):
             dx = colsum_rows(ds)
         if r is not None and ds is not None and ctx.slot_r is not None and ctx.slot_r.first is None:
             ctx.slot_r.first = ds                      # the block input's other consumer (conv_1) adds its gradient into this
+            if _DEFER["on"]:
+                _DEFER["acc_targets"].add(ds.data_ptr())   # (fp32: the filter gradient that reads ds as its dy must not wait, _wgrad_call)
         return dx, (ds if r is not None else None), _grad_ret(dgamma, sg), _grad_ret(dbeta, sbt), _grad_ret(dalpha, sa), None, None, None, None
 
 
