@@ -126,14 +126,15 @@ def test_full_size_network_c5_bf16(dev):
     z, net, logits, loss, sm, pred, lab, K = _run_case(dev, "c5")
     s = (slice(None),) + (slice(None, None, STRIDE),) * 3
     got, ref = logits[s].cpu().numpy(), z["logits_sample"]
+    # measured in round 4 (profiles/r04_golden_full_errors.txt): logits 1.23e-2, loss 1.1e-6, predictions 99.29 %, gradient 8.2 %
     assert rel_l2(got, ref) < 1.5e-2, rel_l2(got, ref)
-    assert abs(loss - float(z["loss"])) < 5e-4, (loss, float(z["loss"]))
+    assert abs(loss - float(z["loss"])) < 2e-5, (loss, float(z["loss"]))
     assert (pred[s].cpu().numpy() == z["pred_sample"]).mean() >= 0.99
     errs = _grad_errors(z, net)
     names = list(map(str, z["names"]))
     num = sum((e[1] * float(z["grad_norm"][names.index(e[0])])) ** 2 for e in errs)
     den = sum(float(v) ** 2 for v in z["grad_norm"])
-    assert (num / den) ** 0.5 < 0.1, (num / den) ** 0.5
+    assert (num / den) ** 0.5 < 0.095, (num / den) ** 0.5          # (the oracle against itself under a 1e-7 input perturbation: 0.081)
 
 
 def test_full_size_network_c5_b16_storage(dev):
@@ -146,14 +147,16 @@ def test_full_size_network_c5_b16_storage(dev):
     z, net, logits, loss, sm, pred, lab, K = _run_case(dev, "c5s")
     s = (slice(None),) + (slice(None, None, STRIDE),) * 3
     got, ref = logits[s].cpu().numpy(), z["logits_sample"]
-    assert rel_l2(got, ref) < 3e-2, rel_l2(got, ref)
-    assert abs(loss - float(z["loss"])) < 1e-3, (loss, float(z["loss"]))
+    # measured in round 4 (profiles/r04_golden_full_errors.txt): logits 2.31e-2, loss 1.5e-6, predictions 98.57 %, gradient 11.2 %
+    # (round 3's bounds were 3e-2 / 1e-3 / 0.3: 30 % to three orders of magnitude of slack)
+    assert rel_l2(got, ref) < 2.7e-2, rel_l2(got, ref)
+    assert abs(loss - float(z["loss"])) < 2e-5, (loss, float(z["loss"]))
     assert (pred[s].cpu().numpy() == z["pred_sample"]).mean() >= 0.98
     errs = _grad_errors(z, net)
     names = list(map(str, z["names"]))
     num = sum((e[1] * float(z["grad_norm"][names.index(e[0])])) ** 2 for e in errs)
     den = sum(float(v) ** 2 for v in z["grad_norm"])
-    assert (num / den) ** 0.5 < 0.3, (num / den) ** 0.5
+    assert (num / den) ** 0.5 < 0.14, (num / den) ** 0.5
 
 
 def test_teacher_forced_layers_c5_b16(dev):
