@@ -44,6 +44,8 @@ extern "C" {
 /* bf16 filter images for vnet_conv_fwd_bf16: [cin chunk 16][tap][cout block 32][cin half][32 cout][8 cin] */
 #define VNET_PACK_FWD_BF16 3   /* conv forward, operands rounded to bf16 (RNE)                              */
 #define VNET_PACK_BWD_BF16 4   /* conv backward-data (flipped taps, cin<->cout), bf16                       */
+#define VNET_PACK_BOTH_BF16 5  /* vnet_pack_weights_batched only: BOTH bf16 images of a 5^3 filter from one read of w
+                                * (descriptor: {w, wp_fwd, 5, T, I, O, wp_bwd, 0}; I and O multiples of 32)      */
 
 /* or-ed into VNET_PACK_FWD / _BWD / _UP: the fp32 image holds the filter ROUNDED to bf16 (bf16-storage mode of the 2^3 convs) */
 #define VNET_PACK_ROUND_BF16 16

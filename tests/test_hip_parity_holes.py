@@ -264,7 +264,8 @@ def test_batch_norm_statistics_from_the_conv_epilogue(dev, mode, ks, stride, sha
     check_close("moving variance", mv, (0.99 + 0.01 * var).cpu().numpy(), 1e-6)
 
 
-@pytest.mark.parametrize("taps,I,O", [(125, 16, 16), (125, 32, 16), (125, 4, 16), (125, 24, 40), (8, 16, 32), (125, 6, 10)])
+@pytest.mark.parametrize("taps,I,O", [(125, 16, 16), (125, 32, 16), (125, 4, 16), (125, 24, 40), (8, 16, 32), (125, 6, 10),
+                                      (125, 32, 32), (125, 64, 32), (125, 32, 96)])      # whole 32-channel blocks: both bf16 images from one read
 def test_batched_filter_repack_equals_single_pack(dev, taps, I, O):
     """The one-launch repack of every registered filter (after each optimiser step) must produce, bit for bit, the images
     the single-filter packer produces -- all five layouts (fp32 forward / backward-data / transposed, bf16 forward / backward)."""

@@ -796,6 +796,49 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const long long* __re
     const bool r16 = ((int)d[2] & VNET_PACK_ROUND_BF16) != 0;
     const int mode = (int)d[2] & ~VNET_PACK_ROUND_BF16, T = (int)d[3], I = (int)d[4], O = (int)d[5];
     const int CQ = (int)d[6], NP = (int)d[7];
+    if (mode == VNET_PACK_BOTH_BF16) {
+        // Both bf16 images of a filter from ONE read (round 4): the two separate passes read every fp32 weight twice (352 MB for the
+        // C5 network's 44 M parameters, + 176 MB of images).  A workgroup stages one tap's [32 ci][32 co] fp32 slice in LDS (rows of
+        // 128 contiguous bytes) and emits its 128 forward units (8 consecutive ci of one co: a column walk) and its 128
+        // backward-data units (8 consecutive co of one ci, at the flipped tap: a row walk) -- the same 16-byte units, the same
+        // RNE rounding, the same image positions as the two modes below (bit-identical images: tests/test_hip_b16.py).
+        __shared__ float sl[32][33];
+        const uint32_t nci = (uint32_t)I / 32, nco = (uint32_t)O / 32, per_t = nci * nco, ntiles = (uint32_t)T * per_t;
+        const uint32_t NPf = nco, NPb = nci;                 // cout blocks of the forward image, "cout" (= ci) blocks of the backward one
+        u32x4* outf = reinterpret_cast<u32x4*>(wp);
+        u32x4* outb = reinterpret_cast<u32x4*>(d[6]);
+        const int tid = threadIdx.x;
+        for (uint32_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+            const uint32_t t = tix / per_t, rem = tix - t * per_t, bi = rem / nco, bo = rem - bi * nco;
+            const float* wt = w + ((size_t)t * I + bi * 32) * O + bo * 32;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = (tid >> 5) + 8 * j, c = tid & 31;
+                sl[r][c] = wt[(size_t)r * O + c];
+            }
+            __syncthreads();
+            const uint32_t m = tid & 31, kg = (tid >> 5) & 3;           // unit: 8 k-values kg*8 .. of column / row m
+            if (tid < 128) {
+                // forward image [cin chunk][tap][cout block][cin half][32 cout][8 cin]: n = co = bo*32 + m, k = ci = bi*32 + kg*8 ..
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = sl[kg * 8 + e][m];
+                const uint32_t chunk = bi * 2 + (kg >> 1), hf = kg & 1;
+                const u32x4 r = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+                outf[(((size_t)chunk * T + t) * NPf + bo) * 64 + hf * 32 + m] = r;
+            } else {
+                // backward image: tap T-1-t, n = ci = bi*32 + m, k = co = bo*32 + kg*8 ..
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = sl[m][kg * 8 + e];
+                const uint32_t chunk = bo * 2 + (kg >> 1), hf = kg & 1, tb = (uint32_t)T - 1 - t;
+                const u32x4 r = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+                outb[(((size_t)chunk * T + tb) * NPb + bi) * 64 + hf * 32 + m] = r;
+            }
+            __syncthreads();
+        }
+        return;
+    }
     if (mode == VNET_PACK_FWD_BF16 || mode == VNET_PACK_BWD_BF16) {      // here CQ = cin chunks, NP = cout blocks
         // one 16-byte unit (8 consecutive k of one n) per thread: consecutive lanes = consecutive n, so the forward image reads
         // 8 coalesced rows of the [I][O] slice and the backward image 32 contiguous bytes per lane; 32-bit index arithmetic
