@@ -262,6 +262,22 @@ def hbm_kernel_table(dev, bf16, classes, iters=50):
     p_ = torch.zeros(n, device=dev); g_ = torch.full((n,), 1e-3, device=dev); m_ = torch.zeros(n, device=dev); v_ = torch.zeros(n, device=dev)
     timed("adam 43.9M parameters", 7 * n * 4, lambda: L.vnet_adam_apply(P_(p_), P_(g_), P_(m_), P_(v_), n, 1e-3, 0.9, 0.999, 1e-8, 1.0, st))
     del p_, g_, m_, v_
+    # the batched filter repack after the optimiser (model.py:649-662's variables -> the kernels' packed images): the three
+    # bottom-level filters (5^3, 256 -> 256), both images; bf16: ONE read of the fp32 weights for the two bf16 images (round 4)
+    with ops.context(ops.OpsContext()):
+        fl = [torch.nn.Parameter(torch.randn(5, 5, 5, 256, 256, device=dev) * 0.01) for _ in range(3)]
+        modes = (ops.PACK_FWD_BF16, ops.PACK_BWD_BF16) if bf16 else (ops.PACK_FWD, ops.PACK_BWD)
+        for w_ in fl:
+            for md in modes:
+                ops.packed_weights(w_, md, 125, 256, 256)
+        ops.invalidate_packed()
+        ops.repack_registered()                       # (builds the descriptor table)
+        descs, nrows = ops._PACK_REG["descs"], ops._PACK_REG["nrows"]
+        npar = 3 * 125 * 256 * 256
+        timed("repack 3 x (5^3, 256->256), forward + backward-data images", npar * (4 + (4 if bf16 else 8)),
+              lambda: L.vnet_pack_weights_batched(P_(descs), nrows, st))
+        ops.clear_pack_registry()
+        del fl, descs
     torch.cuda.empty_cache()
     return out
 
