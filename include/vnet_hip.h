@@ -44,6 +44,8 @@ extern "C" {
 /* bf16 filter images for vnet_conv_fwd_bf16: [cin chunk 16][tap][cout block 32][cin half][32 cout][8 cin] */
 #define VNET_PACK_FWD_BF16 3   /* conv forward, operands rounded to bf16 (RNE)                              */
 #define VNET_PACK_BWD_BF16 4   /* conv backward-data (flipped taps, cin<->cout), bf16                       */
+#define VNET_PACK_BOTH 6       /* vnet_pack_weights_batched only: the fp32 forward AND backward-data images from one read of w
+                                * (descriptor: {w, wp_fwd, 6, T, I, O, wp_bwd, 0}; I and O multiples of 32)                  */
 #define VNET_PACK_BOTH_BF16 5  /* vnet_pack_weights_batched only: BOTH bf16 images of a 5^3 filter from one read of w
                                 * (descriptor: {w, wp_fwd, 5, T, I, O, wp_bwd, 0}; I and O multiples of 32)      */
 

@@ -839,6 +839,35 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const long long* __re
         }
         return;
     }
+    if (mode == VNET_PACK_BOTH) {
+        // the fp32 twin: forward image wp[t][ci/4][co][ci%4] and backward-data image wp[T-1-t][co/4][ci][co%4] from one read
+        __shared__ float sl[32][33];
+        const uint32_t nci = (uint32_t)I / 32, nco = (uint32_t)O / 32, per_t = nci * nco, ntiles = (uint32_t)T * per_t;
+        float4* outf = reinterpret_cast<float4*>(wp);
+        float4* outb = reinterpret_cast<float4*>(d[6]);
+        const int tid = threadIdx.x;
+        for (uint32_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+            const uint32_t t = tix / per_t, rem = tix - t * per_t, bi = rem / nco, bo = rem - bi * nco;
+            const float* wt = w + ((size_t)t * I + bi * 32) * O + bo * 32;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = (tid >> 5) + 8 * j, c = tid & 31;
+                sl[r][c] = wt[(size_t)r * O + c];
+            }
+            __syncthreads();
+            const uint32_t m = tid & 31, kg = tid >> 5;                 // 8 groups of 4 k-values x 32 columns / rows
+            {
+                const float4 v = make_float4(sl[kg * 4][m], sl[kg * 4 + 1][m], sl[kg * 4 + 2][m], sl[kg * 4 + 3][m]);
+                outf[((size_t)t * (I / 4) + bi * 8 + kg) * O + bo * 32 + m] = v;
+            }
+            {
+                const float4 v = make_float4(sl[m][kg * 4], sl[m][kg * 4 + 1], sl[m][kg * 4 + 2], sl[m][kg * 4 + 3]);
+                outb[((size_t)(T - 1 - t) * (O / 4) + bo * 8 + kg) * I + bi * 32 + m] = v;
+            }
+            __syncthreads();
+        }
+        return;
+    }
     if (mode == VNET_PACK_FWD_BF16 || mode == VNET_PACK_BWD_BF16) {      // here CQ = cin chunks, NP = cout blocks
         // one 16-byte unit (8 consecutive k of one n) per thread: consecutive lanes = consecutive n, so the forward image reads
         // 8 coalesced rows of the [I][O] slice and the backward image 32 contiguous bytes per lane; 32-bit index arithmetic

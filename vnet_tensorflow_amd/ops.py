@@ -20,7 +20,7 @@ BN_EPS = 1e-3        # reference networks.py:259 epsilon=0.001
 BN_MOMENTUM = 0.99   # reference networks.py:259 momentum=0.99
 
 ACT = {None: 0, "none": 0, "relu": 1, "prelu": 2, "lrelu": 3}
-PACK_FWD, PACK_BWD, PACK_UP, PACK_FWD_BF16, PACK_BWD_BF16, PACK_BOTH_BF16 = 0, 1, 2, 3, 4, 5
+PACK_FWD, PACK_BWD, PACK_UP, PACK_FWD_BF16, PACK_BWD_BF16, PACK_BOTH_BF16, PACK_BOTH = 0, 1, 2, 3, 4, 5, 6
 
 # Arithmetic of the 5x5x5 convolutions (forward, backward-data and filter gradient): "fp32" = exact fp32 MFMA (the reference's
 # arithmetic), "bf16" = operands rounded to bf16, fp32 accumulation (BASELINE config C5).  Everything else
@@ -291,17 +291,20 @@ def repack_registered():
         # a filter with BOTH bf16 images registered (forward + backward-data: every 5^3 filter of a bf16 training step) and whole
         # 32-channel blocks: one descriptor, one read of w for the two images (VNET_PACK_BOTH_BF16; -0.06 ms per C5 step)
         both = {}
+        fams = {PACK_FWD_BF16: 0, PACK_BWD_BF16: 0, PACK_FWD: 1, PACK_BWD: 1}       # (the plain fp32 pair the same way: VNET_PACK_BOTH)
         if _PACK_BOTH["on"]:
             for w, (mode, taps, I, O), wp in ents:
-                if mode in (PACK_FWD_BF16, PACK_BWD_BF16) and I % 32 == 0 and O % 32 == 0:
-                    both.setdefault(w.data_ptr(), {})[mode] = wp
+                if mode in fams and I % 32 == 0 and O % 32 == 0:
+                    both.setdefault((w.data_ptr(), fams[mode]), {})[mode] = wp
         done = set()
         for w, (mode, taps, I, O), wp in ents:
-            pair = both.get(w.data_ptr(), {})
-            if mode in (PACK_FWD_BF16, PACK_BWD_BF16) and len(pair) == 2 and I % 32 == 0 and O % 32 == 0:
-                if w.data_ptr() not in done:
-                    done.add(w.data_ptr())
-                    rows.append([w.data_ptr(), pair[PACK_FWD_BF16].data_ptr(), PACK_BOTH_BF16, taps, I, O, pair[PACK_BWD_BF16].data_ptr(), 0])
+            key = (w.data_ptr(), fams.get(mode))
+            pair = both.get(key, {})
+            if mode in fams and len(pair) == 2 and I % 32 == 0 and O % 32 == 0:
+                if key not in done:
+                    done.add(key)
+                    f, bk, mb = (PACK_FWD_BF16, PACK_BWD_BF16, PACK_BOTH_BF16) if fams[mode] == 0 else (PACK_FWD, PACK_BWD, PACK_BOTH)
+                    rows.append([w.data_ptr(), pair[f].data_ptr(), mb, taps, I, O, pair[bk].data_ptr(), 0])
                 continue
             cq, npad = ctypes.c_int(), ctypes.c_int()
             check(L.vnet_packed_dims(mode, taps, I, O, ctypes.byref(cq), ctypes.byref(npad)), "vnet_packed_dims")
