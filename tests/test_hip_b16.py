@@ -266,7 +266,8 @@ def _bn_reference(x, r, gamma, beta, act, alpha, dy):
 @pytest.mark.parametrize("M,C,act,res", [((2, 6, 7, 9), 16, "prelu", True), ((1, 8, 8, 8), 32, "relu", False),
                                          ((1, 4, 4, 4), 256, "prelu", True), ((1, 5, 3, 7), 8, None, False),
                                          ((1, 32, 32, 32), 16, "prelu", False), ((1, 16, 16, 16), 128, "prelu", True),
-                                         ((2, 16, 16, 16), 64, "relu", False)])
+                                         ((2, 16, 16, 16), 64, "relu", False), ((1, 32, 32, 32), 64, "prelu", True),
+                                         ((1, 9, 11, 13), 32, "prelu", True), ((1, 16, 16, 16), 256, None, False)])
 @pytest.mark.parametrize("small", [True, False])
 def test_bn_act_b16(dev, M, C, act, res, small, monkeypatch):
     """small: tensors of <= 8192 rows take the one-launch-per-direction kernels (vnet_bn_small_*_b16); False: the streaming kernels
