@@ -418,6 +418,7 @@ typedef struct vnet_wgrad_job {
                  * FINE tensor [B,D,H,W,C0], dy = the COARSE tensor [B,ceil(D/2),ceil(H/2),ceil(W/2),Cout], dw [8][C0][Cout]
                  * (arguments of vnet_conv2_wgrad_b16; C1 = 0, Cin_dw = C0) */
 } vnet_wgrad_job;
+size_t vnet_wgrad_job_bytes(void);         /* sizeof(vnet_wgrad_job): a binding checks its own layout against it */
 int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream);
 /* the same for fp32 tensors (x0, x1, dy float; ks = 0 or 5; Cin_dw = C0 + C1): jobs[i] are the arguments of
  * vnet_conv_wgrad(5, 5, 1, ...) for layer i */

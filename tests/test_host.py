@@ -28,6 +28,11 @@ def test_library_exports_every_declared_symbol():
     assert L.vnet_conv_ws_bytes(5, 0, 1, 0, 16, 16, 1, 128, 128, 128) == 0          # no split-K at full resolution
     assert L.vnet_conv_ws_bytes(5, 0, 1, 0, 256, 256, 1, 8, 8, 8) > 0               # split-K at the bottom level
     assert L.vnet_wgrad_ws_bytes(5, 0, 1, 16, 16, 1, 128, 128, 128) > 0
+    # the one struct of the C ABI (vnet_wgrad_job, the grouped filter gradients): the binding's layout is the library's
+    import ctypes
+    assert L.vnet_wgrad_job_bytes() == ctypes.sizeof(_lib.WgradJob) == 88
+    assert L.vnet_conv_wgrad_b16_group(None, 0, None) == 0 and L.vnet_conv_wgrad_group(None, 0, None) == 0      # empty groups: no launch
+    assert L.vnet_conv_wgrad_b16_group(None, 3, None) == -1
 
 
 def test_no_cpu_fallback_and_argument_errors():

@@ -100,6 +100,7 @@ SIGNATURES = {
     "vnet_conv_fwd_b16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vnet_conv_fwd_b16_padded": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "vnet_conv_wgrad_b16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "vnet_wgrad_job_bytes": (_sz, []),
     "vnet_conv_wgrad_b16_group": (_i, [_vp, _i, _vp]),
     "vnet_conv_wgrad_group": (_i, [_vp, _i, _vp]),
     "vnet_conv2_fwd_b16": (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),

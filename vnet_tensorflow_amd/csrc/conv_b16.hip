@@ -333,6 +333,8 @@ __global__ void __launch_bounds__(512) wgrad5_f32_group_kernel(WgradGroup g) {
 
 extern "C" {
 
+size_t vnet_wgrad_job_bytes(void) { return sizeof(vnet_wgrad_job); }
+
 int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream) {
     if (n < 0 || (n > 0 && !jobs)) return VNET_E_BADARG;
     std::vector<GroupItem> items;
