@@ -49,6 +49,11 @@ extern "C" {
 #define VNET_PACK_BOTH_BF16 5  /* vnet_pack_weights_batched only: BOTH bf16 images of a 5^3 filter from one read of w
                                 * (descriptor: {w, wp_fwd, 5, T, I, O, wp_bwd, 0}; I and O multiples of 32)      */
 
+/* f32x3 filter images for vnet_conv_fwd_x3: every weight split exactly into three bf16 pieces (h, m, l),
+ * [k chunk 16][tap pair 65][n block 16][piece 3][64 lanes][8 k] (csrc/conv_x3.h) */
+#define VNET_PACK_FWD_X3 7     /* conv forward (k = ci, n = co)                                              */
+#define VNET_PACK_BWD_X3 8     /* conv backward-data (flipped taps, k = co, n = ci)                          */
+
 /* or-ed into VNET_PACK_FWD / _BWD / _UP: the fp32 image holds the filter ROUNDED to bf16 (bf16-storage mode of the 2^3 convs) */
 #define VNET_PACK_ROUND_BF16 16
 
@@ -139,6 +144,22 @@ int vnet_conv_bf16_stats_rows_x16(int Cin, int Cy0, int Cy1, int C0, int C1, int
 int vnet_conv_fwd_bf16_stats(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
                              float* y, int Cout, int B, int D, int H, int W,
                              const float* res, float* stats, void* ws, size_t ws_bytes, void* stream);   /* see vnet_conv_fwd_stats */
+
+/* ---- f32x3 (round 5): the 5^3 stride-1 convolution in fp32 accuracy on the bf16 matrix pipe -------------------------
+ * Replaces tf.nn.convolution (layers2.py:59-63 from networks.py:316,333,346) and Conv3DBackpropInput (model.py:660) like
+ * vnet_conv_fwd, for fp32 tensors: every operand is split EXACTLY into three bf16 pieces (x = h + m + l) and a product is
+ * the fp32-accumulated sum of six bf16 products (hh, hm, mh, mm, hl, lh; the dropped terms are below 2^-24 of the product,
+ * i.e. below fp32's own rounding).  Not bit-identical to the fp32 MFMA kernels; held to the same 2e-6 against the fp64 oracle.
+ * wp: vnet_pack_weights(VNET_PACK_FWD_X3) for the forward conv, VNET_PACK_BWD_X3 for backward-data (then C0 / Cy0, Cy1 are
+ * those of the backward problem).  Channel counts multiples of 16 (VNET_E_UNSUPPORTED otherwise); vnet_conv_x3_ok tells
+ * whether the kernel is the better choice for a shape (enough 2x8x16 bricks x 16-cout blocks for one round of the chip).
+ * acc: NULL, y0 (y0 += conv, see vnet_conv_fwd_acc) or another tensor of y0's shape (Cy1 == 0) added out of place.
+ * res / stats: as vnet_conv_fwd_stats, rows = vnet_conv_x3_stats_rows (one per brick), Cy1 == 0.  No workspace. */
+int vnet_conv_x3_ok(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W);
+int vnet_conv_x3_stats_rows(int B, int D, int H, int W);
+int vnet_conv_fwd_x3(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
+                     float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
+                     const float* acc, const float* res, float* stats, void* stream);
 
 /* bf16 SHADOWS (round 2).  In bf16 mode every convolution input is produced by a batch-norm / dropout kernel (forward) or
  * a batch-norm backward kernel (dy); the *_x16 producers below write, next to the fp32 tensor, its bf16 image (RNE -- the very

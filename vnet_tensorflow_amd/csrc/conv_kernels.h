@@ -761,6 +761,8 @@ __device__ __forceinline__ void pack_bf16_elem(int mode, const float* __restrict
     wp[idx] = (unsigned short)(pk_bf16(v, 0.f) & 0xffffu);
 }
 
+#include "x3_pack.h"
+
 // ------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------
@@ -796,6 +798,12 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const long long* __re
     const bool r16 = ((int)d[2] & VNET_PACK_ROUND_BF16) != 0;
     const int mode = (int)d[2] & ~VNET_PACK_ROUND_BF16, T = (int)d[3], I = (int)d[4], O = (int)d[5];
     const int CQ = (int)d[6], NP = (int)d[7];
+    if (mode == VNET_PACK_FWD_X3 || mode == VNET_PACK_BWD_X3) {     // f32x3 images (conv_x3.h): CQ = k chunks, NP = n blocks of 16
+        const uint32_t units = (uint32_t)CQ * X3_NPAIR * NP * 64;
+        for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < units; u += gridDim.x * blockDim.x)
+            x3_pack_unit(mode == VNET_PACK_BWD_X3, w, reinterpret_cast<u32x4*>(wp), I, O, NP, u);
+        return;
+    }
     if (mode == VNET_PACK_BOTH_BF16) {
         // Both bf16 images of a filter from ONE read (round 4): the two separate passes read every fp32 weight twice (352 MB for the
         // C5 network's 44 M parameters, + 176 MB of images).  A workgroup stages one tap's [32 ci][32 co] fp32 slice in LDS (rows of

@@ -28,6 +28,10 @@ extern "C" {
 const char* vnet_version(void) { return "vnet_hip 0.2 (gfx950; fp32 MFMA 16x16x4, bf16 MFMA 32x32x16 / 16x16x32)"; }
 
 size_t vnet_packed_weight_floats(int mode, int taps, int I, int O) {
+    if (mode == VNET_PACK_FWD_X3 || mode == VNET_PACK_BWD_X3) {         // three bf16 images, size still quoted in floats
+        int nchunk, ncob; x3_packed_dims(mode == VNET_PACK_BWD_X3, I, O, &nchunk, &ncob);
+        return (size_t)nchunk * X3_NPAIR * ncob * 3 * 256;
+    }
     if (mode == VNET_PACK_FWD_BF16 || mode == VNET_PACK_BWD_BF16) {     // bf16 image, size still quoted in floats
         int nchunk, ncob; packed_dims_bf16(mode, I, O, &nchunk, &ncob);
         return (size_t)nchunk * taps * ncob * 512 / 2;
@@ -38,6 +42,15 @@ size_t vnet_packed_weight_floats(int mode, int taps, int I, int O) {
 
 int vnet_pack_weights(int mode, const float* w, float* wp, int taps, int I, int O, void* stream) {
     if (!w || !wp || taps <= 0 || I <= 0 || O <= 0) return VNET_E_BADARG;
+    if (mode == VNET_PACK_FWD_X3 || mode == VNET_PACK_BWD_X3) {
+        if (taps != 125) return VNET_E_UNSUPPORTED;
+        int nchunk, ncob; x3_packed_dims(mode == VNET_PACK_BWD_X3, I, O, &nchunk, &ncob);
+        const uint32_t units = (uint32_t)nchunk * X3_NPAIR * ncob * 64;
+        hipLaunchKernelGGL(x3_pack_kernel, dim3(min(4096u, (units + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           mode == VNET_PACK_BWD_X3 ? 1 : 0, w, reinterpret_cast<u32x4*>(wp), I, O, ncob, units);
+        VNET_LAUNCH_CHECK();
+        return VNET_OK;
+    }
     if (mode == VNET_PACK_FWD_BF16 || mode == VNET_PACK_BWD_BF16) {
         int nchunk, ncob; packed_dims_bf16(mode, I, O, &nchunk, &ncob);
         const size_t total = (size_t)nchunk * taps * ncob * 512;
@@ -60,6 +73,7 @@ int vnet_pack_weights(int mode, const float* w, float* wp, int taps, int I, int 
 
 int vnet_packed_dims(int mode, int taps, int I, int O, int* CQ, int* NP) {
     if (!CQ || !NP) return VNET_E_BADARG;
+    if (mode == VNET_PACK_FWD_X3 || mode == VNET_PACK_BWD_X3) { x3_packed_dims(mode == VNET_PACK_BWD_X3, I, O, CQ, NP); return VNET_OK; }   // (k chunks, n blocks of 16)
     if (mode == VNET_PACK_FWD_BF16 || mode == VNET_PACK_BWD_BF16) { packed_dims_bf16(mode, I, O, CQ, NP); return VNET_OK; }   // (chunks, cout blocks)
     mode &= ~VNET_PACK_ROUND_BF16;
     if (mode < 0 || mode > 2) return VNET_E_BADARG;

@@ -1,0 +1,310 @@
+// conv_x3.h -- "f32x3": fp32 5x5x5 convolutions on the bf16 matrix pipe (gfx950), round 5.
+//
+// tf.nn.convolution (reference layers2.py:59-63, called from networks.py:316,333,346) and its Conv3DBackpropInput (autodiff,
+// model.py:660) in fp32 accuracy WITHOUT the fp32 MFMA (v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 rate on this part).
+// Every fp32 operand is split exactly into three bf16 pieces
+//     x = h + m + l,   h = RNE_bf16(x), m = RNE_bf16(x - h), l = RNE_bf16(x - h - m)      (8 + 8 + 8 significant bits: no remainder)
+// and a product x * w is formed from SIX bf16 products accumulated in fp32 by v_mfma_f32_16x16x32_bf16:
+//     xh wh + xh wm + xm wh + xm wm + xh wl + xl wh            (the three dropped terms are <= 2^-24 |x w|: below fp32's own rounding)
+// measured (profiles/r03_split_bf16_probe.txt): rel-L2 9.9e-7 against float64, the fp32 MFMA itself 1.13e-6.
+//
+// Kernel (forward and, with the flipped / transposed filter image, backward-data):
+//   * D[16 cout][16 voxels] per MFMA, K = 32 = a PAIR of taps x 16 cin (pairs as in the bf16 16-cout kernel: (dz, dz+1) for
+//     dz = 0, 2 -> a tile-plane offset for lanes 32..63; dz = 4: (dy, dy+1) -> a tile-row offset; (4,4,dx) alone) = 65 pairs per chunk;
+//   * brick 2 x 8 x 16 output voxels x 16 cout per item, persistent 8-wave workgroups (one per CU) walk (brick, cout block) items;
+//     the brick + halo of one 16-cin chunk is split while it is committed and sits in LDS as three bf16 images
+//     [piece][cin half][voxel][8 cin] (138 KB): a B fragment is one ds_read_b128 per piece, lane base + compile-time offset;
+//   * the two z-planes of the brick go to two groups of four waves; the four waves of a group hold the SAME 8 output rows (32
+//     accumulator registers) and split K: wave kw owns the tap column dx = kw (13 pairs) and a quarter of the column dx = 4
+//     (16 / 16 / 16 / 17 pairs, rotated by chunk).  So every filter fragment is fetched by exactly two waves of the workgroup,
+//     straight from L2 into VGPRs (3 KB per pair, ~16 B/clk/CU) and never touches LDS;
+//   * y-sliding reuse: a wave walks the tile rows j of a (dz pair, dx) once and feeds row j to the output rows m = j - dy of
+//     every dy it owns: 12 row fragments (x3 pieces) for 40 (row, dy) steps = 240 MFMAs: 0.15 KB of LDS reads per MFMA;
+//   * the four partial bricks of a group meet in LDS (tile space, 64 KB) at the end of an item; each wave sums and stores 2 rows;
+//   * the next tile (next chunk / next item) is prefetched global -> registers under the MFMAs and split + committed between
+//     two barriers.
+#pragma once
+#include "conv_kernels.h"
+
+namespace {
+
+constexpr int X3_TZ = 2, X3_TY = 8, X3_TX = 16;
+constexpr int X3_IZ = X3_TZ + 4, X3_IY = X3_TY + 4, X3_IX = X3_TX + 4;
+constexpr int X3_NV = X3_IZ * X3_IY * X3_IX;             // 1440 tile voxels
+constexpr int X3_PLANEB = X3_NV * 16;                    // one (piece, cin half) plane: 23040 B (a multiple of 256: bank-neutral)
+constexpr int X3_PIECEB = 2 * X3_PLANEB;
+constexpr int X3_TILEB = 3 * X3_PIECEB;                  // 138240
+constexpr int X3_ROWB = X3_IX * 16, X3_ZB = X3_IY * X3_IX * 16;
+constexpr int X3_LDS = X3_TILEB + 8 * 32 * 4 + 64 * 8;   // + epilogue statistics [8 waves][32] + a dump slot per lane
+
+// ---- the K loop pieces -------------------------------------------------------------------------------------------------------
+// A fragments of NP consecutive pairs (piece-major per pair: h, m, l), global -> registers
+template <int NP>
+__device__ __forceinline__ void x3_load_a(bf16x8 (&A)[NP][3], const u32x4* __restrict__ ap, int astride) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) A[p][s] = __builtin_bit_cast(bf16x8, ap[(size_t)p * astride + s * 64]);
+}
+
+__device__ __forceinline__ void x3_read_b(bf16x8 (&B)[3], const unsigned char* p) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) B[s] = *reinterpret_cast<const bf16x8*>(p + s * X3_PIECEB);
+}
+
+// the six products of one (A pair, B row): piece indices (A, B); small terms first
+#define X3_PROD_A(k) ((k) == 0 ? 2 : (k) == 1 ? 0 : (k) == 2 ? 1 : (k) == 3 ? 1 : (k) == 4 ? 0 : 0)
+#define X3_PROD_B(k) ((k) == 0 ? 0 : (k) == 1 ? 2 : (k) == 2 ? 1 : (k) == 3 ? 0 : (k) == 4 ? 1 : 0)
+
+// taps (dz pair, dy = DY0 .. DY0 + NDY - 1, dx) on the 8 output rows of this wave's plane: tile rows jr = DY0 .. DY0 + NDY + 6, row jr
+// feeds output row m = jr - dy.  bz: lane base + plane pair + dx.
+template <int DY0, int NDY>
+__device__ __forceinline__ void x3_zrows(f32x4 (&acc)[8], const unsigned char* bz, const bf16x8 (&A)[NDY][3]) {
+    constexpr int J0 = DY0, J1 = DY0 + NDY + 7;
+    bf16x8 Bn[3];
+    x3_read_b(Bn, bz + J0 * X3_ROWB);
+#pragma unroll
+    for (int jr = J0; jr < J1; ++jr) {
+        bf16x8 B[3] = {Bn[0], Bn[1], Bn[2]};
+        if (jr + 1 < J1) x3_read_b(Bn, bz + (jr + 1) * X3_ROWB);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int d = 0; d < NDY; ++d) {
+                const int m = jr - DY0 - d;
+                if (m >= 0 && m < 8) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[d][X3_PROD_A(k)], B[X3_PROD_B(k)], acc[m], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// plane dz = 4 of column dx: pairs (dy 0|1), (dy 2|3) from row-pair fragments (lanes 32..63 one row further), (dy 4 | nothing) from
+// single rows (both lane halves read the same row; the filter's second half is zero)
+__device__ __forceinline__ void x3_yrows(f32x4 (&acc)[8], const unsigned char* by, const unsigned char* b0, const bf16x8 (&A)[3][3]) {
+    bf16x8 Bn[3];
+    x3_read_b(Bn, by);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {                  // row pair (k | k + 1): output row k with q = 0, row k - 2 with q = 1
+        bf16x8 B[3] = {Bn[0], Bn[1], Bn[2]};
+        if (k + 1 < 10) x3_read_b(Bn, by + (k + 1) * X3_ROWB); else x3_read_b(Bn, b0 + 4 * X3_ROWB);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            if (k < 8) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][X3_PROD_A(t)], B[X3_PROD_B(t)], acc[k], 0, 0, 0);
+            if (k >= 2) acc[k - 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1][X3_PROD_A(t)], B[X3_PROD_B(t)], acc[k - 2], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {                   // single rows m + 4
+        bf16x8 B[3] = {Bn[0], Bn[1], Bn[2]};
+        if (m + 1 < 8) x3_read_b(Bn, b0 + (m + 5) * X3_ROWB);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2][X3_PROD_A(t)], B[X3_PROD_B(t)], acc[m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv5_x3_kernel(ConvArgs a) {
+    constexpr int NT = 512;
+    using XT = XTile<X3_IZ, X3_IY, X3_IX, NT>;
+    static_assert(XT::PER * XT::RPI == XT::ROWS, "every staging pass covers whole tile rows");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* tile = smem;
+    float* red = reinterpret_cast<float*>(smem);                              // after an item's K loop: [8 waves][8 rows][64 lanes][4]
+    float* sred = reinterpret_cast<float*>(smem + X3_TILEB);                  // [8 waves][2 x 16] epilogue statistics
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* dump = smem + X3_TILEB + 8 * 32 * 4 + lane * 8;
+    const int j = lane & 15, g = lane >> 4, half = g & 1, hi = g >> 1;
+    const int grp = wave >> 2, kw = wave & 3;
+
+    const int base0 = half * X3_PLANEB + ((grp * X3_IY) * X3_IX + j) * 16;
+    const unsigned char* bZ = tile + base0 + hi * X3_ZB;                      // taps (dz, dz + 1)
+    const unsigned char* bY = tile + base0 + hi * X3_ROWB + 4 * X3_ZB;        // taps (4, dy), (4, dy + 1)
+    const unsigned char* b0 = tile + base0 + 4 * X3_ZB;                       // tap (4, 4)
+
+    const int ncob = a.CoutP >> 4;
+    const int nbrick = a.B * a.nbz * a.nby * a.nbx;
+    const int nitems = nbrick * ncob;
+    const int G8 = gridDim.x >> 3;                                            // workgroups per XCD (grid is a multiple of 8)
+    const int per_xcd = (nitems + 7) >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int i_lo = xcd * per_xcd, i_hi = min(nitems, i_lo + per_xcd);
+    if (i_lo + slot >= i_hi) return;
+    const int nmine = (i_hi - i_lo - slot + G8 - 1) / G8;                     // items i_lo + slot + i * G8
+    const int nch = a.nchunks;
+    const int nsteps = nmine * nch;
+    const int astride = ncob * 3 * 64;                                        // u32x4 units between consecutive pairs
+    const u32x4* wq = reinterpret_cast<const u32x4*>(a.wp) + lane;
+
+    auto item_coords = [&](int it, int& b, int& bz, int& by, int& bx, int& cob) {
+        int item = i_lo + slot + it * G8;
+        cob = item % ncob; item /= ncob;
+        bx = item % a.nbx; item /= a.nbx;
+        by = item % a.nby; item /= a.nby;
+        bz = item % a.nbz; b = item / a.nbz;
+    };
+    float4 pv[XT::PER];
+    auto tile_issue = [&](int step) {
+        const int it = step / nch, ch = step - it * nch;
+        int b, bz, by, bx, cob;
+        item_coords(it, b, bz, by, bx, cob);
+        XT::template issue_part<0, XT::PER>(pv, a.x0, a.x1, a.C0, a.C1, ch, b, bz * X3_TZ - 2, by * X3_TY - 2, bx * X3_TX - 2, a.Di, a.Hi, a.Wi, tid);
+    };
+    auto tile_commit = [&]() {
+        const int r0 = tid / XT::COLS, col = tid - r0 * XT::COLS;
+        const int ix = col >> 2, cq = col & 3;
+        unsigned char* base = tile + (cq >> 1) * X3_PLANEB + ix * 16 + (cq & 1) * 8;
+        const bool act = r0 < XT::RPI;
+#pragma unroll
+        for (int k = 0; k < XT::PER; ++k) {
+            const int row = r0 + k * XT::RPI;
+            u32x2 h, m, l;
+            x3_split4(pv[k], h, m, l);
+            unsigned char* dst = act ? base + row * X3_ROWB : dump;
+            unsigned char* dst1 = act ? dst + X3_PIECEB : dump;
+            unsigned char* dst2 = act ? dst + 2 * X3_PIECEB : dump;
+            *reinterpret_cast<u32x2*>(dst) = h;
+            *reinterpret_cast<u32x2*>(dst1) = m;
+            *reinterpret_cast<u32x2*>(dst2) = l;
+        }
+    };
+
+    tile_issue(0);
+    tile_commit();
+    __syncthreads();
+
+    f32x4 acc[8];
+    for (int step = 0; step < nsteps; ++step) {
+        const int it = step / nch, ch = step - it * nch;
+        const bool first = ch == 0, last = ch == nch - 1, more = step + 1 < nsteps;
+        int b, bz, by, bx, cob;
+        item_coords(it, b, bz, by, bx, cob);
+        if (first) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int kc = (kw + ch) & 3;                                       // tap column of this wave in this chunk
+        const u32x4* wc = wq + ((size_t)ch * X3_NPAIR * ncob + cob) * 3 * 64;   // pair 0 of (chunk, cout block)
+        {
+            bf16x8 A[5][3];
+            x3_load_a<5>(A, wc + (size_t)(kc * 5) * astride, astride);                 // (dz 0|1, dx = kc)
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) tile_issue(step + 1);                                            // behind the first filter loads: they must not queue behind the tile's
+            __builtin_amdgcn_sched_barrier(0);
+            x3_zrows<0, 5>(acc, bZ + kc * 16, A);
+        }
+        {
+            bf16x8 A[5][3];
+            x3_load_a<5>(A, wc + (size_t)(25 + kc * 5) * astride, astride);            // (dz 2|3, dx = kc)
+            x3_zrows<0, 5>(acc, bZ + 2 * X3_ZB + kc * 16, A);
+        }
+        {
+            bf16x8 A[3][3];
+            x3_load_a<3>(A, wc + (size_t)(50 + kc * 3) * astride, astride);            // (dz 4, dx = kc)
+            x3_yrows(acc, bY + kc * 16, b0 + kc * 16, A);
+        }
+        // the column dx = 4 in four parts (3 / 3 / 3 / 4 pairs)
+        if (kc == 0) {
+            bf16x8 A[3][3];
+            x3_load_a<3>(A, wc + (size_t)(20) * astride, astride);
+            x3_zrows<0, 3>(acc, bZ + 4 * 16, A);
+        } else if (kc == 1) {
+            {
+                bf16x8 A[2][3];
+                x3_load_a<2>(A, wc + (size_t)(23) * astride, astride);
+                x3_zrows<3, 2>(acc, bZ + 4 * 16, A);
+            }
+            {
+                bf16x8 A[1][3];
+                x3_load_a<1>(A, wc + (size_t)(45) * astride, astride);
+                x3_zrows<0, 1>(acc, bZ + 2 * X3_ZB + 4 * 16, A);
+            }
+        } else if (kc == 2) {
+            bf16x8 A[3][3];
+            x3_load_a<3>(A, wc + (size_t)(46) * astride, astride);
+            x3_zrows<1, 3>(acc, bZ + 2 * X3_ZB + 4 * 16, A);
+        } else {
+            {
+                bf16x8 A[1][3];
+                x3_load_a<1>(A, wc + (size_t)(49) * astride, astride);
+                x3_zrows<4, 1>(acc, bZ + 2 * X3_ZB + 4 * 16, A);
+            }
+            {
+                bf16x8 A[3][3];
+                x3_load_a<3>(A, wc + (size_t)(62) * astride, astride);
+                x3_yrows(acc, bY + 4 * 16, b0 + 4 * 16, A);
+            }
+        }
+        __syncthreads();                                   // every wave is done reading the tile
+        if (last) {
+            // the four partial bricks of each group meet in LDS; wave kw sums and stores the output rows 2 kw, 2 kw + 1
+#pragma unroll
+            for (int m = 0; m < 8; ++m) *reinterpret_cast<f32x4*>(red + ((wave * 8 + m) * 64 + lane) * 4) = acc[m];
+            __syncthreads();
+            const int co0 = cob * 16, co = co0 + 4 * g;
+            f32x4 o[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int m = 2 * kw + t;
+                o[t] = *reinterpret_cast<const f32x4*>(red + (((grp * 4 + 0) * 8 + m) * 64 + lane) * 4);
+#pragma unroll
+                for (int k = 1; k < 4; ++k) o[t] += *reinterpret_cast<const f32x4*>(red + (((grp * 4 + k) * 8 + m) * 64 + lane) * 4);
+            }
+            float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias && co < a.Cout) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bias4[k] = a.bias[co + k];
+            }
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+            const int oz = bz * X3_TZ + grp, ox = bx * X3_TX + j;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int oy = by * X3_TY + 2 * kw + t;
+                if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo || co >= a.Cout) continue;
+                const size_t ov = ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+                float e[4] = {o[t][0] + bias4[0], o[t][1] + bias4[1], o[t][2] + bias4[2], o[t][3] + bias4[3]};
+                if constexpr (STATS) {
+                    float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a.res) rr = *reinterpret_cast<const float4*>(a.res + ov * a.Cout + co);
+                    const float vv[4] = {e[0] + rr.x, e[1] + rr.y, e[2] + rr.z, e[3] + rr.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { s1[k] += vv[k]; s2[k] += vv[k] * vv[k]; }
+                }
+                float* p = (co < a.Cy0) ? a.y0 + ov * a.Cy0 + co : a.y1 + ov * a.Cy1 + (co - a.Cy0);
+                if (a.accum) {
+                    const float4 old = *reinterpret_cast<const float4*>(a.accsrc ? a.accsrc + ov * a.Cy0 + co : p);
+                    e[0] += old.x; e[1] += old.y; e[2] += old.z; e[3] += old.w;
+                }
+                *reinterpret_cast<float4*>(p) = make_float4(e[0], e[1], e[2], e[3]);
+            }
+            if constexpr (STATS) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    s1[k] = row16_sum(s1[k]); s2[k] = row16_sum(s2[k]);
+                    if (j == 0) { sred[wave * 32 + 4 * g + k] = s1[k]; sred[wave * 32 + 16 + 4 * g + k] = s2[k]; }
+                }
+            }
+            __syncthreads();                               // the partial bricks are read; the statistics of all waves are in sred
+            if constexpr (STATS) {
+                int brick = (i_lo + slot + it * G8) / ncob;
+                stats_row_write<8, 16>(sred, a.stats, (size_t)brick, co0, a.Cout, tid);
+            }
+        }
+        if (more) tile_commit();
+        __syncthreads();
+    }
+}
+
+// does the f32x3 kernel take this 5^3 stride-1 problem?  (whole 16-channel blocks on both sides, enough items for one round of the chip)
+inline bool x3_conv_ok(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W) {
+    if (C0 <= 0 || Cy0 <= 0 || (C0 & 15) || (C1 & 15) || (Cy0 & 15) || (Cy1 & 15)) return false;
+    const long items = (long)B * ceil_div(D, X3_TZ) * ceil_div(H, X3_TY) * ceil_div(W, X3_TX) * ((Cy0 + Cy1) / 16);
+    return items >= 256 && W >= 16;
+}
+
+}  // namespace

@@ -1,0 +1,69 @@
+// conv_x3.hip -- entry points of the f32x3 convolution family (conv_x3.h): fp32 tensors in and out, fp32 accuracy, bf16 matrix pipe.
+#include "conv_x3.h"
+
+namespace {
+
+int x3_grid() {
+    // one persistent workgroup per CU, a multiple of 8 (the kernels partition their items by XCD = blockIdx % 8)
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int& c = cached[dev & 63];
+    if (c == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        c = n / 8 * 8;
+    }
+    return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vnet_conv_x3_ok(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W) {
+    return x3_conv_ok(C0, C1, Cy0, Cy1, B, D, H, W) ? 1 : 0;
+}
+
+int vnet_conv_x3_stats_rows(int B, int D, int H, int W) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    return B * ceil_div(D, X3_TZ) * ceil_div(H, X3_TY) * ceil_div(W, X3_TX);
+}
+
+int vnet_conv_fwd_x3(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
+                     float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
+                     const float* acc, const float* res, float* stats, void* stream) {
+    if (!x0 || !wp || !y0 || C0 <= 0 || Cy0 <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return VNET_E_BADARG;
+    if ((C1 > 0 && !x1) || (Cy1 > 0 && !y1) || C1 < 0 || Cy1 < 0) return VNET_E_BADARG;
+    if ((C0 & 15) || (C1 & 15) || (Cy0 & 15) || (Cy1 & 15)) return VNET_E_UNSUPPORTED;
+    if ((stats || res) && Cy1 > 0) return VNET_E_BADARG;
+    if (acc && acc != y0 && Cy1 > 0) return VNET_E_BADARG;
+    if ((long long)D * H * W * (C0 > C1 ? C0 : C1) >= (1ll << 31)) return VNET_E_UNSUPPORTED;
+    ConvArgs a{};
+    a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1;
+    a.wp = reinterpret_cast<const float4*>(wp); a.bias = bias;
+    a.y0 = y0; a.y1 = y1; a.Cy0 = Cy0; a.Cy1 = Cy1; a.Cout = Cy0 + Cy1;
+    a.B = B; a.Di = D; a.Hi = H; a.Wi = W; a.Do = D; a.Ho = H; a.Wo = W;
+    a.nchunks = a.Cin / 16; a.CQ = a.nchunks * 4; a.CoutP = a.Cout;
+    a.nbz = ceil_div(D, X3_TZ); a.nby = ceil_div(H, X3_TY); a.nbx = ceil_div(W, X3_TX);
+    a.pad = 2; a.padx = 2; a.vec_in = 1; a.vec_out = 1;
+    a.accum = acc ? 1 : 0; a.accsrc = (acc && acc != y0) ? acc : nullptr;
+    a.res = res; a.stats = stats;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = x3_grid();
+    if (stats) {
+        auto k = conv5_x3_kernel<true>;
+        static unsigned long long attr_done = 0;
+        if (int ae = ensure_lds(k, X3_LDS, attr_done)) return ae;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), X3_LDS, st, a);
+    } else {
+        auto k = conv5_x3_kernel<false>;
+        static unsigned long long attr_done = 0;
+        if (int ae = ensure_lds(k, X3_LDS, attr_done)) return ae;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), X3_LDS, st, a);
+    }
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+}  // extern "C"

@@ -21,6 +21,7 @@ BN_MOMENTUM = 0.99   # reference networks.py:259 momentum=0.99
 
 ACT = {None: 0, "none": 0, "relu": 1, "prelu": 2, "lrelu": 3}
 PACK_FWD, PACK_BWD, PACK_UP, PACK_FWD_BF16, PACK_BWD_BF16, PACK_BOTH_BF16, PACK_BOTH = 0, 1, 2, 3, 4, 5, 6
+PACK_FWD_X3, PACK_BWD_X3 = 7, 8
 
 # Arithmetic of the 5x5x5 convolutions (forward, backward-data and filter gradient): "fp32" = exact fp32 MFMA (the reference's
 # arithmetic), "bf16" = operands rounded to bf16, fp32 accumulation (BASELINE config C5).  Everything else
@@ -37,7 +38,7 @@ PACK_FWD, PACK_BWD, PACK_UP, PACK_FWD_BF16, PACK_BWD_BF16, PACK_BOTH_BF16, PACK_
 # context exactly as before.  The switch is per process, not per thread: models take turns, they do not run concurrently.
 class OpsContext(object):
     def __init__(self):
-        self.compute = {"dtype": "fp32", "store16": False, "name": "fp32"}
+        self.compute = {"dtype": "fp32", "store16": False, "name": "fp32", "split3": False}
         self.pg = {"on": False, "streams": {}, "used": set(), "keep": []}
         self.pack_epoch = [0]
         self.pack_reg = {"entries": [], "descs": None, "device": None}     # every (filter, mode) ever packed: repacked in one launch
@@ -97,10 +98,14 @@ PACK_ROUND16 = 16
 
 
 def set_compute_dtype(dtype):
-    if dtype not in ("fp32", "bf16", "bf16_operands"):
-        raise VnetHipError("compute dtype must be 'fp32', 'bf16' or 'bf16_operands', got %r" % (dtype,))
-    _COMPUTE["dtype"] = "fp32" if dtype == "fp32" else "bf16"
+    if dtype not in ("fp32", "fp32_split3", "bf16", "bf16_operands"):
+        raise VnetHipError("compute dtype must be 'fp32', 'fp32_split3', 'bf16' or 'bf16_operands', got %r" % (dtype,))
+    _COMPUTE["dtype"] = "fp32" if dtype in ("fp32", "fp32_split3") else "bf16"
     _COMPUTE["store16"] = dtype == "bf16"
+    # "fp32_split3" (round 5, csrc/conv_x3.h): fp32 tensors and fp32 accuracy, but the 5^3 convolutions form every product from six
+    # bf16 products of exactly split operands (x = h + m + l) on the bf16 matrix pipe; layers the f32x3 kernels do not take
+    # (vnet_conv_x3_ok) keep the fp32 MFMA kernels
+    _COMPUTE["split3"] = dtype == "fp32_split3"
     _COMPUTE["name"] = dtype
 
 
@@ -482,6 +487,32 @@ def _conv_call(ks, stride, up, x0, x1, wp, bias, y0, y1, dims_in, dims_out, kx=0
         check(fn(ks, kx, stride, up, _ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias),
                  _ptr(y0), Cy0, _ptr(y1), Cy1, B, *dims_in, *dims_out,
                  _ptr(ws), nb, _stream()), "vnet_conv_fwd")
+
+
+_X3 = {"force": False}       # (tests) take the f32x3 kernels for every shape they can run, not only where they pay
+
+
+def _x3_ok(C0, C1, Cy0, Cy1, B, dims):
+    if not _COMPUTE.get("split3"):
+        return False
+    if _X3["force"]:
+        return C0 % 16 == 0 and C1 % 16 == 0 and Cy0 % 16 == 0 and Cy1 % 16 == 0
+    return _lib.lib().vnet_conv_x3_ok(C0, C1, Cy0, Cy1, B, *dims) == 1
+
+
+def _conv_x3_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res=None):
+    """5^3 stride-1 conv, fp32 in / out, products from three-way split bf16 operands (vnet_conv_fwd_x3)."""
+    L = _lib.lib()
+    B = x0.shape[0]
+    C0, C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
+    Cy0, Cy1 = y0.shape[-1], (y1.shape[-1] if y1 is not None else 0)
+    nvox = B * dims[0] * dims[1] * dims[2]
+    flops = 2.0 * nvox * 125 * (C0 + C1) * (Cy0 + Cy1)
+    nbytes = 4.0 * (nvox * (C0 + C1) + nvox * (Cy0 + Cy1) + 125 * (C0 + C1) * (Cy0 + Cy1) + (Cy0 + Cy1))
+    tag = "conv-x3 k5 s1 %d^3x%d %d->%d" % (dims[2], B, C0 + C1, Cy0 + Cy1)
+    with _Timed(tag, flops, nbytes):
+        check(L.vnet_conv_fwd_x3(_ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias), _ptr(y0), Cy0, _ptr(y1), Cy1, B, *dims,
+                                 _ptr(y0) if accum else None, _ptr(res), _ptr(stats), _stream()), "vnet_conv_fwd_x3")
 
 
 def _conv_bf16_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res=None, acc_src=None):
@@ -969,6 +1000,8 @@ class _ConvFn(torch.autograd.Function):
             _conv2_b16(False, x0, w, b, y, dims_out, (Di, Hi, Wi), O, I)
         elif ks == 2 and stride == 2 and x1 is None and res is None:
             _conv2_b16(True, x0, w, b, y, (Di, Hi, Wi), dims_out, I, O, stats=stats)
+        elif ks == 5 and stride == 1 and not up and _x3_ok(C0, C1, O, 0, B, dims_out):
+            _conv_x3_call(x0, x1, packed_weights(w, PACK_FWD_X3, 125, I, O), b, y, None, dims_out, stats=stats, res=res)
         else:
             if wp is None:
                 wp = packed_weights(w, PACK_UP, 8, I, O) if up else packed_weights(w, PACK_FWD, ks ** 3, I, O)
@@ -1089,6 +1122,8 @@ class _ConvFn(torch.autograd.Function):
                 _conv_bf16_call(dy, None, packed_weights(w, PACK_BWD_BF16, 125, I, O), None, dx0, dx1, din, accum=accum, acc_src=oop)
                 if oop is not None:
                     slot0.total = dx0
+            elif ks == 5 and _x3_ok(O, 0, C0, C1, B, din):
+                _conv_x3_call(dy, None, packed_weights(w, PACK_BWD_X3, 125, I, O), None, dx0, dx1, din, accum=accum)
             else:
                 wp = packed_weights(w, PACK_BWD, ks ** 3, I, O)
                 _conv_call(ks, 1, 0, dy, None, wp, None, dx0, dx1, dout, din, accum=accum)
@@ -1231,6 +1266,8 @@ def _epilogue_stats_buffer(bf16, ks, kx, stride, x0, x1, O, dims_out):
         # what the statistics pass costs (+1..3 % per launch, residual re-read on the input conv): the fused form is worth
         # 0.07 ms of a 25.7 ms step; VNET_BN_STATS_FP32=0 keeps it to the split-K launches (statistics from the reduce kernel)
         rows = 0
+        if ks == 5 and stride == 1 and kx in (0, 5) and _FUSE["bn_stats_fp32_direct"] and _x3_ok(C0, C1, O, 0, B, dims_out):
+            rows = L.vnet_conv_x3_stats_rows(B, *dims_out)                    # f32x3 kernel: one row per 2x8x16 brick
         if ks == 2 and stride == 2 and x1 is None and _DIRECT2["on"]:
             rows = L.vnet_conv2_direct_stats_rows(C0, O, B, *dims_out)        # the LDS-free direct kernel (levels 1-2): one row per workgroup
         if rows <= 0:
