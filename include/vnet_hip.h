@@ -161,6 +161,14 @@ int vnet_conv_fwd_x3(const float* x0, int C0, const float* x1, int C1, const voi
                      float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
                      const float* acc, const float* res, float* stats, void* stream);
 
+/* Filter gradient of the same convolution (Conv3DBackpropFilterV2 behind model.py:660) with the six-product arithmetic:
+ * dw [125][C0 + C1][Cout] (TF layout).  Channel counts multiples of 16; ws >= vnet_wgrad_x3_ws_bytes (partial slabs, reduced by
+ * this call or -- between vnet_wgrad_defer(1) and vnet_wgrad_flush -- by the flush). */
+int vnet_wgrad_x3_ok(int C0, int C1, int Cout, int B, int D, int H, int W);
+size_t vnet_wgrad_x3_ws_bytes(int Cin, int Cout, int B, int D, int H, int W);
+int vnet_conv_wgrad_x3(const float* x0, int C0, const float* x1, int C1, const float* dy, int Cout, float* dw,
+                       int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream);
+
 /* bf16 SHADOWS (round 2).  In bf16 mode every convolution input is produced by a batch-norm / dropout kernel (forward) or
  * a batch-norm backward kernel (dy); the *_x16 producers below write, next to the fp32 tensor, its bf16 image (RNE -- the very
  * rounding the kernels above apply while staging), and these entry points stage THAT: half the bytes through L2, no

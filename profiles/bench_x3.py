@@ -35,6 +35,28 @@ for P, ci, co in shapes:
         out.append((mode, ms, flops / ms / 1e9))
         if mode == "fp32":
             yref = y.clone()
+    # filter gradient of the same layer
+    dy = torch.randn(1, P, P, P, co, device=dev)
+    dw = torch.empty(5, 5, 5, ci, co, device=dev)
+    outw = []
+    for mode in ("fp32", "fp32_split3"):
+        ops.set_compute_dtype(mode)
+        f = (lambda: ops._wgrad_call(5, 1, x, None, dy, dw, (P, P, P), (P, P, P))) if mode == "fp32" else (lambda: ops._wgrad_x3_call(x, None, dy, dw, (P, P, P)))
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        outw.append((ms, flops / ms / 1e9))
+        if mode == "fp32":
+            dwref = dw.clone()
+    errw = float((dw - dwref).norm() / dwref.norm())
     err = float((y - yref).norm() / yref.norm())
-    print("%3d^3 %3d->%3d  " % (P, ci, co) + "  ".join("%s %.3f ms %.1f TF/s" % o for o in out) + "  x%.2f  rel(x3 - fp32) %.2e" % (out[0][1] / out[1][1], err), flush=True)
+    print("%3d^3 %3d->%3d  " % (P, ci, co) + "  ".join("%s %.3f ms %.1f TF/s" % o for o in out) + "  x%.2f  rel(x3 - fp32) %.2e" % (out[0][1] / out[1][1], err)
+          + " | wgrad %.3f ms %.1f TF/s -> %.3f ms %.1f TF/s x%.2f rel %.2e" % (outw[0] + outw[1] + (outw[0][0] / outw[1][0], errw)), flush=True)
 ops.set_compute_dtype("fp32")

@@ -51,6 +51,7 @@ def test_conv5_x3(dev, split3, shape):
     y.backward(g(dy, dev))
     recs = ops.profile_stop()
     assert sum(1 for r in recs if r[0].startswith("conv-x3")) == 2, [r[0] for r in recs]     # forward and backward-data took the f32x3 kernel
+    assert sum(1 for r in recs if r[0].startswith("wgrad-x3")) == 1, [r[0] for r in recs]    # and so did the filter gradient
     check_close(tag + " dx0", tx0.grad, dx_ref[..., :C0], 2e-6)
     if C1:
         check_close(tag + " dx1", tx1.grad, dx_ref[..., C0:], 2e-6)

@@ -300,6 +300,209 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Filter gradient (Conv3DBackpropFilterV2 behind model.py:660) with the same six-product arithmetic:
+//   D[16 cout][16 cin] per tap += A[cout][k = 32 voxels] * B[32 voxels][cin, tap-shifted]      (v_mfma_f32_16x16x32_bf16 x 6)
+// Structure of the bf16 row-reuse kernel (wgrad5_bf16_rr_kernel), on a 2 x 8 x 16 brick: x tile (6 x 12 x 20 voxels x 16 cin)
+// and dy tile (256 voxels x 16 cout) are split while they are committed and sit in LDS as three bf16 images [piece][voxel][16 ch]
+// (32-byte rows: 138 + 24 KB -- all of the CU's LDS); fragments by ds_read_b64_tr_b16 (a tap shift is a whole number of rows).
+// A k-step is two x-rows (y, y + 1) of one output plane; lane group g: row g & 1, x half g >> 1 (row pitch 640 B = 128 mod 256:
+// the two groups of an LDS service half use disjoint banks; the dy tile's 512-byte rows swap their 128-byte halves on odd rows
+// for the same reason).  The B fragment of (k-step s, tap dy) is row pair j = 2 s + dy: a wave owns three (dz, dx) columns with all
+// five dy, one column at a time, and keeps a sliding window of five row-pair fragments (x3 pieces): 2 new B + 1 A fragment triple per
+// 30 MFMAs.  The 25th column (4, 4) gives one tap to each of the waves 0..4.  One (16 cin, 16 cout) block per workgroup, bricks
+// split over nsplit workgroups, next brick's tiles prefetched global -> registers under the MFMAs, partial slabs + the usual reduce.
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr int XW_XPB = X3_NV * 32;                    // one piece of the x tile: 46080 B
+constexpr int XW_DPB = X3_TZ * X3_TY * X3_TX * 32;    // one piece of the dy tile: 8192 B
+constexpr int XW_LDS = 3 * XW_XPB + 3 * XW_DPB;       // 162816 of 163840
+constexpr int XW_XROW = X3_IX * 32, XW_XPLANE = X3_IY * X3_IX * 32;
+
+// three-piece fragment: 2 transpose reads per piece (voxels +0..3 at lo, +4..7 at hi)
+__device__ __forceinline__ void xw_frag(bf16x8 (&F)[3], const unsigned char* lo, const unsigned char* hi, int pieceb) {
+    typedef s16x4 __attribute__((address_space(3))) * lp;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lo + s * pieceb));
+        const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(hi + s * pieceb));
+        const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        F[s] = __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+__device__ __forceinline__ void xw_mfma6(f32x4& acc, const bf16x8 (&A)[3], const bf16x8 (&B)[3]) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[X3_PROD_A(k)], B[X3_PROD_B(k)], acc, 0, 0, 0);
+}
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) wgrad5_x3_kernel(WgradArgs a) {
+    constexpr int NT = 512;
+    using XT = XTile<X3_IZ, X3_IY, X3_IX, NT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xt = smem;
+    unsigned char* dyt = smem + 3 * XW_XPB;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int split = blockIdx.x;
+    const int chunk = blockIdx.y / a.ncob, cob = blockIdx.y - chunk * a.ncob;
+    const int co0 = cob * 16;
+
+    const int lane_x = (((g & 1) * X3_IX + (g >> 1) * 8) + (i >> 2)) * 32 + (i & 3) * 8;
+    const unsigned char* pb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int q = 3 * wave + c, dz = q / 5, dx = q - dz * 5;
+        pb[c] = xt + dz * XW_XPLANE + dx * 32 + lane_x;
+    }
+    const bool extra = wave < 5;
+    const unsigned char* pe = xt + 4 * XW_XPLANE + (extra ? wave : 0) * XW_XROW + 4 * 32 + lane_x;
+    const int lane_d = (((g & 1) * 16 + (g >> 1) * 8) + (i >> 2)) * 32 + (i & 3) * 8;
+    const unsigned char* pa_lo = dyt + lane_d + (g & 1) * 128;
+    const unsigned char* pa_hi = dyt + lane_d + (1 - (g & 1)) * 128;
+
+    f32x4 acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float4 px[XT::PER], pd[2];
+    auto brick_coords = [&](int brick, int& b, int& bz, int& by, int& bx) {
+        bx = brick % a.nbx; brick /= a.nbx;
+        by = brick % a.nby; brick /= a.nby;
+        bz = brick % a.nbz; b = brick / a.nbz;
+    };
+    auto issue = [&](int brick) {
+        int b, bz, by, bx;
+        brick_coords(brick, b, bz, by, bx);
+        XT::template issue_part<0, XT::PER>(px, a.x0, a.x1, a.C0, a.C1, chunk, b, bz * X3_TZ - 2, by * X3_TY - 2, bx * X3_TX - 2, a.Di, a.Hi, a.Wi, tid);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int q = tid + k * NT;
+            const int v = q >> 2, cq = q & 3;
+            const int vx = v & 15, vy = (v >> 4) & 7, vz = v >> 7;
+            const int oz = bz * X3_TZ + vz, oy = by * X3_TY + vy, ox = bx * X3_TX + vx;
+            const int c = co0 + cq * 4;
+            const bool ok = oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout;
+            const size_t ov = ok ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
+            const float4 t = *reinterpret_cast<const float4*>(a.dy + ov * a.Cout + (ok ? c : 0));
+            pd[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&]() {
+        const int r0 = tid / XT::COLS, col = tid - r0 * XT::COLS;
+        if (r0 < XT::RPI) {
+            unsigned char* base = xt + (col >> 2) * 32 + (col & 3) * 8;
+#pragma unroll
+            for (int k = 0; k < XT::PER; ++k) {
+                const int row = r0 + k * XT::RPI;
+                u32x2 h, m, l;
+                x3_split4(px[k], h, m, l);
+                unsigned char* dst = base + row * XW_XROW;
+                *reinterpret_cast<u32x2*>(dst) = h;
+                *reinterpret_cast<u32x2*>(dst + XW_XPB) = m;
+                *reinterpret_cast<u32x2*>(dst + 2 * XW_XPB) = l;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int q = tid + k * NT;
+            const int v = q >> 2, cq = q & 3;
+            const int vx = v & 15, row = v >> 4;
+            u32x2 h, m, l;
+            x3_split4(pd[k], h, m, l);
+            unsigned char* dst = dyt + (row * 16 + (vx ^ ((row & 1) << 2))) * 32 + cq * 8;
+            *reinterpret_cast<u32x2*>(dst) = h;
+            *reinterpret_cast<u32x2*>(dst + XW_DPB) = m;
+            *reinterpret_cast<u32x2*>(dst + 2 * XW_DPB) = l;
+        }
+    };
+
+    if (split < a.nbrick) issue(split);
+    for (int brick = split; brick < a.nbrick; brick += a.nsplit) {
+        __syncthreads();                               // every wave is done reading the previous tiles
+        commit();
+        __syncthreads();
+        if (brick + a.nsplit < a.nbrick) {
+            issue(brick + a.nsplit);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll 1
+        for (int zz = 0; zz < X3_TZ; ++zz) {
+            const int zx = zz * XW_XPLANE, zd = zz * (X3_TY * 16 * 32);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const unsigned char* p = pb[c] + zx;
+                bf16x8 F[5][3], A[3], An[3];
+#pragma unroll
+                for (int r = 0; r < 5; ++r) xw_frag(F[r], p + r * XW_XROW, p + r * XW_XROW + 128, XW_XPB);
+                xw_frag(An, pa_lo + zd, pa_hi + zd, XW_DPB);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) A[q] = An[q];
+                    if (s + 1 < 4) xw_frag(An, pa_lo + zd + (s + 1) * 1024, pa_hi + zd + (s + 1) * 1024, XW_DPB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    xw_mfma6(acc[c * 5 + 0], A, F[(2 * s + 0) % 5]);
+                    xw_mfma6(acc[c * 5 + 1], A, F[(2 * s + 1) % 5]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + 1 < 4) {                   // the two window slots that just died take the row pairs 2 s + 5, 2 s + 6
+                        xw_frag(F[(2 * s + 0) % 5], p + (2 * s + 5) * XW_XROW, p + (2 * s + 5) * XW_XROW + 128, XW_XPB);
+                        xw_frag(F[(2 * s + 1) % 5], p + (2 * s + 6) * XW_XROW, p + (2 * s + 6) * XW_XROW + 128, XW_XPB);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    xw_mfma6(acc[c * 5 + 2], A, F[(2 * s + 2) % 5]);
+                    xw_mfma6(acc[c * 5 + 3], A, F[(2 * s + 3) % 5]);
+                    xw_mfma6(acc[c * 5 + 4], A, F[(2 * s + 4) % 5]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (extra) {                               // (wave-uniform) tap (4, dy = wave, 4)
+                const unsigned char* p = pe + zx;
+                bf16x8 E[3], En[3], A[3], An[3];
+                xw_frag(En, p, p + 128, XW_XPB);
+                xw_frag(An, pa_lo + zd, pa_hi + zd, XW_DPB);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) { A[q] = An[q]; E[q] = En[q]; }
+                    if (s + 1 < 4) {
+                        xw_frag(An, pa_lo + zd + (s + 1) * 1024, pa_hi + zd + (s + 1) * 1024, XW_DPB);
+                        xw_frag(En, p + (2 * s + 2) * XW_XROW, p + (2 * s + 2) * XW_XROW + 128, XW_XPB);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    xw_mfma6(acc[15], A, E);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    // lane holds dW[tap][ci = chunk*16 + i][co = co0 + 4*g + {0..3}]
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        int tap;
+        if (t < 15) { const int q = 3 * wave + t / 5, dz = q / 5, dx = q - dz * 5; tap = (dz * 5 + t % 5) * 5 + dx; }
+        else { if (!extra) continue; tap = (4 * 5 + wave) * 5 + 4; }
+        float* dst = a.part + ((size_t)(split * 125 + tap) * a.CinP + chunk * 16 + i) * a.CoutP + co0 + g * 4;
+        const f32x4 r = acc[t];
+        *reinterpret_cast<float4*>(dst) = make_float4(r.x, r.y, r.z, r.w);
+    }
+}
+
+struct X3WgradPlan { int nbz, nby, nbx, nbrick, nsplit, nblk; };
+inline X3WgradPlan x3_plan_wgrad(int Cin, int Cout, int B, int D, int H, int W) {
+    X3WgradPlan p{};
+    p.nbz = ceil_div(D, X3_TZ); p.nby = ceil_div(H, X3_TY); p.nbx = ceil_div(W, X3_TX);
+    p.nbrick = B * p.nbz * p.nby * p.nbx;
+    p.nblk = (Cin / 16) * (Cout / 16);
+    p.nsplit = max(1, min(p.nbrick, ceil_div(256, p.nblk)));
+    return p;
+}
+inline bool x3_wgrad_ok(int C0, int C1, int Cout, int B, int D, int H, int W) {
+    if (C0 <= 0 || Cout <= 0 || (C0 & 15) || (C1 & 15) || (Cout & 15) || W < 16) return false;
+    const X3WgradPlan p = x3_plan_wgrad(C0 + C1, Cout, B, D, H, W);
+    return p.nbrick >= 4 * p.nsplit;                   // at least four bricks per workgroup: the first tile load is exposed
+}
+
 // does the f32x3 kernel take this 5^3 stride-1 problem?  (whole 16-channel blocks on both sides, enough items for one round of the chip)
 inline bool x3_conv_ok(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W) {
     if (C0 <= 0 || Cy0 <= 0 || (C0 & 15) || (C1 & 15) || (Cy0 & 15) || (Cy1 & 15)) return false;

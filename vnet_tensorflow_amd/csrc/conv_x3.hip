@@ -66,4 +66,42 @@ int vnet_conv_fwd_x3(const float* x0, int C0, const float* x1, int C1, const voi
     return VNET_OK;
 }
 
+int vnet_wgrad_x3_ok(int C0, int C1, int Cout, int B, int D, int H, int W) {
+    return x3_wgrad_ok(C0, C1, Cout, B, D, H, W) ? 1 : 0;
+}
+
+size_t vnet_wgrad_x3_ws_bytes(int Cin, int Cout, int B, int D, int H, int W) {
+    if (Cin <= 0 || Cout <= 0 || (Cin & 15) || (Cout & 15) || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const X3WgradPlan p = x3_plan_wgrad(Cin, Cout, B, D, H, W);
+    return (size_t)p.nsplit * 125 * Cin * Cout * sizeof(float);
+}
+
+int vnet_conv_wgrad_x3(const float* x0, int C0, const float* x1, int C1, const float* dy, int Cout, float* dw,
+                       int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    if (!x0 || !dy || !dw || C0 <= 0 || Cout <= 0 || B <= 0 || C1 < 0 || (C1 > 0 && !x1)) return VNET_E_BADARG;
+    if (D <= 0 || H <= 0 || W <= 0) return VNET_E_BADARG;
+    if ((C0 & 15) || (C1 & 15) || (Cout & 15)) return VNET_E_UNSUPPORTED;
+    if ((long long)D * H * W * (C0 > C1 ? C0 : C1) >= (1ll << 31)) return VNET_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    WgradArgs a{};
+    a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.dy = dy; a.Cout = Cout;
+    a.B = B; a.Di = D; a.Hi = H; a.Wi = W; a.Do = D; a.Ho = H; a.Wo = W;
+    a.CinP = a.Cin; a.CoutP = Cout; a.pad = 2; a.padx = 2; a.vec_in = 1; a.vec_dy = 1;
+    const X3WgradPlan p = x3_plan_wgrad(a.Cin, Cout, B, D, H, W);
+    a.ncob = Cout / 16; a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.nbrick = p.nbrick; a.nsplit = p.nsplit;
+    const size_t need = (size_t)p.nsplit * 125 * a.Cin * Cout * sizeof(float);
+    const bool direct = p.nsplit == 1;                 // one slab: the slab IS dw (TF layout [tap][Cin][Cout])
+    if (!direct && (!ws || ws_bytes < need)) return VNET_E_WORKSPACE;
+    a.part = direct ? dw : reinterpret_cast<float*>(ws);
+    auto k = wgrad5_x3_kernel;
+    static unsigned long long attr_done = 0;
+    if (int ae = ensure_lds(k, XW_LDS, attr_done)) return ae;
+    hipLaunchKernelGGL(k, dim3(p.nsplit, p.nblk), dim3(512), XW_LDS, st, a);
+    VNET_LAUNCH_CHECK();
+    if (direct) return VNET_OK;
+    launch_wgrad_reduce(a.part, p.nsplit, 125, a.CinP, a.CoutP, a.Cin, Cout, dw, st);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
 }  // extern "C"

@@ -814,6 +814,31 @@ def _wgrad_bf16_call(x0, x1, dy, dw, dims, owner=None):
                                      _ptr(ws), nb, _stream()), "vnet_conv_wgrad_bf16")
 
 
+def _wgrad_x3_ok(C0, C1, Co, B, dims):
+    if not _COMPUTE.get("split3"):
+        return False
+    if _X3["force"]:
+        return C0 % 16 == 0 and C1 % 16 == 0 and Co % 16 == 0
+    return _lib.lib().vnet_wgrad_x3_ok(C0, C1, Co, B, *dims) == 1
+
+
+def _wgrad_x3_call(x0, x1, dy, dw, dims, owner=None):
+    """Filter gradient of the 5^3 stride-1 conv, fp32 tensors, products from three-way split bf16 operands (vnet_conv_wgrad_x3)."""
+    L = _lib.lib()
+    B = x0.shape[0]
+    C0, C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
+    Co = dy.shape[-1]
+    nb = L.vnet_wgrad_x3_ws_bytes(C0 + C1, Co, B, *dims)
+    ws = _wgrad_workspace(dw, nb, owner is None, owner)
+    nvox = B * dims[0] * dims[1] * dims[2]
+    flops = 2.0 * nvox * 125 * (C0 + C1) * Co
+    nbytes = 4.0 * (nvox * (C0 + C1 + Co) + 125 * (C0 + C1) * Co)
+    tag = "wgrad-x3 k5 s1 %d^3x%d %d->%d" % (dims[2], B, C0 + C1, Co)
+    with _Timed(tag, flops, nbytes), _immediate_reduce(owner is None):
+        check(L.vnet_conv_wgrad_x3(_ptr(x0), C0, _ptr(x1), C1, _ptr(dy), Co, _ptr(dw), B, *dims, _ptr(ws), nb, _stream()),
+              "vnet_conv_wgrad_x3")
+
+
 def _wgrad_call(ks, stride, x0, x1, dy, dw, dims_in, dims_out, kx=0, immediate=False, owner=None):
     L = _lib.lib()
     immediate = immediate or owner is None          # no sink to keep the slabs on: reduce on the spot
@@ -1081,6 +1106,8 @@ class _ConvFn(torch.autograd.Function):
                     _wgrad_call(2, 2, dy, None, x0, dw, dout, din, owner=sw)
                 elif ctx.bf16:
                     _wgrad_bf16_call(x0, x1, dy, dw, din, owner=sw)
+                elif ks == 5 and stride == 1 and _wgrad_x3_ok(C0, C1, O, B, din):
+                    _wgrad_x3_call(x0, x1, dy, dw, din, owner=sw)
                 else:
                     _wgrad_call(ks, stride, x0, x1, dy, dw, din, dout, owner=sw)
         finally:
