@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3     # MI355X fp32 matrix = vector peak (MI355X_MICROARCH.md)
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak (no sparsity)
+PEAK_F32X3_TFLOPS = 2500.0 / 6.0   # fp32-equivalent peak of the six-bf16-product arithmetic (416.7)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -53,7 +54,8 @@ def parse():
     ap.add_argument("--cpu-patch", type=int, default=0, help="CPU baseline patch edge (0 = the benchmarked patch itself)")
     ap.add_argument("--pin-core", type=int, default=-1,
                     help="pin this process to ONE host core before the GPU is initialised (host-overhead experiment)")
-    ap.add_argument("--compute", choices=("fp32", "bf16"), default="fp32",
+    ap.add_argument("--no-x3", action="store_true", help="skip the fp32_split3 sub-measurement (same network, 5^3 convolutions on the bf16 pipe, N=1)")
+    ap.add_argument("--compute", choices=("fp32", "fp32_split3", "bf16"), default="fp32",
                     help="fp32 = the reference's arithmetic (headline metric); bf16 = bf16 activations in HBM and bf16 operands "
                          "into the matrix cores, fp32 accumulate (BASELINE config C5 with --channels 4 --classes 5)")
     return ap.parse_args()
@@ -286,9 +288,9 @@ def peak_for(bf16):
     return PEAK_BF16_TFLOPS if bf16 else PEAK_FP32_TFLOPS
 
 
-def family_tags(P, B, bf16):
+def family_tags(P, B, bf16, x3=False):
     """Launch tags (ops._Timed) of decoder level 1 / conv_1: forward 32->16, backward-data 16->32, filter gradient."""
-    c, w = ("conv-bf16", "wgrad-bf16") if bf16 else ("conv", "wgrad")
+    c, w = ("conv-bf16", "wgrad-bf16") if bf16 else (("conv-x3", "wgrad-x3") if x3 else ("conv", "wgrad"))
     return {"%s k5 s1 %d^3x%d 32->16" % (c, P, B), "%s k5 s1 %d^3x%d 16->32" % (c, P, B), "%s k5 s1 %d^3x%d 32->16" % (w, P, B)}
 
 
@@ -327,7 +329,8 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
         torch.cuda.synchronize()
 
     bf16 = compute == "bf16"
-    fam = family_tags(patch, batch, bf16)
+    x3 = compute == "fp32_split3"
+    fam = family_tags(patch, batch, bf16, x3)
     timed = set(fam) | {ops.WGRAD_GROUP_TAG}     # + the grouped launch of the other 5^3 filter gradients (bf16 storage)
     full_table = bool(os.environ.get("BENCH_KERNEL_TABLE"))
     graph = m._graph_mode() != "off"
@@ -402,13 +405,15 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
         pmc = latest_pmc()                                        # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
         if pmc and patch == 128 and batch == 1:
             fams = json.load(open(pmc)).get("families", {})
-            ent = fams.get("bf16" if bf16 else "fp32")
+            ent = fams.get("bf16" if bf16 else ("f32x3" if x3 else "fp32"))
             if ent:
                 traffic = ent["hbm_bytes_per_launch"]             # mean over the family's three launches
                 tper = ent.get("per_kernel")                      # forward / backward-data / filter gradient, each per launch
                 tsrc = "profiles/%s: rocprofv3 --pmc passes of this command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), not this run" % os.path.basename(pmc)
-        peak = PEAK_BF16_TFLOPS if bf16 else PEAK_FP32_TFLOPS
+        peak = PEAK_BF16_TFLOPS if bf16 else (PEAK_F32X3_TFLOPS if x3 else PEAK_FP32_TFLOPS)
         kname = ("conv5_bf16_c16_kernel (fwd 32->16) + conv5_bf16_r32_kernel (bwd-data 16->32) + wgrad5_bf16_rr_kernel (row-reuse filter gradient), bf16 tensors in and out" if bf16
+                 else "conv5_x3_kernel (fwd 32->16, bwd-data 16->32) + wgrad5_x3_kernel: fp32 tensors, six v_mfma_f32_16x16x32_bf16 per product of "
+                      "exactly split operands; peak = 2500 / 6 TF/s fp32-equivalent" if x3
                  else "conv_kernel<5,1,4,8,8,4,4,{1,2}> (fwd 32->16, bwd-data 16->32) + wgrad_kernel<5,1,4,4,16,1,16>")
         res["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
@@ -432,7 +437,7 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
             "avg_ms": round(v[3] / v[0], 4), "tflops": round(v[1] / (v[3] * 1e-3) / 1e12, 1),
             "frac_of_peak": round(v[1] / (v[3] * 1e-3) / 1e12 / peak_for(bf16), 4), "launches_timed": v[0],
             "note": "incl. its split-K slab writes; the slabs' one batched reduce is a separate launch"}
-    if world == 1 and patch == 128 and not os.environ.get("BENCH_NO_HBM_TABLE"):
+    if world == 1 and patch == 128 and not x3 and not os.environ.get("BENCH_NO_HBM_TABLE"):
         del m
         gc.collect()
         res["hbm_kernels"] = hbm_kernel_table(dev, bf16, classes)
@@ -499,7 +504,7 @@ def main():
         out = {"metric": metric, "value": r["value"],
                "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+               "vs_baseline": None, "dtype": "bf16" if bf16 else ("f32 (3xbf16 split operands, fp32 accumulate)" if args.compute == "fp32_split3" else "f32"), "data": "synthetic",
                "config": {"workload": "V-Net (16ch,4 levels,(1,2,3,3),3) train step fwd+Dice+bwd+Adam, %d^3 patch, %d modality, %d classes, "
                                       "batch %d/GPU (BASELINE configs[%d])" % (P, args.channels, args.classes, args.batch, 4 if bf16 else (2 if world == 1 else 3)),
                           "global_batch": world * args.batch, "parallelism": "dp%d" % world, "bn": "per-replica",
@@ -511,14 +516,24 @@ def main():
         for k in ("conv_ms_per_step", "conv_tflops"):
             if k in r:
                 out[k] = r[k]
-    if world == 1 and not bf16 and not args.no_c5 and args.patch == 128 and args.channels == 1:
+    if world == 1 and args.compute == "fp32" and not args.no_c5 and args.patch == 128 and args.channels == 1:
         # BASELINE configs[4] per-GPU workload on the same record (outside the headline's timed region)
         c5 = measure(args, args.patch, args.batch, 4, 5, "bf16", rank, local, world)
         c5["metric"] = "training patches/sec (128^3x4ch, 5 classes, bf16 storage + bf16 conv operands / fp32 accumulate, fp32 BN statistics and Dice sums), 1 GPU"
         c5["dtype"] = "bf16"
         c5["steps"], c5["warmup"] = args.steps, args.warmup
         out["c5_bf16"] = c5
-    if world == 1 and not bf16 and not args.no_c2 and args.patch == 128 and args.channels == 1:
+    if world == 1 and args.compute == "fp32" and not args.no_x3 and args.patch == 128 and args.channels == 1:
+        # the headline workload with ComputeDtype fp32_split3: reported NEXT TO the native fp32 number, never as `value`
+        x3r = measure(args, args.patch, args.batch, args.channels, args.classes, "fp32_split3", rank, local, world)
+        out["c3_f32x3"] = {"metric": "training patches/sec (128^3x1ch, fp32 tensors; 5^3 convolutions of the levels >= 32^3 as six bf16 MFMA "
+                                     "products of exactly split operands, fp32 accumulate), 1 GPU",
+                           "dtype": "f32 (3xbf16 split operands, fp32 accumulate)", "value": x3r["value"], "unit": "patches/s",
+                           "ms_per_step": x3r["ms_per_step"], "steps": args.steps, "warmup": args.warmup, "final_loss": x3r["final_loss"],
+                           "step_enqueue": x3r["step_enqueue"], "roofline": x3r["roofline"], "sustained": x3r.get("sustained"),
+                           "parity": "tests/test_hip_x3.py (2e-6 vs the fp64 oracle, the fp32-MFMA kernels' bound) and "
+                                     "tests/test_hip_golden_full.py::test_full_size_network_fp32[c3-fp32_split3] (the fp32 bounds, unchanged)"}
+    if world == 1 and not bf16 and args.compute == "fp32" and not args.no_c2 and args.patch == 128 and args.channels == 1:
         # BASELINE configs[1]: 64^3 patch, 1 modality, 2 classes, batch 2, fp32 -- the same measurement on a second model
         c2 = measure(args, 64, 2, 1, 2, "fp32", rank, local, world)
         out["c2_64cube_b2"] = {"metric": "training patches/sec (64^3x1ch fp32, batch 2), 1 GPU (BASELINE configs[1])", "value": c2["value"], "unit": "patches/s",

@@ -28,7 +28,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _run_case(dev, case):
+def _run_case(dev, case, compute=None):
     from vnet_tensorflow_amd import networks, ops
     fname, P, B, cin, K, seed, rounding = CASES[case]
     z = np.load(os.path.join(GOLD, fname))
@@ -37,7 +37,7 @@ def _run_case(dev, case):
     ref_net.GetNetwork(np.zeros((1, 16, 16, 16, cin)))             # creates the variables in the fixture's order
     assert list(store.vars.keys()) == [str(n) for n in z["names"]]
     x, lab = O.synthetic_batch(B, P, cin, K, seed=seed)
-    ops.set_compute_dtype({"bf16": "bf16_operands", "storage": "bf16"}.get(rounding, "fp32"))
+    ops.set_compute_dtype(compute or {"bf16": "bf16_operands", "storage": "bf16"}.get(rounding, "fp32"))
     try:
         net = networks.VNet(K, 0.0, 16, 4, (1, 2, 3, 3), 3, True, "prelu", device=dev)
         net.variables.values = {k: v.v for k, v in store.vars.items()}
@@ -82,10 +82,12 @@ def _grad_errors(z, net):
     return out
 
 
-@pytest.mark.parametrize("case", ["c3", "c2"])
-def test_full_size_network_fp32(dev, case):
-    """BASELINE configs[2]/[3] (128^3, B=1 -- the exact BENCH workload) and configs[1] (64^3, B=2) at full width."""
-    z, net, logits, loss, sm, pred, lab, K = _run_case(dev, case)
+@pytest.mark.parametrize("case,compute", [("c3", "fp32"), ("c2", "fp32"), ("c3", "fp32_split3"), ("c2", "fp32_split3")])
+def test_full_size_network_fp32(dev, case, compute):
+    """BASELINE configs[2]/[3] (128^3, B=1 -- the exact BENCH workload) and configs[1] (64^3, B=2) at full width; and the same
+    fixtures at the SAME bounds with ComputeDtype fp32_split3 (round 5: the 5^3 convolutions of the levels with enough bricks form
+    their products from six bf16 products of exactly split operands, csrc/conv_x3.h)."""
+    z, net, logits, loss, sm, pred, lab, K = _run_case(dev, case, compute)
     s = (slice(None),) + (slice(None, None, STRIDE),) * 3
     got = logits[s].cpu().numpy()
     ref = z["logits_sample"]

@@ -240,8 +240,9 @@ class image2label(object):
         self.label_filename = T['Data']['LabelFilename']
         self.synthetic = T['Data'].get('Synthetic')            # extension: synthetic generator (no NIfTI shipped)
         self.compute_dtype = T.get('ComputeDtype', 'fp32')            # extension: 'bf16' = BASELINE config C5 arithmetic
-        if self.compute_dtype not in ('fp32', 'bf16', 'bf16_operands'):
-            raise SystemExit("Invalid ComputeDtype %r (fp32 | bf16 | bf16_operands)" % (self.compute_dtype,))
+        # 'fp32_split3' (round 5): fp32 tensors and fp32 accuracy, the 5^3 convolutions on the bf16 matrix pipe (csrc/conv_x3.h)
+        if self.compute_dtype not in ('fp32', 'fp32_split3', 'bf16', 'bf16_operands'):
+            raise SystemExit("Invalid ComputeDtype %r (fp32 | fp32_split3 | bf16 | bf16_operands)" % (self.compute_dtype,))
         if self.compute_dtype == 'bf16':
             # since round 3 'bf16' means bf16 STORAGE (every activation a bf16 tensor; the operand-rounding form of round 2 is
             # 'bf16_operands'); its kernels move 8-channel units whose count is a power of two: fail HERE, not at the first forward
@@ -384,7 +385,7 @@ class image2label(object):
             # launch the bucket all-reduces once this fraction of the gradient bytes exists (parallel.py): keeps the
             # collective off the 256-CU-planned deep-level kernels; TrainingSetting.AllReduceHoldFraction / VNET_DP_HOLD
             # (bf16 mode: the backward pass that is left after encoder level 3 is shorter than the all-reduce -> launch when ready)
-            default_hold = 0.99 if ops.get_compute_dtype() == "fp32" else 0.0
+            default_hold = 0.99 if ops.get_compute_dtype() in ("fp32", "fp32_split3") else 0.0
             hold = float(os.environ.get("VNET_DP_HOLD", getattr(self, "allreduce_hold_fraction", default_hold)))
             # two-pass backward (pass 1: output layer, decoder, bottom level = 81 % of the gradient bytes; pass 2: encoder):
             # the replayed step is then gradients graph 1 -> all-reduce of pass 1's buckets (asynchronous) -> gradients graph 2
