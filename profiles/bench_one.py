@@ -1,5 +1,5 @@
 """Micro-benchmark of ONE 5^3 convolution problem in one mode (for rocprofv3 --pmc passes):
-   python profiles/bench_one.py <conv|wgrad> <fp32|bf16|bf16_operands> P Cin Cout [iters]
+   python profiles/bench_one.py <conv|wgrad> <fp32|fp32_split3|bf16|bf16_operands> P Cin Cout [iters]
    bf16 = bf16 storage (bf16 tensors in and out), bf16_operands = round 2's fp32 tensors + bf16 shadows"""
 import sys
 import torch
@@ -34,6 +34,8 @@ def run():
         ops._wgrad5_b16_call(x, None, dy, dw, (P, P, P), ci)
     elif mode == 'bf16_operands':
         ops._wgrad_bf16_call(x, None, dy, dw, (P, P, P))
+    elif mode == 'fp32_split3':
+        ops._wgrad_x3_call(x, None, dy, dw, (P, P, P))
     else:
         ops._wgrad_call(5, 1, x, None, dy, dw, (P, P, P), (P, P, P))
 

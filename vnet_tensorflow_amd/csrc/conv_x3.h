@@ -37,19 +37,40 @@ constexpr int X3_TILEB = 3 * X3_PIECEB;                  // 138240
 constexpr int X3_ROWB = X3_IX * 16, X3_ZB = X3_IY * X3_IX * 16;
 constexpr int X3_LDS = X3_TILEB + 8 * 32 * 4 + 64 * 8;   // + epilogue statistics [8 waves][32] + a dump slot per lane
 
+// Compile-time loop: body(std::integral_constant<int, k>) for k = 0 .. N - 1.  NOT `#pragma unroll`: when hipcc's IndVarSimplify visits
+// a not-yet-unrolled loop it sinks every side-effect-free instruction of the loop's preheader that the loop does not use to behind the
+// loop (sinkUnusedInvariants) -- i.e. the tails of the MFMA chains of the piece in front of it, whose B fragments then stay live
+// across the whole piece: +88 VGPRs, 49 spilled, scratch reloads between the prefetch loads (found by -opt-bisect-limit, round 5).
+template <int K, int N, typename F>
+__device__ __forceinline__ void x3_for_impl(F&& f) {
+    if constexpr (K < N) { f(std::integral_constant<int, K>{}); x3_for_impl<K + 1, N>(f); }
+}
+template <int N, typename F>
+__device__ __forceinline__ void x3_for(F&& f) { x3_for_impl<0, N>(f); }
+
 // ---- the K loop pieces -------------------------------------------------------------------------------------------------------
 // A fragments of NP consecutive pairs (piece-major per pair: h, m, l), global -> registers
+// (a UNIFORM base + a uniform 32-bit unit offset + the lane: the saddr form of global_load; with the lane folded into a 64-bit vector
+//  pointer every fragment address is a 64-bit vector multiply-add and a register pair)
+typedef const __attribute__((address_space(1))) u32x4* x3_gw_t;
 template <int NP>
-__device__ __forceinline__ void x3_load_a(bf16x8 (&A)[NP][3], const u32x4* __restrict__ ap, int astride) {
-#pragma unroll
-    for (int p = 0; p < NP; ++p)
-#pragma unroll
-        for (int s = 0; s < 3; ++s) A[p][s] = __builtin_bit_cast(bf16x8, ap[(size_t)p * astride + s * 64]);
+__device__ __forceinline__ void x3_load_a(bf16x8 (&A)[NP][3], const u32x4* __restrict__ wbase, unsigned u0, unsigned ustride, int lane) {
+    x3_for<NP * 3>([&](auto I) {
+        constexpr int p = decltype(I)::value / 3, s = decltype(I)::value % 3;
+        A[p][s] = __builtin_bit_cast(bf16x8, *(x3_gw_t)(wbase + (u0 + (unsigned)p * ustride + (unsigned)s * 64u) + lane));
+    });
+}
+__device__ __forceinline__ void x3_load_a1(bf16x8 (&A)[3], const u32x4* __restrict__ wbase, unsigned u0, int lane) {
+    x3_for<3>([&](auto I) {
+        constexpr int s = decltype(I)::value;
+        A[s] = __builtin_bit_cast(bf16x8, *(x3_gw_t)(wbase + (u0 + (unsigned)s * 64u) + lane));
+    });
 }
 
 __device__ __forceinline__ void x3_read_b(bf16x8 (&B)[3], const unsigned char* p) {
-#pragma unroll
-    for (int s = 0; s < 3; ++s) B[s] = *reinterpret_cast<const bf16x8*>(p + s * X3_PIECEB);
+    B[0] = *reinterpret_cast<const bf16x8*>(p);
+    B[1] = *reinterpret_cast<const bf16x8*>(p + X3_PIECEB);
+    B[2] = *reinterpret_cast<const bf16x8*>(p + 2 * X3_PIECEB);
 }
 
 // the six products of one (A pair, B row): piece indices (A, B); small terms first
@@ -58,53 +79,60 @@ __device__ __forceinline__ void x3_read_b(bf16x8 (&B)[3], const unsigned char* p
 
 // taps (dz pair, dy = DY0 .. DY0 + NDY - 1, dx) on the 8 output rows of this wave's plane: tile rows jr = DY0 .. DY0 + NDY + 6, row jr
 // feeds output row m = jr - dy.  bz: lane base + plane pair + dx.
-template <int DY0, int NDY>
-__device__ __forceinline__ void x3_zrows(f32x4 (&acc)[8], const unsigned char* bz, const bf16x8 (&A)[NDY][3]) {
+// (A0: index of the first of the NDY pairs in A -- slices of a larger register array without a cast, which would send it to scratch)
+template <int DY0, int NDY, int A0 = 0, int NA = NDY>
+__device__ __forceinline__ void x3_zrows(f32x4 (&acc)[8], const unsigned char* bz, const bf16x8 (&A)[NA][3]) {
     constexpr int J0 = DY0, J1 = DY0 + NDY + 7;
     bf16x8 Bn[3];
     x3_read_b(Bn, bz + J0 * X3_ROWB);
-#pragma unroll
-    for (int jr = J0; jr < J1; ++jr) {
+    x3_for<J1 - J0>([&](auto JI) {
+        constexpr int jr = J0 + decltype(JI)::value;
         bf16x8 B[3] = {Bn[0], Bn[1], Bn[2]};
-        if (jr + 1 < J1) x3_read_b(Bn, bz + (jr + 1) * X3_ROWB);
+        if constexpr (jr + 1 < J1) x3_read_b(Bn, bz + (jr + 1) * X3_ROWB);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-#pragma unroll
-            for (int d = 0; d < NDY; ++d) {
-                const int m = jr - DY0 - d;
-                if (m >= 0 && m < 8) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[d][X3_PROD_A(k)], B[X3_PROD_B(k)], acc[m], 0, 0, 0);
-            }
+        x3_for<6 * NDY>([&](auto KI) {
+            constexpr int k = decltype(KI)::value / NDY, d = decltype(KI)::value % NDY, m = jr - DY0 - d;
+            if constexpr (m >= 0 && m < 8)
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[A0 + d][X3_PROD_A(k)], B[X3_PROD_B(k)], acc[m], 0, 0, 0);
+        });
         __builtin_amdgcn_sched_barrier(0);
-    }
+    });
 }
 
-// plane dz = 4 of column dx: pairs (dy 0|1), (dy 2|3) from row-pair fragments (lanes 32..63 one row further), (dy 4 | nothing) from
-// single rows (both lane halves read the same row; the filter's second half is zero)
-__device__ __forceinline__ void x3_yrows(f32x4 (&acc)[8], const unsigned char* by, const unsigned char* b0, const bf16x8 (&A)[3][3]) {
+// plane dz = 4 of column dx: pairs (dy 0|1), (dy 2|3) from row-pair fragments (lanes 32..63 one row further): A[A0], A[A0 + 1]
+template <int A0, int NA>
+__device__ __forceinline__ void x3_yrows_pairs(f32x4 (&acc)[8], const unsigned char* by, const bf16x8 (&A)[NA][3]) {
     bf16x8 Bn[3];
     x3_read_b(Bn, by);
-#pragma unroll
-    for (int k = 0; k < 10; ++k) {                  // row pair (k | k + 1): output row k with q = 0, row k - 2 with q = 1
+    x3_for<10>([&](auto KI) {                       // row pair (k | k + 1): output row k with q = 0, row k - 2 with q = 1
+        constexpr int k = decltype(KI)::value;
         bf16x8 B[3] = {Bn[0], Bn[1], Bn[2]};
-        if (k + 1 < 10) x3_read_b(Bn, by + (k + 1) * X3_ROWB); else x3_read_b(Bn, b0 + 4 * X3_ROWB);
+        if constexpr (k + 1 < 10) x3_read_b(Bn, by + (k + 1) * X3_ROWB);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            if (k < 8) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][X3_PROD_A(t)], B[X3_PROD_B(t)], acc[k], 0, 0, 0);
-            if (k >= 2) acc[k - 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1][X3_PROD_A(t)], B[X3_PROD_B(t)], acc[k - 2], 0, 0, 0);
-        }
+        x3_for<6>([&](auto TI) {
+            constexpr int t = decltype(TI)::value;
+            if constexpr (k < 8) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[A0][X3_PROD_A(t)], B[X3_PROD_B(t)], acc[k], 0, 0, 0);
+            if constexpr (k >= 2) acc[k - 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[A0 + 1][X3_PROD_A(t)], B[X3_PROD_B(t)], acc[k - 2], 0, 0, 0);
+        });
         __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {                   // single rows m + 4
+    });
+}
+// tap (4, 4, dx) alone (the filter's second half is zero): single rows m + 4, both lane halves read the same row: A[A0]
+template <int A0, int NA>
+__device__ __forceinline__ void x3_yrows_single(f32x4 (&acc)[8], const unsigned char* b0, const bf16x8 (&A)[NA][3]) {
+    bf16x8 Bn[3];
+    x3_read_b(Bn, b0 + 4 * X3_ROWB);
+    x3_for<8>([&](auto MI) {
+        constexpr int m = decltype(MI)::value;
         bf16x8 B[3] = {Bn[0], Bn[1], Bn[2]};
-        if (m + 1 < 8) x3_read_b(Bn, b0 + (m + 5) * X3_ROWB);
+        if constexpr (m + 1 < 8) x3_read_b(Bn, b0 + (m + 5) * X3_ROWB);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 6; ++t) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2][X3_PROD_A(t)], B[X3_PROD_B(t)], acc[m], 0, 0, 0);
+        x3_for<6>([&](auto TI) {
+            constexpr int t = decltype(TI)::value;
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[A0][X3_PROD_A(t)], B[X3_PROD_B(t)], acc[m], 0, 0, 0);
+        });
         __builtin_amdgcn_sched_barrier(0);
-    }
+    });
 }
 
 template <bool STATS>
@@ -118,7 +146,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     float* sred = reinterpret_cast<float*>(smem + X3_TILEB);                  // [8 waves][2 x 16] epilogue statistics
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned char* dump = smem + X3_TILEB + 8 * 32 * 4 + lane * 8;
     const int j = lane & 15, g = lane >> 4, half = g & 1, hi = g >> 1;
     const int grp = wave >> 2, kw = wave & 3;
 
@@ -138,8 +165,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int nmine = (i_hi - i_lo - slot + G8 - 1) / G8;                     // items i_lo + slot + i * G8
     const int nch = a.nchunks;
     const int nsteps = nmine * nch;
-    const int astride = ncob * 3 * 64;                                        // u32x4 units between consecutive pairs
-    const u32x4* wq = reinterpret_cast<const u32x4*>(a.wp) + lane;
+    const unsigned astride = (unsigned)ncob * 3u * 64u;                       // u32x4 units between consecutive pairs
+    const u32x4* wbase = reinterpret_cast<const u32x4*>(a.wp);
 
     auto item_coords = [&](int it, int& b, int& bz, int& by, int& bx, int& cob) {
         int item = i_lo + slot + it * G8;
@@ -148,146 +175,193 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         by = item % a.nby; item /= a.nby;
         bz = item % a.nbz; b = item / a.nbz;
     };
-    float4 pv[XT::PER];
+    // Tile staging: a thread owns one (x, channel quad) column and walks the 72 (z, y) rows of the tile in steps of 6: row = r0 + 6 k,
+    // i.e. iz = k >> 1, iy = r0 + 6 (k & 1).  Loads are 16 bytes from ONE uniform 64-bit base (source tensor, sample, chunk) + a 32-bit
+    // element offset; out-of-volume units load a device zero line -- a select on the ADDRESS: a select on the data makes hipcc wait
+    // for the whole tile right where it was issued (s_memtime stamps: 4 K cycles in front of every step's first MFMA).
+    typedef const __attribute__((address_space(1))) f32x4* gf4_t;
+    f32x4 pv[XT::PER];
+    // (480 threads cover the 6 x 80 columns of a pass; the last 32 repeat the work of the 32 threads one row block before them -- same
+    //  loads, same stores -- instead of being masked: a per-row select on the store address is loop-invariant, and hipcc hoists all 36
+    //  of them out of the step loop and spills them)
+    const int stid = tid < XT::RPI * XT::COLS ? tid : tid - XT::COLS;
+    const int sr0 = stid / XT::COLS, scol = stid - sr0 * XT::COLS;
+    const int six = scol >> 2, scq = scol & 3;
     auto tile_issue = [&](int step) {
         const int it = step / nch, ch = step - it * nch;
         int b, bz, by, bx, cob;
         item_coords(it, b, bz, by, bx, cob);
-        XT::template issue_part<0, XT::PER>(pv, a.x0, a.x1, a.C0, a.C1, ch, b, bz * X3_TZ - 2, by * X3_TY - 2, bx * X3_TX - 2, a.Di, a.Hi, a.Wi, tid);
+        const int c0 = ch * 16;
+        const bool first = c0 < a.C0;
+        const int cs = first ? a.C0 : a.C1;
+        const float* src = (first ? a.x0 + c0 : a.x1 + (c0 - a.C0)) + (size_t)b * a.Di * a.Hi * a.Wi * cs;
+        const int gz0 = bz * X3_TZ - 2, gy = by * X3_TY - 2 + sr0, gx = bx * X3_TX - 2 + six;
+        const bool xok = (unsigned)gx < (unsigned)a.Wi;
+        const bool yok0 = xok && (unsigned)gy < (unsigned)a.Hi, yok1 = xok && (unsigned)(gy + 6) < (unsigned)a.Hi;
+        const int rs = a.Wi * cs;
+        const int off0 = (gy * a.Wi + gx) * cs + scq * 4;
+        x3_for<XT::PER>([&](auto KI) {
+            constexpr int k = decltype(KI)::value;
+            const int gz = gz0 + (k >> 1);
+            const bool ok = ((k & 1) ? yok1 : yok0) && (unsigned)gz < (unsigned)a.Di;
+            const int off = off0 + gz * a.Hi * rs + (k & 1) * 6 * rs;
+            gf4_t p = ok ? (gf4_t)(src + off) : (gf4_t)(vnet_zero_line);
+            pv[k] = *p;
+        });
     };
+    const unsigned cbase = (unsigned)((scq >> 1) * X3_PLANEB + six * 16 + (scq & 1) * 8 + sr0 * X3_ROWB);
     auto tile_commit = [&]() {
-        const int r0 = tid / XT::COLS, col = tid - r0 * XT::COLS;
-        const int ix = col >> 2, cq = col & 3;
-        unsigned char* base = tile + (cq >> 1) * X3_PLANEB + ix * 16 + (cq & 1) * 8;
-        const bool act = r0 < XT::RPI;
-#pragma unroll
-        for (int k = 0; k < XT::PER; ++k) {
-            const int row = r0 + k * XT::RPI;
+        // (opaque per call: the 36 store addresses depend only on the thread, hipcc would otherwise compute them once in front of the
+        //  step loop and keep -- spill -- them for the whole kernel: scratch reloads between the prefetch loads)
+        unsigned cb = cbase;
+        asm volatile("" : "+v"(cb));
+        unsigned char* base = tile + cb;
+        x3_for<XT::PER>([&](auto KI) {
+            constexpr int k = decltype(KI)::value;
             u32x2 h, m, l;
-            x3_split4(pv[k], h, m, l);
-            unsigned char* dst = act ? base + row * X3_ROWB : dump;
-            unsigned char* dst1 = act ? dst + X3_PIECEB : dump;
-            unsigned char* dst2 = act ? dst + 2 * X3_PIECEB : dump;
+            x3_split4(make_float4(pv[k][0], pv[k][1], pv[k][2], pv[k][3]), h, m, l);
+            unsigned char* dst = base + k * XT::RPI * X3_ROWB;
             *reinterpret_cast<u32x2*>(dst) = h;
-            *reinterpret_cast<u32x2*>(dst1) = m;
-            *reinterpret_cast<u32x2*>(dst2) = l;
-        }
+            *reinterpret_cast<u32x2*>(dst + X3_PIECEB) = m;
+            *reinterpret_cast<u32x2*>(dst + 2 * X3_PIECEB) = l;
+        });
+    };
+    // filter fragments of this wave's first piece of a step: (dz 0|1, dx = kc), five pairs
+    auto first_a = [&](bf16x8 (&A)[5][3], int step) {
+        const int it = step / nch, ch = step - it * nch;
+        const int cob = (i_lo + slot + it * G8) % ncob;
+        const int kc = (kw + ch) & 3;
+        x3_load_a<5>(A, wbase, ((unsigned)(ch * X3_NPAIR * ncob + cob) * 3u * 64u) + (unsigned)(kc * 5) * astride, astride, lane);
     };
 
     tile_issue(0);
     tile_commit();
+    bf16x8 A1[5][3];
+    first_a(A1, 0);
     __syncthreads();
 
     f32x4 acc[8];
+    VNET_STAMP_DECL;
     for (int step = 0; step < nsteps; ++step) {
+        VNET_STAMP_STEP(step);
+        VNET_STAMP(0);
         const int it = step / nch, ch = step - it * nch;
         const bool first = ch == 0, last = ch == nch - 1, more = step + 1 < nsteps;
         int b, bz, by, bx, cob;
         item_coords(it, b, bz, by, bx, cob);
-        if (first) {
-#pragma unroll
-            for (int m = 0; m < 8; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        if (first) x3_for<8>([&](auto MI) { acc[decltype(MI)::value] = f32x4{0.f, 0.f, 0.f, 0.f}; });
         const int kc = (kw + ch) & 3;                                       // tap column of this wave in this chunk
-        const u32x4* wc = wq + ((size_t)ch * X3_NPAIR * ncob + cob) * 3 * 64;   // pair 0 of (chunk, cout block)
+#ifndef X3_NO_PRIO
+        // The two waves of a SIMD (w, w + 4) run the same pieces; the matrix pipe goes to the OLDER one whenever both have an MFMA
+        // ready (s_memtime stamps: waves 0-3 finish their 780 MFMAs after 19 K cycles, waves 4-7 -- alone, at a single wave's rate --
+        // after 31 K).  Priority for the younger half during the first two pieces, for the older one afterwards: both halves reach the
+        // barrier together.
+        if (grp) __builtin_amdgcn_s_setprio(1);
+#endif
+        const unsigned wc = (unsigned)(ch * X3_NPAIR * ncob + cob) * 3u * 64u;      // pair 0 of (chunk, cout block), in 16-byte units
+        // Every piece's filter fragments are loaded one piece ahead (the first piece's before the barrier that ends the previous
+        // step): the two waves of a SIMD run the same piece sequence in near lockstep, so an L2 round trip at a piece head stalls both.
+        bf16x8 A2[5][3];
+        x3_load_a<5>(A2, wbase, wc + (unsigned)(25 + kc * 5) * astride, astride, lane);        // (dz 2|3, dx = kc)
+        __builtin_amdgcn_sched_barrier(0);
+        x3_zrows<0, 5>(acc, bZ + kc * 16, A1);                                          // (dz 0|1, dx = kc)
+        VNET_STAMP(1);
+        bf16x8 A3[4][3];
+        x3_load_a1(A3[0], wbase, wc + (unsigned)(50 + kc * 3) * astride, lane);          // (dz 4, dx = kc)
+        x3_load_a1(A3[1], wbase, wc + (unsigned)(51 + kc * 3) * astride, lane);
+        x3_load_a1(A3[2], wbase, wc + (unsigned)(52 + kc * 3) * astride, lane);
+        x3_load_a1(A3[3], wbase, wc + 64u * astride, lane);                             // tap (4, 4, 4): goes with kc == 3
+        __builtin_amdgcn_sched_barrier(0);
+        x3_zrows<0, 5>(acc, bZ + 2 * X3_ZB + kc * 16, A2);
+        VNET_STAMP(2);
+        // the column dx = 4 in four parts (3 / 3 / 3 / 3 + 1 pairs): pairs 20-22 | 23, 24, 45 | 46-48 | 49, 62, 63 (+ 64 above)
+        bf16x8 A4[3][3];
         {
-            bf16x8 A[5][3];
-            x3_load_a<5>(A, wc + (size_t)(kc * 5) * astride, astride);                 // (dz 0|1, dx = kc)
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) tile_issue(step + 1);                                            // behind the first filter loads: they must not queue behind the tile's
-            __builtin_amdgcn_sched_barrier(0);
-            x3_zrows<0, 5>(acc, bZ + kc * 16, A);
+            const int p0 = kc == 0 ? 20 : kc == 1 ? 23 : kc == 2 ? 46 : 49;
+            const int p1 = kc == 0 ? 21 : kc == 1 ? 24 : kc == 2 ? 47 : 62;
+            const int p2 = kc == 0 ? 22 : kc == 1 ? 45 : kc == 2 ? 48 : 63;
+            x3_load_a1(A4[0], wbase, wc + (unsigned)p0 * astride, lane);
+            x3_load_a1(A4[1], wbase, wc + (unsigned)p1 * astride, lane);
+            x3_load_a1(A4[2], wbase, wc + (unsigned)p2 * astride, lane);
         }
-        {
-            bf16x8 A[5][3];
-            x3_load_a<5>(A, wc + (size_t)(25 + kc * 5) * astride, astride);            // (dz 2|3, dx = kc)
-            x3_zrows<0, 5>(acc, bZ + 2 * X3_ZB + kc * 16, A);
-        }
-        {
-            bf16x8 A[3][3];
-            x3_load_a<3>(A, wc + (size_t)(50 + kc * 3) * astride, astride);            // (dz 4, dx = kc)
-            x3_yrows(acc, bY + kc * 16, b0 + kc * 16, A);
-        }
-        // the column dx = 4 in four parts (3 / 3 / 3 / 4 pairs)
+        __builtin_amdgcn_sched_barrier(0);
+        // the next tile's loads go out HERE: behind every filter load this step's MFMAs still wait for (vmcnt counts in order), and
+        // late enough that its 48 registers are not live next to two five-pair filter sets (the first two pieces)
+#ifndef X3_NO_PRIO
+        if (grp) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
+#endif
+        tile_issue(min(step + 1, nsteps - 1));         // (unconditional: a branch around an issue makes hipcc merge two vmcnt states)
+        __builtin_amdgcn_sched_barrier(0);
+        x3_yrows_pairs<0, 4>(acc, bY + kc * 16, A3);
+        x3_yrows_single<2, 4>(acc, b0 + kc * 16, A3);
+        if (kc == 3) x3_yrows_single<3, 4>(acc, b0 + 4 * 16, A3);
+        VNET_STAMP(3);
+        first_a(A1, min(step + 1, nsteps - 1));
+        __builtin_amdgcn_sched_barrier(0);
         if (kc == 0) {
-            bf16x8 A[3][3];
-            x3_load_a<3>(A, wc + (size_t)(20) * astride, astride);
-            x3_zrows<0, 3>(acc, bZ + 4 * 16, A);
+            x3_zrows<0, 3>(acc, bZ + 4 * 16, A4);
         } else if (kc == 1) {
-            {
-                bf16x8 A[2][3];
-                x3_load_a<2>(A, wc + (size_t)(23) * astride, astride);
-                x3_zrows<3, 2>(acc, bZ + 4 * 16, A);
-            }
-            {
-                bf16x8 A[1][3];
-                x3_load_a<1>(A, wc + (size_t)(45) * astride, astride);
-                x3_zrows<0, 1>(acc, bZ + 2 * X3_ZB + 4 * 16, A);
-            }
+            x3_zrows<3, 2, 0, 3>(acc, bZ + 4 * 16, A4);
+            x3_zrows<0, 1, 2, 3>(acc, bZ + 2 * X3_ZB + 4 * 16, A4);
         } else if (kc == 2) {
-            bf16x8 A[3][3];
-            x3_load_a<3>(A, wc + (size_t)(46) * astride, astride);
-            x3_zrows<1, 3>(acc, bZ + 2 * X3_ZB + 4 * 16, A);
+            x3_zrows<1, 3>(acc, bZ + 2 * X3_ZB + 4 * 16, A4);
         } else {
-            {
-                bf16x8 A[1][3];
-                x3_load_a<1>(A, wc + (size_t)(49) * astride, astride);
-                x3_zrows<4, 1>(acc, bZ + 2 * X3_ZB + 4 * 16, A);
-            }
-            {
-                bf16x8 A[3][3];
-                x3_load_a<3>(A, wc + (size_t)(62) * astride, astride);
-                x3_yrows(acc, bY + 4 * 16, b0 + 4 * 16, A);
-            }
+            x3_zrows<4, 1, 0, 3>(acc, bZ + 2 * X3_ZB + 4 * 16, A4);
+            x3_yrows_pairs<1, 3>(acc, bY + 4 * 16, A4);
         }
+        VNET_STAMP(4);
+#ifndef X3_NO_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();                                   // every wave is done reading the tile
+        VNET_STAMP(5);
         if (last) {
             // the four partial bricks of each group meet in LDS; wave kw sums and stores the output rows 2 kw, 2 kw + 1
-#pragma unroll
-            for (int m = 0; m < 8; ++m) *reinterpret_cast<f32x4*>(red + ((wave * 8 + m) * 64 + lane) * 4) = acc[m];
+            x3_for<8>([&](auto MI) { constexpr int m = decltype(MI)::value; *reinterpret_cast<f32x4*>(red + ((wave * 8 + m) * 64 + lane) * 4) = acc[m]; });
             __syncthreads();
             const int co0 = cob * 16, co = co0 + 4 * g;
             f32x4 o[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            x3_for<2>([&](auto TI) {
+                constexpr int t = decltype(TI)::value;
                 const int m = 2 * kw + t;
-                o[t] = *reinterpret_cast<const f32x4*>(red + (((grp * 4 + 0) * 8 + m) * 64 + lane) * 4);
-#pragma unroll
-                for (int k = 1; k < 4; ++k) o[t] += *reinterpret_cast<const f32x4*>(red + (((grp * 4 + k) * 8 + m) * 64 + lane) * 4);
-            }
+                const float* rp = red + ((grp * 4 * 8 + m) * 64 + lane) * 4;
+                o[t] = (*reinterpret_cast<const f32x4*>(rp) + *reinterpret_cast<const f32x4*>(rp + 8 * 64 * 4)) +
+                       (*reinterpret_cast<const f32x4*>(rp + 2 * 8 * 64 * 4) + *reinterpret_cast<const f32x4*>(rp + 3 * 8 * 64 * 4));
+            });
             float bias4[4] = {0.f, 0.f, 0.f, 0.f};
             if (a.bias && co < a.Cout) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) bias4[k] = a.bias[co + k];
+                const float4 bb = *reinterpret_cast<const float4*>(a.bias + co);
+                bias4[0] = bb.x; bias4[1] = bb.y; bias4[2] = bb.z; bias4[3] = bb.w;
             }
             float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
             const int oz = bz * X3_TZ + grp, ox = bx * X3_TX + j;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            x3_for<2>([&](auto TI) {
+                constexpr int t = decltype(TI)::value;
                 const int oy = by * X3_TY + 2 * kw + t;
-                if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo || co >= a.Cout) continue;
-                const size_t ov = ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
-                float e[4] = {o[t][0] + bias4[0], o[t][1] + bias4[1], o[t][2] + bias4[2], o[t][3] + bias4[3]};
-                if constexpr (STATS) {
-                    float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (a.res) rr = *reinterpret_cast<const float4*>(a.res + ov * a.Cout + co);
-                    const float vv[4] = {e[0] + rr.x, e[1] + rr.y, e[2] + rr.z, e[3] + rr.w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { s1[k] += vv[k]; s2[k] += vv[k] * vv[k]; }
+                if (oz < a.Do && oy < a.Ho && ox < a.Wo && co < a.Cout) {
+                    const size_t ov = ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+                    float e[4] = {o[t][0] + bias4[0], o[t][1] + bias4[1], o[t][2] + bias4[2], o[t][3] + bias4[3]};
+                    if constexpr (STATS) {
+                        float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (a.res) rr = *reinterpret_cast<const float4*>(a.res + ov * a.Cout + co);
+                        const float vv[4] = {e[0] + rr.x, e[1] + rr.y, e[2] + rr.z, e[3] + rr.w};
+                        s1[0] += vv[0]; s1[1] += vv[1]; s1[2] += vv[2]; s1[3] += vv[3];
+                        s2[0] += vv[0] * vv[0]; s2[1] += vv[1] * vv[1]; s2[2] += vv[2] * vv[2]; s2[3] += vv[3] * vv[3];
+                    }
+                    float* p = (co < a.Cy0) ? a.y0 + ov * a.Cy0 + co : a.y1 + ov * a.Cy1 + (co - a.Cy0);
+                    if (a.accum) {
+                        const float4 old = *reinterpret_cast<const float4*>(a.accsrc ? a.accsrc + ov * a.Cy0 + co : p);
+                        e[0] += old.x; e[1] += old.y; e[2] += old.z; e[3] += old.w;
+                    }
+                    *reinterpret_cast<float4*>(p) = make_float4(e[0], e[1], e[2], e[3]);
                 }
-                float* p = (co < a.Cy0) ? a.y0 + ov * a.Cy0 + co : a.y1 + ov * a.Cy1 + (co - a.Cy0);
-                if (a.accum) {
-                    const float4 old = *reinterpret_cast<const float4*>(a.accsrc ? a.accsrc + ov * a.Cy0 + co : p);
-                    e[0] += old.x; e[1] += old.y; e[2] += old.z; e[3] += old.w;
-                }
-                *reinterpret_cast<float4*>(p) = make_float4(e[0], e[1], e[2], e[3]);
-            }
+            });
             if constexpr (STATS) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                x3_for<4>([&](auto KI) {
+                    constexpr int k = decltype(KI)::value;
                     s1[k] = row16_sum(s1[k]); s2[k] = row16_sum(s2[k]);
                     if (j == 0) { sred[wave * 32 + 4 * g + k] = s1[k]; sred[wave * 32 + 16 + 4 * g + k] = s2[k]; }
-                }
+                });
             }
             __syncthreads();                               // the partial bricks are read; the statistics of all waves are in sred
             if constexpr (STATS) {
@@ -295,8 +369,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 stats_row_write<8, 16>(sred, a.stats, (size_t)brick, co0, a.Cout, tid);
             }
         }
+        VNET_STAMP(6);
         if (more) tile_commit();
+        VNET_STAMP(7);
         __syncthreads();
+        VNET_STAMP(8);
+        VNET_STAMP_FLUSH(step, wave, lane, 9);
     }
 }
 

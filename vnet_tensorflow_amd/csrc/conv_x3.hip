@@ -104,4 +104,9 @@ int vnet_conv_wgrad_x3(const float* x0, int C0, const float* x1, int C1, const f
     return VNET_OK;
 }
 
+#ifdef VNET_STAMPS
+// experiment build only (profiles/x3_stamps.sh): where conv5_x3_kernel writes its s_memtime stamps (4 steps x 8 waves x 12 int64)
+int vnet_debug_set_stamps_x3(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf)); }
+#endif
+
 }  // extern "C"
