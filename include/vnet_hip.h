@@ -154,12 +154,13 @@ int vnet_conv_fwd_bf16_stats(const float* x0, int C0, const float* x1, int C1, c
  * those of the backward problem).  Channel counts multiples of 16 (VNET_E_UNSUPPORTED otherwise); vnet_conv_x3_ok tells
  * whether the kernel is the better choice for a shape (enough 2x8x16 bricks x 16-cout blocks for one round of the chip).
  * acc: NULL, y0 (y0 += conv, see vnet_conv_fwd_acc) or another tensor of y0's shape (Cy1 == 0) added out of place.
- * res / stats: as vnet_conv_fwd_stats, rows = vnet_conv_x3_stats_rows (one per brick), Cy1 == 0.  No workspace. */
+ * res / stats: as vnet_conv_fwd_stats, rows = vnet_conv_x3_stats_rows, Cy1 == 0.  ws >= vnet_conv_x3_ws_bytes. */
 int vnet_conv_x3_ok(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W);
-int vnet_conv_x3_stats_rows(int B, int D, int H, int W);
+int vnet_conv_x3_stats_rows(int Cin, int Cout, int B, int D, int H, int W);
+size_t vnet_conv_x3_ws_bytes(int Cin, int Cout, int B, int D, int H, int W);   /* > 0: the deep levels split their channel chunks over workgroups (partial slabs + reduce) */
 int vnet_conv_fwd_x3(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
                      float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
-                     const float* acc, const float* res, float* stats, void* stream);
+                     const float* acc, const float* res, float* stats, void* ws, size_t ws_bytes, void* stream);
 
 /* Filter gradient of the same convolution (Conv3DBackpropFilterV2 behind model.py:660) with the six-product arithmetic:
  * dw [125][C0 + C1][Cout] (TF layout).  Channel counts multiples of 16; ws >= vnet_wgrad_x3_ws_bytes (partial slabs, reduced by

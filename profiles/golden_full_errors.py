@@ -2,8 +2,10 @@ import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from tests import test_hip_golden_full as T
 dev = torch.device("cuda", 0)
+import os
+compute = os.environ.get("GOLDEN_COMPUTE")          # e.g. fp32_split3 (default: the fixture's own mode)
 for case in sys.argv[1:]:
-    z, net, logits, loss, sm, pred, lab, K = T._run_case(dev, case)
+    z, net, logits, loss, sm, pred, lab, K = T._run_case(dev, case, compute)
     errs = T._grad_errors(z, net)
     print(case, "loss err", abs(loss - float(z["loss"])))
     for e in sorted(errs, key=lambda e: -e[1])[:25]:

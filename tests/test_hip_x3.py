@@ -28,6 +28,8 @@ def split3():
     (1, 6, 16, 32, 64, 0, 16),     # four chunks: every rotation of the tap columns
     (1, 3, 5, 7, 16, 0, 48),       # a volume smaller than one brick, three cout blocks
     (1, 2, 8, 40, 48, 0, 32),      # three chunks, ragged x
+    (1, 8, 8, 16, 128, 0, 32),     # few items, eight chunks: the chunks split over four workgroups per item (partial slabs + reduce)
+    (1, 4, 16, 16, 32, 32, 32),    # K split with two sources
 ])
 def test_conv5_x3(dev, split3, shape):
     ops = split3
@@ -83,7 +85,7 @@ def test_x3_epilogue_statistics_accumulate_and_residual(dev, split3):
     y_ref = O.conv_nd_fwd(x, w, 1) + b
     tx, tw, tb, tr = g(x, dev), g(w, dev), g(b, dev), g(r, dev)
     wp = ops.packed_weights(tw, ops.PACK_FWD_X3, 125, C, Co)
-    rows = L.vnet_conv_x3_stats_rows(B, D, H, W)
+    rows = L.vnet_conv_x3_stats_rows(C, Co, B, D, H, W)
     assert rows == 3 * 2 * 2
     stats = torch.full((rows, 2 * Co), float("nan"), device=dev)
     y = torch.empty((B, D, H, W, Co), device=dev)

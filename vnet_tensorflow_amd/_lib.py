@@ -22,8 +22,9 @@ SIGNATURES = {
     "vnet_packed_dims": (_i, [_i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "vnet_pack_weights_batched": (_i, [_vp, _i, _vp]),
     "vnet_conv_x3_ok": (_i, [_i] * 8),
-    "vnet_conv_x3_stats_rows": (_i, [_i] * 4),
-    "vnet_conv_fwd_x3": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "vnet_conv_x3_stats_rows": (_i, [_i] * 6),
+    "vnet_conv_x3_ws_bytes": (_sz, [_i] * 6),
+    "vnet_conv_fwd_x3": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vnet_wgrad_x3_ok": (_i, [_i] * 7),
     "vnet_wgrad_x3_ws_bytes": (_sz, [_i] * 6),
     "vnet_conv_wgrad_x3": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),

@@ -156,20 +156,21 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
     const int ncob = a.CoutP >> 4;
     const int nbrick = a.B * a.nbz * a.nby * a.nbx;
-    const int nitems = nbrick * ncob;
+    const int nks = a.nz;                                                     // K splits (chunk ranges of a.cps chunks; partial slabs in a.part)
+    const int nitems = nbrick * ncob * nks;
     const int G8 = gridDim.x >> 3;                                            // workgroups per XCD (grid is a multiple of 8)
     const int per_xcd = (nitems + 7) >> 3;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int i_lo = xcd * per_xcd, i_hi = min(nitems, i_lo + per_xcd);
     if (i_lo + slot >= i_hi) return;
     const int nmine = (i_hi - i_lo - slot + G8 - 1) / G8;                     // items i_lo + slot + i * G8
-    const int nch = a.nchunks;
+    const int nch = a.cps;                                                    // chunks per item
     const int nsteps = nmine * nch;
     const unsigned astride = (unsigned)ncob * 3u * 64u;                       // u32x4 units between consecutive pairs
     const u32x4* wbase = reinterpret_cast<const u32x4*>(a.wp);
 
     auto item_coords = [&](int it, int& b, int& bz, int& by, int& bx, int& cob) {
-        int item = i_lo + slot + it * G8;
+        int item = (i_lo + slot + it * G8) / nks;
         cob = item % ncob; item /= ncob;
         bx = item % a.nbx; item /= a.nbx;
         by = item % a.nby; item /= a.nby;
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int sr0 = stid / XT::COLS, scol = stid - sr0 * XT::COLS;
     const int six = scol >> 2, scq = scol & 3;
     auto tile_issue = [&](int step) {
-        const int it = step / nch, ch = step - it * nch;
+        const int it = step / nch, ch = ((i_lo + slot + it * G8) % nks) * nch + (step - it * nch);
         int b, bz, by, bx, cob;
         item_coords(it, b, bz, by, bx, cob);
         const int c0 = ch * 16;
@@ -228,8 +229,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     };
     // filter fragments of this wave's first piece of a step: (dz 0|1, dx = kc), five pairs
     auto first_a = [&](bf16x8 (&A)[5][3], int step) {
-        const int it = step / nch, ch = step - it * nch;
-        const int cob = (i_lo + slot + it * G8) % ncob;
+        const int it = step / nch, item = i_lo + slot + it * G8, ch = (item % nks) * nch + (step - it * nch);
+        const int cob = (item / nks) % ncob;
         const int kc = (kw + ch) & 3;
         x3_load_a<5>(A, wbase, ((unsigned)(ch * X3_NPAIR * ncob + cob) * 3u * 64u) + (unsigned)(kc * 5) * astride, astride, lane);
     };
@@ -245,8 +246,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int step = 0; step < nsteps; ++step) {
         VNET_STAMP_STEP(step);
         VNET_STAMP(0);
-        const int it = step / nch, ch = step - it * nch;
-        const bool first = ch == 0, last = ch == nch - 1, more = step + 1 < nsteps;
+        const int it = step / nch, lc = step - it * nch, ks = (i_lo + slot + it * G8) % nks, ch = ks * nch + lc;
+        const bool first = lc == 0, last = lc == nch - 1, more = step + 1 < nsteps;
         int b, bz, by, bx, cob;
         item_coords(it, b, bz, by, bx, cob);
         if (first) x3_for<8>([&](auto MI) { acc[decltype(MI)::value] = f32x4{0.f, 0.f, 0.f, 0.f}; });
@@ -340,6 +341,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const int oy = by * X3_TY + 2 * kw + t;
                 if (oz < a.Do && oy < a.Ho && ox < a.Wo && co < a.Cout) {
                     const size_t ov = ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+                    if (a.part) {                          // K split: the raw partial sums; bias / accumulate / statistics belong to the reduce
+                        *reinterpret_cast<f32x4*>(a.part + (size_t)ks * a.part_stride + ov * a.CoutP + co) = o[t];
+                        return;
+                    }
                     float e[4] = {o[t][0] + bias4[0], o[t][1] + bias4[1], o[t][2] + bias4[2], o[t][3] + bias4[3]};
                     if constexpr (STATS) {
                         float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -365,7 +370,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
             __syncthreads();                               // the partial bricks are read; the statistics of all waves are in sred
             if constexpr (STATS) {
-                int brick = (i_lo + slot + it * G8) / ncob;
+                int brick = (i_lo + slot + it * G8) / (ncob * nks);
                 stats_row_write<8, 16>(sred, a.stats, (size_t)brick, co0, a.Cout, tid);
             }
         }
@@ -581,11 +586,20 @@ inline bool x3_wgrad_ok(int C0, int C1, int Cout, int B, int D, int H, int W) {
     return p.nbrick >= 4 * p.nsplit;                   // at least four bricks per workgroup: the first tile load is exposed
 }
 
-// does the f32x3 kernel take this 5^3 stride-1 problem?  (whole 16-channel blocks on both sides, enough items for one round of the chip)
-inline bool x3_conv_ok(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W) {
-    if (C0 <= 0 || Cy0 <= 0 || (C0 & 15) || (C1 & 15) || (Cy0 & 15) || (Cy1 & 15)) return false;
-    const long items = (long)B * ceil_div(D, X3_TZ) * ceil_div(H, X3_TY) * ceil_div(W, X3_TX) * ((Cy0 + Cy1) / 16);
-    return items >= 256 && W >= 16;
+// does the f32x3 kernel take this 5^3 stride-1 problem?  (whole 16-channel blocks on both sides, rows of >= 16 voxels, and enough
+// (brick, cout block) items for one round of the chip -- if need be with the channel chunks split over several workgroups:
+// partial slabs + splitk_reduce_kernel, the deep levels)
+struct X3Plan { int ok, nks, cps; long items; };
+inline X3Plan x3_plan_conv(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W) {
+    X3Plan p{0, 1, 0, 0};
+    if (C0 <= 0 || Cy0 <= 0 || (C0 & 15) || (C1 & 15) || (Cy0 & 15) || (Cy1 & 15) || W < 16) return p;
+    const int nch = (C0 + C1) / 16;
+    p.items = (long)B * ceil_div(D, X3_TZ) * ceil_div(H, X3_TY) * ceil_div(W, X3_TX) * ((Cy0 + Cy1) / 16);
+    p.cps = nch;
+    while (p.items * p.nks < 256 && p.cps % 2 == 0 && p.cps >= 4) { p.nks *= 2; p.cps /= 2; }      // at least two chunks per item
+    p.ok = p.items * p.nks >= 192;
+    return p;
 }
+inline bool x3_conv_ok(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W) { return x3_plan_conv(C0, C1, Cy0, Cy1, B, D, H, W).ok != 0; }
 
 }  // namespace

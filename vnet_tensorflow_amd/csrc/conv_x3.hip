@@ -25,14 +25,27 @@ int vnet_conv_x3_ok(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W
     return x3_conv_ok(C0, C1, Cy0, Cy1, B, D, H, W) ? 1 : 0;
 }
 
-int vnet_conv_x3_stats_rows(int B, int D, int H, int W) {
-    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+// rows of the epilogue-statistics buffer [rows][2][Cout]: one per 2x8x16 brick, or (K-split launches) one per block of the reduce
+int vnet_conv_x3_stats_rows(int Cin, int Cout, int B, int D, int H, int W) {
+    if (Cin <= 0 || Cout <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const X3Plan p = x3_plan_conv(Cin, 0, Cout, 0, B, D, H, W);
+    if (p.nks > 1) {
+        if (Cout > 256 || 256 % Cout) return 0;
+        const size_t total = (size_t)B * D * H * W * Cout;
+        return (int)min((size_t)2048, (total + 255) / 256);
+    }
     return B * ceil_div(D, X3_TZ) * ceil_div(H, X3_TY) * ceil_div(W, X3_TX);
+}
+
+size_t vnet_conv_x3_ws_bytes(int Cin, int Cout, int B, int D, int H, int W) {
+    if (Cin <= 0 || Cout <= 0 || (Cin & 15) || (Cout & 15) || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const X3Plan p = x3_plan_conv(Cin, 0, Cout, 0, B, D, H, W);
+    return p.nks > 1 ? (size_t)p.nks * B * D * H * W * Cout * sizeof(float) : 0;
 }
 
 int vnet_conv_fwd_x3(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
                      float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
-                     const float* acc, const float* res, float* stats, void* stream) {
+                     const float* acc, const float* res, float* stats, void* ws, size_t ws_bytes, void* stream) {
     if (!x0 || !wp || !y0 || C0 <= 0 || Cy0 <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return VNET_E_BADARG;
     if ((C1 > 0 && !x1) || (Cy1 > 0 && !y1) || C1 < 0 || Cy1 < 0) return VNET_E_BADARG;
     if ((C0 & 15) || (C1 & 15) || (Cy0 & 15) || (Cy1 & 15)) return VNET_E_UNSUPPORTED;
@@ -49,9 +62,19 @@ int vnet_conv_fwd_x3(const float* x0, int C0, const float* x1, int C1, const voi
     a.pad = 2; a.padx = 2; a.vec_in = 1; a.vec_out = 1;
     a.accum = acc ? 1 : 0; a.accsrc = (acc && acc != y0) ? acc : nullptr;
     a.res = res; a.stats = stats;
+    // (the plan is that of the whole problem: the same whether the channels come from one source or two, go to one output or two)
+    const X3Plan p = x3_plan_conv(a.Cin, 0, a.Cout, 0, B, D, H, W);
+    a.nz = p.nks; a.cps = p.cps ? p.cps : a.nchunks;
+    const size_t nvox = (size_t)B * D * H * W;
+    if (p.nks > 1) {
+        const size_t need = (size_t)p.nks * nvox * a.Cout * sizeof(float);
+        if (!ws || ws_bytes < need) return VNET_E_WORKSPACE;
+        if (stats && (a.Cout > 256 || 256 % a.Cout)) return VNET_E_UNSUPPORTED;
+        a.part = reinterpret_cast<float*>(ws); a.part_stride = nvox * a.Cout;
+    }
     hipStream_t st = (hipStream_t)stream;
     const int grid = x3_grid();
-    if (stats) {
+    if (stats && p.nks == 1) {
         auto k = conv5_x3_kernel<true>;
         static unsigned long long attr_done = 0;
         if (int ae = ensure_lds(k, X3_LDS, attr_done)) return ae;
@@ -63,6 +86,13 @@ int vnet_conv_fwd_x3(const float* x0, int C0, const float* x1, int C1, const voi
         hipLaunchKernelGGL(k, dim3(grid), dim3(512), X3_LDS, st, a);
     }
     VNET_LAUNCH_CHECK();
+    if (p.nks > 1) {
+        const size_t total = nvox * a.Cout;
+        const int blocks = (int)min((size_t)2048, (total + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, a.part_stride, p.nks, bias,
+                           y0, y1, Cy0, Cy1, a.CoutP, nvox, a.accum, a.res, a.stats, a.accsrc);
+        VNET_LAUNCH_CHECK();
+    }
     return VNET_OK;
 }
 

@@ -489,7 +489,9 @@ def _conv_call(ks, stride, up, x0, x1, wp, bias, y0, y1, dims_in, dims_out, kx=0
                  _ptr(ws), nb, _stream()), "vnet_conv_fwd")
 
 
-_X3 = {"force": False}       # (tests) take the f32x3 kernels for every shape they can run, not only where they pay
+# force: (tests) take the f32x3 kernels for every shape they can run, not only where they pay;  ksplit: the deep levels (few bricks:
+# channel chunks split over workgroups, partial slabs + reduce) take them too (VNET_X3_KSPLIT=0: A/B measurements)
+_X3 = {"force": False, "ksplit": _os.environ.get("VNET_X3_KSPLIT", "1") != "0"}
 
 
 def _x3_ok(C0, C1, Cy0, Cy1, B, dims):
@@ -497,7 +499,10 @@ def _x3_ok(C0, C1, Cy0, Cy1, B, dims):
         return False
     if _X3["force"]:
         return C0 % 16 == 0 and C1 % 16 == 0 and Cy0 % 16 == 0 and Cy1 % 16 == 0
-    return _lib.lib().vnet_conv_x3_ok(C0, C1, Cy0, Cy1, B, *dims) == 1
+    L = _lib.lib()
+    if L.vnet_conv_x3_ok(C0, C1, Cy0, Cy1, B, *dims) != 1:
+        return False
+    return _X3["ksplit"] or L.vnet_conv_x3_ws_bytes(C0 + C1, Cy0 + Cy1, B, *dims) == 0
 
 
 def _conv_x3_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res=None):
@@ -510,9 +515,11 @@ def _conv_x3_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res=N
     flops = 2.0 * nvox * 125 * (C0 + C1) * (Cy0 + Cy1)
     nbytes = 4.0 * (nvox * (C0 + C1) + nvox * (Cy0 + Cy1) + 125 * (C0 + C1) * (Cy0 + Cy1) + (Cy0 + Cy1))
     tag = "conv-x3 k5 s1 %d^3x%d %d->%d" % (dims[2], B, C0 + C1, Cy0 + Cy1)
+    nb = L.vnet_conv_x3_ws_bytes(C0 + C1, Cy0 + Cy1, B, *dims)
+    ws = workspace(nb, x0.device) if nb else None
     with _Timed(tag, flops, nbytes):
         check(L.vnet_conv_fwd_x3(_ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias), _ptr(y0), Cy0, _ptr(y1), Cy1, B, *dims,
-                                 _ptr(y0) if accum else None, _ptr(res), _ptr(stats), _stream()), "vnet_conv_fwd_x3")
+                                 _ptr(y0) if accum else None, _ptr(res), _ptr(stats), _ptr(ws), nb, _stream()), "vnet_conv_fwd_x3")
 
 
 def _conv_bf16_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res=None, acc_src=None):
@@ -1294,7 +1301,7 @@ def _epilogue_stats_buffer(bf16, ks, kx, stride, x0, x1, O, dims_out):
         # 0.07 ms of a 25.7 ms step; VNET_BN_STATS_FP32=0 keeps it to the split-K launches (statistics from the reduce kernel)
         rows = 0
         if ks == 5 and stride == 1 and kx in (0, 5) and _FUSE["bn_stats_fp32_direct"] and _x3_ok(C0, C1, O, 0, B, dims_out):
-            rows = L.vnet_conv_x3_stats_rows(B, *dims_out)                    # f32x3 kernel: one row per 2x8x16 brick
+            rows = L.vnet_conv_x3_stats_rows(C0 + C1, O, B, *dims_out)        # f32x3 kernel: one row per 2x8x16 brick (or per reduce block)
         if ks == 2 and stride == 2 and x1 is None and _DIRECT2["on"]:
             rows = L.vnet_conv2_direct_stats_rows(C0, O, B, *dims_out)        # the LDS-free direct kernel (levels 1-2): one row per workgroup
         if rows <= 0:
