@@ -211,3 +211,65 @@ def test_bf16_storage_mode_two_restatements_agree(cin, K, variant):
         if n > 1e-12:
             worst = max(worst, float(np.linalg.norm(gt - r["grads"][k]) / n))
     assert worst < 1e-8, worst       # (measured 4e-14 .. 7e-12 on these seeded cases: no rounding flipped)
+
+
+# ---- the reference's own graph-building code, executed once in the build container (tests/golden/make_ref_wiring.py) ------------
+_WIRING = sorted(f[len("ref_wiring_"):-4] for f in os.listdir(os.path.join(os.path.dirname(__file__), "golden"))
+                 if f.startswith("ref_wiring_") and f.endswith(".npz"))
+
+
+@pytest.mark.parametrize("case", _WIRING)
+def test_reference_wiring_matches_oracle_and_product_names(case):
+    """Fixtures made by RUNNING networks.VNet.GetNetwork (networks.py:246-365) / VNet.VNet.network_fn (VNet.py:26-155) / layers2
+    (layers2.py:59-99) / model.dice_coe (model.py:26-85) from /root/reference against a NumPy-eager stand-in for tf.* (the
+    stand-in's arithmetic and TF naming rules are this repo's: this pins WIRING, creation ORDER and variable NAMES -- the checkpoint
+    contract -- not TensorFlow's numerics; parity stays unpinned by the reference).  Checked here: the oracle creates the same
+    trainables in the same order with the same shapes and the same moving-statistics set, its logits, its moving-average updates
+    and its three dice_coe forms agree to 1e-10; the product's variable store (vnet_tensorflow_amd/_scope.py via networks / VNet)
+    creates the same names, shapes and order."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_wiring_%s.npz" % case))
+    variant, cin, K, C, levels, convs, bottom, act = [str(v) for v in z["config"]]
+    cin, K, C, levels, bottom = int(cin), int(K), int(C), int(levels), int(bottom)
+    convs = tuple(int(v) for v in convs.split(","))
+    names = [str(n) for n in z["names"]]
+    trainable = [bool(t) for t in z["trainable"]]
+    shapes = [tuple(int(v) for v in str(s).split(",")) if str(s) else () for s in z["shapes"]]
+    values = {n: z["v:" + n].astype(np.float64) for n in names}
+    x = z["x"].astype(np.float64)
+
+    ps = O.ParamStore(rng=np.random.default_rng(0), values=values)
+    net = O.VNetOracle(K, 0.0, C, levels, convs, bottom, act, variant, ps)
+    for n in names:                                                     # injected moving statistics
+        if not trainable[names.index(n)]:
+            ps.state[n] = values[n].copy()
+    logits = net.GetNetwork(x)
+    want_tr = [(n, s) for n, s, t in zip(names, shapes, trainable) if t]
+    assert [(n, tuple(ps.vars[n].v.shape)) for n in ps.order] == want_tr
+    assert set(ps.state) == {n for n, t in zip(names, trainable) if not t}
+    # tf.layers.BatchNormalization.build order: gamma, beta, moving_mean, moving_variance, consecutively
+    for i, n in enumerate(names):
+        if n.endswith("/gamma"):
+            base = n[:-len("gamma")]
+            assert names[i + 1:i + 4] == [base + "beta", base + "moving_mean", base + "moving_variance"]
+    got = logits.v if hasattr(logits, "v") else logits
+    assert np.abs(got - z["logits"]).max() < 1e-10 * max(1.0, np.abs(z["logits"]).max())
+    for n in ps.state:                                                  # the update ops of one training step (incl. the dead batch-norms)
+        assert np.abs(ps.state[n] - z["u:" + n]).max() < 1e-10, n
+    # model.dice_coe as the loss switch calls it (model.py:503-504, 70-75)
+    zc = z["logits"] - z["logits"].max(-1, keepdims=True)
+    sm = np.exp(zc) / np.exp(zc).sum(-1, keepdims=True)
+    oh = np.eye(K)[z["labels"].astype(np.int64)]
+    ax = (1, 2, 3)
+    assert abs(float(O.dice_coe(O.const(sm), oh, 'sorensen', ax).v) - float(z["dice_sorensen"])) < 1e-12
+    assert abs(float(O.dice_coe(O.const(sm), oh, 'jaccard', ax).v) - float(z["dice_jaccard"])) < 1e-12
+    assert abs(float(O.dice_coe(O.const(sm), oh, 'sorensen', ax, weights=list(z["dice_weights"])).v) - float(z["dice_weighted_sorensen"])) < 1e-12
+
+    # the product's mirrored modules create the same variables (names, shapes, creation order)
+    from vnet_tensorflow_amd import networks, VNet
+    shape = tuple(x.shape)
+    if variant == "networks":
+        pnet = networks.VNet(K, 0.0, C, levels, convs, bottom, True, act, device="cpu").build(shape)
+    else:
+        pnet = VNet.VNet(K, 1.0, C, levels, convs, bottom, True, act, device="cpu").build(shape)
+    assert [(n, tuple(p.shape)) for n, p in pnet.named_parameters()] == want_tr
+    assert set(pnet.variables.buffers) == {n for n, t in zip(names, trainable) if not t}
