@@ -1,9 +1,14 @@
-"""Turns the rocprofv3 CSVs of one profiling round (gpurun_out/<dir>) into the committed summaries:
-  profiles/<tag>_kernel_stats.csv      copy of `rocprofv3 --kernel-trace --stats` for `python bench.py`
-  profiles/<tag>_pmc.json              FETCH_SIZE / WRITE_SIZE per launch of the dominant kernels
-Usage: python profiles/summarize.py gpurun_out/prof2 r01
-FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE under-reports a wide coalesced stream by 2x
-(MI355X_MICROARCH.md, HBM section), so the read side is doubled; WRITE_SIZE is taken as reported (uncalibrated)."""
+"""Turns the rocprofv3 CSVs of one profiling round (gpurun_out/<dir>, made by profiles/collect.sh) into the committed summaries:
+  profiles/<tag>_kernel_stats_<leg>.csv   `rocprofv3 --kernel-trace --stats` of `python bench.py <leg>`, ONE LEG PER RUN (fp32 headline,
+                                          x3 = fp32_split3, c5 = bf16 4-modality / 5-class, c2 = 64^3 batch 2): every row is one
+                                          problem shape per kernel instantiation or -- for the persistent-grid kernels -- one leg
+  profiles/<tag>_pmc.json                 FETCH_SIZE / WRITE_SIZE per launch of the dominant kernels, per leg
+Usage: python profiles/summarize.py gpurun_out/prof5 r05
+Round 5: rounds 1-4 profiled ONE command that ran all legs; the persistent-grid kernels (fp32 filter gradient:
+131072 threads whatever the shape) then averaged the 128^3 and the 64^3 B=2 launches into one row.  Family members are now picked
+per leg by (kernel, grid, position in the step's launch order), the step count taken from the once-per-step softmax_dice_bwd kernel.
+FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE under-reports a wide coalesced stream by 2x (MI355X_MICROARCH.md, HBM
+section), so the read side is doubled; WRITE_SIZE is taken as reported (uncalibrated)."""
 import csv
 import json
 import os
@@ -11,10 +16,28 @@ import shutil
 import sys
 from collections import defaultdict
 
-# launches per step of the C5 network's 32-cout row-pair kernel without statistics / of the row-reuse filter gradient with TZ = 4
-# (checked against the per-step launch counts the script prints)
-FAM_BWD_PER_STEP = None
-FAM_WGRAD_PER_STEP = None
+LEGS = ("fp32", "x3", "c5", "c2")
+KEEP = ("conv_kernel<", "wgrad_kernel<", "conv5_bf16", "wgrad5_bf16", "wgrad5_b16", "conv5_x3", "wgrad5_x3", "conv2_", "bn_", "input_")
+
+# The kernel family bench.py reports = decoder level 1 conv_1 at 128^3: forward 32->16, backward-data 16->32, filter gradient.
+# A member: (role, kernel-name prefix, grid or None, position in the step: an index into that kernel's launches of one step, or
+# "longest").  Every step launches the same sequence, so the launches of a (name, grid) split into nsteps equal groups.
+FAMILIES = {
+    "fp32": ("fp32", [("fwd", "conv_kernel<5, 1, 4, 8, 8, 4, 4, 1, false, 5, true", "2097152", 0),
+                      ("bwd", "conv_kernel<5, 1, 4, 8, 8, 4, 4, 2, false, 5, false", "2097152", 0),
+                      ("wgrad", "wgrad_kernel<5, 1, 4, 4, 16, 1, 16, 5", "131072", 0)]),
+    # fp32_split3: persistent kernels (grid = CUs x 512 whatever the problem), and the plain instantiation serves the K-split forward
+    # launches of the 16^3 level as well as every backward-data launch: a member is the LONGEST launch of its kernel in a step -- the
+    # 128^3 launches of dec1/conv_1 (268 GF each) take twice as long as any other layer's
+    "f32x3": ("x3", [("fwd", "conv5_x3_kernel<true>", None, "longest"),
+                     ("bwd", "conv5_x3_kernel<false>", None, "longest"),
+                     ("wgrad", "wgrad5_x3_kernel", None, "longest")]),
+    # C5, bf16 storage: forward with statistics 16->16, 32->16 = the second launch of the plain 16-cout kernel (the 4->16 input conv is
+    # the x-im2col instantiation); backward-data 16->32 and the stand-alone filter gradient are the first launches of their kernels
+    "bf16": ("c5", [("fwd", "conv5_bf16_c16_kernel<4, 8, 16, true, true, true, false>", None, 1),
+                    ("bwd", "conv5_bf16_r32_kernel<false, true>", None, 0),
+                    ("wgrad", "wgrad5_bf16_rr_kernel<4, false>", None, 0)]),
+}
 
 
 def short(name):
@@ -22,118 +45,100 @@ def short(name):
     return name.split("(")[0]
 
 
+def read_pass(path, counter):
+    """{(kernel, grid): [(value, duration ns), ...] in dispatch order}; several rows per dispatch (one per XCD) are summed."""
+    per_dispatch, meta = defaultdict(float), {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        key = int(r["Dispatch_Id"])
+        per_dispatch[key] += float(r["Counter_Value"])
+        meta[key] = (short(r["Kernel_Name"]), r["Grid_Size"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    seqs = defaultdict(list)
+    for key in sorted(per_dispatch):
+        name, grid, dur = meta[key]
+        seqs[(name, grid)].append((per_dispatch[key], dur))
+    return seqs
+
+
 def main(src, tag):
     here = os.path.dirname(os.path.abspath(__file__))
-    shutil.copy(os.path.join(src, "stats_kernel_stats.csv"), os.path.join(here, tag + "_kernel_stats.csv"))
-    if os.path.exists(os.path.join(src, "serial_kernel_stats.csv")):      # VNET_PARAM_GRAD_STREAM=0: no kernels overlap
-        shutil.copy(os.path.join(src, "serial_kernel_stats.csv"), os.path.join(here, tag + "_kernel_stats_serial.csv"))
-    pmc = {}
-    ordered = {}
-    for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-        path = os.path.join(src, which + "_counter_collection.csv")
-        if not os.path.exists(path):
+    out = {"note": "per launch; KB from rocprofv3 --pmc (separate passes, one leg per run); fetch doubled per the gfx950 correction",
+           "legs": {}, "families": {}}
+    for leg in LEGS:
+        st = os.path.join(src, leg + "_kernel_stats.csv")
+        if os.path.exists(st):
+            shutil.copy(st, os.path.join(here, "%s_kernel_stats_%s.csv" % (tag, leg)))
+        seqs = {}
+        for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            path = os.path.join(src, "%s_%s_counter_collection.csv" % (leg, which))
+            if os.path.exists(path):
+                seqs[counter] = read_pass(path, counter)
+        if not seqs:
             continue
-        agg = defaultdict(lambda: [0, 0.0, 0.0])
-        # several rows per dispatch (one per XCD/instance) -> sum per dispatch first
-        per_dispatch = defaultdict(float)
-        meta = {}
-        for r in csv.DictReader(open(path)):
-            if r["Counter_Name"] != counter:
+        kern = {}
+        for key in sorted(set().union(*[set(s) for s in seqs.values()])):
+            name, grid = key
+            if not name.startswith(KEEP):
                 continue
-            key = r["Dispatch_Id"]
-            per_dispatch[key] += float(r["Counter_Value"])
-            meta[key] = (short(r["Kernel_Name"]), r["Grid_Size"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-        seqs = defaultdict(list)
-        for key in sorted(per_dispatch, key=int):
-            name, grid, dur = meta[key]
-            seqs[(name, grid)].append((per_dispatch[key], dur))
-        ordered[counter] = seqs
-        for key, val in per_dispatch.items():
-            name, grid, dur = meta[key]
-            a = agg[(name, grid)]
-            a[0] += 1
-            a[1] += val
-            a[2] += dur
-        pmc[counter] = agg
-    out = {"note": "per launch; KB from rocprofv3 --pmc (separate passes); fetch doubled per the gfx950 correction", "kernels": {}}
-    keys = set()
-    for agg in pmc.values():
-        keys |= set(agg)
-    for key in sorted(keys):
-        name, grid = key
-        if not (name.startswith("conv_kernel<") or name.startswith("wgrad_kernel<") or name.startswith("conv5_bf16") or name.startswith("wgrad5_bf16") or name.startswith("wgrad5_b16")
-                or name.startswith("conv2_") or name.startswith("bn_") or name.startswith("input_")):
-            continue
-        e = {"grid_threads": int(grid)}
-        if "FETCH_SIZE" in pmc and key in pmc["FETCH_SIZE"]:
-            n, v, d = pmc["FETCH_SIZE"][key]
-            e["launches"] = n
-            e["fetch_KB_reported"] = v / n
-            e["hbm_read_bytes"] = 2.0 * 1024.0 * v / n
-            e["avg_us_profiled"] = d / n / 1e3
-        if "WRITE_SIZE" in pmc and key in pmc["WRITE_SIZE"]:
-            n, v, d = pmc["WRITE_SIZE"][key]
-            e["hbm_write_bytes"] = 1024.0 * v / n
-        e["hbm_bytes_per_launch"] = e.get("hbm_read_bytes", 0.0) + e.get("hbm_write_bytes", 0.0)
-        out["kernels"]["%s grid=%s" % (name, grid)] = e
-    # The kernel family bench.py reports = decoder level 1 conv_1 at 128^3: forward 32->16, backward-data 16->32, filter gradient.
-    # A member is (kernel-name regex, launches of that name+grid per training step, position among them in launch order):
-    # every step launches the same sequence, so dispatch i of a name+grid is position i mod per_step.
-    fams = {"fp32": [("fwd", r"conv_kernel<5, 1, 4, 8, 8, 4, 4, 1, false, 5, true", "2097152", 1, 0),
-                     ("bwd", r"conv_kernel<5, 1, 4, 8, 8, 4, 4, 2, false, 5, false", "2097152", 1, 0),
-                     ("wgrad", r"wgrad_kernel<5, 1, 4, 4, 16, 1, 16, 5", "131072", 1, 0)],
-            # C5, bf16 storage: persistent kernels (grid = CUs x 512 whatever the problem), so launch order tells them apart:
-            # forward with statistics 16->16, 32->16 (the second launch of the plain 16-cout kernel; the 4->16 input conv is the
-            # x-im2col instantiation); backward starts at decoder level 1, so its backward-data 16->32 and its filter gradient
-            # are the first launches of their kernels in a step
-            "bf16": [("fwd", r"conv5_bf16_c16_kernel<4, 8, 16, true, true, true, false>", None, 2, 1),
-                     ("bwd", r"conv5_bf16_r32_kernel<false, true>", None, FAM_BWD_PER_STEP, 0),
-                     ("wgrad", r"wgrad5_bf16_rr_kernel<4, false>", None, FAM_WGRAD_PER_STEP, 0)]}
-    out["families"] = {}
-    for fam, members in fams.items():
-        per_kernel, used, nsteps = {}, [], 0
-        for which, pat, grid, per_step, pos in members:
-            e = {}
-            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-                d = ordered.get(counter, {})
-                keys = [k for k in d if k[0].startswith(pat) and (grid is None or k[1] == grid)]
-                if len(keys) != 1:
-                    continue
-                seq = d[keys[0]]
-                if per_step is None:        # derived from the family's first member (known launches per step)
-                    if not nsteps:
+            e = {"grid_threads": int(grid)}
+            if key in seqs.get("FETCH_SIZE", {}):
+                sq = seqs["FETCH_SIZE"][key]
+                e["launches"] = len(sq)
+                e["hbm_read_bytes"] = 2.0 * 1024.0 * sum(v for v, _ in sq) / len(sq)
+                e["avg_us_profiled"] = sum(d for _, d in sq) / len(sq) / 1e3
+            if key in seqs.get("WRITE_SIZE", {}):
+                sq = seqs["WRITE_SIZE"][key]
+                e["hbm_write_bytes"] = 1024.0 * sum(v for v, _ in sq) / len(sq)
+            e["hbm_bytes_per_launch"] = e.get("hbm_read_bytes", 0.0) + e.get("hbm_write_bytes", 0.0)
+            kern["%s grid=%s" % (name, grid)] = e
+        out["legs"][leg] = kern
+        # training steps of this run: the once-per-step kernel
+        any_seq = next(iter(seqs.values()))
+        nsteps = sum(len(v) for k, v in any_seq.items() if k[0].startswith("softmax_dice_bwd_kernel"))
+        for fam, (fleg, members) in FAMILIES.items():
+            if fleg != leg:
+                continue
+            per_kernel, used = {}, []
+            for role, pat, grid, pos in members:
+                e = {}
+                for counter, sq in seqs.items():
+                    keys = [k for k in sq if k[0].startswith(pat) and (grid is None or k[1] == grid)]
+                    if len(keys) != 1 or not nsteps:
                         continue
+                    seq = sq[keys[0]]
                     if len(seq) % nsteps:
-                        # round 4: the filter gradients of a step run as ONE grouped launch; the row-reuse kernel is launched on its
-                        # own only for the layer bench.py times (decoder level 1 conv_1, in the eager steps after the timed region):
-                        # every stand-alone launch of the run is that layer
+                        # (C5: the stand-alone filter gradient exists only in the eager steps that time the family -- every launch is that layer)
                         per_step = 1
                     else:
                         per_step = len(seq) // nsteps
-                elif not nsteps:
-                    nsteps = len(seq) // per_step
-                if len(seq) % per_step:
-                    print("WARNING: %s: %d launches is not a multiple of %d per step" % (keys[0], len(seq), per_step))
-                    continue
-                sel = seq[pos::per_step]
-                e[counter] = sum(v for v, _ in sel) / len(sel)
-                e["launches"] = len(sel)
-                e["avg_us_profiled"] = sum(t for _, t in sel) / len(sel) / 1e3
-                e["kernel"] = "%s grid=%s, launch %d of %d per step" % (keys[0][0], keys[0][1], pos + 1, per_step)
-            if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
-                rd, wr = 2.0 * 1024.0 * e["FETCH_SIZE"], 1024.0 * e["WRITE_SIZE"]
-                per_kernel[which] = {"kernel": e["kernel"], "launches": e["launches"], "hbm_read_bytes": round(rd), "hbm_write_bytes": round(wr),
-                                   "hbm_bytes_per_launch": round(rd + wr), "avg_us_profiled": round(e["avg_us_profiled"], 1)}
-                used.append(e["kernel"])
-        if len(per_kernel) == len(members):
-            out["families"][fam] = {"kernels": used, "per_kernel": per_kernel,
-                                    "hbm_bytes_per_launch": round(sum(v["hbm_bytes_per_launch"] for v in per_kernel.values()) / len(per_kernel))}
-        else:
-            print("WARNING: family %s incomplete: %s" % (fam, sorted(per_kernel)))
+                    if pos == "longest":
+                        sel = [max(seq[i:i + per_step], key=lambda vt: vt[1]) for i in range(0, len(seq), per_step)]
+                        where = "the longest of %d launches per step" % per_step
+                    else:
+                        sel = seq[pos % per_step::per_step]
+                        where = "launch %d of %d per step" % (pos % per_step + 1, per_step)
+                    e[counter] = sum(v for v, _ in sel) / len(sel)
+                    e["launches"] = len(sel)
+                    e["avg_us_profiled"] = sum(t for _, t in sel) / len(sel) / 1e3
+                    e["kernel"] = "%s grid=%s, %s" % (keys[0][0], keys[0][1], where)
+                if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+                    rd, wr = 2.0 * 1024.0 * e["FETCH_SIZE"], 1024.0 * e["WRITE_SIZE"]
+                    per_kernel[role] = {"kernel": e["kernel"], "launches": e["launches"], "hbm_read_bytes": round(rd), "hbm_write_bytes": round(wr),
+                                        "hbm_bytes_per_launch": round(rd + wr), "avg_us_profiled": round(e["avg_us_profiled"], 1)}
+                    used.append(e["kernel"])
+            if len(per_kernel) == len(members):
+                out["families"][fam] = {"leg": leg, "steps_profiled": nsteps, "kernels": used, "per_kernel": per_kernel,
+                                        "hbm_bytes_per_launch": round(sum(v["hbm_bytes_per_launch"] for v in per_kernel.values()) / len(per_kernel))}
+            else:
+                print("WARNING: family %s incomplete: %s" % (fam, sorted(per_kernel)))
     json.dump(out, open(os.path.join(here, tag + "_pmc.json"), "w"), indent=1)
-    for k, e in out["kernels"].items():
-        print("%-70s n=%3d read %8.1f MB write %8.1f MB  %8.1f us" % (k, e.get("launches", 0), e.get("hbm_read_bytes", 0) / 1e6,
-                                                                      e.get("hbm_write_bytes", 0) / 1e6, e.get("avg_us_profiled", 0)))
+    for leg, kern in out["legs"].items():
+        for k, e in kern.items():
+            print("%-5s %-72s n=%3d read %8.1f MB write %8.1f MB  %8.1f us" % (leg, k[:72], e.get("launches", 0), e.get("hbm_read_bytes", 0) / 1e6,
+                                                                               e.get("hbm_write_bytes", 0) / 1e6, e.get("avg_us_profiled", 0)))
+    for fam, f in out["families"].items():
+        print(fam, {r: (v["hbm_bytes_per_launch"] / 1e6, v["avg_us_profiled"], v["launches"]) for r, v in f["per_kernel"].items()})
 
 
 if __name__ == "__main__":
