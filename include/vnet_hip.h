@@ -8,8 +8,9 @@
  * Conventions
  *   - all tensors are float32, channels-last (NDHWC), contiguous; labels are int32.
  *   - every pointer is a DEVICE pointer owned by the caller (incl. workspace `ws`); the library
- *     allocates nothing and keeps no state (one opt-in exception: the queue of deferred
- *     filter-gradient reduces between vnet_wgrad_defer(1) and vnet_wgrad_flush); all work is
+ *     allocates nothing and keeps no per-call state (two opt-in exceptions, both caller-driven: the per-stream queue of
+ *     deferred filter-gradient reduces between vnet_wgrad_defer(1, stream) and vnet_wgrad_flush(stream), and the tuning
+ *     switches, read once from the environment and changed only through vnet_set_option); all work is
  *     enqueued on `stream` (hipStream_t); no hidden synchronisation -> safe to overlap with RCCL
  *     on another stream and to capture into a hipGraph.  bf16 shadows (`*_x16`) are 2-byte images
  *     of fp32 tensors that the caller allocates next to them.
@@ -66,6 +67,12 @@ extern "C" {
 #define VNET_LOSS_MIXED    32  /* mixed_* = dice + Alpha * xent (model.py:524-556)        */
 
 const char* vnet_version(void);
+
+/* Tuning switches.  The library reads its handful of switches ONCE from the environment (VNET_<NAME>, first use) and never on a
+ * launch path; afterwards they change only through vnet_set_option(name, value) -> previous value (NaN: unknown name).  Names:
+ * WGRAD_ZS, WGRAD_RR, CONV_IN4, WGRAD_GROUP_ROUNDS, WGRAD_GROUP_DEBUG, BF16_DEEP, BF16_DEEP_TARGET. */
+double vnet_set_option(const char* name, double value);
+double vnet_get_option(const char* name);
 
 /* ---- weight repacking ---------------------------------------------------------------------
  * Re-lays a TF filter (layers2.py:60 `weights`, DHWIO [taps][I][O]) into the MFMA-fragment
@@ -191,13 +198,14 @@ size_t vnet_wgrad_bf16_ws_bytes(int Cin, int Cout, int B, int D, int H, int W);
 int vnet_conv_wgrad_bf16(const float* x0, int C0, const float* x1, int C1, const float* dy, int Cout, float* dw,
                          int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream);
 
-/* Deferred reduces of the filter-gradient slabs.  vnet_wgrad_defer(1): vnet_conv_wgrad / vnet_conv_wgrad_bf16[_x16] leave
- * their partial slabs in the caller's workspace (which must then stay untouched, one per layer) and queue the reduce;
- * vnet_wgrad_flush runs all queued reduces in one launch (the host's end-of-backward hook; model.py:660-666 has the
- * gradients complete only when compute_gradients returns, too).  Returns the previous setting / the queue length / status.
- * Results are bit-identical to the immediate per-layer reduce. */
-int vnet_wgrad_defer(int on);
-int vnet_wgrad_pending(void);
+/* Deferred reduces of the filter-gradient slabs, PER STREAM.  vnet_wgrad_defer(1, stream): the filter-gradient entry points that
+ * launch on `stream` leave their partial slabs in the caller's workspace (which must then stay untouched, one per layer) and queue
+ * the reduce on that stream's queue; vnet_wgrad_flush(stream) runs the stream's queued reduces in one launch (the host's
+ * end-of-backward hook; model.py:660-666 has the gradients complete only when compute_gradients returns, too).  Returns the
+ * previous setting / the queue length / status.  Results are bit-identical to the immediate per-layer reduce.  Streams do not
+ * see each other's queues: two models on two streams (or host threads) defer and flush independently. */
+int vnet_wgrad_defer(int on, void* stream);
+int vnet_wgrad_pending(void* stream);
 int vnet_wgrad_flush(void* stream);
 
 /* ---- convolution filter gradient (the Conv3DBackpropFilterV2 autodiff builds at model.py:660)
@@ -450,9 +458,6 @@ typedef struct vnet_wgrad_job {
 } vnet_wgrad_job;
 size_t vnet_wgrad_job_bytes(void);         /* sizeof(vnet_wgrad_job): a binding checks its own layout against it */
 int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream);
-/* the same for fp32 tensors (x0, x1, dy float; ks = 0 or 5; Cin_dw = C0 + C1): jobs[i] are the arguments of
- * vnet_conv_wgrad(5, 5, 1, ...) for layer i */
-int vnet_conv_wgrad_group(const vnet_wgrad_job* jobs, int n, void* stream);
 /* 2^3 stride-2 convolution (up = 0) / 2^3 transposed convolution (up = 1), bf16 in / bf16 out.  wp: the fp32 packed image of
  * the bf16-ROUNDED filter, vnet_pack_weights(VNET_PACK_FWD | VNET_PACK_ROUND_BF16, 8, Cin, Cout) resp. VNET_PACK_UP | ...;
  * accum: y += result (one rounding of the sum); stats (up = 0 only): rows = vnet_conv_stats_rows(2, 0, 2, 0, ...);

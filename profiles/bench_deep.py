@@ -5,7 +5,7 @@ import os
 import sys
 import torch
 sys.path.insert(0, '.')
-from vnet_tensorflow_amd import ops
+from vnet_tensorflow_amd import ops, _lib
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 dev = torch.device('cuda', 0)
@@ -15,7 +15,7 @@ if os.environ.get("BENCH_SHAPES"):
 
 
 def bench(P, c0, c1, co, deep):
-    os.environ["VNET_BF16_DEEP"] = deep
+    _lib.set_option("BF16_DEEP", int(deep))          # (round 5: the library reads its switches once; flips go through vnet_set_option)
     x0 = torch.randn(1, P, P, P, c0, device=dev).to(torch.bfloat16)
     x1 = torch.randn(1, P, P, P, c1, device=dev).to(torch.bfloat16) if c1 else None
     w = torch.randn(5, 5, 5, c0 + c1, co, device=dev) * 0.05

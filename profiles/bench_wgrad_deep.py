@@ -5,7 +5,7 @@ import os
 import sys
 import torch
 sys.path.insert(0, '.')
-from vnet_tensorflow_amd import ops
+from vnet_tensorflow_amd import ops, _lib
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 dev = torch.device('cuda', 0)
@@ -40,9 +40,9 @@ for (P, c0, c1, co) in SHAPES:
     x0, x1, dy, dw = tensors(P, c0, c1, co)
     out = []
     for zs in ("0", "1"):
-        os.environ["VNET_WGRAD_ZS"] = zs
+        _lib.set_option("WGRAD_ZS", int(zs))
         out.append(timeit(lambda: ops._wgrad5_b16_call(x0, x1, dy, dw, (P, P, P), c0 + c1)))
-    os.environ.pop("VNET_WGRAD_ZS")
+    _lib.set_option("WGRAD_ZS", 2)
     fl = 2.0 * P ** 3 * 125 * (c0 + c1) * co
     print("wgrad-b16 %2d^3 %3d->%3d   round-3 kernel %6.1f us %7.1f TF/s   z-streaming %6.1f us %7.1f TF/s   x%.2f" % (
         P, c0 + c1, co, out[0] * 1e3, fl / out[0] / 1e9, out[1] * 1e3, fl / out[1] / 1e9, out[0] / out[1]), flush=True)
@@ -62,9 +62,7 @@ def group():
 
 for label, env in (("every layer on its own (round 3)", {"VNET_WGRAD_GROUP": "0"}),
                    ("grouped, round-3 kernel bodies", {"VNET_WGRAD_ZS": "0"}), ("grouped, z-streaming everywhere", {"VNET_WGRAD_ZS": "1"}), ("grouped, z-streaming below 32^3 (default)", {})):
-    for k in ("VNET_WGRAD_GROUP", "VNET_WGRAD_ZS"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
+    _lib.set_option("WGRAD_ZS", int(env.get("VNET_WGRAD_ZS", 2)))
     ops.set_wgrad_group(env.get("VNET_WGRAD_GROUP", "1") != "0")
     t = timeit(group)
     print("15 deep layers of C5, %-42s %7.1f us %7.1f TF/s" % (label, t * 1e3, fl / t / 1e9), flush=True)

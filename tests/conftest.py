@@ -29,3 +29,16 @@ def _main_stream_param_grads():
     if ops is not None:
         ops.join_param_grad_stream()
         ops.set_param_grad_stream(False)
+
+
+@pytest.fixture
+def lib_option():
+    """lib_option(name, value): vnet_set_option for the duration of a test (the library reads its switches once; tests flip them here)."""
+    from vnet_tensorflow_amd import _lib
+    saved = []
+
+    def setopt(name, value):
+        saved.append((name, _lib.set_option(name, float(value))))
+    yield setopt
+    for name, prev in reversed(saved):
+        _lib.set_option(name, prev)

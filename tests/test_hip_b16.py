@@ -70,11 +70,11 @@ def _conv5_inputs(shape, seed):
 
 
 @pytest.mark.parametrize("shape", CONV5_SHAPES)
-def test_conv5_b16_against_oracle_and_fp32_output_kernels(dev, shape, monkeypatch):
+def test_conv5_b16_against_oracle_and_fp32_output_kernels(dev, shape, monkeypatch, lib_option):
     from vnet_tensorflow_amd import ops
-    monkeypatch.setenv("VNET_WGRAD_RR", "0")        # the bit-exact link below is to the generic filter-gradient kernel (the row-reuse
+    lib_option("WGRAD_RR", "0")        # the bit-exact link below is to the generic filter-gradient kernel (the row-reuse
                                                     # kernel sums in another order: test_row_reuse_filter_gradient)
-    monkeypatch.setenv("VNET_BF16_DEEP", "0")       # ... and to the generic forward kernels (round 4: shapes with few bricks and whole
+    lib_option("BF16_DEEP", "0")       # ... and to the generic forward kernels (round 4: shapes with few bricks and whole
                                                     # 32-cout blocks take the deep-level kernel, which splits K over the waves --
                                                     # against the oracle and against these kernels in tests/test_hip_deep.py)
     B, D, H, W, C0, C1, Co = shape
@@ -523,7 +523,7 @@ def test_forward_ops_in_situ(dev, variant, cin, K, monkeypatch):
     (1, 4, 8, 32, 32, 0, 32),      # two cout blocks
     (1, 6, 9, 33, 64, 0, 32),      # four chunks x two cout blocks, ragged
 ])
-def test_row_reuse_filter_gradient(dev, shape, monkeypatch):
+def test_row_reuse_filter_gradient(dev, shape, monkeypatch, lib_option):
     """wgrad5_bf16_rr_kernel (4 x 8 x 32 bricks, a k-step = one x-row, sliding window of row fragments in registers) forced onto
     small volumes: same bf16 x bf16 products as the generic kernel, another summation order -> 2e-6 against the oracle, and against
     the generic kernel."""
@@ -534,7 +534,7 @@ def test_row_reuse_filter_gradient(dev, shape, monkeypatch):
     _, dw_ex = O.conv_nd_bwd(xcat, rb(w), dy, 1, need_dx=False)
     got = {}
     for mode in ("2", "0"):
-        monkeypatch.setenv("VNET_WGRAD_RR", mode)
+        lib_option("WGRAD_RR", mode)
         dw = torch.empty(w.shape, dtype=torch.float32, device=dev)
         ops._wgrad5_b16_call(g16(x0, dev), g16(x1, dev) if C1 else None, g16(dy, dev), dw, (D, H, W), C0 + C1)
         torch.cuda.synchronize()

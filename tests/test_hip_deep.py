@@ -31,11 +31,11 @@ DEEP_SHAPES = [
 
 @pytest.mark.parametrize("target", [None, "1"])
 @pytest.mark.parametrize("shape", DEEP_SHAPES)
-def test_deep_conv_forward_backward_against_oracle(dev, shape, target, monkeypatch):
+def test_deep_conv_forward_backward_against_oracle(dev, shape, target, monkeypatch, lib_option):
     """target "1": no K split over workgroups -- every chunk of the layer in ONE workgroup (up to 16: the ring wraps five times)."""
     from vnet_tensorflow_amd import ops
     if target is not None:
-        monkeypatch.setenv("VNET_BF16_DEEP_TARGET", target)
+        lib_option("BF16_DEEP_TARGET", target)
     B, D, H, W, C0, C1, Co = shape
     if target is not None and B * D * H * W * (C0 + C1) * Co > 5e8:
         pytest.skip("one workgroup per brick at this size only repeats the default plan")
@@ -45,7 +45,7 @@ def test_deep_conv_forward_backward_against_oracle(dev, shape, target, monkeypat
     dx_ex, dw_ex = O.conv_nd_bwd(xcat, rb(w), dy, 1)
     outs = {}
     for deep in ("1", "0"):
-        monkeypatch.setenv("VNET_BF16_DEEP", deep)
+        lib_option("BF16_DEEP", deep)
         tx0 = g16(x0, dev).requires_grad_(True)
         tx1 = g16(x1, dev).requires_grad_(True) if C1 else None
         tw, tb = g(w, dev).requires_grad_(True), g(b, dev).requires_grad_(True)
@@ -69,12 +69,12 @@ def test_deep_conv_forward_backward_against_oracle(dev, shape, target, monkeypat
 
 @pytest.mark.parametrize("shape", [(1, 8, 8, 8, 64, 0, 64), (1, 32, 32, 32, 64, 0, 64), (2, 5, 9, 17, 32, 0, 32), (1, 8, 16, 16, 64, 0, 32)])
 @pytest.mark.parametrize("target", [None, "1"])
-def test_deep_conv_statistics_accumulate_and_determinism(dev, shape, target, monkeypatch):
+def test_deep_conv_statistics_accumulate_and_determinism(dev, shape, target, monkeypatch, lib_option):
     """Epilogue statistics (of the ROUNDED output + residual; from the kernel's own epilogue without a K split, from the reduce
     kernel with one), accumulate mode in place and out of place, two launches bit-equal."""
     from vnet_tensorflow_amd import ops
     if target is not None:
-        monkeypatch.setenv("VNET_BF16_DEEP_TARGET", target)
+        lib_option("BF16_DEEP_TARGET", target)
     B, D, H, W, C0, C1, Co = shape
     x0, _, w, b, dy = _conv5_inputs(shape, sum(shape) + 7)
     rng = np.random.default_rng(3)

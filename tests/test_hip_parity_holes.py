@@ -356,8 +356,8 @@ def test_deferred_batched_filter_gradient_reduce(dev, compute, cin):
                 with ops.deferred_wgrad_reduce(defer):
                     loss.backward()
                     ops.join_param_grad_stream()
-                    queued[defer] = L.vnet_wgrad_pending()
-                assert L.vnet_wgrad_pending() == 0
+                    queued[defer] = L.vnet_wgrad_pending(ops._stream())
+                assert L.vnet_wgrad_pending(ops._stream()) == 0
             torch.cuda.synchronize()
             grads[defer] = {n: p.grad.detach().cpu().numpy().copy() for n, p in net.named_parameters()}
     finally:

@@ -30,12 +30,11 @@ GROUP = [
 ]
 
 
-def test_group_with_2cube_layers_and_the_padded_input_layer(dev, monkeypatch):
+def test_group_with_2cube_layers(dev):
     """The other members of a V-Net pass: the 2^3 stride-2 filter gradients (ks = 2 jobs: x = the fine tensor, dy = the coarse one;
     their dw is the filter gradient of the down conv and, with the roles of the tensors swapped by the caller, of the transposed conv)
-    and the zero-padded network input (4 real channels of 8: the x-im2col form of the row-reuse body), next to 5^3 layers."""
+    next to 5^3 layers.  (The zero-padded network input keeps its own launch: tests/test_hip_b16.py.)"""
     from vnet_tensorflow_amd import ops
-    monkeypatch.setitem(ops._GROUP, "in4", True)      # (off by default: inside the C5 group that layer measured slower than on its own)
     rng = np.random.default_rng(77)
     five = [(1, 8, 16, 32, 32, 0, 32), (1, 8, 8, 8, 64, 0, 64)]
     two = [(1, 16, 16, 32, 16, 32), (2, 9, 10, 12, 32, 64), (1, 8, 8, 8, 64, 128), (1, 16, 16, 16, 8, 16)]     # B, D, H, W (fine), Cin, Cout
@@ -56,25 +55,16 @@ def test_group_with_2cube_layers_and_the_padded_input_layer(dev, monkeypatch):
             sink = ops.GradSink(dw)
             ops._wgrad2_b16_call(g16(xf, dev), g16(dyc, dev), dw, (D, H, W), dc, owner=sink)
             jobs.append(("2^3 %s" % ((B, D, H, W, Ci, Co),), dw, sink, O.conv_nd_bwd(xf, np.zeros((2, 2, 2, Ci, Co)), dyc, 2, need_dx=False)[1]))
-        # the network input: 3 modalities zero-padded to 8 channels, dw has the 3 real input channels
-        B, D, H, W, Co = 1, 8, 16, 32, 16
-        xin = np.zeros((B, D, H, W, 8))
-        xin[..., :3] = rb(rng.standard_normal((B, D, H, W, 3)))
-        dyi = rb(rng.standard_normal((B, D, H, W, Co)))
-        dw = torch.full((5, 5, 5, 3, Co), float("nan"), dtype=torch.float32, device=dev)
-        sink = ops.GradSink(dw)
-        ops._wgrad5_b16_call(g16(xin, dev), None, g16(dyi, dev), dw, (D, H, W), 3, owner=sink)
-        jobs.append(("padded input", dw, sink, O.conv_nd_bwd(xin[..., :3], np.zeros((5, 5, 5, 3, Co)), dyi, 1, need_dx=False)[1]))
         assert len(ops._DEFER["jobs"]) == len(jobs)
     torch.cuda.synchronize()
     for name, dw, _, ex in jobs:
         check_close("group member " + name, dw, ex, 2e-6)
 
 
-def _run_group(dev, shapes, rounds=None, monkeypatch=None):
+def _run_group(dev, shapes, rounds=None, lib_option=None):
     from vnet_tensorflow_amd import ops
     if rounds is not None:
-        monkeypatch.setenv("VNET_WGRAD_GROUP_ROUNDS", rounds)
+        lib_option("WGRAD_GROUP_ROUNDS", rounds)
     ins, outs, sinks = [], [], []
     for k, shape in enumerate(shapes):
         B, D, H, W, C0, C1, Co = shape
@@ -94,10 +84,10 @@ def _run_group(dev, shapes, rounds=None, monkeypatch=None):
 
 
 @pytest.mark.parametrize("rounds", [None, "8", "0.25", "0"])
-def test_group_members_against_oracle(dev, rounds, monkeypatch):
+def test_group_members_against_oracle(dev, rounds, lib_option):
     """rounds: the plan's workgroups per CU -- 8 splits every layer over many workgroups (slabs + reduce everywhere), 0.25 leaves
     most layers unsplit (direct writes of dw), 0 launches every layer on its own."""
-    ins, outs = _run_group(dev, GROUP, rounds, monkeypatch)
+    ins, outs = _run_group(dev, GROUP, rounds, lib_option)
     for shape, (x0, x1, dy), dw in zip(GROUP, ins, outs):
         xcat = x0 if x1 is None else np.concatenate((x0, x1), -1)
         _, dw_ex = O.conv_nd_bwd(xcat, np.zeros((5, 5, 5, xcat.shape[-1], dy.shape[-1])), dy, 1)
@@ -133,11 +123,11 @@ ZS_SHAPES = [
 
 
 @pytest.mark.parametrize("shape", ZS_SHAPES)
-def test_z_streaming_kernel_against_oracle(dev, shape, monkeypatch):
+def test_z_streaming_kernel_against_oracle(dev, shape, monkeypatch, lib_option):
     """csrc/wgrad_zs.h on its own (VNET_WGRAD_ZS=1 routes the per-layer entry point to it): column steps split over workgroups,
     slabs + reduce; and with a workspace of ONE slab (no split: every step of a (chunk, cout block) in one workgroup)."""
     from vnet_tensorflow_amd import ops, _lib
-    monkeypatch.setenv("VNET_WGRAD_ZS", "1")
+    lib_option("WGRAD_ZS", "1")
     B, D, H, W, C0, C1, Co = shape
     x0, x1, w, b, dy = _conv5_inputs(shape, sum(shape) + 17)
     xcat = x0 if x1 is None else np.concatenate((x0, x1), -1)
@@ -209,77 +199,3 @@ def test_training_step_gradients_do_not_depend_on_the_grouping(dev, P, monkeypat
     assert max(grouped) >= 10 and min(grouped) == 0, grouped     # one pass collected the 5^3 layers, the other none
 
 
-F32_GROUP = [
-    (1, 8, 16, 16, 32, 0, 16),      # wide bricks (4 x 4 x 16), one cout block per workgroup
-    (1, 8, 8, 32, 16, 16, 32),      # ... two sources, two cout blocks, two tap groups
-    (1, 8, 8, 8, 32, 0, 64),        # small bricks (4 x 8 x 8), two cout blocks
-    (2, 5, 9, 7, 16, 0, 16),        # ... ragged, batch 2, one cout block
-    (1, 4, 4, 16, 6, 0, 16),        # 6 input channels: not a shape of the grouped kernels -> the layer's own launch
-]
-
-
-@pytest.mark.parametrize("rounds", [None, "8", "0.25"])
-def test_fp32_group_members_against_oracle(dev, rounds, monkeypatch):
-    """vnet_conv_wgrad_group: the fp32 tensors' 5^3 filter gradients of a pass in one launch (off by default in the product path:
-    VNET_WGRAD_GROUP_F32) -- every member against the fp64 oracle at fp32 accuracy, two runs bit-identical."""
-    from vnet_tensorflow_amd import ops
-    monkeypatch.setitem(ops._GROUP, "f32", True)
-    if rounds is not None:
-        monkeypatch.setenv("VNET_WGRAD_GROUP_ROUNDS", rounds)
-    outs = []
-    for rep in range(2):
-        res = []
-        with ops.deferred_wgrad_reduce():
-            for k, shape in enumerate(F32_GROUP):
-                B, D, H, W, C0, C1, Co = shape
-                rng = np.random.default_rng(500 + k)
-                x0 = rng.standard_normal((B, D, H, W, C0)).astype(np.float32)
-                x1 = rng.standard_normal((B, D, H, W, C1)).astype(np.float32) if C1 else None
-                dy = rng.standard_normal((B, D, H, W, Co)).astype(np.float32)
-                dw = torch.full((5, 5, 5, C0 + C1, Co), float("nan"), dtype=torch.float32, device=dev)
-                sink = ops.GradSink(dw)
-                ops._wgrad_call(5, 1, g(x0, dev), g(x1, dev) if C1 else None, g(dy, dev), dw, (D, H, W), (D, H, W), owner=sink)
-                res.append((shape, x0, x1, dy, dw, sink))
-            assert len(ops._DEFER["jobs32"]) == len(F32_GROUP)
-        torch.cuda.synchronize()
-        outs.append(res)
-    for (shape, x0, x1, dy, dw, _), (_, _, _, _, dw2, _) in zip(*outs):
-        xcat = x0 if x1 is None else np.concatenate((x0, x1), -1)
-        _, dw_ex = O.conv_nd_bwd(xcat.astype(np.float64), np.zeros((5, 5, 5, xcat.shape[-1], dy.shape[-1])), dy.astype(np.float64), 1, need_dx=False)
-        check_close("fp32 group rounds=%s %s" % (rounds, shape), dw, dw_ex, 2e-6)
-        assert torch.equal(dw, dw2)
-
-
-def test_fp32_training_step_with_the_group(dev, monkeypatch):
-    """fp32 V-Net, one fwd + bwd, grouped vs every layer on its own.  The fp32 backward-data kernels accumulate a residual block's
-    second gradient IN PLACE into the batch-norm's ds -- which is also the dy of the block's last filter gradient: that layer must
-    not wait for the group (ops._DEFER["acc_targets"]).  Data gradients and every ungrouped layer: bit-identical; grouped layers:
-    summation order."""
-    from vnet_tensorflow_amd import ops
-    from vnet_tensorflow_amd.model import image2label
-    from oracle.vnet_oracle import synthetic_batch
-    from tests.test_hip_train_loop import _cfg
-    import pathlib
-    monkeypatch.setenv("VNET_STEP_GRAPH", "0")
-    monkeypatch.setenv("VNET_PARAM_GRAD_STREAM", "0")      # one stream, as in the replayed step graph (a side stream's launches never wait)
-    x, lab = synthetic_batch(1, 32, 1, 2, seed=6)
-    xt, lt = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
-    res, counts = {}, []
-    launch = ops._launch_wgrad_group
-    monkeypatch.setattr(ops, "_launch_wgrad_group", lambda jobs, entry: (counts.append((entry, len(jobs))), launch(jobs, entry))[1])
-    for on in (True, False):
-        monkeypatch.setitem(ops._GROUP, "f32", on)
-        np.random.seed(9)
-        cfg = _cfg(pathlib.Path("/tmp"), PatchShape=[32] * 3, BatchSize=1)
-        cfg["TrainingSetting"]["Networks"].update(NumChannel=16, NumLevels=3, NumConvolutions=[1, 2, 3], BottomConvolutions=2)
-        m = image2label(None, cfg, device=dev, verbose=False)
-        m.read_config(); m.build_model_graph(); m._setup_training()
-        with ops.context(m.ctx):
-            loss = m._compute_gradients(xt, lt, 0.0)
-        torch.cuda.synchronize()
-        res[on] = (float(loss.detach()), m.flat.grad.clone())
-    assert res[True][0] == res[False][0]
-    ga, gb = res[True][1], res[False][1]
-    scale = float(gb.abs().max())
-    assert torch.isfinite(ga).all() and float((ga - gb).abs().max()) <= 2e-6 * scale, (float((ga - gb).abs().max()), scale)
-    assert counts and counts[0][0] == "vnet_conv_wgrad_group" and 3 <= counts[0][1] <= 12, counts     # some layers joined; the multi-convolution blocks' last ones (4 here) did not

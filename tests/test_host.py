@@ -31,7 +31,10 @@ def test_library_exports_every_declared_symbol():
     # the one struct of the C ABI (vnet_wgrad_job, the grouped filter gradients): the binding's layout is the library's
     import ctypes
     assert L.vnet_wgrad_job_bytes() == ctypes.sizeof(_lib.WgradJob) == 88
-    assert L.vnet_conv_wgrad_b16_group(None, 0, None) == 0 and L.vnet_conv_wgrad_group(None, 0, None) == 0      # empty groups: no launch
+    assert L.vnet_conv_wgrad_b16_group(None, 0, None) == 0      # an empty group: no launch
+    # tuning switches: read once from the environment, changed only through the ABI
+    assert L.vnet_get_option(b"WGRAD_RR") == 1.0 and L.vnet_set_option(b"WGRAD_RR", 2.0) == 1.0 and L.vnet_set_option(b"WGRAD_RR", 1.0) == 2.0
+    assert L.vnet_get_option(b"NO_SUCH_OPTION") != L.vnet_get_option(b"NO_SUCH_OPTION")          # NaN
     assert L.vnet_conv_wgrad_b16_group(None, 3, None) == -1
 
 

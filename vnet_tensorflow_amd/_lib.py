@@ -17,6 +17,8 @@ _vp, _i, _i64, _f, _sz, _u64, _d = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int6
 # name -> (restype, argtypes) : must list every symbol include/vnet_hip.h declares
 SIGNATURES = {
     "vnet_version": (ctypes.c_char_p, []),
+    "vnet_set_option": (_d, [ctypes.c_char_p, _d]),
+    "vnet_get_option": (_d, [ctypes.c_char_p]),
     "vnet_packed_weight_floats": (_sz, [_i, _i, _i, _i]),
     "vnet_pack_weights": (_i, [_i, _vp, _vp, _i, _i, _i, _vp]),
     "vnet_packed_dims": (_i, [_i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
@@ -50,8 +52,8 @@ SIGNATURES = {
     "vnet_conv_fwd_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "vnet_wgrad_bf16_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "vnet_conv_wgrad_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
-    "vnet_wgrad_defer": (_i, [_i]),
-    "vnet_wgrad_pending": (_i, []),
+    "vnet_wgrad_defer": (_i, [_i, _vp]),
+    "vnet_wgrad_pending": (_i, [_vp]),
     "vnet_wgrad_flush": (_i, [_vp]),
     "vnet_conv_wgrad_bf16_x16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "vnet_conv_fwd_bf16_x16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -109,7 +111,6 @@ SIGNATURES = {
     "vnet_conv_wgrad_b16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "vnet_wgrad_job_bytes": (_sz, []),
     "vnet_conv_wgrad_b16_group": (_i, [_vp, _i, _vp]),
-    "vnet_conv_wgrad_group": (_i, [_vp, _i, _vp]),
     "vnet_conv2_fwd_b16": (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "vnet_conv2_wgrad_b16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "vnet_conv2_direct_ok": (_i, [_i, _i]),
@@ -139,6 +140,14 @@ class WgradJob(ctypes.Structure):
 
 
 ERRORS = {-1: "VNET_E_BADARG", -2: "VNET_E_UNSUPPORTED", -3: "VNET_E_WORKSPACE"}
+
+
+def set_option(name, value):
+    """vnet_set_option: returns the previous value.  name without the VNET_ prefix, e.g. set_option("BF16_DEEP", 0)."""
+    prev = lib().vnet_set_option(name.encode(), float(value))
+    if prev != prev:
+        raise VnetHipError("unknown library option %r" % (name,))
+    return prev
 
 
 class VnetHipError(RuntimeError):
@@ -173,18 +182,18 @@ def lib():
             fn = getattr(L, name)          # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
             if name == "vnet_conv_b16_stats_rows":
-                setattr(L, name, _memo(fn, ("VNET_BF16_DEEP", "VNET_BF16_DEEP_TARGET")))     # (the kernel choice follows these switches)
+                setattr(L, name, _memo(fn, (b"BF16_DEEP", b"BF16_DEEP_TARGET"), L))     # (the kernel choice follows these options)
             elif name.endswith("_ws_bytes") or name.endswith("_stats_rows") or name.endswith("_stats_rows_x16") or name == "vnet_conv_stats_from_reduce" or name == "vnet_packed_weight_floats":
                 setattr(L, name, _memo(fn))    # pure size queries, asked before every launch: answer repeats from a dict
         _lib = L
     return _lib
 
 
-def _memo(fn, env=None):
+def _memo(fn, opts=None, L=None):
     cache = {}
 
     def cached(*args):
-        key = args if env is None else args + tuple(os.environ.get(e) for e in env)
+        key = args if opts is None else args + tuple(L.vnet_get_option(o) for o in opts)
         r = cache.get(key)
         if r is None:
             r = cache[key] = fn(*args)

@@ -129,9 +129,8 @@ int vnet_conv_wgrad_b16(const void* x0, int C0, const void* x1, int C1, const vo
     a.pad = 2; a.padx = 2; a.vec_in = 1; a.vec_dy = 1;
     // z-streaming kernel (wgrad_zs.h; VNET_WGRAD_ZS=1): 16 cin x 32 cout per workgroup, column steps split over workgroups
     {
-        const char* zs_env = getenv("VNET_WGRAD_ZS");
         const bool in4z = Cin_dw <= 4 && C0 == 8 && C1 == 0;
-        if (zs_env && atoi(zs_env) == 1 && zs_shape_ok(C0, C1, Cout) && zs_depth_ok(D, W) && !in4z && (size_t)D * H * W * max(max(C0, C1), Cout) < ((size_t)1 << 31)) {
+        if (tuning().wgrad_zs == 1 && zs_shape_ok(C0, C1, Cout) && zs_depth_ok(D, W) && !in4z && (size_t)D * H * W * max(max(C0, C1), Cout) < ((size_t)1 << 31)) {
             const int nitems = zs_geometry(a);
             const int nblock = (a.CinP / 16) * a.ncob;
             const size_t slab = (size_t)125 * a.CinP * a.CoutP * sizeof(float);
@@ -158,8 +157,7 @@ int vnet_conv_wgrad_b16(const void* x0, int C0, const void* x1, int C1, const vo
     a.part = direct ? dw : reinterpret_cast<float*>(ws);
     int e;
     // row-reuse kernel (4 x 8 x 32 bricks, one 16-cout block per workgroup): wide volumes with at least two bricks per workgroup
-    const char* rr_env = getenv("VNET_WGRAD_RR");          // 0: never, 1 (default): where it pays, 2: wherever it applies (tests)
-    const int rr_mode = rr_env ? atoi(rr_env) : 1;
+    const int rr_mode = tuning().wgrad_rr;                 // 0: never, 1 (default): where it pays, 2: wherever it applies (tests)
     const int rr_nbrick = B * ceil_div(D, 4) * ceil_div(H, 8) * ceil_div(W, 32);
     const int rr_base = (a.CinP / 16) * (a.CoutP / 16);
     const int rr_nsplit = max(1, min(rr_nbrick, ceil_div(256, rr_base)));
@@ -169,8 +167,7 @@ int vnet_conv_wgrad_b16(const void* x0, int C0, const void* x1, int C1, const vo
         direct = rr_nsplit == 1 && a.CinP == Cin_dw && a.CoutP == Cout;
         a.part = direct ? dw : reinterpret_cast<float*>(ws);
         // the zero-padded network input (Cin_dw <= 4 real channels of 8): x-im2col form, 10 instead of 25 tap pairs per k-step
-        const char* in4_env = getenv("VNET_CONV_IN4");
-        const bool in4 = Cin_dw <= 4 && C0 == 8 && C1 == 0 && !(in4_env && atoi(in4_env) == 0);
+        const bool in4 = Cin_dw <= 4 && C0 == 8 && C1 == 0 && tuning().conv_in4 != 0;
         e = in4 ? launch_wgrad_bf16_rr<4, true>(a, rr_nsplit, a.ncob, st) : launch_wgrad_bf16_rr<4>(a, rr_nsplit, a.ncob, st);
         if (e) return e;
         if (direct) return VNET_OK;
@@ -206,7 +203,7 @@ int vnet_conv_wgrad_b16(const void* x0, int C0, const void* x1, int C1, const vo
 // layer's result depends on its nsplit only (tests compare against the oracle, not against the ungrouped launch, bit for bit).
 namespace {
 constexpr int WG_MAXJ = 32;          // (a V-Net of 5 levels: 22 5^3 + 8 2^3 convolutions; the table travels in the 4 KB of kernel arguments)
-enum { WG_RR = 0, WG_S16 = 1, WG_S8 = 2, WG_ZS32 = 3, WG_ZS16 = 4, WG_ZS8 = 5, WG_RR_IN4 = 6,
+enum { WG_RR = 0, WG_S16 = 1, WG_S8 = 2, WG_ZS32 = 3, WG_ZS16 = 4, WG_ZS8 = 5,
        WG_K2_W2 = 7, WG_K2_W4 = 8, WG_K2_S2 = 9, WG_K2_S4 = 10 };     // 2^3 stride 2: wide / small bricks x 2 / 4 cout blocks
 struct WgradGroupJob {                // what the kernel bodies read of WgradArgs, 96 bytes
     const void* x0; const void* x1; const void* dy; float* part;
@@ -235,7 +232,6 @@ __global__ void __launch_bounds__(512) wgrad5_b16_group_kernel(WgradGroup g) {
     const int ny = (a.CinP / 16) * a.ncob;
     switch (q.fam) {
         case WG_RR: wgrad5_bf16_rr_body<4, false>(a, split, rest); break;
-        case WG_RR_IN4: wgrad5_bf16_rr_body<4, true>(a, split, rest); break;
         case WG_S16: wgrad5_bf16_body<4, 4, 16, 2, 8, true>(a, split, rest % ny, rest / ny); break;
         case WG_ZS32: wgrad5_b16_zs_body<32>(a, split, rest); break;
         case WG_ZS16: wgrad5_b16_zs_body<16>(a, split, rest); break;
@@ -275,7 +271,7 @@ int launch_wgrad_group(std::vector<GroupItem>& items, double rounds, K k, size_t
     }
     std::stable_sort(items.begin(), items.end(), [](const GroupItem& p, const GroupItem& q) {
         return p.unit * ceil_div(p.nbrick, p.a.nsplit) > q.unit * ceil_div(q.nbrick, q.a.nsplit); });
-    if (getenv("VNET_WGRAD_GROUP_DEBUG")) {
+    if (tuning().group_debug) {
         fprintf(stderr, "[wgrad group] %zu layers, total %.0f units, target %.1f units per workgroup\n", items.size(), total, target);
         for (const GroupItem& it : items)
             fprintf(stderr, "  fam %2d  %3d^3 (D %d) %3d->%3d  blocks %3d  bricks %5d  unit %.3f  nsplit %3d  -> %4d workgroups of %.1f units\n",
@@ -305,30 +301,6 @@ int launch_wgrad_group(std::vector<GroupItem>& items, double rounds, K k, size_t
     return VNET_OK;
 }
 
-// fp32 tensors (the reference's arithmetic): the fp32-MFMA filter-gradient bodies of csrc/wgrad_body.inc, four families
-enum { WF_W1 = 0, WF_W2 = 1, WF_S1 = 2, WF_S2 = 3 };      // wide (4x4x16) / small (4x8x8) bricks x 1 / 2 cout blocks per workgroup
-__global__ void __launch_bounds__(512) wgrad5_f32_group_kernel(WgradGroup g) {
-    int j = 0;
-#pragma unroll 1
-    for (int k = 1; k < g.n; ++k) if (blockIdx.x >= g.blk0[k]) j = k;
-    const WgradGroupJob& q = g.job[j];
-    WgradArgs a;
-    a.x0 = reinterpret_cast<const float*>(q.x0); a.x1 = reinterpret_cast<const float*>(q.x1); a.dy = reinterpret_cast<const float*>(q.dy);
-    a.part = q.part; a.C0 = q.C0; a.C1 = q.C1; a.Cin = q.C0 + q.C1; a.Cout = q.Cout; a.B = q.B;
-    a.Di = a.Do = q.D; a.Hi = a.Ho = q.H; a.Wi = a.Wo = q.W; a.CinP = q.CinP; a.CoutP = q.CoutP; a.ncob = q.ncob;
-    a.nbz = q.nbz; a.nby = q.nby; a.nbx = q.nbx; a.nbrick = q.nbrick; a.nsplit = q.nsplit;
-    a.pad = 2; a.padx = 2; a.vec_in = 1; a.vec_dy = 1;
-    const unsigned local = blockIdx.x - g.blk0[j];
-    const int split = (int)(local % (unsigned)a.nsplit);
-    const int rest = (int)(local / (unsigned)a.nsplit);
-    const int ny = (a.CinP / 16) * a.ncob;
-    switch (q.fam) {
-        case WF_W1: wgrad_body<5, 1, 4, 4, 16, 1, 16, 5, false>(a, split, rest, 0); break;
-        case WF_W2: wgrad_body<5, 1, 4, 4, 16, 2, 8, 5, false>(a, split, rest % ny, rest / ny); break;
-        case WF_S1: wgrad_body<5, 1, 4, 8, 8, 1, 16, 5, false>(a, split, rest, 0); break;
-        default: wgrad_body<5, 1, 4, 8, 8, 2, 8, 5, false>(a, split, rest % ny, rest / ny); break;
-    }
-}
 }  // namespace
 
 extern "C" {
@@ -338,12 +310,10 @@ size_t vnet_wgrad_job_bytes(void) { return sizeof(vnet_wgrad_job); }
 int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream) {
     if (n < 0 || (n > 0 && !jobs)) return VNET_E_BADARG;
     std::vector<GroupItem> items;
-    const char* genv = getenv("VNET_WGRAD_GROUP_ROUNDS");
-    const double rounds = genv ? atof(genv) : 2.0;
-    const char* zenv = getenv("VNET_WGRAD_ZS");
-    // VNET_WGRAD_ZS: 0 = round-3 kernel bodies only, 1 = the z-streaming kernel wherever it applies, 2 (default) = below 32 voxels
+    const double rounds = tuning().group_rounds;
+    // WGRAD_ZS: 0 = round-3 kernel bodies only, 1 = the z-streaming kernel wherever it applies, 2 (default) = below 32 voxels
     // per row only: at 32^3 the row-reuse body with many bricks per workgroup measures faster (profiles/r04_wgrad_group.txt)
-    const int zs_mode = zenv ? atoi(zenv) : 2;
+    const int zs_mode = tuning().wgrad_zs;
     const bool zs_on = zs_mode != 0;
     const int zs_maxw = zs_mode == 2 ? 31 : (1 << 30);
     for (int q = 0; q < n; ++q) {
@@ -381,9 +351,9 @@ int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream) {
         const bool in4 = J.Cin_dw <= 4 && J.C0 == 8 && J.C1 == 0;
         const bool ok = !(J.C0 & 15) && !(J.C1 & 15) && !(J.Cout & 7) && al16p(J.x0) && al16p(J.x1) && al16p(J.dy) && !in4;
         int fam = -1;
-        const char* in4_env = getenv("VNET_CONV_IN4");
-        if (in4 && !(in4_env && atoi(in4_env) == 0) && J.W >= 32 && J.H >= 8 && !(J.Cout & 7) && al16p(J.x0) && al16p(J.dy))
-            fam = WG_RR_IN4;          // the zero-padded network input: x-im2col form of the row-reuse body, 10 instead of 25 tap pairs
+        // (the zero-padded network input keeps its own launch -- the x-im2col form of the row-reuse body: inside the group it measured
+        //  +0.07 ms on the C5 step, round 4)
+        if (in4) fam = -1;
         else if (ok && zs_on && J.W <= zs_maxw && zs_shape_ok(J.C0, J.C1, J.Cout) && zs_depth_ok(J.D, J.W) && (size_t)J.D * J.H * J.W * max(max(J.C0, J.C1), J.Cout) < ((size_t)1 << 31))
             fam = J.W >= 32 ? WG_ZS32 : (J.W >= 16 ? WG_ZS16 : WG_ZS8);
         else if (ok && J.W >= 32 && J.H >= 8) fam = WG_RR;
@@ -405,9 +375,9 @@ int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream) {
             const int nitems = zs_geometry(a);
             (void)nitems;
             it.nblock = (CinP / 16) * a.ncob; it.unit = 0.4;                 // a column step: 256 voxels x 16 cin x 32 cout x 125 taps
-        } else if (fam == WG_RR || fam == WG_RR_IN4) {
+        } else if (fam == WG_RR) {
             a.ncob = CoutP / 16; a.nbz = ceil_div(J.D, 4); a.nby = ceil_div(J.H, 8); a.nbx = ceil_div(J.W, 32);
-            it.nblock = (CinP / 16) * a.ncob; it.unit = fam == WG_RR ? 1.0 : 0.6;          // (x-im2col form: 10 of 25 tap pairs, the same tiles)
+            it.nblock = (CinP / 16) * a.ncob; it.unit = 1.0;
         } else {
             a.ncob = CoutP / 32; a.nbz = ceil_div(J.D, 4);
             if (fam == WG_S16) { a.nby = ceil_div(J.H, 4); a.nbx = ceil_div(J.W, 16); }
@@ -421,46 +391,6 @@ int vnet_conv_wgrad_b16_group(const vnet_wgrad_job* jobs, int n, void* stream) {
     static unsigned long long attr_done = 0;
     constexpr size_t LDS_RR = (size_t)8 * 12 * 36 * 32 + (size_t)4 * 8 * 32 * 32;
     return launch_wgrad_group(items, rounds, wgrad5_b16_group_kernel, LDS_RR, attr_done, stream);
-}
-
-// The same for fp32 tensors (x0, x1, dy float; ks = 5 only): the 5^3 filter gradients of a pass in one launch.
-int vnet_conv_wgrad_group(const vnet_wgrad_job* jobs, int n, void* stream) {
-    if (n < 0 || (n > 0 && !jobs)) return VNET_E_BADARG;
-    std::vector<GroupItem> items;
-    const char* genv = getenv("VNET_WGRAD_GROUP_ROUNDS");
-    const double rounds = genv ? atof(genv) : 2.0;
-    for (int q = 0; q < n; ++q) {
-        const vnet_wgrad_job& J = jobs[q];
-        if (!J.x0 || !J.dy || !J.dw || J.C0 <= 0 || J.Cout <= 0 || J.B <= 0 || J.C1 < 0 || (J.C1 > 0 && !J.x1)) return VNET_E_BADARG;
-        if (J.D <= 0 || J.H <= 0 || J.W <= 0 || (J.ks != 0 && J.ks != 5) || J.Cin_dw != J.C0 + J.C1) return VNET_E_BADARG;
-        const int Cin = J.C0 + J.C1;
-        WgradPlan p = plan_wgrad(5, 5, 1, Cin, J.Cout, J.B, J.D, J.H, J.W);
-        const bool ok = !(J.C0 & 3) && !(J.C1 & 3) && !(J.Cout & 3) && (p.ns == 1 || p.ns == 2) && rounds > 0.0 &&
-                        (size_t)J.D * J.H * J.W * max(max(J.C0, J.C1), J.Cout) < ((size_t)1 << 31);
-        if (!ok) {
-            const int e = vnet_conv_wgrad(5, 5, 1, reinterpret_cast<const float*>(J.x0), J.C0, reinterpret_cast<const float*>(J.x1), J.C1,
-                                          reinterpret_cast<const float*>(J.dy), J.Cout, J.dw, J.B, J.D, J.H, J.W, J.D, J.H, J.W, J.ws, J.ws_bytes, stream);
-            if (e) return e;
-            continue;
-        }
-        GroupItem it{};
-        WgradArgs& a = it.a;
-        a.x0 = reinterpret_cast<const float*>(J.x0); a.x1 = reinterpret_cast<const float*>(J.x1); a.C0 = J.C0; a.C1 = J.C1; a.Cin = Cin;
-        a.dy = reinterpret_cast<const float*>(J.dy); a.Cout = J.Cout;
-        a.B = J.B; a.Di = J.D; a.Hi = J.H; a.Wi = J.W; a.Do = J.D; a.Ho = J.H; a.Wo = J.W;
-        a.CinP = round_up(Cin, 16); a.CoutP = round_up(J.Cout, 16); a.pad = 2; a.padx = 2; a.vec_in = 1; a.vec_dy = 1;
-        a.ncob = p.ncob; a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.nbrick = p.nbrick;
-        it.fam = p.small ? (p.ns == 2 ? WF_S2 : WF_S1) : (p.ns == 2 ? WF_W2 : WF_W1);
-        it.nblock = (a.CinP / 16) * p.ncob * p.ntg; it.nbrick = p.nbrick; it.Cin_dw = Cin; it.T3 = 125;
-        // 256 voxels x 16 cin x (16 cout x 128 taps | 32 cout x 64 taps): the same MFMAs, but one cout block per workgroup stages the
-        // same x tile for half the output: 19.6 vs 15.3 us per brick in the stand-alone launches at 128^3 / 64^3
-        it.unit = p.ns == 1 ? 1.28 : 1.0;
-        it.dw = J.dw; it.ws = J.ws; it.ws_bytes = J.ws_bytes;
-        items.push_back(it);
-    }
-    static unsigned long long attr_done = 0;
-    constexpr size_t LDS_F32 = ((size_t)8 * 8 * 20 * 16 + (size_t)4 * 4 * 16 * 2 * 16) * 4;
-    return launch_wgrad_group(items, rounds, wgrad5_f32_group_kernel, LDS_F32, attr_done, stream);
 }
 
 // 2^3 stride-2 convolution (up = 0: [B,Di,Hi,Wi,Cin] -> [B,Do,Ho,Wo,Cout]) or 2^3 transposed convolution (up = 1) on bf16

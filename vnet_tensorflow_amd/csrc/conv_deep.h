@@ -54,8 +54,7 @@ struct DeepPlan { int use, nbz, nby, nbx, ncob, nsplit, cps; };
 inline DeepPlan plan_conv_deep(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W, bool ignore_env = false) {
     DeepPlan p{};
     const int Cin = C0 + C1, Cout = Cy0 + Cy1;
-    const char* env = getenv("VNET_BF16_DEEP");          // 0: off (the generic kernels; read per call: tests and A/B runs flip it)
-    if (!ignore_env && env && atoi(env) == 0) return p;
+    if (!ignore_env && tuning().bf16_deep == 0) return p;          // option BF16_DEEP = 0: the generic kernels (tests and A/B runs flip it)
     if ((Cout & 31) || (C0 & 15) || (C1 & 15) || (Cy0 & 7) || (Cy1 & 7) || Cin < 16) return p;     // (16-byte epilogue accesses)
     if (conv_bf16_use_c16(Cin, Cout, C0, C1, Cy0, Cy1, B, D, H, W)) return p;
     const int nchunks = Cin / 16;
@@ -68,8 +67,7 @@ inline DeepPlan plan_conv_deep(int C0, int C1, int Cy0, int Cy1, int B, int D, i
         Bf16Plan g = plan_conv_bf16(Cin, Cout, B, D, H, W);
         if (g.nsplit * g.nz == 1) return p;          // the row-pair kernel takes it
     }
-    const char* tenv = ignore_env ? nullptr : getenv("VNET_BF16_DEEP_TARGET");      // workgroups the K split aims for (tests: 1 = no split)
-    const int tgt = tenv ? atoi(tenv) : 256;
+    const int tgt = ignore_env ? 256 : max(1, tuning().bf16_deep_target);           // workgroups the K split aims for (tests: 1 = no split)
     int ns = (int)max(1l, min((long)nchunks, (tgt + nwg0 - 1) / nwg0));
     p.cps = ceil_div(nchunks, ns);
     p.nsplit = ceil_div(nchunks, p.cps);

@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 #include <mutex>
+#include <unordered_map>
 #include <type_traits>
 #include <vector>
 
@@ -709,12 +710,28 @@ struct ReduceJob { const float* part; float* dw; int nsplit, T3, CinP, CoutP, Ci
 constexpr int REDUCE_BATCH = 32;
 struct ReduceBatch { ReduceJob job[REDUCE_BATCH]; int n; };
 // one queue per process, whichever translation unit launches the filter-gradient kernels (defined in conv_mfma.hip)
-struct DeferState { std::mutex mu; bool on = false; std::vector<ReduceJob> pending; };
+// One queue PER STREAM (round 5): a filter-gradient entry point defers iff deferral is on for the stream it launches on, and a
+// flush takes that stream's jobs only -- models that work on different streams (or host threads) never see each other's queue.
+// (Rounds 2-4: one process-wide queue; a flush on stream A would have run the reduces queued from stream B.)
+struct DeferQueue { bool on = false; std::vector<ReduceJob> pending; };
+struct DeferState { std::mutex mu; std::unordered_map<hipStream_t, DeferQueue> q; };
 __attribute__((visibility("hidden"))) DeferState& defer_state();
+// Tuning switches of the library: read ONCE from the environment (first use), changed afterwards only through vnet_set_option --
+// no getenv on a launch path (round 5; rounds 2-4 read seven variables per call).  One instance per process (conv_mfma.hip).
+struct Tuning {
+    int wgrad_zs;            // VNET_WGRAD_ZS: z-streaming filter gradient (bf16): 0 never, 1 wherever it applies, 2 (default) rows < 32 voxels, grouped launch only
+    int wgrad_rr;            // VNET_WGRAD_RR: row-reuse filter gradient (bf16): 0 never, 1 (default) where it pays, 2 wherever it applies
+    int conv_in4;            // VNET_CONV_IN4: x-im2col form of the zero-padded network input (bf16 storage), default 1
+    double group_rounds;     // VNET_WGRAD_GROUP_ROUNDS: rounds of the 256 CUs the grouped filter-gradient launch plans for (default 2; <= 0: every layer on its own)
+    int group_debug;         // VNET_WGRAD_GROUP_DEBUG: print the group's plan
+    int bf16_deep;           // VNET_BF16_DEEP: deep-level bf16 kernel (csrc/conv_deep.h), default 1
+    int bf16_deep_target;    // VNET_BF16_DEEP_TARGET: workgroups its K split aims for (default 256)
+};
+__attribute__((visibility("hidden"))) Tuning& tuning();
 }  // namespace vnet_detail
 namespace {
 using vnet_detail::ReduceJob; using vnet_detail::ReduceBatch; using vnet_detail::REDUCE_BATCH;
-using vnet_detail::DeferState; using vnet_detail::defer_state;
+using vnet_detail::DeferState; using vnet_detail::DeferQueue; using vnet_detail::defer_state; using vnet_detail::tuning;
 
 __global__ void __launch_bounds__(256) wgrad_reduce_batched_kernel(ReduceBatch b) {
     int j = 0;
@@ -732,8 +749,9 @@ void launch_wgrad_reduce(const float* part, int nsplit, int T3, int CinP, int Co
     {
         DeferState& ds = defer_state();
         std::lock_guard<std::mutex> lk(ds.mu);
-        if (ds.on) {
-            ds.pending.push_back(ReduceJob{part, dw, nsplit, T3, CinP, CoutP, Cin, Cout, vec ? 1 : 0, 0u});
+        auto it = ds.q.find(st);
+        if (it != ds.q.end() && it->second.on) {
+            it->second.pending.push_back(ReduceJob{part, dw, nsplit, T3, CinP, CoutP, Cin, Cout, vec ? 1 : 0, 0u});
             return;
         }
     }

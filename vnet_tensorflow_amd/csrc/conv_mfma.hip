@@ -18,12 +18,52 @@
 // The same file holds the bf16-operand variants of the 5^3 convolution and of its filter gradient (BASELINE
 // config C5: v_mfma_f32_32x32x16_bf16 / v_mfma_f32_16x16x32_bf16 with LDS transpose reads) further down.
 #include "conv_kernels.h"
+#include <string.h>
 
 namespace vnet_detail {
 DeferState& defer_state() { static DeferState s; return s; }
+static Tuning tuning_from_env() {
+    auto geti = [](const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; };
+    Tuning t{};
+    t.wgrad_zs = geti("VNET_WGRAD_ZS", 2); t.wgrad_rr = geti("VNET_WGRAD_RR", 1); t.conv_in4 = geti("VNET_CONV_IN4", 1);
+    const char* g = getenv("VNET_WGRAD_GROUP_ROUNDS");
+    t.group_rounds = g ? atof(g) : 2.0;
+    t.group_debug = getenv("VNET_WGRAD_GROUP_DEBUG") ? 1 : 0;
+    t.bf16_deep = geti("VNET_BF16_DEEP", 1); t.bf16_deep_target = geti("VNET_BF16_DEEP_TARGET", 256);
+    return t;
+}
+Tuning& tuning() { static Tuning t = tuning_from_env(); return t; }
 }  // namespace vnet_detail
 
+namespace {
+double* option_slot(const char* name, int** ip) {
+    vnet_detail::Tuning& t = vnet_detail::tuning();
+    *ip = nullptr;
+    if (!name) return nullptr;
+    if (!strcmp(name, "WGRAD_ZS")) *ip = &t.wgrad_zs;
+    else if (!strcmp(name, "WGRAD_RR")) *ip = &t.wgrad_rr;
+    else if (!strcmp(name, "CONV_IN4")) *ip = &t.conv_in4;
+    else if (!strcmp(name, "WGRAD_GROUP_DEBUG")) *ip = &t.group_debug;
+    else if (!strcmp(name, "BF16_DEEP")) *ip = &t.bf16_deep;
+    else if (!strcmp(name, "BF16_DEEP_TARGET")) *ip = &t.bf16_deep_target;
+    else if (!strcmp(name, "WGRAD_GROUP_ROUNDS")) return &t.group_rounds;
+    return nullptr;
+}
+}  // namespace
+
 extern "C" {
+
+// tuning switches (names = the environment variables without the VNET_ prefix); returns the previous value, NaN for an unknown name
+double vnet_set_option(const char* name, double value) {
+    int* ip; double* dp = option_slot(name, &ip);
+    if (ip) { const double prev = *ip; *ip = (int)value; return prev; }
+    if (dp) { const double prev = *dp; *dp = value; return prev; }
+    return __builtin_nan("");
+}
+double vnet_get_option(const char* name) {
+    int* ip; double* dp = option_slot(name, &ip);
+    return ip ? (double)*ip : (dp ? *dp : __builtin_nan(""));
+}
 
 const char* vnet_version(void) { return "vnet_hip 0.2 (gfx950; fp32 MFMA 16x16x4, bf16 MFMA 32x32x16 / 16x16x32)"; }
 
@@ -316,18 +356,20 @@ int vnet_conv_fwd_bf16_x16(const void* x0h, int C0, const void* x1h, int C1, con
 
 extern "C" {
 
-int vnet_wgrad_defer(int on) {
+int vnet_wgrad_defer(int on, void* stream) {
     DeferState& ds = defer_state();
     std::lock_guard<std::mutex> lk(ds.mu);
-    const int prev = ds.on ? 1 : 0;
-    ds.on = on != 0;
+    DeferQueue& q = ds.q[(hipStream_t)stream];
+    const int prev = q.on ? 1 : 0;
+    q.on = on != 0;
     return prev;
 }
 
-int vnet_wgrad_pending(void) {
+int vnet_wgrad_pending(void* stream) {
     DeferState& ds = defer_state();
     std::lock_guard<std::mutex> lk(ds.mu);
-    return (int)ds.pending.size();
+    auto it = ds.q.find((hipStream_t)stream);
+    return it == ds.q.end() ? 0 : (int)it->second.pending.size();
 }
 
 int vnet_wgrad_flush(void* stream) {
@@ -335,7 +377,11 @@ int vnet_wgrad_flush(void* stream) {
     std::vector<ReduceJob> jobs;
     {
         std::lock_guard<std::mutex> lk(ds.mu);
-        jobs.swap(ds.pending);
+        auto it = ds.q.find((hipStream_t)stream);
+        if (it != ds.q.end()) {
+            jobs.swap(it->second.pending);
+            if (!it->second.on) ds.q.erase(it);              // (streams come and go: no entry outlives its deferring pass)
+        }
     }
     hipStream_t st = (hipStream_t)stream;
     for (size_t i0 = 0; i0 < jobs.size(); i0 += REDUCE_BATCH) {

@@ -591,7 +591,7 @@ def _wgrad5_b16_call(x0, x1, dy, dw, dims, cin_dw, owner=None):
     nbytes = 2.0 * nvox * (C0 + C1 + Co) + 4.0 * 125 * (C0 + C1) * Co
     tag = _wgrad_tag(True, 5, 0, 1, dims[2], B, C0 + C1, Co)
     if (_DEFER["on"] and owner is not None and _GROUP["on"] and not _timed_tag(tag) and _LAUNCH_ON[0] is None
-            and dims[0] * dims[1] * dims[2] <= _GROUP["max_voxels"] and (_GROUP["in4"] or not (cin_dw <= 4 and C0 == 8 and C1 == 0))):
+            and dims[0] * dims[1] * dims[2] <= _GROUP["max_voxels"] and not (cin_dw <= 4 and C0 == 8 and C1 == 0)):
         # a deep-level layer of a pass whose filter gradients nobody reads before it ends: launched together with the others when the
         # pass ends (vnet_conv_wgrad_b16_group); the tensors stay alive -- and unmodified, see _ConvFn.backward -- until then
         _DEFER["jobs"].append((x0, x1, dy, dw, ws, nb, int(cin_dw), B, tuple(dims), flops, nbytes, 5))
@@ -701,16 +701,14 @@ def colsum16(x16, C, out):
 # launch reduces all of them when the context ends (26 reduce launches of ~7 us per V-Net step otherwise).  Only for a backward
 # pass whose filter gradients nobody reads before it ends (model.image2label: not the eager data-parallel step, whose bucket
 # all-reduces start from the gradient hooks).
-_DEFER = {"on": False, "jobs": [], "dy_ptrs": set(), "jobs32": [], "acc_targets": set()}
+_DEFER = {"on": False, "jobs": [], "dy_ptrs": set(), "stream": None}
 # grouped launch of the 5^3 filter gradients of a deferring pass (layers up to 128^3 voxels; measured: 32^3 and below -0.23 ms,
 # all levels -0.33 ms per C5 step) (bf16 storage; include/vnet_hip.h:
 # vnet_conv_wgrad_b16_group).  VNET_WGRAD_GROUP=0: every layer launches its own kernel as it did through round 3.
 _GROUP = {"on": _os.environ.get("VNET_WGRAD_GROUP", "1") != "0", "max_voxels": int(_os.environ.get("VNET_WGRAD_GROUP_MAXVOX", 128 ** 3)),
-          "k2": _os.environ.get("VNET_WGRAD_GROUP_K2", "1") != "0", "in4": _os.environ.get("VNET_WGRAD_GROUP_IN4", "0") != "0", "f32": _os.environ.get("VNET_WGRAD_GROUP_F32", "0") != "0"}
-# (f32: the fp32 tensors' 5^3 filter gradients as a group, vnet_conv_wgrad_group: built and tested, OFF by default -- those launches
-#  are 0.2-2 ms each and already at 0.83 of the fp32 peak: -0.07 ms of 25.3 with 8 rounds, +0.1 ms with 2)
-# (k2: the 2^3 stride-2 filter gradients join too -- -0.05 ms per C5 step; in4: the zero-padded network input's x-im2col filter
-#  gradient can join but measures +0.07 ms inside the group, so it keeps its own launch)
+          "k2": _os.environ.get("VNET_WGRAD_GROUP_K2", "1") != "0"}
+# (k2: the 2^3 stride-2 filter gradients join too -- -0.05 ms per C5 step.  Round 4 also built the group for fp32 tensors and let the
+#  zero-padded network input join; both measured no gain -- DESIGN 4.5 -- and were removed in round 5)
 
 
 WGRAD_GROUP_TAG = "wgrad-group"
@@ -723,11 +721,7 @@ def set_wgrad_group(on):
 def _flush_wgrad_group(launch=True):
     """Launch the collected filter gradients (the reduces of their slabs join the deferred queue) and let go of their tensors."""
     jobs, _DEFER["jobs"] = _DEFER["jobs"], []
-    jobs32, _DEFER["jobs32"] = _DEFER["jobs32"], []
     _DEFER["dy_ptrs"] = set()
-    _DEFER["acc_targets"] = set()
-    if launch and jobs32:
-        _launch_wgrad_group(jobs32, "vnet_conv_wgrad_group")
     if not jobs or not launch:
         return
     _launch_wgrad_group(jobs, "vnet_conv_wgrad_b16_group")
@@ -752,8 +746,10 @@ def deferred_wgrad_reduce(on=True):
         yield
         return
     L = _lib.lib()
+    st = _stream()                            # the library's queues are per stream: this pass defers on the stream it launches on
     _DEFER["on"] = True
-    L.vnet_wgrad_defer(1)
+    _DEFER["stream"] = st
+    L.vnet_wgrad_defer(1, st)
     try:
         yield
     except BaseException:
@@ -761,16 +757,16 @@ def deferred_wgrad_reduce(on=True):
         # the caller sees the original one (model._train_step_graph turns a refused capture into eager steps)
         _DEFER["on"] = False
         _flush_wgrad_group(launch=False)
-        L.vnet_wgrad_defer(0)
-        L.vnet_wgrad_flush(_stream())
+        L.vnet_wgrad_defer(0, st)
+        L.vnet_wgrad_flush(st)
         raise
     else:
         try:
             _flush_wgrad_group()                  # (still deferring: the reduces of its slabs join the one batched launch below)
         finally:
             _DEFER["on"] = False
-            L.vnet_wgrad_defer(0)
-        check(L.vnet_wgrad_flush(_stream()), "vnet_wgrad_flush")
+            L.vnet_wgrad_defer(0, st)
+        check(L.vnet_wgrad_flush(st), "vnet_wgrad_flush")
 
 
 def _wgrad_workspace(dw, nbytes, immediate, owner):
@@ -792,11 +788,12 @@ def _immediate_reduce(immediate):
         yield
         return
     L = _lib.lib()
-    L.vnet_wgrad_defer(0)
+    st = _DEFER.get("stream")
+    L.vnet_wgrad_defer(0, st)
     try:
         yield
     finally:
-        L.vnet_wgrad_defer(1)
+        L.vnet_wgrad_defer(1, st)
 
 
 def _wgrad_bf16_call(x0, x1, dy, dw, dims, owner=None):
@@ -859,14 +856,6 @@ def _wgrad_call(ks, stride, x0, x1, dy, dw, dims_in, dims_out, kx=0, immediate=F
     flops = 2.0 * nout * taps * (C0 + C1) * Co
     nbytes = 4.0 * (nin * (C0 + C1) + nout * Co + taps * (C0 + C1) * Co)
     tag = _wgrad_tag(False, ks, kx, stride, dims_out[2], B, C0 + C1, Co)
-    if (_DEFER["on"] and not immediate and _GROUP["on"] and _GROUP["f32"] and ks == 5 and stride == 1 and kx in (0, 5)
-            and not _timed_tag(tag) and _LAUNCH_ON[0] is None and x0.dtype == torch.float32 and dy.dtype == torch.float32
-            and dims_out[0] * dims_out[1] * dims_out[2] <= _GROUP["max_voxels"] and dy.data_ptr() not in _DEFER["acc_targets"]):
-        # fp32 tensors: joins the pass's grouped launch (vnet_conv_wgrad_group) -- unless its dy is a tensor another convolution's
-        # backward-data will add its gradient INTO in place (a residual block's ds, registered by the batch-norm's backward): the
-        # fp32 kernels have no out-of-place accumulate, so that layer's filter gradient runs now, as it always did
-        _DEFER["jobs32"].append((x0, x1, dy, dw, ws, nb, C0 + C1, B, tuple(dims_out), flops, nbytes, 5))
-        return
     with _Timed(tag, flops, nbytes), _immediate_reduce(immediate):
         check(L.vnet_conv_wgrad(ks, kx, stride, _ptr(x0), C0, _ptr(x1), C1, _ptr(dy), Co, _ptr(dw),
                                 B, *dims_in, *dims_out, _ptr(ws), nb, _stream()), "vnet_conv_wgrad")
@@ -1541,8 +1530,6 @@ class _BnActFn(torch.autograd.Function):
             dx = colsum_rows(ds)
         if r is not None and ds is not None and ctx.slot_r is not None and ctx.slot_r.first is None:
             ctx.slot_r.first = ds                      # the block input's other consumer (conv_1) adds its gradient into this
-            if _DEFER["on"]:
-                _DEFER["acc_targets"].add(ds.data_ptr())   # (fp32: the filter gradient that reads ds as its dy must not wait, _wgrad_call)
         return dx, (ds if r is not None else None), _grad_ret(dgamma, sg), _grad_ret(dbeta, sbt), _grad_ret(dalpha, sa), None, None, None, None
 
 
