@@ -91,6 +91,10 @@ static int conv_fwd_b16_impl(const void* x0, int C0, const void* x1, int C1, con
     Bf16Plan p = plan_conv_bf16(a.Cin, a.Cout, B, D, H, W);
     // deep levels (few bricks, wide channels): the K-split-over-waves kernel of conv_deep.h
     const bool al16_all = al16p(y0) && al16p(y1) && al16p(acc16) && al16p(res16);          // (its epilogue moves 16 bytes per lane)
+    // (vnet_conv_b16_stats_rows sizes the caller's buffer for the deep kernel's bricks wherever plan_conv_deep takes the
+    //  shape; tensors that are only 8-byte aligned would silently fall back to the generic kernels, which write another number of
+    //  partial rows -- refuse that combination instead of folding unwritten rows into the batch-norm moments)
+    if (stats && !a.in4 && !al16_all && plan_conv_deep(C0, C1, Cy0, Cy1, B, D, H, W).use) return VNET_E_UNSUPPORTED;
     const DeepPlan dp = (a.in4 || !al16_all) ? DeepPlan{} : plan_conv_deep(C0, C1, Cy0, Cy1, B, D, H, W);
     if (dp.use) { a.nbz = dp.nbz; a.nby = dp.nby; a.nbx = dp.nbx; a.cps = dp.cps; a.nz = 1; }
     else { a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.cps = p.cps; a.nz = p.nz; }
@@ -252,10 +256,10 @@ template <typename K>
 int launch_wgrad_group(std::vector<GroupItem>& items, double rounds, K k, size_t lds, unsigned long long& attr_done, void* stream) {
     if (items.empty()) return VNET_OK;
     hipStream_t st = (hipStream_t)stream;
-    // work shares: a workgroup should carry total / (256 CUs x rounds); a layer block of `nbrick` bricks is split accordingly
+    // work shares: a workgroup should carry total / (CUs x rounds); a layer block of `nbrick` bricks is split accordingly
     double total = 0.0;
     for (const GroupItem& it : items) total += it.unit * it.nblock * it.nbrick;
-    const double target = total / (256.0 * rounds);
+    const double target = total / ((double)device_cus() * rounds);
     for (GroupItem& it : items) {
         const size_t slab = (size_t)it.T3 * it.a.CinP * it.a.CoutP * sizeof(float);
         int ns = (int)ceil(it.unit * it.nbrick / target - 1e-9);

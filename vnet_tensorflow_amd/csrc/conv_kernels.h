@@ -726,6 +726,9 @@ struct Tuning {
     int group_debug;         // VNET_WGRAD_GROUP_DEBUG: print the group's plan
     int bf16_deep;           // VNET_BF16_DEEP: deep-level bf16 kernel (csrc/conv_deep.h), default 1
     int bf16_deep_target;    // VNET_BF16_DEEP_TARGET: workgroups its K split aims for (default 256)
+    int f32_small;           // VNET_F32_SMALL: fp32 5^3 convolutions on volumes narrower than 16: 0 = 8x8x8 bricks / 8 waves (rounds 1-4),
+                             // 1 = 4x8x8 bricks / 4 waves (two workgroups per CU), 2 (default) = ... and 4x4x4 bricks for volumes <= 4^3
+                             // (profiles/r05_bench_small.txt: 4^3 x 2 256->256 135 -> 30 us, 8^3 x 2 128->128 65 -> 39 us, 8^3 256->256 71.6 -> 69.4 us)
 };
 __attribute__((visibility("hidden"))) Tuning& tuning();
 }  // namespace vnet_detail
@@ -1027,6 +1030,20 @@ int ensure_lds(K kernel, size_t bytes, unsigned long long& done_mask) {
     return e;
 }
 
+// compute units of the current device (cached per device; 256 on MI355X)
+inline int device_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int& c = cached[dev & 63];
+    if (c == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        c = n;
+    }
+    return c;
+}
+
 int pick_ns(int CoutP) { return (CoutP % 64 == 0) ? 4 : (CoutP % 32 == 0) ? 2 : 1; }
 
 struct ConvPlan { int ns, ncob, nbz, nby, nbx, nsplit, cps, small, nz, half, tiny; };
@@ -1047,6 +1064,8 @@ ConvPlan plan_conv(int ks, int stride, int up, int Cin, int Cout, int B, int Do,
     // load latency / bandwidth, more tiles in flight per CU help (128^3 -> 64^3: 47.8 -> 38.8 us, profiles/bench_updown.py)
     if (stride == 2 && !up) { if (p.small) brick_counts<2, 8, 8>(Do, Ho, Wo, p); else brick_counts<1, 4, 16>(Do, Ho, Wo, p); }
     else if (ks == 5 && !up && !p.small) { p.half = 1; brick_counts<4, 8, 8>(Do, Ho, Wo, p); }
+    else if (ks == 5 && !up && tuning().f32_small >= 2 && Do <= 4 && Ho <= 4 && Wo <= 4 && Cin >= 32) { p.half = 2; brick_counts<4, 4, 4>(Do, Ho, Wo, p); }      // (Cin >= 32: never the 5x5x1 input block)
+    else if (ks == 5 && !up && tuning().f32_small >= 1) { p.half = 1; brick_counts<4, 8, 8>(Do, Ho, Wo, p); }
     else if (up && !p.small) brick_counts<2, 4, 16>(Do, Ho, Wo, p);       // transposed conv: 128 input voxels per 4-wave workgroup (55.5 -> 52.5 us at 128^3)
     else { if (p.small) brick_counts<8, 8, 8>(Do, Ho, Wo, p); else brick_counts<4, 8, 16>(Do, Ho, Wo, p); }
     const int nchunks = round_up(Cin, 16) / 16;
@@ -1055,10 +1074,13 @@ ConvPlan plan_conv(int ks, int stride, int up, int Cin, int Cout, int B, int Do,
     if (ks == 5 && !up) {
         const long nb = (long)B * p.nbz * p.nby * p.nbx;
         const int ncob1 = p.ns * p.ncob;                      // cout blocks at NS = 1
-        if (nb * p.ncob < 256 && nb * ncob1 >= 256) {         // fill the chip WITHOUT split-K if a narrower block can
-            while (nb * p.ncob < 256) { p.ns /= 2; p.ncob *= 2; }
+        // (4x4x4 bricks: a workgroup is four waves with one 16-voxel subtile each and a 32 KB tile -- several share a CU, so aim for two
+        //  rounds of workgroups: 4^3 x 2 256->256 34.3 -> 29.9 us; on the 4x8x8 bricks of the 8^3 volumes it cost 2 %)
+        const long fill = p.half == 2 ? 512 : 256;
+        if (nb * p.ncob < fill && nb * ncob1 >= fill) {       // fill the chip WITHOUT split-K if a narrower block can
+            while (nb * p.ncob < fill) { p.ns /= 2; p.ncob *= 2; }
         } else {
-            while (p.ns > 1 && nb * p.ncob * nchunks < 256) { p.ns /= 2; p.ncob *= 2; }
+            while (p.ns > 1 && nb * p.ncob * nchunks < fill) { p.ns /= 2; p.ncob *= 2; }
         }
     }
     if (ks == 2 && !up) {                                     // 2^3 stride-2 conv at the coarse levels: narrower cout blocks first

@@ -30,6 +30,7 @@ static Tuning tuning_from_env() {
     t.group_rounds = g ? atof(g) : 2.0;
     t.group_debug = getenv("VNET_WGRAD_GROUP_DEBUG") ? 1 : 0;
     t.bf16_deep = geti("VNET_BF16_DEEP", 1); t.bf16_deep_target = geti("VNET_BF16_DEEP_TARGET", 256);
+    t.f32_small = geti("VNET_F32_SMALL", 2);
     return t;
 }
 Tuning& tuning() { static Tuning t = tuning_from_env(); return t; }
@@ -46,6 +47,7 @@ double* option_slot(const char* name, int** ip) {
     else if (!strcmp(name, "WGRAD_GROUP_DEBUG")) *ip = &t.group_debug;
     else if (!strcmp(name, "BF16_DEEP")) *ip = &t.bf16_deep;
     else if (!strcmp(name, "BF16_DEEP_TARGET")) *ip = &t.bf16_deep_target;
+    else if (!strcmp(name, "F32_SMALL")) *ip = &t.f32_small;
     else if (!strcmp(name, "WGRAD_GROUP_ROUNDS")) return &t.group_rounds;
     return nullptr;
 }
@@ -204,14 +206,16 @@ static int conv_fwd_impl(int ks, int kx, int stride, int up, const float* x0, in
     int e;
     if (a.stats && nslab == 1) {     // statistics in the conv epilogue: the STATS instantiations (split-K launches take theirs from the reduce)
         if (is5) {
-            if (kx == 1) e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false, 1, true>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 8, 4, 4, false, 1, true>(a, p, st);
-            else e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false, 5, true>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 8, 4, 4, false, 5, true>(a, p, st);
+            if (kx == 1) e = (p.small && !p.half) ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false, 1, true>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 8, 4, 4, false, 1, true>(a, p, st);
+            else e = p.half == 2 ? launch_conv_ns<5, 1, 4, 4, 4, 4, 1, false, 5, true>(a, p, st)
+                   : (p.small && !p.half) ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false, 5, true>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 8, 4, 4, false, 5, true>(a, p, st);
         } else {
             e = p.small ? launch_conv_ns<2, 2, 2, 8, 8, 4, 2, false, 2, true>(a, p, st) : launch_conv_ns<2, 2, 1, 4, 16, 4, 1, false, 2, true>(a, p, st);
         }
     } else if (is5) {
-        if (kx == 1) e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false, 1>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 8, 4, 4, false, 1>(a, p, st);
-        else e = p.small ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 8, 4, 4, false>(a, p, st);
+        if (kx == 1) e = (p.small && !p.half) ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false, 1>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 8, 4, 4, false, 1>(a, p, st);
+        else e = p.half == 2 ? launch_conv_ns<5, 1, 4, 4, 4, 4, 1, false>(a, p, st)
+               : (p.small && !p.half) ? launch_conv_ns<5, 1, 8, 8, 8, 8, 4, false>(a, p, st) : launch_conv_ns<5, 1, 4, 8, 8, 4, 4, false>(a, p, st);
     } else if (isdown) {
         e = p.small ? launch_conv_ns<2, 2, 2, 8, 8, 4, 2, false>(a, p, st) : launch_conv_ns<2, 2, 1, 4, 16, 4, 1, false>(a, p, st);
     } else {

@@ -3,19 +3,7 @@
 
 namespace {
 
-int x3_grid() {
-    // one persistent workgroup per CU, a multiple of 8 (the kernels partition their items by XCD = blockIdx % 8)
-    static int cached[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    int& c = cached[dev & 63];
-    if (c == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-        c = n / 8 * 8;
-    }
-    return c;
-}
+int x3_grid() { return device_cus() / 8 * 8; }     // one persistent workgroup per CU, a multiple of 8 (items are partitioned by XCD = blockIdx % 8)
 
 }  // namespace
 
