@@ -726,6 +726,7 @@ struct Tuning {
     int group_debug;         // VNET_WGRAD_GROUP_DEBUG: print the group's plan
     int bf16_deep;           // VNET_BF16_DEEP: deep-level bf16 kernel (csrc/conv_deep.h), default 1
     int bf16_deep_target;    // VNET_BF16_DEEP_TARGET: workgroups its K split aims for (default 256)
+    int x3_nb2;              // VNET_X3_NB2: f32x3 convolution, two 16-cout blocks per item where the layer allows (default 1)
     int f32_small;           // VNET_F32_SMALL: fp32 5^3 convolutions on volumes narrower than 16: 0 = 8x8x8 bricks / 8 waves (rounds 1-4),
                              // 1 = 4x8x8 bricks / 4 waves (two workgroups per CU), 2 (default) = ... and 4x4x4 bricks for volumes <= 4^3
                              // (profiles/r05_bench_small.txt: 4^3 x 2 256->256 135 -> 30 us, 8^3 x 2 128->128 65 -> 39 us, 8^3 256->256 71.6 -> 69.4 us)

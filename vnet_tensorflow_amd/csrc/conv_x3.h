@@ -35,7 +35,7 @@ constexpr int X3_PLANEB = X3_NV * 16;                    // one (piece, cin half
 constexpr int X3_PIECEB = 2 * X3_PLANEB;
 constexpr int X3_TILEB = 3 * X3_PIECEB;                  // 138240
 constexpr int X3_ROWB = X3_IX * 16, X3_ZB = X3_IY * X3_IX * 16;
-constexpr int X3_LDS = X3_TILEB + 8 * 32 * 4 + 64 * 8;   // + epilogue statistics [8 waves][32] + a dump slot per lane
+constexpr int X3_LDS = X3_TILEB + 2 * 8 * 32 * 4;        // + epilogue statistics [NB <= 2][8 waves][32]
 
 // Compile-time loop: body(std::integral_constant<int, k>) for k = 0 .. N - 1.  NOT `#pragma unroll`: when hipcc's IndVarSimplify visits
 // a not-yet-unrolled loop it sinks every side-effect-free instruction of the loop's preheader that the loop does not use to behind the
@@ -135,14 +135,17 @@ __device__ __forceinline__ void x3_yrows_single(f32x4 (&acc)[8], const unsigned 
     });
 }
 
-template <bool STATS>
+// NB: 16-cout blocks per item (1 or 2).  With two, a step runs the four pieces twice on the SAME tile -- once per block, one block's
+// accumulators and filter fragments at a time -- so the tile commit, its two barriers and the item's reduction are paid once per
+// 2 x 6240 MFMAs instead of once per 6240.
+template <bool STATS, int NB>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv5_x3_kernel(ConvArgs a) {
     constexpr int NT = 512;
     using XT = XTile<X3_IZ, X3_IY, X3_IX, NT>;
     static_assert(XT::PER * XT::RPI == XT::ROWS, "every staging pass covers whole tile rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* tile = smem;
-    float* red = reinterpret_cast<float*>(smem);                              // after an item's K loop: [8 waves][8 rows][64 lanes][4]
+    float* red = reinterpret_cast<float*>(smem);                              // after an item's K loop: [8 waves][NB][8 rows][64 lanes][4]
     float* sred = reinterpret_cast<float*>(smem + X3_TILEB);                  // [8 waves][2 x 16] epilogue statistics
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -154,10 +157,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const unsigned char* bY = tile + base0 + hi * X3_ROWB + 4 * X3_ZB;        // taps (4, dy), (4, dy + 1)
     const unsigned char* b0 = tile + base0 + 4 * X3_ZB;                       // tap (4, 4)
 
-    const int ncob = a.CoutP >> 4;
+    const int ncob = a.CoutP >> 4, ncobg = ncob / NB;                         // 16-cout blocks; groups of NB blocks = items per brick
     const int nbrick = a.B * a.nbz * a.nby * a.nbx;
     const int nks = a.nz;                                                     // K splits (chunk ranges of a.cps chunks; partial slabs in a.part)
-    const int nitems = nbrick * ncob * nks;
+    const int nitems = nbrick * ncobg * nks;
     const int G8 = gridDim.x >> 3;                                            // workgroups per XCD (grid is a multiple of 8)
     const int per_xcd = (nitems + 7) >> 3;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -171,7 +174,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
     auto item_coords = [&](int it, int& b, int& bz, int& by, int& bx, int& cob) {
         int item = (i_lo + slot + it * G8) / nks;
-        cob = item % ncob; item /= ncob;
+        cob = (item % ncobg) * NB; item /= ncobg;
         bx = item % a.nbx; item /= a.nbx;
         by = item % a.nby; item /= a.nby;
         bz = item % a.nbz; b = item / a.nbz;
@@ -227,21 +230,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             *reinterpret_cast<u32x2*>(dst + 2 * X3_PIECEB) = l;
         });
     };
-    // filter fragments of this wave's first piece of a step: (dz 0|1, dx = kc), five pairs
-    auto first_a = [&](bf16x8 (&A)[5][3], int step) {
-        const int it = step / nch, item = i_lo + slot + it * G8, ch = (item % nks) * nch + (step - it * nch);
-        const int cob = (item / nks) % ncob;
-        const int kc = (kw + ch) & 3;
-        x3_load_a<5>(A, wbase, ((unsigned)(ch * X3_NPAIR * ncob + cob) * 3u * 64u) + (unsigned)(kc * 5) * astride, astride, lane);
-    };
-
     tile_issue(0);
     tile_commit();
-    bf16x8 A1[5][3];
-    first_a(A1, 0);
     __syncthreads();
 
-    f32x4 acc[8];
+    f32x4 acc[NB][8];
     VNET_STAMP_DECL;
     for (int step = 0; step < nsteps; ++step) {
         VNET_STAMP_STEP(step);
@@ -250,84 +243,89 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         const bool first = lc == 0, last = lc == nch - 1, more = step + 1 < nsteps;
         int b, bz, by, bx, cob;
         item_coords(it, b, bz, by, bx, cob);
-        if (first) x3_for<8>([&](auto MI) { acc[decltype(MI)::value] = f32x4{0.f, 0.f, 0.f, 0.f}; });
+        if (first) x3_for<8 * NB>([&](auto MI) { acc[decltype(MI)::value / 8][decltype(MI)::value % 8] = f32x4{0.f, 0.f, 0.f, 0.f}; });
         const int kc = (kw + ch) & 3;                                       // tap column of this wave in this chunk
-#ifndef X3_NO_PRIO
-        // The two waves of a SIMD (w, w + 4) run the same pieces; the matrix pipe goes to the OLDER one whenever both have an MFMA
-        // ready (s_memtime stamps: waves 0-3 finish their 780 MFMAs after 19 K cycles, waves 4-7 -- alone, at a single wave's rate --
-        // after 31 K).  Priority for the younger half during the first two pieces, for the older one afterwards: both halves reach the
-        // barrier together.
-        if (grp) __builtin_amdgcn_s_setprio(1);
-#endif
-        const unsigned wc = (unsigned)(ch * X3_NPAIR * ncob + cob) * 3u * 64u;      // pair 0 of (chunk, cout block), in 16-byte units
-        // Every piece's filter fragments are loaded one piece ahead (the first piece's before the barrier that ends the previous
-        // step): the two waves of a SIMD run the same piece sequence in near lockstep, so an L2 round trip at a piece head stalls both.
-        bf16x8 A2[5][3];
-        x3_load_a<5>(A2, wbase, wc + (unsigned)(25 + kc * 5) * astride, astride, lane);        // (dz 2|3, dx = kc)
-        __builtin_amdgcn_sched_barrier(0);
-        x3_zrows<0, 5>(acc, bZ + kc * 16, A1);                                          // (dz 0|1, dx = kc)
-        VNET_STAMP(1);
-        bf16x8 A3[4][3];
-        x3_load_a1(A3[0], wbase, wc + (unsigned)(50 + kc * 3) * astride, lane);          // (dz 4, dx = kc)
-        x3_load_a1(A3[1], wbase, wc + (unsigned)(51 + kc * 3) * astride, lane);
-        x3_load_a1(A3[2], wbase, wc + (unsigned)(52 + kc * 3) * astride, lane);
-        x3_load_a1(A3[3], wbase, wc + 64u * astride, lane);                             // tap (4, 4, 4): goes with kc == 3
-        __builtin_amdgcn_sched_barrier(0);
-        x3_zrows<0, 5>(acc, bZ + 2 * X3_ZB + kc * 16, A2);
-        VNET_STAMP(2);
-        // the column dx = 4 in four parts (3 / 3 / 3 / 3 + 1 pairs): pairs 20-22 | 23, 24, 45 | 46-48 | 49, 62, 63 (+ 64 above)
-        bf16x8 A4[3][3];
-        {
-            const int p0 = kc == 0 ? 20 : kc == 1 ? 23 : kc == 2 ? 46 : 49;
-            const int p1 = kc == 0 ? 21 : kc == 1 ? 24 : kc == 2 ? 47 : 62;
-            const int p2 = kc == 0 ? 22 : kc == 1 ? 45 : kc == 2 ? 48 : 63;
-            x3_load_a1(A4[0], wbase, wc + (unsigned)p0 * astride, lane);
-            x3_load_a1(A4[1], wbase, wc + (unsigned)p1 * astride, lane);
-            x3_load_a1(A4[2], wbase, wc + (unsigned)p2 * astride, lane);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // the next tile's loads go out HERE: behind every filter load this step's MFMAs still wait for (vmcnt counts in order), and
-        // late enough that its 48 registers are not live next to two five-pair filter sets (the first two pieces)
-#ifndef X3_NO_PRIO
-        if (grp) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
-#endif
-        tile_issue(min(step + 1, nsteps - 1));         // (unconditional: a branch around an issue makes hipcc merge two vmcnt states)
-        __builtin_amdgcn_sched_barrier(0);
-        x3_yrows_pairs<0, 4>(acc, bY + kc * 16, A3);
-        x3_yrows_single<2, 4>(acc, b0 + kc * 16, A3);
-        if (kc == 3) x3_yrows_single<3, 4>(acc, b0 + 4 * 16, A3);
-        VNET_STAMP(3);
-        first_a(A1, min(step + 1, nsteps - 1));
-        __builtin_amdgcn_sched_barrier(0);
-        if (kc == 0) {
-            x3_zrows<0, 3>(acc, bZ + 4 * 16, A4);
-        } else if (kc == 1) {
-            x3_zrows<3, 2, 0, 3>(acc, bZ + 4 * 16, A4);
-            x3_zrows<0, 1, 2, 3>(acc, bZ + 2 * X3_ZB + 4 * 16, A4);
-        } else if (kc == 2) {
-            x3_zrows<1, 3>(acc, bZ + 2 * X3_ZB + 4 * 16, A4);
-        } else {
-            x3_zrows<4, 1, 0, 3>(acc, bZ + 2 * X3_ZB + 4 * 16, A4);
-            x3_yrows_pairs<1, 3>(acc, bY + 4 * 16, A4);
-        }
+        // The two waves of a SIMD (w, w + 4) run the same pieces; the matrix pipe goes to the OLDER one whenever both have an MFMA ready
+        // (s_memtime stamps: waves 0-3 finished their 780 MFMAs after 19 K cycles, waves 4-7 -- alone, at a single wave's rate -- after
+        // 31 K).  Priority for the younger half during the first two pieces, for the older one afterwards: both halves reach the barrier
+        // together, and because the halves are then half a pass apart, the L2 round trip of a piece's filter fragments (loaded at the
+        // piece's head, into ONE register set) hides under the other half's MFMAs: a prefetch one piece ahead (a second set of 60
+        // registers) measured the same (profiles/r05_x3_experiments.txt) and is what kept two cout blocks per item from fitting.
+        x3_for<NB>([&](auto NBI) {
+            constexpr int nb = decltype(NBI)::value;
+            const unsigned wc = (unsigned)(ch * X3_NPAIR * ncob + cob + nb) * 3u * 64u;      // pair 0 of (chunk, cout block), in 16-byte units
+            bf16x8 A[5][3];
+            if (grp) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            x3_load_a<5>(A, wbase, wc + (unsigned)(kc * 5) * astride, astride, lane);               // (dz 0|1, dx = kc)
+            __builtin_amdgcn_sched_barrier(0);
+            x3_zrows<0, 5>(acc[nb], bZ + kc * 16, A);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (nb == 0) VNET_STAMP(1);
+            x3_load_a<5>(A, wbase, wc + (unsigned)(25 + kc * 5) * astride, astride, lane);          // (dz 2|3, dx = kc)
+            __builtin_amdgcn_sched_barrier(0);
+            x3_zrows<0, 5>(acc[nb], bZ + 2 * X3_ZB + kc * 16, A);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (nb == 0) VNET_STAMP(2);
+            x3_load_a1(A[0], wbase, wc + (unsigned)(50 + kc * 3) * astride, lane);                  // (dz 4, dx = kc)
+            x3_load_a1(A[1], wbase, wc + (unsigned)(51 + kc * 3) * astride, lane);
+            x3_load_a1(A[2], wbase, wc + (unsigned)(52 + kc * 3) * astride, lane);
+            x3_load_a1(A[3], wbase, wc + 64u * astride, lane);                                     // tap (4, 4, 4): goes with kc == 3
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
+            // the next tile's loads go out in the LAST pass, behind this piece's filter loads (vmcnt counts in order) and late enough
+            // that its 48 registers are live for two pieces only; unconditional: a branch around an issue merges two vmcnt states
+            if constexpr (nb == NB - 1) tile_issue(min(step + 1, nsteps - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            x3_yrows_pairs<0, 5>(acc[nb], bY + kc * 16, A);
+            x3_yrows_single<2, 5>(acc[nb], b0 + kc * 16, A);
+            if (kc == 3) x3_yrows_single<3, 5>(acc[nb], b0 + 4 * 16, A);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (nb == 0) VNET_STAMP(3);
+            // the column dx = 4 in four parts (3 / 3 / 3 / 3 + 1 pairs): pairs 20-22 | 23, 24, 45 | 46-48 | 49, 62, 63 (+ 64 above)
+            {
+                const int p0 = kc == 0 ? 20 : kc == 1 ? 23 : kc == 2 ? 46 : 49;
+                const int p1 = kc == 0 ? 21 : kc == 1 ? 24 : kc == 2 ? 47 : 62;
+                const int p2 = kc == 0 ? 22 : kc == 1 ? 45 : kc == 2 ? 48 : 63;
+                x3_load_a1(A[0], wbase, wc + (unsigned)p0 * astride, lane);
+                x3_load_a1(A[1], wbase, wc + (unsigned)p1 * astride, lane);
+                x3_load_a1(A[2], wbase, wc + (unsigned)p2 * astride, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kc == 0) {
+                x3_zrows<0, 3, 0, 5>(acc[nb], bZ + 4 * 16, A);
+            } else if (kc == 1) {
+                x3_zrows<3, 2, 0, 5>(acc[nb], bZ + 4 * 16, A);
+                x3_zrows<0, 1, 2, 5>(acc[nb], bZ + 2 * X3_ZB + 4 * 16, A);
+            } else if (kc == 2) {
+                x3_zrows<1, 3, 0, 5>(acc[nb], bZ + 2 * X3_ZB + 4 * 16, A);
+            } else {
+                x3_zrows<4, 1, 0, 5>(acc[nb], bZ + 2 * X3_ZB + 4 * 16, A);
+                x3_yrows_pairs<1, 5>(acc[nb], bY + 4 * 16, A);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
         VNET_STAMP(4);
-#ifndef X3_NO_PRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
         __syncthreads();                                   // every wave is done reading the tile
         VNET_STAMP(5);
         if (last) {
             // the four partial bricks of each group meet in LDS; wave kw sums and stores the output rows 2 kw, 2 kw + 1
-            x3_for<8>([&](auto MI) { constexpr int m = decltype(MI)::value; *reinterpret_cast<f32x4*>(red + ((wave * 8 + m) * 64 + lane) * 4) = acc[m]; });
+            x3_for<8 * NB>([&](auto MI) {
+                constexpr int nb = decltype(MI)::value / 8, m = decltype(MI)::value % 8;
+                *reinterpret_cast<f32x4*>(red + (((wave * NB + nb) * 8 + m) * 64 + lane) * 4) = acc[nb][m];
+            });
             __syncthreads();
-            const int co0 = cob * 16, co = co0 + 4 * g;
+            x3_for<NB>([&](auto NBI) {
+            constexpr int nb = decltype(NBI)::value;
+            const int co0 = (cob + nb) * 16, co = co0 + 4 * g;
             f32x4 o[2];
             x3_for<2>([&](auto TI) {
                 constexpr int t = decltype(TI)::value;
                 const int m = 2 * kw + t;
-                const float* rp = red + ((grp * 4 * 8 + m) * 64 + lane) * 4;
-                o[t] = (*reinterpret_cast<const f32x4*>(rp) + *reinterpret_cast<const f32x4*>(rp + 8 * 64 * 4)) +
-                       (*reinterpret_cast<const f32x4*>(rp + 2 * 8 * 64 * 4) + *reinterpret_cast<const f32x4*>(rp + 3 * 8 * 64 * 4));
+                constexpr int WS = NB * 8 * 64 * 4;                    // floats between two waves' partial bricks
+                const float* rp = red + (((grp * 4 * NB + nb) * 8 + m) * 64 + lane) * 4;
+                o[t] = (*reinterpret_cast<const f32x4*>(rp) + *reinterpret_cast<const f32x4*>(rp + WS)) +
+                       (*reinterpret_cast<const f32x4*>(rp + 2 * WS) + *reinterpret_cast<const f32x4*>(rp + 3 * WS));
             });
             float bias4[4] = {0.f, 0.f, 0.f, 0.f};
             if (a.bias && co < a.Cout) {
@@ -365,13 +363,17 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 x3_for<4>([&](auto KI) {
                     constexpr int k = decltype(KI)::value;
                     s1[k] = row16_sum(s1[k]); s2[k] = row16_sum(s2[k]);
-                    if (j == 0) { sred[wave * 32 + 4 * g + k] = s1[k]; sred[wave * 32 + 16 + 4 * g + k] = s2[k]; }
+                    if (j == 0) { sred[(nb * 8 + wave) * 32 + 4 * g + k] = s1[k]; sred[(nb * 8 + wave) * 32 + 16 + 4 * g + k] = s2[k]; }
                 });
             }
+            });
             __syncthreads();                               // the partial bricks are read; the statistics of all waves are in sred
             if constexpr (STATS) {
-                int brick = (i_lo + slot + it * G8) / (ncob * nks);
-                stats_row_write<8, 16>(sred, a.stats, (size_t)brick, co0, a.Cout, tid);
+                int brick = (i_lo + slot + it * G8) / (ncobg * nks);
+                x3_for<NB>([&](auto NBI) {
+                    constexpr int nb = decltype(NBI)::value;
+                    stats_row_write<8, 16>(sred + nb * 8 * 32, a.stats, (size_t)brick, (cob + nb) * 16, a.Cout, tid);
+                });
             }
         }
         VNET_STAMP(6);

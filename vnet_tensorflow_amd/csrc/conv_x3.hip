@@ -62,17 +62,18 @@ int vnet_conv_fwd_x3(const float* x0, int C0, const float* x1, int C1, const voi
     }
     hipStream_t st = (hipStream_t)stream;
     const int grid = x3_grid();
-    if (stats && p.nks == 1) {
-        auto k = conv5_x3_kernel<true>;
-        static unsigned long long attr_done = 0;
-        if (int ae = ensure_lds(k, X3_LDS, attr_done)) return ae;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(512), X3_LDS, st, a);
-    } else {
-        auto k = conv5_x3_kernel<false>;
-        static unsigned long long attr_done = 0;
-        if (int ae = ensure_lds(k, X3_LDS, attr_done)) return ae;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(512), X3_LDS, st, a);
+    // two 16-cout blocks per item where the layer has them and still fills the chip twice (a block pair never straddles y0 / y1)
+    const bool nb2 = (a.Cout % 32 == 0) && (Cy0 % 32 == 0) && p.items * p.nks >= 4 * (long)grid && tuning().x3_nb2 != 0;
+#define VNET_X3_GO(STATSV, NBV)                                                          \
+    {                                                                                    \
+        auto k = conv5_x3_kernel<STATSV, NBV>;                                           \
+        static unsigned long long attr_done = 0;                                         \
+        if (int ae = ensure_lds(k, X3_LDS, attr_done)) return ae;                        \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), X3_LDS, st, a);                     \
     }
+    if (stats && p.nks == 1) { if (nb2) VNET_X3_GO(true, 2) else VNET_X3_GO(true, 1) }
+    else { if (nb2) VNET_X3_GO(false, 2) else VNET_X3_GO(false, 1) }
+#undef VNET_X3_GO
     VNET_LAUNCH_CHECK();
     if (p.nks > 1) {
         const size_t total = nvox * a.Cout;
