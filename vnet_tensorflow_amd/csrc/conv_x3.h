@@ -513,6 +513,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
 #pragma unroll 1
         for (int zz = 0; zz < X3_TZ; ++zz) {
+            // (priority alternation between the two waves of a SIMD, as in the convolution kernel: the matrix pipe goes to the older wave
+            //  whenever both are ready, so without it waves 0-3 finish a brick early and waves 4-7 finish it alone at a single wave's rate)
+            if ((wave >> 2) ^ zz) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
             const int zx = zz * XW_XPLANE, zd = zz * (X3_TY * 16 * 32);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -561,6 +564,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         }
     }
+    __builtin_amdgcn_s_setprio(0);
     // lane holds dW[tap][ci = chunk*16 + i][co = co0 + 4*g + {0..3}]
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
