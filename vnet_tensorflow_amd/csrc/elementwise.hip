@@ -689,27 +689,43 @@ __global__ void __launch_bounds__(EW_BLOCK) softmax_dice_fwd_kernel(LossP p) {
     const float* lg = p.logits + (size_t)b * p.V * K;
     const int32_t* lb = p.labels + (size_t)b * p.V;
     const size_t stride = (size_t)gridDim.x * EW_BLOCK;
-    for (size_t v = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x; v < p.V; v += stride) {
-        float z[K];
+    // (round 5: four voxels of a thread per trip, their loads issued together -- clamped addresses, so none is conditional --
+    //  before the first exp: one voxel per trip left a single 12-byte request per thread in flight)
+    constexpr int U = 4;
+    for (size_t v0 = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x; v0 < p.V; v0 += U * stride) {
+        float zz[U][K]; int labs[U];
 #pragma unroll
-        for (int k = 0; k < K; ++k) z[k] = lg[v * K + k];
-        float mx = z[0]; int am = 0;
+        for (int u = 0; u < U; ++u) {
+            const size_t vc = (v0 + u * stride < p.V) ? v0 + u * stride : v0;
 #pragma unroll
-        for (int k = 1; k < K; ++k) if (z[k] > mx) { mx = z[k]; am = k; }
-        float e[K], se = 0.f;
-#pragma unroll
-        for (int k = 0; k < K; ++k) { e[k] = expf(z[k] - mx); se += e[k]; }
-        const float inv = 1.f / se;
-        const int lab = lb[v];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float pk = e[k] * inv;
-            const float t = (lab == k) ? 1.f : 0.f;
-            aI[k] += pk * t; aL[k] += jac ? pk * pk : pk; aR[k] += t;
-            if (p.softmax_out) p.softmax_out[((size_t)b * p.V + v) * K + k] = pk;
-            if (lab == k) aX += (wx ? p.weights[k] : 1.f) * (logf(se) - (z[k] - mx));
+            for (int k = 0; k < K; ++k) zz[u][k] = lg[vc * K + k];
+            labs[u] = lb[vc];
         }
-        if (p.pred_out) p.pred_out[(size_t)b * p.V + v] = am;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t v = v0 + u * stride;
+            if (v >= p.V) break;
+            float z[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) z[k] = zz[u][k];
+            float mx = z[0]; int am = 0;
+#pragma unroll
+            for (int k = 1; k < K; ++k) if (z[k] > mx) { mx = z[k]; am = k; }
+            float e[K], se = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) { e[k] = expf(z[k] - mx); se += e[k]; }
+            const float inv = 1.f / se;
+            const int lab = labs[u];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float pk = e[k] * inv;
+                const float t = (lab == k) ? 1.f : 0.f;
+                aI[k] += pk * t; aL[k] += jac ? pk * pk : pk; aR[k] += t;
+                if (p.softmax_out) p.softmax_out[((size_t)b * p.V + v) * K + k] = pk;
+                if (lab == k) aX += (wx ? p.weights[k] : 1.f) * (logf(se) - (z[k] - mx));
+            }
+            if (p.pred_out) p.pred_out[(size_t)b * p.V + v] = am;
+        }
     }
     // block reduce 3K+1 values
     __shared__ float sh[4][3 * K + 1];
@@ -728,11 +744,43 @@ __global__ void __launch_bounds__(EW_BLOCK) softmax_dice_fwd_kernel(LossP p) {
 
 // one thread: evaluates the loss switch (model.py:495-558) from the float64 sums, stores
 // coef[b][k][0] = dloss/dI, coef[b][k][1] = dloss/dL, coef[2BK] = xent coefficient (per voxel)
-__global__ void loss_finalize_kernel(const double* __restrict__ sums, int B, int K, double V, int kind,
-                                     const float* __restrict__ weights, float alpha, float smooth,
-                                     float* loss_out, float* dice_out, float* coef) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// (round 5: the column sums of the partial rows -- a launch of their own through round 4 -- are formed HERE, by the one workgroup
+//  that then evaluates the loss: thread = (column % 32, one of 32 row groups), 16 row loads of a thread in flight
+//  together, the row groups meet in LDS in a fixed order: deterministic, float64, one launch less in front of the backward
+//  pass.  A first version that reduced the columns one after the other (one block reduction each) paid a memory round trip per
+//  column: 16.7 us against 13.5 us for the two launches.)
+__global__ void __launch_bounds__(1024) loss_finalize_kernel(const float* __restrict__ partial, int nblk, double* __restrict__ sums,
+                                                             int B, int K, double V, int kind,
+                                                             const float* __restrict__ weights, float alpha, float smooth,
+                                                             float* loss_out, float* dice_out, float* coef) {
     const int NS = 3 * K + 1;
+    constexpr int RG = 32, U = 16;                        // row groups (1024 threads = 32 columns x 32 row groups), loads in flight per thread
+    __shared__ double shc[RG][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    for (int b = 0; b < B; ++b)
+        for (int c0 = 0; c0 < NS; c0 += 32) {
+            const int c = min(c0 + cl, NS - 1);
+            const float* col = partial + (size_t)b * nblk * NS + c;
+            double acc = 0.0;
+            for (int r0 = rg; r0 < nblk; r0 += RG * U) {
+                float v[U];
+#pragma unroll
+                for (int q = 0; q < U; ++q) v[q] = col[(size_t)min(r0 + q * RG, nblk - 1) * NS];      // (clamped: every load unconditional, in flight together)
+#pragma unroll
+                for (int q = 0; q < U; ++q) acc += (r0 + q * RG < nblk) ? (double)v[q] : 0.0;
+            }
+            shc[rg][cl] = acc;
+            __syncthreads();
+            if (threadIdx.x < 32 && c0 + cl < NS) {
+                double t = 0.0;
+#pragma unroll
+                for (int q = 0; q < RG; ++q) t += shc[q][cl];
+                sums[b * NS + c0 + cl] = t;
+            }
+            __syncthreads();
+        }
+    __threadfence_block();
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int base = kind & 15;
     const bool weighted = (kind & VNET_LOSS_WEIGHTED) != 0, mixed = (kind & VNET_LOSS_MIXED) != 0;
     double xsum = 0; for (int b = 0; b < B; ++b) xsum += sums[b * NS + 3 * K];
@@ -958,11 +1006,6 @@ __global__ void __launch_bounds__(256) head_finalize_kernel(const float* __restr
 }
 
 // loss partial rows [b][blk][3K+1] -> float64 sums [b][3K+1]
-__global__ void __launch_bounds__(256) loss_colsum_kernel(const float* __restrict__ partial, int nblk, int NS, double* __restrict__ sums) {
-    const int b = blockIdx.y, col = blockIdx.x;
-    const double s = block_colsum_d(partial + (size_t)b * nblk * NS, nblk, NS, col);
-    if (threadIdx.x == 0) sums[b * NS + col] = s;
-}
 
 
 // =======================================================================================================
@@ -1919,9 +1962,7 @@ int vnet_softmax_dice_fwd(const float* logits, const int32_t* labels, int B, int
     K_SWITCH(K, hipLaunchKernelGGL(softmax_dice_fwd_kernel<KK>, dim3(nblk, B), dim3(EW_BLOCK), 0, st, p));
     VNET_LAUNCH_CHECK();
     double* sums = reinterpret_cast<double*>((char*)ws + align_up((size_t)B * EW_MAXBLK * (3 * K + 1) * sizeof(float), 16));
-    hipLaunchKernelGGL(loss_colsum_kernel, dim3(3 * K + 1, B), dim3(256), 0, st, p.partial, nblk, 3 * K + 1, sums);
-    VNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, sums, B, K, (double)V, loss_kind, weights, alpha,
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, p.partial, nblk, sums, B, K, (double)V, loss_kind, weights, alpha,
                        smooth, loss_out, dice_out, coef);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
@@ -1955,9 +1996,7 @@ int vnet_dice_coe_fwd(const float* output, const float* target, int B, int64_t V
     K_SWITCH(K, hipLaunchKernelGGL(dice_sums_kernel<KK>, dim3(nblk, B), dim3(EW_BLOCK), 0, st, output, target, (size_t)V, jaccard, partial));
     VNET_LAUNCH_CHECK();
     const int kind = (jaccard ? VNET_LOSS_JACCARD : VNET_LOSS_SORENSEN) | (weights ? VNET_LOSS_WEIGHTED : 0);
-    hipLaunchKernelGGL(loss_colsum_kernel, dim3(3 * K + 1, B), dim3(256), 0, st, partial, nblk, 3 * K + 1, sums);
-    VNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, sums, B, K, (double)V, kind, weights, 0.f,
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, nblk, sums, B, K, (double)V, kind, weights, 0.f,
                        smooth, loss_tmp, dice_out, coef);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
