@@ -12,8 +12,9 @@
  *     deferred filter-gradient reduces between vnet_wgrad_defer(1, stream) and vnet_wgrad_flush(stream), and the tuning
  *     switches, read once from the environment and changed only through vnet_set_option); all work is
  *     enqueued on `stream` (hipStream_t); no hidden synchronisation -> safe to overlap with RCCL
- *     on another stream and to capture into a hipGraph.  bf16 shadows (`*_x16`) are 2-byte images
- *     of fp32 tensors that the caller allocates next to them.
+ *     on another stream and to capture into a hipGraph.  `*_b16` entry points take bf16 TENSORS
+ *     (2-byte elements, same NDHWC indexing); round 2's bf16 shadows of fp32 tensors (`*_x16`, `vnet_conv_*_bf16`) were
+ *     retired in round 5 -- the storage mode supersedes them.
  *   - return value: 0 on success, a negative VNET_E_* code for argument errors, or a positive
  *     hipError_t from the launch.  Nothing throws, nothing exits.
  */
@@ -70,7 +71,8 @@ const char* vnet_version(void);
 
 /* Tuning switches.  The library reads its handful of switches ONCE from the environment (VNET_<NAME>, first use) and never on a
  * launch path; afterwards they change only through vnet_set_option(name, value) -> previous value (NaN: unknown name).  Names:
- * WGRAD_ZS, WGRAD_RR, CONV_IN4, WGRAD_GROUP_ROUNDS, WGRAD_GROUP_DEBUG, BF16_DEEP, BF16_DEEP_TARGET. */
+ * WGRAD_ZS, WGRAD_RR, CONV_IN4, WGRAD_GROUP_ROUNDS, WGRAD_GROUP_DEBUG, BF16_DEEP, BF16_DEEP_TARGET, F32_SMALL, X3_NB2 (INTEGRATION.md,
+ * "Switches"). */
 double vnet_set_option(const char* name, double value);
 double vnet_get_option(const char* name);
 
@@ -132,26 +134,6 @@ int vnet_conv_fwd_stats(int ks, int kx, int stride, const float* x0, int C0, con
                         int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                         const float* res, float* stats, void* ws, size_t ws_bytes, void* stream);
 
-/* ---- bf16-operand 5x5x5 stride-1 convolution (BASELINE config C5: bf16 compute, fp32 accumulate) ----------
- * Same contract as vnet_conv_fwd(ks=5, stride=1): fp32 NDHWC tensors in and out, two-source input, split output,
- * bias; x and the filter are rounded to bf16 (round-to-nearest-even) on the way into the matrix cores and the
- * products are accumulated in fp32 (v_mfma_f32_32x32x16_bf16).  wp: vnet_pack_weights(VNET_PACK_FWD_BF16) for the
- * forward conv, VNET_PACK_BWD_BF16 for backward-data (then Cin/Cout are those of the backward problem). */
-size_t vnet_conv_bf16_ws_bytes(int Cin, int Cout, int B, int D, int H, int W);
-int vnet_conv_fwd_bf16(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
-                       float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
-                       void* ws, size_t ws_bytes, void* stream);
-
-int vnet_conv_fwd_bf16_acc(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
-                           float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
-                           void* ws, size_t ws_bytes, void* stream);     /* y += conv(x), see vnet_conv_fwd_acc */
-
-int vnet_conv_bf16_stats_rows(int Cin, int Cy0, int Cy1, int C0, int C1, int B, int D, int H, int W);
-int vnet_conv_bf16_stats_rows_x16(int Cin, int Cy0, int Cy1, int C0, int C1, int B, int D, int H, int W);   /* for vnet_conv_fwd_bf16_x16 (its own brick shapes) */
-int vnet_conv_fwd_bf16_stats(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
-                             float* y, int Cout, int B, int D, int H, int W,
-                             const float* res, float* stats, void* ws, size_t ws_bytes, void* stream);   /* see vnet_conv_fwd_stats */
-
 /* ---- f32x3 (round 5): the 5^3 stride-1 convolution in fp32 accuracy on the bf16 matrix pipe -------------------------
  * Replaces tf.nn.convolution (layers2.py:59-63 from networks.py:316,333,346) and Conv3DBackpropInput (model.py:660) like
  * vnet_conv_fwd, for fp32 tensors: every operand is split EXACTLY into three bf16 pieces (x = h + m + l) and a product is
@@ -177,26 +159,8 @@ size_t vnet_wgrad_x3_ws_bytes(int Cin, int Cout, int B, int D, int H, int W);
 int vnet_conv_wgrad_x3(const float* x0, int C0, const float* x1, int C1, const float* dy, int Cout, float* dw,
                        int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream);
 
-/* bf16 SHADOWS (round 2).  In bf16 mode every convolution input is produced by a batch-norm / dropout kernel (forward) or
- * a batch-norm backward kernel (dy); the *_x16 producers below write, next to the fp32 tensor, its bf16 image (RNE -- the very
- * rounding the kernels above apply while staging), and these entry points stage THAT: half the bytes through L2, no
- * conversion, bit-identical results.  x0h/x1h/dyh: 16-byte aligned, 2-byte elements, same NDHWC indexing; channel counts
- * multiples of 8 (VNET_E_UNSUPPORTED otherwise -- use the fp32-source entry points).  res/stats as in
- * vnet_conv_fwd_bf16_stats (stats requires Cy1 == 0).  acc: NULL, or a tensor added to the result -- acc == y0 is
- * vnet_conv_fwd_bf16_acc (y0 += conv); any other tensor of y0's shape (Cy1 == 0) gives y0 = conv + acc out of place, which is
- * what backward-data needs when the other gradient of a forked tensor IS this convolution's input dy (a one-convolution
- * residual block, networks.py:314-318). */
-int vnet_conv_fwd_bf16_x16(const void* x0h, int C0, const void* x1h, int C1, const void* wp, const float* bias,
-                           float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
-                           const float* acc, const float* res, float* stats, void* ws, size_t ws_bytes, void* stream);
-int vnet_conv_wgrad_bf16_x16(const void* x0h, int C0, const void* x1h, int C1, const void* dyh, int Cout, float* dw,
-                             int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream);
-
-/* filter gradient of the same convolution with x and dy rounded to bf16, fp32 accumulation
- * (v_mfma_f32_16x16x32_bf16 fed by LDS transpose reads); dw is fp32 in TF layout [125][Cin][Cout]. */
+/* workspace of vnet_conv_wgrad_b16 (bf16 storage, below): partial slabs of the split over bricks */
 size_t vnet_wgrad_bf16_ws_bytes(int Cin, int Cout, int B, int D, int H, int W);
-int vnet_conv_wgrad_bf16(const float* x0, int C0, const float* x1, int C1, const float* dy, int Cout, float* dw,
-                         int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream);
 
 /* Deferred reduces of the filter-gradient slabs, PER STREAM.  vnet_wgrad_defer(1, stream): the filter-gradient entry points that
  * launch on `stream` leave their partial slabs in the caller's workspace (which must then stay untouched, one per layer) and queue
@@ -257,9 +221,6 @@ int vnet_bn_stats(const float* x, const float* r, int bcast, int64_t M, int C, f
 int vnet_bn_act_fwd(const float* x, const float* r, int bcast, int64_t M, int C,
                     const float* mean, const float* invstd, const float* gamma, const float* beta,
                     int act, const float* alpha, float* y, void* stream);
-int vnet_bn_act_fwd_x16(const float* x, const float* r, int bcast, int64_t M, int C,
-                        const float* mean, const float* invstd, const float* gamma, const float* beta,
-                        int act, const float* alpha, float* y, void* yh /* NULL or bf16 shadow of y, C % 4 == 0 */, void* stream);
 /* backward: pass 1 reduces dgamma,dbeta,dalpha; pass 2 writes ds (gradient w.r.t. s = x + r;
  * the same tensor is the gradient of both x and r).  bcast=1: ds has C channels (caller sums). */
 int vnet_bn_act_bwd(const float* dy, const float* x, const float* r, int bcast, int64_t M, int C,
@@ -293,10 +254,6 @@ int vnet_bn_act_bwd_apply(const float* dy, const float* x, const float* r, int b
                           int act, const float* alpha, const float* sum_dz, const float* sum_dz_xhat, double M_total,
                           const float* xhat_coef /* NULL, or [C]: ds += xhat * xhat_coef (batch-norm chains) */,
                           float* ds, void* stream);
-int vnet_bn_act_bwd_apply_x16(const float* dy, const float* x, const float* r, int bcast, int64_t M, int C,
-                              const float* mean, const float* invstd, const float* gamma, const float* beta,
-                              int act, const float* alpha, const float* sum_dz, const float* sum_dz_xhat, double M_total,
-                              const float* xhat_coef, float* ds, void* dsh /* NULL or bf16 shadow of ds */, void* stream);
 
 /* Batch-norm CHAINS of the decoder, evaluated in closed form on ONE tensor x (the convolution output):
  *   kind 0 (networks.py:333-337, block with one convolution): y1 = BN1(x); y2 = BN2(y1); out = act(BN3(y1 + y2))
@@ -380,8 +337,6 @@ int vnet_momentum_apply_dev(float* p, const float* g, float* acc, int64_t n, con
                             int nesterov, float gscale, void* stream);
 int vnet_dropout_fwd_dev(const float* x, float* y, uint8_t* mask, int64_t n, float rate, uint64_t seed,
                          const void* state, void* stream);
-int vnet_dropout_fwd_x16(const float* x, float* y, void* yh /* NULL or bf16 shadow of y */, uint8_t* mask, int64_t n, float rate,
-                         uint64_t seed, const void* state /* NULL: host step */, void* stream);
 
 /* ---- hard metrics (model.py:588-626): K x K confusion matrix cm[label][prediction] as float64 counts;
  * accuracy, per-class tp/tn/fp/fn, sensitivity, specificity and hard Dice 2tp/(2tp+fp+fn) follow on the host. */
@@ -423,10 +378,10 @@ int vnet_colsum_b16(const void* x16, float* out, int64_t M, int C, void* ws, siz
 /* 5^3 stride-1 convolution, bf16 in / bf16 out; forward (VNET_PACK_FWD_BF16) and backward-data (VNET_PACK_BWD_BF16).
  * acc16: NULL, or a bf16 tensor of y0's shape that is added before the rounding (== y0: in place; else out of place, Cy1 = 0);
  * res16 / stats: batch-norm statistics of the ROUNDED output (+ res16) in the epilogue, rows = vnet_conv_b16_stats_rows;
- * ws >= vnet_conv_b16_ws_bytes.  Result == RNE(what vnet_conv_fwd_bf16_x16 writes in fp32), bit for bit, wherever the two take
- * the same kernels.  Round 4: few bricks and whole 32-cout blocks / 16-cin chunks (the deep levels: 32^3 64->64, 16^3 128->128,
+ * ws >= vnet_conv_b16_ws_bytes.  Operands bf16, products accumulated in fp32 (v_mfma_f32_32x32x16_bf16 / 16x16x32), ONE rounding of
+ * the result.  Round 4: few bricks and whole 32-cout blocks / 16-cin chunks (the deep levels: 32^3 64->64, 16^3 128->128,
  * 8^3 256->256 and their two-source / backward-data relatives) take the K-split-over-waves kernel of csrc/conv_deep.h, which sums
- * in another (fixed) order; environment VNET_BF16_DEEP=0 keeps the generic kernels. */
+ * in another (fixed) order; option BF16_DEEP = 0 keeps the generic kernels. */
 size_t vnet_conv_b16_ws_bytes(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W);
 int vnet_conv_b16_stats_rows(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W);
 int vnet_conv_fwd_b16(const void* x0, int C0, const void* x1, int C1, const void* wp, const float* bias,

@@ -40,7 +40,7 @@ with tempfile.TemporaryDirectory() as tmp:
     ops.set_compute_dtype("fp32")
     del m
     torch.cuda.empty_cache()
-    for compute in ("fp32", "bf16_operands", "bf16"):
+    for compute in ("fp32", "bf16"):
         out = subprocess.run([os.path.join(ROOT, "vnet_tensorflow_amd", "vnet_infer"), "--weights", w, "--image", v,
                               "--label-out", os.path.join(tmp, "lab.npy"), "--classes", "2", "--channels", "16", "--levels", "4",
                               "--convs", "1,2,3,3", "--bottom", "3", "--patch", "128,128,128", "--stride", "64,64,64", "--batch", "2",

@@ -1,6 +1,6 @@
 """Micro-benchmark of ONE 5^3 convolution problem in one mode (for rocprofv3 --pmc passes):
-   python profiles/bench_one.py <conv|wgrad> <fp32|fp32_split3|bf16|bf16_operands> P Cin Cout [iters]
-   bf16 = bf16 storage (bf16 tensors in and out), bf16_operands = round 2's fp32 tensors + bf16 shadows"""
+   python profiles/bench_one.py <conv|wgrad> <fp32|fp32_split3|bf16> P Cin Cout [iters]
+   bf16 = bf16 storage (bf16 tensors in and out)"""
 import sys
 import torch
 sys.path.insert(0, '.')
@@ -20,8 +20,6 @@ if os.environ.get("BENCH_ZERO"):          # DVFS probe: all-zero operands toggle
     x.zero_(); dy.zero_()
     with torch.no_grad():
         w.zero_()
-if mode == 'bf16_operands' and ci % 8 == 0 and co % 8 == 0:          # as in a training step: producers leave bf16 shadows (VNET_BF16_SHADOW=0: off)
-    x, dy = ops.with_shadow(x), ops.with_shadow(dy)
 if mode == 'bf16':
     x, dy = x.to(torch.bfloat16), dy.to(torch.bfloat16)
 
@@ -32,8 +30,6 @@ def run():
             ops._ConvFn.apply(x, None, w, b, 5, 1, False, None)
     elif mode == 'bf16':
         ops._wgrad5_b16_call(x, None, dy, dw, (P, P, P), ci)
-    elif mode == 'bf16_operands':
-        ops._wgrad_bf16_call(x, None, dy, dw, (P, P, P))
     elif mode == 'fp32_split3':
         ops._wgrad_x3_call(x, None, dy, dw, (P, P, P))
     else:

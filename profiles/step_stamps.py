@@ -29,7 +29,7 @@ wp = ops.packed_weights(w, ops.PACK_FWD_BF16, 125, ci, co)
 y = torch.empty(*shp, co, device=dev, dtype=torch.bfloat16)
 stats = None
 if want_stats:
-    rows = L.vnet_conv_bf16_stats_rows_x16(ci, co, 0, min(ci, 16), ci - min(ci, 16), 1, P, P, P)
+    rows = L.vnet_conv_b16_stats_rows(min(ci, 16), ci - min(ci, 16), co, 0, 1, P, P, P)
     stats = torch.zeros(rows, 2, co, device=dev)
 dbg = torch.zeros(4 * 8 * 12, dtype=torch.int64, device=dev)
 fn = L.vnet_debug_set_stamps

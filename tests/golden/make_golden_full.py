@@ -34,7 +34,6 @@ CASES = {
     # name: (file, P, B, cin, K, input seed, conv operand rounding)
     "c3": ("c3_128cube.npz", 128, 1, 1, 2, 1000, None),
     "c2": ("c2_64cube_b2.npz", 64, 2, 1, 2, 3000, None),
-    "c5": ("c5_128cube_bf16.npz", 128, 1, 4, 5, 1000, "bf16"),
     "c5s": ("c5_128cube_b16.npz", 128, 1, 4, 5, 1000, "storage"),
 }
 

@@ -50,6 +50,8 @@ CONV5_SHAPES = [
     (1, 16, 32, 64, 16, 16, 16),   # ... two chunks (paired bricks), two sources (decoder concat)
     (1, 16, 32, 64, 8, 0, 16),     # the zero-padded network input (4 modalities -> 8 channels)
     (2, 5, 9, 17, 16, 16, 16),     # ragged dims, batch 2
+    (1, 30, 50, 70, 8, 8, 16),     # persistent 16-cout kernel on a volume that is no multiple of its 4x8x16 brick, two sources
+    (2, 33, 40, 49, 16, 0, 16),    # ... odd brick counts per workgroup, batch 2
     (1, 8, 32, 64, 32, 0, 32),     # row-pair kernel (32-cout blocks, >= 256 items would need more bricks: generic here)
     (1, 16, 64, 64, 32, 0, 32),    # row-pair kernel
     (1, 8, 16, 32, 64, 0, 64),     # two cout blocks per workgroup
@@ -95,21 +97,6 @@ def test_conv5_b16_against_oracle_and_fp32_output_kernels(dev, shape, monkeypatc
     check_close(tag + " dw", tw.grad, dw_ex, 2e-6)
     assert tw.grad.dtype == torch.float32 and tb.grad.dtype == torch.float32
     check_close(tag + " db", tb.grad, dy.reshape(-1, Co).sum(0), 2e-6, atol=1e-6 * float(np.abs(dy).reshape(-1, Co).sum(0).max()))
-    # bit-exact link to the round-2 kernels (bf16 sources, fp32 outputs): same main loop, same summation order
-    ops.set_compute_dtype("bf16_operands")
-    try:
-        fx0 = ops.with_shadow(tx0.detach().float()).requires_grad_(True)
-        fx1 = ops.with_shadow(tx1.detach().float()).requires_grad_(True) if C1 else None
-        fw, fb = tw.detach().clone().requires_grad_(True), tb.detach().clone().requires_grad_(True)
-        y32 = ops.conv(fx0, fw, fb, 5, 1, x1=fx1)
-        assert torch.equal(y32.detach().to(BF), y.detach()), tag + ": forward is not RNE(fp32-output kernel)"
-        y32.backward(ops.with_shadow(g16(dy, dev).float()))
-        assert torch.equal(fx0.grad.to(BF), tx0.grad), tag + ": backward-data is not RNE(fp32-output kernel)"
-        if C1:
-            assert torch.equal(fx1.grad.to(BF), tx1.grad)
-        assert torch.equal(fw.grad, tw.grad), tag + ": filter gradient differs from the round-2 kernel"
-    finally:
-        ops.set_compute_dtype("fp32")
 
 
 @pytest.mark.parametrize("cin,dims,stats", [(4, (32, 64, 64), False), (3, (33, 64, 70), True), (1, (32, 64, 64), False)])
@@ -150,7 +137,8 @@ def test_conv5_b16_zero_padded_input_x_im2col(dev, cin, dims, stats, monkeypatch
     check_close("in4 dw", tw.grad, dw_ex, 2e-6)
 
 
-@pytest.mark.parametrize("shape", [(1, 16, 32, 64, 16, 0, 16), (1, 16, 64, 64, 32, 0, 32), (1, 8, 16, 32, 64, 0, 64), (1, 8, 8, 8, 32, 0, 32)])
+@pytest.mark.parametrize("shape", [(1, 16, 32, 64, 16, 0, 16), (1, 16, 64, 64, 32, 0, 32), (1, 8, 16, 32, 64, 0, 64), (1, 8, 8, 8, 32, 0, 32),
+                                   (1, 30, 50, 70, 16, 0, 16)])      # ragged bricks: voxels outside the volume must not be counted
 def test_conv5_b16_epilogue_statistics_and_accumulation(dev, shape):
     """Statistics of the ROUNDED output (+ bf16 residual) from the epilogue == a separate statistics pass over the stored tensor;
     accumulate mode (in place and out of place) rounds the SUM once."""

@@ -47,22 +47,23 @@ def _oracle_block(xcat, w, z0, y0, x0, rb=None):
     return y[:, s[0]:s[0] + 12, s[1]:s[1] + 12, s[2]:s[2] + 12, :]
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "fp32_split3"])
 @pytest.mark.parametrize("C0,C1,Co", [(16, 0, 16), (16, 16, 16), (16, 0, 32)])
 def test_conv5_full_resolution_against_oracle_crops(dev, mode, C0, C1, Co):
     """The north-star kernel (5^3 conv, 16/32 channels @128^3): forward, backward-data and filter gradient against the
-    oracle on crops.  fp32: rel-L2 2e-6.  bf16: same bound against the oracle with bf16-rounded operands."""
+    oracle on crops, rel-L2 2e-6 -- the fp32 MFMA kernels and (round 5) the f32x3 kernels: exactly split bf16 operands, six
+    products each, the SAME bound.  (bf16 storage at this size: tests/test_hip_golden_full.py, teacher-forced layers.)"""
     from vnet_tensorflow_amd import ops
     gen = torch.Generator(device="cpu").manual_seed(1234 + C0 + C1 + Co)
     x0 = torch.randn(1, P, P, P, C0, generator=gen)
     x1 = torch.randn(1, P, P, P, C1, generator=gen) if C1 else None
     w = torch.randn(5, 5, 5, C0 + C1, Co, generator=gen) * 0.05
     b = torch.randn(Co, generator=gen)
-    rb = O.round_bf16 if mode == "bf16" else None
+    rb = None
     tx0 = x0.to(dev).requires_grad_(True)
     tx1 = x1.to(dev).requires_grad_(True) if C1 else None
     tw, tb = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
-    ops.set_compute_dtype("bf16_operands" if mode == "bf16" else mode)
+    ops.set_compute_dtype(mode)
     try:
         y = ops.conv(tx0, tw, tb, 5, 1, x1=tx1)
         xcat = x0.numpy() if x1 is None else np.concatenate((x0.numpy(), x1.numpy()), -1)
@@ -130,25 +131,24 @@ def test_conv5_full_resolution_exact_known_answers(dev):
     assert float(yu.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "fp32_split3"])
 def test_conv_identities_full_resolution(dev, mode):
     """Linearity in x, adjointness of backward-data, and the filter gradient as the adjoint in w, with fp64 dot
-    products over all 128^3 x 16..32 values (2e-6 of |a||b|: sums of 3e7 fp32 terms; for bf16 the identities hold
-    for the ROUNDED operators, so dy and x are pre-rounded to bf16-representable values)."""
+    products over all 128^3 x 16..32 values (2e-6 of |a||b|: sums of 3e7 fp32 terms), fp32 MFMA and f32x3 kernels."""
     from vnet_tensorflow_amd import ops
     Ci, Co = 32, 16
-    q = (lambda t: t.to(torch.bfloat16).float()) if mode == "bf16" else (lambda t: t)
+    q = lambda t: t
     x, z = q(torch.randn(1, P, P, P, Ci, device=dev)), q(torch.randn(1, P, P, P, Ci, device=dev))
     w = q(torch.randn(5, 5, 5, Ci, Co, device=dev) * 0.05).requires_grad_(True)
     dw_dir = q(torch.randn(5, 5, 5, Ci, Co, device=dev) * 0.05)
     zero_b = torch.zeros(Co, device=dev)
     yv = q(torch.randn(1, P, P, P, Co, device=dev))
-    ops.set_compute_dtype("bf16_operands" if mode == "bf16" else mode)
+    ops.set_compute_dtype(mode)
     try:
         xr = x.clone().requires_grad_(True)
         cx = ops.conv(xr, w, zero_b, 5, 1)
         cz = ops.conv(z, w, zero_b, 5, 1)
-        if mode == "fp32":
+        if True:
             lin = ops.conv(2.0 * x - 0.5 * z, w, zero_b, 5, 1)
             assert rel_l2(lin.detach().cpu().numpy(), (2.0 * cx - 0.5 * cz).detach().cpu().numpy()) < 1e-5
         cx.backward(yv)

@@ -13,7 +13,6 @@ BIN = os.path.join(ROOT, "vnet_tensorflow_amd", "vnet_infer")
 
 
 @pytest.mark.parametrize("cin,K,levels,convs,bottom,batch,compute", [(1, 2, 2, [1, 2], 1, 2, "fp32"), (2, 3, 3, [1, 2, 3], 2, 3, "fp32"),
-                                                                     (4, 5, 2, [2, 2], 1, 2, "bf16_operands"),
                                                                      (4, 5, 2, [2, 2], 1, 2, "bf16"), (1, 2, 3, [1, 2, 2], 1, 2, "bf16")])
 def test_native_driver_matches_python_evaluate(tmp_path, dev, cin, K, levels, convs, bottom, batch, compute):
     from vnet_tensorflow_amd import model as M
@@ -24,7 +23,7 @@ def test_native_driver_matches_python_evaluate(tmp_path, dev, cin, K, levels, co
                                "SegmentationClasses": list(range(K)), "BatchSize": 1, "PatchShape": [16, 16, 16],
                                "Networks": {"Name": "VNet", "Dropout": 0.0, "NumChannel": 8, "NumLevels": levels,
                                             "NumCovolutions": convs, "BottomConvolutions": bottom},
-                               # (both sides: "bf16" = bf16 tensors end to end, "bf16_operands" = fp32 tensors + bf16 shadows)
+                               # (both sides: "bf16" = bf16 tensors end to end)
                                "ComputeDtype": compute,
                                "Optimizer": {"Name": "Adam", "InitialLearningRate": 1e-3, "Decay": {"Factor": 0.99, "Steps": 100}},
                                "Loss": {"Name": "sorensen"}},

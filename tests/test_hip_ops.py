@@ -53,52 +53,6 @@ def test_conv5(dev, shape):
 
 
 @pytest.mark.parametrize("shape", [
-    (1, 8, 16, 32, 16, 0, 16),     # wide brick, one cout block (16 padded to 32)
-    (2, 5, 9, 17, 16, 16, 16),     # ragged dims, two-source, batch 2
-    (1, 8, 8, 16, 32, 0, 32),
-    (1, 8, 16, 32, 64, 0, 64),     # two cout blocks per workgroup, four chunks
-    (1, 8, 8, 8, 32, 32, 32),      # cube brick, split-K
-    (1, 4, 4, 4, 128, 0, 128),     # split-K + dz split
-    (1, 2, 2, 2, 64, 0, 64),
-    (1, 6, 7, 9, 4, 4, 8),         # narrow channels (config C5 has a 4-channel input)
-    (1, 6, 6, 18, 3, 0, 16),       # scalar gather
-    (1, 4, 6, 16, 16, 0, 5),       # scalar scatter
-])
-def test_conv5_bf16(dev, shape):
-    """bf16-compute mode: operands rounded to bf16 (RNE), fp32 accumulation -- against the oracle convolution of the
-    ROUNDED operands (x, w / dy, w / x, dy), so the tolerance stays fp32-roundoff class (2e-6)."""
-    from vnet_tensorflow_amd import ops
-    B, D, H, W, C0, C1, Co = shape
-    rng = np.random.default_rng(sum(shape) + 7)
-    x0 = rng.standard_normal((B, D, H, W, C0))
-    x1 = rng.standard_normal((B, D, H, W, C1)) if C1 else None
-    w = rng.standard_normal((5, 5, 5, C0 + C1, Co)) * 0.1
-    b = rng.standard_normal(Co)
-    xcat = x0 if x1 is None else np.concatenate((x0, x1), -1)
-    y_ref = O.conv_nd_fwd(O.round_bf16(xcat), O.round_bf16(w), 1) + b
-    dy = rng.standard_normal(y_ref.shape)
-    dx_ref, _ = O.conv_nd_bwd(xcat, O.round_bf16(w), O.round_bf16(dy), 1)
-    _, dw_ref = O.conv_nd_bwd(O.round_bf16(xcat), w, O.round_bf16(dy), 1)
-    tx0 = g(x0, dev).requires_grad_(True)
-    tx1 = g(x1, dev).requires_grad_(True) if C1 else None
-    tw, tb = g(w, dev).requires_grad_(True), g(b, dev).requires_grad_(True)
-    ops.set_compute_dtype("bf16_operands")
-    try:
-        y = ops.conv(tx0, tw, tb, 5, 1, x1=tx1)
-        tag = "conv-bf16 [%d,%d,%d,%d] %d+%d->%d" % shape
-        check_close(tag + " fwd", y, y_ref, 2e-6)
-        y.backward(g(dy, dev))
-    finally:
-        ops.set_compute_dtype("fp32")
-    check_close(tag + " dx0", tx0.grad, dx_ref[..., :C0], 2e-6)
-    if C1:
-        check_close(tag + " dx1", tx1.grad, dx_ref[..., C0:], 2e-6)
-    check_close(tag + " dw", tw.grad, dw_ref, 2e-6)
-    # and it is within bf16 operand-rounding distance of the exact convolution (2^-8 relative per operand)
-    check_close(tag + " vs exact", y, O.conv_nd_fwd(xcat, w, 1) + b, 1e-2)
-
-
-@pytest.mark.parametrize("shape", [
     (1, 8, 16, 32, 16, 0, 32),
     (2, 4, 8, 16, 32, 0, 64),
     (1, 8, 8, 8, 64, 0, 128),

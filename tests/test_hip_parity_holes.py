@@ -181,7 +181,7 @@ def test_conv_bias_gradient_closed_form(dev, variant):
     assert nb >= 8
 
 
-@pytest.mark.parametrize("compute", ["fp32", "bf16_operands"])
+@pytest.mark.parametrize("compute", ["fp32"])
 def test_gradient_accumulation_in_the_producing_kernel(dev, compute):
     """Tensors with two consumers (skip connection, residual block input): the second gradient is added by the backward-data
     kernel that produces it (y += ..., ops.fork) instead of an autodiff add kernel.  Same two fp32 numbers are added either
@@ -210,9 +210,8 @@ def test_gradient_accumulation_in_the_producing_kernel(dev, compute):
         ops.set_compute_dtype("fp32")
     for n in grads[True][0]:
         assert np.array_equal(grads[True][0][n], grads[False][0][n]), n
-    # 3 levels: 3 skip forks + residual forks at levels 2, 3 and the bottom = 6 full-tensor adds saved; in bf16 mode also the
-    # level-1 block (ONE convolution: the other gradient is that convolution's own dy -> added out of place in its epilogue)
-    assert grads[False][1] - grads[True][1] >= (7 if compute == "bf16_operands" else 6), (grads[False][1], grads[True][1])
+    # 3 levels: 3 skip forks + residual forks at levels 2, 3 and the bottom = 6 full-tensor adds saved
+    assert grads[False][1] - grads[True][1] >= 6, (grads[False][1], grads[True][1])
 
 
 @pytest.mark.parametrize("mode,ks,stride,shape,Cin,Cout,residual", [
@@ -220,9 +219,6 @@ def test_gradient_accumulation_in_the_producing_kernel(dev, compute):
     ("fp32", 5, 1, (2, 24, 20, 28), 8, 24, False),        # ragged bricks: voxels outside the volume must not be counted
     ("fp32", 5, 1, (1, 8, 8, 8), 64, 64, True),           # split-K: statistics come from the reduce kernel
     ("fp32", 2, 2, (1, 32, 32, 32), 16, 32, False),       # 2^3 stride-2 down convolution
-    ("bf16_operands", 5, 1, (1, 64, 64, 128), 16, 16, True),       # 16-output-channel bf16 kernel (persistent workgroups)
-    ("bf16_operands", 5, 1, (1, 32, 32, 32), 32, 32, False),       # generic bf16 kernel
-    ("bf16_operands", 5, 1, (1, 8, 8, 8), 128, 128, True),         # bf16 split-K
 ])
 def test_batch_norm_statistics_from_the_conv_epilogue(dev, mode, ks, stride, shape, Cin, Cout, residual):
     """The convolution writes per-workgroup partial sums of y (+ residual) and its square; the batch-norm behind it only
@@ -290,46 +286,7 @@ def test_batched_filter_repack_equals_single_pack(dev, taps, I, O):
         ops.clear_pack_registry()
 
 
-@pytest.mark.parametrize("shape,C0,C1,Cout", [((1, 30, 50, 70), 12, 8, 12), ((2, 33, 40, 49), 4, 0, 16), ((1, 37, 49, 65), 16, 16, 8)])
-def test_bf16_16cout_kernel_ragged(dev, shape, C0, C1, Cout):
-    """conv5_bf16_c16_kernel (persistent workgroups, 4x8x16 bricks, two-chunk pairing) on volumes that are no multiple of the
-    brick, two-source inputs whose channel counts are no multiple of 16, fewer than 16 output channels, odd brick counts per
-    workgroup: forward against the rounded-operand oracle (2e-6), the accumulating form (y += conv) and the epilogue
-    statistics."""
-    from vnet_tensorflow_amd import ops, _lib
-    B, D, H, W = shape
-    assert _lib.lib().vnet_conv_bf16_stats_rows(C0 + C1, Cout, 0, C0, C1, B, D, H, W) == B * -(-D // 4) * -(-H // 8) * -(-W // 16)
-    gen = torch.Generator().manual_seed(D * H + W)
-    x0 = torch.randn(B, D, H, W, C0, generator=gen)
-    x1 = torch.randn(B, D, H, W, C1, generator=gen) if C1 else None
-    w = torch.randn(5, 5, 5, C0 + C1, Cout, generator=gen) * 0.05
-    b = torch.randn(Cout, generator=gen)
-    xcat = x0.numpy() if x1 is None else np.concatenate((x0.numpy(), x1.numpy()), -1)
-    ref = O.conv_nd_fwd(O.round_bf16(xcat.astype(np.float64)), O.round_bf16(w.numpy().astype(np.float64)), 1) + b.numpy().astype(np.float64)
-    ops.set_compute_dtype("bf16_operands")
-    try:
-        with torch.no_grad():
-            tx0, tx1 = x0.to(dev), (x1.to(dev) if C1 else None)
-            tw, tb = torch.nn.Parameter(w.to(dev)), b.to(dev)
-            y = ops.conv(tx0, tw, tb, 5, 1, x1=tx1, bn_stats=True)
-            check_close("c16 forward", y, ref, 2e-6)
-            st = y._vnet_stats
-            tot = st.partial.double().sum(0).cpu().numpy()
-            yd = y.double().reshape(-1, Cout)
-            check_close("epilogue sums", tot[:Cout], yd.sum(0).cpu().numpy(), 1e-5, atol=1e-2)
-            check_close("epilogue sums of squares", tot[Cout:], (yd * yd).sum(0).cpu().numpy(), 1e-5)
-            # accumulating form through the C ABI directly
-            L = _lib.lib()
-            acc = torch.full_like(y, 0.5)
-            wp = ops.packed_weights(tw, ops.PACK_FWD_BF16, 125, C0 + C1, Cout)
-            _lib.check(L.vnet_conv_fwd_bf16_acc(tx0.data_ptr(), C0, tx1.data_ptr() if C1 else None, C1, wp.data_ptr(), None,
-                                                acc.data_ptr(), Cout, None, 0, B, D, H, W, None, 0, ops._stream()), "acc")
-            check_close("c16 accumulate", acc, ref - b.numpy().astype(np.float64) + 0.5, 2e-6)
-    finally:
-        ops.set_compute_dtype("fp32")
-
-
-@pytest.mark.parametrize("compute,cin", [("fp32", 1), ("fp32", 2), ("bf16", 4), ("bf16_operands", 4)])
+@pytest.mark.parametrize("compute,cin", [("fp32", 1), ("fp32", 2), ("bf16", 4)])
 def test_deferred_batched_filter_gradient_reduce(dev, compute, cin):
     """ops.deferred_wgrad_reduce: the filter-gradient launches leave their partial slabs in per-layer buffers and ONE launch
     reduces all of them at the end of the backward pass (vnet_wgrad_defer / vnet_wgrad_flush).  Same summation order as the

@@ -126,8 +126,11 @@ def test_read_config_contract(tmp_path):
     cfg4["TrainingSetting"]["Networks"]["NumChannel"] = 12
     with pytest.raises(SystemExit, match="NumChannel"):
         image2label(None, cfg4, device="cpu", verbose=False).read_config()
-    cfg4["TrainingSetting"]["ComputeDtype"] = "bf16_operands"
+    cfg4["TrainingSetting"]["ComputeDtype"] = "fp32_split3"                 # (fp32 tensors: any width)
     image2label(None, cfg4, device="cpu", verbose=False).read_config()
+    cfg4["TrainingSetting"]["ComputeDtype"] = "bf16_operands"               # round 2's mode, retired in round 5
+    with pytest.raises(SystemExit, match="retired"):
+        image2label(None, cfg4, device="cpu", verbose=False).read_config()
     cfg4["TrainingSetting"]["ComputeDtype"] = "fp16"
     with pytest.raises(SystemExit, match="ComputeDtype"):
         image2label(None, cfg4, device="cpu", verbose=False).read_config()

@@ -35,28 +35,19 @@ SIGNATURES = {
                            _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "vnet_conv_fwd_acc": (_i, [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i,
                                _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
-    "vnet_conv_fwd_bf16_acc": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "vnet_conv_stats_rows": (_i, [_i] * 11),
     "vnet_conv_stats_from_reduce": (_i, [_i] * 9),
     "vnet_conv_fwd_stats": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i,
                                  _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
-    "vnet_conv_bf16_stats_rows": (_i, [_i] * 9),
-    "vnet_conv_bf16_stats_rows_x16": (_i, [_i] * 9),
-    "vnet_conv_fwd_bf16_stats": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "vnet_bn_finalize_partial": (_i, [_vp, _i, _i, _d, _f, _f, _vp, _vp, _vp, _vp, _vp]),
-    "vnet_conv_bf16_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "vnet_colsum_b16_ws_bytes": (_sz, [_i]),
     "vnet_colsum_b16": (_i, [_vp, _vp, _i64, _i, _vp, _sz, _vp]),
     "vnet_conv_b16_ws_bytes": (_sz, [_i] * 8),
     "vnet_conv_b16_stats_rows": (_i, [_i] * 8),
-    "vnet_conv_fwd_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "vnet_wgrad_bf16_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
-    "vnet_conv_wgrad_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "vnet_wgrad_defer": (_i, [_i, _vp]),
     "vnet_wgrad_pending": (_i, [_vp]),
     "vnet_wgrad_flush": (_i, [_vp]),
-    "vnet_conv_wgrad_bf16_x16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
-    "vnet_conv_fwd_bf16_x16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vnet_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "vnet_conv_wgrad": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp,
                              _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
@@ -74,11 +65,9 @@ SIGNATURES = {
     "vnet_bn_finalize": (_i, [_vp, _d, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "vnet_bn_act_bwd_reduce": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vnet_bn_act_bwd_apply": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp, _vp]),
-    "vnet_bn_act_bwd_apply_x16": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp, _vp, _vp]),
     "vnet_bn_chain_coef_fwd": (_i, [_i, _i, _f, _f] + [_vp] * 14 + [_vp]),
     "vnet_bn_chain_coef_bwd": (_i, [_i, _i, _f, _d] + [_vp] * 15 + [_vp]),
     "vnet_bn_act_fwd": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
-    "vnet_bn_act_fwd_x16": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "vnet_bn_act_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp,
                              _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vnet_act_fwd": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp]),
@@ -98,7 +87,6 @@ SIGNATURES = {
     "vnet_sgd_apply_dev": (_i, [_vp, _vp, _i64, _vp, _f, _vp]),
     "vnet_momentum_apply_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _f, _i, _f, _vp]),
     "vnet_dropout_fwd_dev": (_i, [_vp, _vp, _vp, _i64, _f, _u64, _vp, _vp]),
-    "vnet_dropout_fwd_x16": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _u64, _vp, _vp]),
     "vnet_confusion_ws_bytes": (_sz, [_i]),
     "vnet_confusion_matrix": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
     "vnet_auc_ws_bytes": (_sz, [_i]),
@@ -183,7 +171,7 @@ def lib():
             fn.restype, fn.argtypes = res, args
             if name == "vnet_conv_b16_stats_rows":
                 setattr(L, name, _memo(fn, (b"BF16_DEEP", b"BF16_DEEP_TARGET"), L))     # (the kernel choice follows these options)
-            elif name.endswith("_ws_bytes") or name.endswith("_stats_rows") or name.endswith("_stats_rows_x16") or name == "vnet_conv_stats_from_reduce" or name == "vnet_packed_weight_floats":
+            elif name.endswith("_ws_bytes") or name.endswith("_stats_rows") or name == "vnet_conv_stats_from_reduce" or name == "vnet_packed_weight_floats":
                 setattr(L, name, _memo(fn))    # pure size queries, asked before every launch: answer repeats from a dict
         _lib = L
     return _lib

@@ -22,6 +22,28 @@
 namespace {
 inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline bool al8p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
+
+// workspace bytes / statistics rows of the generic (non-deep) bf16 kernels: functions of the shape only (through round 4 these were
+// entry points of the retired fp32-tensor / bf16-operand mode: vnet_conv_bf16_ws_bytes, vnet_conv_bf16_stats_rows_x16)
+size_t conv_bf16_generic_ws_bytes(int Cin, int Cout, int B, int D, int H, int W) {
+    Bf16Plan p = plan_conv_bf16(Cin, Cout, B, D, H, W);
+    if (p.nsplit * p.nz <= 1) return 0;
+    return (size_t)p.nsplit * p.nz * B * D * H * W * round_up(Cout, 32) * sizeof(float);
+}
+
+int conv_bf16_generic_stats_rows(int Cin, int Cy0, int Cy1, int C0, int C1, int B, int D, int H, int W) {
+    if (Cy1 != 0 || Cy0 <= 0 || (Cy0 & 3) || Cin <= 0 || B <= 0) return 0;
+    if (conv_bf16_use_c16(Cin, Cy0, C0, C1, Cy0, 0, B, D, H, W)) return B * ceil_div(D, 4) * ceil_div(H, 8) * ceil_div(W, 16);
+    Bf16Plan p = plan_conv_bf16(Cin, Cy0, B, D, H, W);
+    if (conv_bf16_use_r32(Cy0, Cy0, 0, B, D, H, W) && p.nsplit * p.nz == 1)
+        return B * ceil_div(D, 4) * ceil_div(H, 16) * ceil_div(W, 16);      // row-pair kernel: one row per 4x16x16 brick
+    if (p.nsplit * p.nz > 1) {
+        if (Cy0 > 256 || 256 % Cy0) return 0;
+        const size_t total = (size_t)B * D * H * W * Cy0;
+        return (int)min((size_t)2048, (total + 255) / 256);
+    }
+    return B * p.nbz * p.nby * p.nbx;
+}
 }  // namespace
 
 extern "C" {
@@ -29,7 +51,7 @@ extern "C" {
 // workspace bytes / epilogue-statistics rows of vnet_conv_fwd_b16 for one problem (the kernel choice is a function of the shape)
 size_t vnet_conv_b16_ws_bytes(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W) {
     // (the larger of the two plans: the zero-padded network input takes the x-im2col kernel whatever the deep plan says)
-    const size_t g = vnet_conv_bf16_ws_bytes(C0 + C1, Cy0 + Cy1, B, D, H, W);
+    const size_t g = conv_bf16_generic_ws_bytes(C0 + C1, Cy0 + Cy1, B, D, H, W);
     const DeepPlan dp = plan_conv_deep(C0, C1, Cy0, Cy1, B, D, H, W, true);      // (whatever VNET_BF16_DEEP says: callers cache this)
     const size_t d = (dp.use && dp.nsplit > 1) ? (size_t)dp.nsplit * B * D * H * W * round_up(Cy0 + Cy1, 32) * sizeof(float) : 0;
     return d > g ? d : g;
@@ -38,7 +60,7 @@ size_t vnet_conv_b16_ws_bytes(int C0, int C1, int Cy0, int Cy1, int B, int D, in
 int vnet_conv_b16_stats_rows(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W) {
     if (Cy1 != 0 || Cy0 <= 0 || (Cy0 & 3) || C0 <= 0 || B <= 0) return 0;
     const DeepPlan dp = plan_conv_deep(C0, C1, Cy0, Cy1, B, D, H, W);
-    if (!dp.use) return vnet_conv_bf16_stats_rows_x16(C0 + C1, Cy0, Cy1, C0, C1, B, D, H, W);
+    if (!dp.use) return conv_bf16_generic_stats_rows(C0 + C1, Cy0, Cy1, C0, C1, B, D, H, W);
     if (dp.nsplit > 1) {                              // statistics from the split-K reduce kernel: one row per reduce block
         if (Cy0 > 256 || 256 % Cy0) return 0;
         const size_t total = (size_t)B * D * H * W * Cy0;

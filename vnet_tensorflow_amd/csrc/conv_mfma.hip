@@ -257,106 +257,6 @@ int vnet_conv_fwd_stats(int ks, int kx, int stride, const float* x0, int C0, con
                          res, stats);
 }
 
-size_t vnet_conv_bf16_ws_bytes(int Cin, int Cout, int B, int D, int H, int W) {
-    Bf16Plan p = plan_conv_bf16(Cin, Cout, B, D, H, W);
-    if (p.nsplit * p.nz <= 1) return 0;
-    return (size_t)p.nsplit * p.nz * B * D * H * W * round_up(Cout, 32) * sizeof(float);
-}
-
-int vnet_conv_bf16_stats_rows_x16(int Cin, int Cy0, int Cy1, int C0, int C1, int B, int D, int H, int W) {
-    if (Cy1 != 0 || Cy0 <= 0 || (Cy0 & 3) || Cin <= 0 || B <= 0) return 0;
-    if (!conv_bf16_use_c16(Cin, Cy0, C0, C1, Cy0, 0, B, D, H, W) && conv_bf16_use_r32(Cy0, Cy0, 0, B, D, H, W)) {
-        Bf16Plan p = plan_conv_bf16(Cin, Cy0, B, D, H, W);
-        if (p.nsplit * p.nz == 1) return B * ceil_div(D, 4) * ceil_div(H, 16) * ceil_div(W, 16);      // row-pair kernel: one row per 4x16x16 brick
-    }
-    return vnet_conv_bf16_stats_rows(Cin, Cy0, Cy1, C0, C1, B, D, H, W);
-}
-
-int vnet_conv_bf16_stats_rows(int Cin, int Cy0, int Cy1, int C0, int C1, int B, int D, int H, int W) {
-    if (Cy1 != 0 || Cy0 <= 0 || (Cy0 & 3) || Cin <= 0 || B <= 0) return 0;
-    if (conv_bf16_use_c16(Cin, Cy0, C0, C1, Cy0, 0, B, D, H, W)) return B * ceil_div(D, 4) * ceil_div(H, 8) * ceil_div(W, 16);
-    Bf16Plan p = plan_conv_bf16(Cin, Cy0, B, D, H, W);
-    if (p.nsplit * p.nz > 1) {
-        if (Cy0 > 256 || 256 % Cy0) return 0;
-        const size_t total = (size_t)B * D * H * W * Cy0;
-        return (int)min((size_t)2048, (total + 255) / 256);
-    }
-    return B * p.nbz * p.nby * p.nbx;
-}
-
-
-// src16: x0 / x1 are bf16 shadows (2-byte elements, same NDHWC indexing) written by the producing kernels
-static int conv_fwd_bf16_impl(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
-                              float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
-                              void* ws, size_t ws_bytes, void* stream, int accum, const float* res = nullptr, float* stats = nullptr,
-                              bool src16 = false, const float* accsrc = nullptr) {
-    if (!x0 || !wp || !y0 || C0 <= 0 || Cy0 <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return VNET_E_BADARG;
-    if ((C1 > 0 && !x1) || (Cy1 > 0 && !y1) || C1 < 0 || Cy1 < 0) return VNET_E_BADARG;
-    if (src16 && ((C0 & 7) || (C1 & 7) || ((reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(x1)) & 15))) return VNET_E_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
-    ConvArgs a{};
-    a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1;
-    a.wp = reinterpret_cast<const float4*>(wp); a.bias = bias;
-    a.y0 = y0; a.y1 = y1; a.Cy0 = Cy0; a.Cy1 = Cy1; a.Cout = Cy0 + Cy1;
-    a.B = B; a.Di = D; a.Hi = H; a.Wi = W; a.Do = D; a.Ho = H; a.Wo = W;
-    a.nchunks = round_up(a.Cin, 16) / 16; a.CQ = a.nchunks * 4;
-    a.CoutP = round_up(a.Cout, 32);
-    a.vec_in = (C0 % 4 == 0) && (C1 % 4 == 0);
-    a.vec_out = (Cy0 % 4 == 0) && (Cy1 % 4 == 0);
-    a.pad = 2; a.padx = 2; a.accum = accum; a.res = res; a.stats = stats;
-    if (accsrc && accsrc != y0) {
-        if (!accum || Cy1 > 0) return VNET_E_BADARG;
-        a.accsrc = accsrc;
-    }
-    if (stats && (src16 ? vnet_conv_bf16_stats_rows_x16(a.Cin, Cy0, Cy1, C0, C1, B, D, H, W)
-                        : vnet_conv_bf16_stats_rows(a.Cin, Cy0, Cy1, C0, C1, B, D, H, W)) == 0) return VNET_E_UNSUPPORTED;
-    Bf16Plan p = plan_conv_bf16(a.Cin, a.Cout, B, D, H, W);
-    a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.cps = p.cps; a.nz = p.nz;
-    const int nslab = p.nsplit * p.nz;
-    const size_t nvox = (size_t)B * D * H * W;
-    if (nslab > 1) {
-        const size_t need = (size_t)nslab * nvox * a.CoutP * sizeof(float);
-        if (!ws || ws_bytes < need) return VNET_E_WORKSPACE;
-        a.part = reinterpret_cast<float*>(ws); a.part_stride = nvox * a.CoutP;
-    }
-    const int e = src16 ? conv_fwd_bf16_go<true>(a, p, nslab, C0, C1, Cy0, Cy1, B, D, H, W, st)
-                        : conv_fwd_bf16_go<false>(a, p, nslab, C0, C1, Cy0, Cy1, B, D, H, W, st);
-    if (e == -1) return VNET_OK;
-    if (e) return e;
-    if (nslab > 1) {
-        const size_t total = nvox * a.Cout;
-        const int blocks = (int)min((size_t)2048, (total + 255) / 256);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.part, a.part_stride, nslab, bias,
-                           y0, y1, Cy0, Cy1, a.CoutP, nvox, a.accum, a.res, a.stats, a.accsrc);
-        VNET_LAUNCH_CHECK();
-    }
-    return VNET_OK;
-}
-
-int vnet_conv_fwd_bf16(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
-                       float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
-                       void* ws, size_t ws_bytes, void* stream) {
-    return conv_fwd_bf16_impl(x0, C0, x1, C1, wp, bias, y0, Cy0, y1, Cy1, B, D, H, W, ws, ws_bytes, stream, 0);
-}
-int vnet_conv_fwd_bf16_acc(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
-                           float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
-                           void* ws, size_t ws_bytes, void* stream) {
-    return conv_fwd_bf16_impl(x0, C0, x1, C1, wp, bias, y0, Cy0, y1, Cy1, B, D, H, W, ws, ws_bytes, stream, 1);
-}
-int vnet_conv_fwd_bf16_stats(const float* x0, int C0, const float* x1, int C1, const void* wp, const float* bias,
-                             float* y, int Cout, int B, int D, int H, int W,
-                             const float* res, float* stats, void* ws, size_t ws_bytes, void* stream) {
-    if (!stats) return VNET_E_BADARG;
-    return conv_fwd_bf16_impl(x0, C0, x1, C1, wp, bias, y, Cout, nullptr, 0, B, D, H, W, ws, ws_bytes, stream, 0, res, stats);
-}
-int vnet_conv_fwd_bf16_x16(const void* x0h, int C0, const void* x1h, int C1, const void* wp, const float* bias,
-                           float* y0, int Cy0, float* y1, int Cy1, int B, int D, int H, int W,
-                           const float* acc, const float* res, float* stats, void* ws, size_t ws_bytes, void* stream) {
-    if (stats && Cy1 > 0) return VNET_E_BADARG;
-    return conv_fwd_bf16_impl(reinterpret_cast<const float*>(x0h), C0, reinterpret_cast<const float*>(x1h), C1, wp, bias,
-                              y0, Cy0, y1, Cy1, B, D, H, W, ws, ws_bytes, stream, acc ? 1 : 0, res, stats, true, acc);
-}
-
 }  // extern "C"
 
 extern "C" {
@@ -463,60 +363,6 @@ int vnet_conv_wgrad(int ks, int kx, int stride, const float* x0, int C0, const f
 size_t vnet_wgrad_bf16_ws_bytes(int Cin, int Cout, int B, int D, int H, int W) {
     WgradPlan p = plan_wgrad(5, 5, 1, Cin, Cout, B, D, H, W, true);
     return (size_t)p.nsplit * 125 * round_up(Cin, 16) * round_up(Cout, 16) * sizeof(float);
-}
-
-static int conv_wgrad_bf16_impl(const float* x0, int C0, const float* x1, int C1, const float* dy, int Cout, float* dw,
-                                int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream, bool src16) {
-    if (!x0 || !dy || !dw || C0 <= 0 || Cout <= 0 || B <= 0 || C1 < 0 || (C1 > 0 && !x1)) return VNET_E_BADARG;
-    if (D <= 0 || H <= 0 || W <= 0) return VNET_E_BADARG;
-    if (src16 && ((C0 & 7) || (C1 & 7) || (Cout & 7) ||
-                  ((reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(dy)) & 15))) return VNET_E_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
-    WgradArgs a{};
-    a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.dy = dy; a.Cout = Cout;
-    a.B = B; a.Di = D; a.Hi = H; a.Wi = W; a.Do = D; a.Ho = H; a.Wo = W;
-    a.CinP = round_up(a.Cin, 16); a.CoutP = round_up(Cout, 16);
-    a.pad = 2; a.padx = 2;
-    a.vec_in = (C0 % 4 == 0) && (C1 % 4 == 0); a.vec_dy = (Cout % 4 == 0);
-    WgradPlan p = plan_wgrad(5, 5, 1, a.Cin, Cout, B, D, H, W, true);
-    a.ncob = p.ncob; a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.nbrick = p.nbrick; a.nsplit = p.nsplit;
-    const size_t need = (size_t)p.nsplit * 125 * a.CinP * a.CoutP * sizeof(float);
-    const bool direct = p.nsplit == 1 && a.CinP == a.Cin && a.CoutP == Cout;
-    if (!direct && (!ws || ws_bytes < need)) return VNET_E_WORKSPACE;
-    a.part = direct ? dw : reinterpret_cast<float*>(ws);
-    int e;
-    if (src16) {
-        if (p.small) {
-            e = p.ns == 2 ? launch_wgrad_bf16<4, 8, 8, 2, 8, true>(a, p.nsplit, p.ncob, p.ntg, st)
-                          : launch_wgrad_bf16<4, 8, 8, 1, 16, true>(a, p.nsplit, p.ncob, p.ntg, st);
-        } else {
-            e = p.ns == 2 ? launch_wgrad_bf16<4, 4, 16, 2, 8, true>(a, p.nsplit, p.ncob, p.ntg, st)
-                          : launch_wgrad_bf16<4, 4, 16, 1, 16, true>(a, p.nsplit, p.ncob, p.ntg, st);
-        }
-    } else if (p.small) {
-        e = p.ns == 2 ? launch_wgrad_bf16<4, 8, 8, 2, 8>(a, p.nsplit, p.ncob, p.ntg, st)
-                      : launch_wgrad_bf16<4, 8, 8, 1, 16>(a, p.nsplit, p.ncob, p.ntg, st);
-    } else {
-        // fp32 sources on wide bricks: always one cout block per workgroup (the two-block instantiation spilled VGPRs next to
-        // its fp32 prefetch registers, profiles/check_isa.sh): twice the cout blocks, one tap group, the same slabs
-        if (p.ns == 2) { a.ncob = p.ncob * 2; e = launch_wgrad_bf16<4, 4, 16, 1, 16>(a, p.nsplit, a.ncob, 1, st); }
-        else e = launch_wgrad_bf16<4, 4, 16, 1, 16>(a, p.nsplit, p.ncob, p.ntg, st);
-    }
-    if (e) return e;
-    if (direct) return VNET_OK;
-    launch_wgrad_reduce(a.part, p.nsplit, 125, a.CinP, a.CoutP, a.Cin, Cout, dw, st);
-    VNET_LAUNCH_CHECK();
-    return VNET_OK;
-}
-
-int vnet_conv_wgrad_bf16(const float* x0, int C0, const float* x1, int C1, const float* dy, int Cout, float* dw,
-                         int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream) {
-    return conv_wgrad_bf16_impl(x0, C0, x1, C1, dy, Cout, dw, B, D, H, W, ws, ws_bytes, stream, false);
-}
-int vnet_conv_wgrad_bf16_x16(const void* x0h, int C0, const void* x1h, int C1, const void* dyh, int Cout, float* dw,
-                             int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream) {
-    return conv_wgrad_bf16_impl(reinterpret_cast<const float*>(x0h), C0, reinterpret_cast<const float*>(x1h), C1,
-                                reinterpret_cast<const float*>(dyh), Cout, dw, B, D, H, W, ws, ws_bytes, stream, true);
 }
 
 }  // extern "C"

@@ -1742,18 +1742,11 @@ int vnet_bn_finalize(const double* sums, double M_total, int C, float eps, float
 int vnet_bn_act_fwd(const float* x, const float* r, int bcast, int64_t M, int C,
                     const float* mean, const float* invstd, const float* gamma, const float* beta,
                     int act, const float* alpha, float* y, void* stream) {
-    return vnet_bn_act_fwd_x16(x, r, bcast, M, C, mean, invstd, gamma, beta, act, alpha, y, nullptr, stream);
-}
-
-int vnet_bn_act_fwd_x16(const float* x, const float* r, int bcast, int64_t M, int C,
-                        const float* mean, const float* invstd, const float* gamma, const float* beta,
-                        int act, const float* alpha, float* y, void* yh, void* stream) {
-    if (yh && (C % 4 != 0 || (reinterpret_cast<uintptr_t>(yh) & 7))) return VNET_E_UNSUPPORTED;
     if (!x || !mean || !invstd || !gamma || !beta || !y || M <= 0 || C <= 0 || C > MAXC) return VNET_E_BADARG;
     if (act == VNET_ACT_PRELU && !alpha) return VNET_E_BADARG;
     if (act < 0 || act > 3) return VNET_E_UNSUPPORTED;
     BnP p{}; p.x = x; p.r = r; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.alpha = alpha;
-    p.out = y; p.outh = reinterpret_cast<unsigned short*>(yh); p.M = (size_t)M; p.C = C; p.bcast = bcast; p.act = act;
+    p.out = y; p.outh = nullptr; p.M = (size_t)M; p.C = C; p.bcast = bcast; p.act = act;
     hipStream_t st = (hipStream_t)stream;
     if (C % 4 == 0) hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(ew_blocks((size_t)M * C / 4 / 4 + 1) ), dim3(EW_BLOCK), 0, st, p);
     else hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(ew_blocks((size_t)M * C / 4 + 1)), dim3(EW_BLOCK), 0, st, p);
@@ -1794,15 +1787,6 @@ int vnet_bn_act_bwd_apply(const float* dy, const float* x, const float* r, int b
                           const float* mean, const float* invstd, const float* gamma, const float* beta,
                           int act, const float* alpha, const float* sum_dz, const float* sum_dz_xhat, double M_total,
                           const float* xhat_coef, float* ds, void* stream) {
-    return vnet_bn_act_bwd_apply_x16(dy, x, r, bcast, M, C, mean, invstd, gamma, beta, act, alpha, sum_dz, sum_dz_xhat, M_total,
-                                     xhat_coef, ds, nullptr, stream);
-}
-
-int vnet_bn_act_bwd_apply_x16(const float* dy, const float* x, const float* r, int bcast, int64_t M, int C,
-                              const float* mean, const float* invstd, const float* gamma, const float* beta,
-                              int act, const float* alpha, const float* sum_dz, const float* sum_dz_xhat, double M_total,
-                              const float* xhat_coef, float* ds, void* dsh, void* stream) {
-    if (dsh && (C % 4 != 0 || (reinterpret_cast<uintptr_t>(dsh) & 7))) return VNET_E_UNSUPPORTED;
     if (!dy || !x || !mean || !invstd || !gamma || !beta || !sum_dz || !sum_dz_xhat || !ds || M <= 0 || M_total <= 0.0 || C <= 0 || C > MAXC)
         return VNET_E_BADARG;
     if (act == VNET_ACT_PRELU && !alpha) return VNET_E_BADARG;
@@ -1810,7 +1794,7 @@ int vnet_bn_act_bwd_apply_x16(const float* dy, const float* x, const float* r, i
     BnP p{}; bn_bwd_fill(p, dy, x, r, bcast, M, C, mean, invstd, gamma, beta, act, alpha);
     p.invM = (float)(1.0 / M_total);
     p.extra = xhat_coef;
-    p.out = ds; p.outh = reinterpret_cast<unsigned short*>(dsh); p.dgamma = sum_dz_xhat; p.dbeta = sum_dz;
+    p.out = ds; p.outh = nullptr; p.dgamma = sum_dz_xhat; p.dbeta = sum_dz;
     if (C % 4 == 0) hipLaunchKernelGGL(bn_act_bwd_apply_kernel<true>, dim3(ew_blocks((size_t)M * C / 4 / 4 + 1)), dim3(EW_BLOCK), 0, st, p);
     else hipLaunchKernelGGL(bn_act_bwd_apply_kernel<false>, dim3(ew_blocks((size_t)M * C / 4 + 1)), dim3(EW_BLOCK), 0, st, p);
     VNET_LAUNCH_CHECK();
@@ -2018,15 +2002,12 @@ int vnet_step_state_set(void* state, float lr, float lr_t, uint64_t step, void* 
     return VNET_OK;
 }
 
-int vnet_dropout_fwd_x16(const float* x, float* y, void* yh, uint8_t* mask, int64_t n, float rate, uint64_t seed, const void* state, void* stream) {
+int vnet_dropout_fwd_dev(const float* x, float* y, uint8_t* mask, int64_t n, float rate, uint64_t seed, const void* state, void* stream) {
     if (!x || !y || !mask || n <= 0 || rate < 0.f || rate >= 1.f) return VNET_E_BADARG;
     hipLaunchKernelGGL(dropout_fwd_kernel, dim3(ew_blocks((size_t)n / 4 + 1)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, y, mask, (size_t)n, rate, seed,
-                       (const StepState*)state, reinterpret_cast<__bf16*>(yh));
+                       (const StepState*)state, (__bf16*)nullptr);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
-}
-int vnet_dropout_fwd_dev(const float* x, float* y, uint8_t* mask, int64_t n, float rate, uint64_t seed, const void* state, void* stream) {
-    return vnet_dropout_fwd_x16(x, y, nullptr, mask, n, rate, seed, state, stream);
 }
 int vnet_dropout_fwd(const float* x, float* y, uint8_t* mask, int64_t n, float rate, uint64_t seed, void* stream) {
     return vnet_dropout_fwd_dev(x, y, mask, n, rate, seed, nullptr, stream);

@@ -145,7 +145,6 @@ static std::map<std::string, Var> load_weights(const std::string& path) {
 // ---- the network (forward only), wired on the C ABI ----------------------------------------------------------------
 struct Tensor {
     float* p;        // fp32 data (null for a bf16-storage tensor)
-    void* h;         // bf16 shadow behind the fp32 data (--compute bf16_operands, vnet_hip.h *_x16) or null
     int B, D, H, W, C;
     void* q = nullptr;   // bf16 data (--compute bf16: bf16 tensors end to end, vnet_hip.h *_b16)
     size_t numel() const { return (size_t)B * D * H * W * C; }
@@ -158,7 +157,6 @@ struct Config {
     int patch[3] = {64, 64, 64}, stride[3] = {64, 64, 64};
     std::string weights, image, label_out, prob_out;
     bool normalise = true;
-    bool bf16 = false;       // --compute bf16_operands: bf16 operands / fp32 accumulation in the 5^3 convolutions, fp32 tensors + bf16 shadows
     bool store16 = false;    // --compute bf16: every activation is a bf16 tensor (BASELINE config C5 as the Python path runs it)
 };
 
@@ -222,17 +220,15 @@ private:
         if (it == vars_.end()) { std::fprintf(stderr, "weights blob has no variable %s\n", name.c_str()); std::exit(1); }
         return it->second;
     }
-    Tensor alloc(int B, int D, int H, int W, int C, bool shadow = false) {
-        Tensor t{nullptr, nullptr, B, D, H, W, C};
-        shadow = shadow && cfg.bf16 && C % 8 == 0;
-        size_t bytes = (t.numel() * (shadow ? 6 : 4) + 255) / 256 * 256;
+    Tensor alloc(int B, int D, int H, int W, int C) {
+        Tensor t{nullptr, B, D, H, W, C};
+        size_t bytes = (t.numel() * 4 + 255) / 256 * 256;
         if (top_ + bytes > arena_bytes_) { std::fprintf(stderr, "activation arena too small\n"); std::exit(1); }
         t.p = (float*)(arena_ + top_); top_ += bytes;
-        if (shadow) t.h = (char*)t.p + t.numel() * 4;
         return t;
     }
     Tensor alloc16(int B, int D, int H, int W, int C) {
-        Tensor t{nullptr, nullptr, B, D, H, W, C};
+        Tensor t{nullptr, B, D, H, W, C};
         size_t bytes = (t.numel() * 2 + 255) / 256 * 256;
         if (top_ + bytes > arena_bytes_) { std::fprintf(stderr, "activation arena too small\n"); std::exit(1); }
         t.q = arena_ + top_; top_ += bytes;
@@ -265,10 +261,9 @@ private:
             // bf16 storage: statistics of the bf16 tensor (+ bf16 residual) -- or of the fp32 1-channel image that is tiled -- in fp32,
             // one rounding of the normalised / activated value
             Tensor y = alloc16(x.B, x.D, x.H, x.W, C);
-            // tiny tensors: one launch -- the Python path's rule INCLUDING its switches (ops._SMALL_BN reads the same two variables:
-            // an A/B run that sets them must flip both drivers, or the native-vs-Python comparison compares different kernels)
-            static const bool small_on = !(std::getenv("VNET_BN_SMALL") && std::string(std::getenv("VNET_BN_SMALL")) == "0");
-            static const long small_rows = std::getenv("VNET_BN_SMALL_ROWS") ? std::atol(std::getenv("VNET_BN_SMALL_ROWS")) : 512;
+            // tiny tensors: one launch -- the Python path's rule (ops._SMALL_BN: on, <= 512 rows)
+            constexpr bool small_on = true;
+            constexpr long small_rows = 512;
             if (!tile && small_on && (long)x.rows() <= small_rows && vnet_bn_small_ok(x.rows(), C)) {
                 ABI_OK(vnet_bn_small_fwd_b16(x.q, res ? res->q : nullptr, x.rows(), C, 1e-3f, 0.99f, g.dev, b.dev, act, alpha, mean, invstd,
                                              nullptr, nullptr, y.q, st_));
@@ -280,9 +275,9 @@ private:
                                        act, alpha, y.q, st_));
             return y;
         }
-        Tensor y = alloc(x.B, x.D, x.H, x.W, C, true);
+        Tensor y = alloc(x.B, x.D, x.H, x.W, C);
         ABI_OK(vnet_bn_stats(x.p, res ? res->p : nullptr, tile ? 1 : 0, x.rows(), C, 1e-3f, 0.99f, mean, invstd, nullptr, nullptr, ws_, ws_bytes_, st_));
-        ABI_OK(vnet_bn_act_fwd_x16(x.p, res ? res->p : nullptr, tile ? 1 : 0, x.rows(), C, mean, invstd, g.dev, b.dev, act, alpha, y.p, y.h, st_));
+        ABI_OK(vnet_bn_act_fwd(x.p, res ? res->p : nullptr, tile ? 1 : 0, x.rows(), C, mean, invstd, g.dev, b.dev, act, alpha, y.p, st_));
         return y;
     }
     // the decoder's batch-norm chains in closed form (include/vnet_hip.h, vnet_bn_chain_coef_fwd): one fused normalisation of x
@@ -307,11 +302,11 @@ private:
             ABI_OK(vnet_bn_act_fwd_b16(x.q, nullptr, 0, x.rows(), C, mean, invstd, ceff, deff, VNET_ACT_PRELU, var(sc + "/alpha").dev, y.q, st_));
             return y;
         }
-        Tensor y = alloc(x.B, x.D, x.H, x.W, C, true);
+        Tensor y = alloc(x.B, x.D, x.H, x.W, C);
         ABI_OK(vnet_bn_stats(x.p, nullptr, 0, x.rows(), C, 1e-3f, 0.99f, mean, invstd, nullptr, nullptr, ws_, ws_bytes_, st_));
         ABI_OK(vnet_bn_chain_coef_fwd(kind, C, 1e-3f, 0.99f, mean, invstd, gp[0], bp[0], gp[1], bp[1], gp[2], bp[2], ceff, deff,
                                       nullptr, nullptr, nullptr, nullptr, st_));
-        ABI_OK(vnet_bn_act_fwd_x16(x.p, nullptr, 0, x.rows(), C, mean, invstd, ceff, deff, VNET_ACT_PRELU, var(sc + "/alpha").dev, y.p, y.h, st_));
+        ABI_OK(vnet_bn_act_fwd(x.p, nullptr, 0, x.rows(), C, mean, invstd, ceff, deff, VNET_ACT_PRELU, var(sc + "/alpha").dev, y.p, st_));
         return y;
     }
     // Cin_w: input channels of the FILTER when the tensor carries zero-padded channels (the cast 4-modality input), else 0
@@ -341,17 +336,6 @@ private:
             return y;
         }
         Tensor y = alloc(x0.B, Do, Ho, Wo, Cout);
-        if (cfg.bf16 && ks == 5 && stride == 1) {
-            float* wpb = pack(sc + "/weights", VNET_PACK_FWD_BF16, 125, Cin, Cout);
-            if (vnet_conv_bf16_ws_bytes(Cin, Cout, x0.B, Do, Ho, Wo) > ws_bytes_) { std::fprintf(stderr, "workspace too small\n"); std::exit(1); }
-            if (x0.h && (!x1 || x1->h))         // every source carries its bf16 image: stage that (half the bytes, no conversion)
-                ABI_OK(vnet_conv_fwd_bf16_x16(x0.h, x0.C, x1 ? x1->h : nullptr, x1 ? x1->C : 0, wpb, var(sc + "/biases").dev,
-                                              y.p, Cout, nullptr, 0, x0.B, x0.D, x0.H, x0.W, nullptr, nullptr, nullptr, ws_, ws_bytes_, st_));
-            else
-                ABI_OK(vnet_conv_fwd_bf16(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, wpb, var(sc + "/biases").dev,
-                                          y.p, Cout, nullptr, 0, x0.B, x0.D, x0.H, x0.W, ws_, ws_bytes_, st_));
-            return y;
-        }
         float* wp = pack(sc + "/weights", VNET_PACK_FWD, ks * ks * ks, Cin, Cout);
         size_t need = vnet_conv_ws_bytes(ks, 0, stride, 0, Cin, Cout, x0.B, Do, Ho, Wo);
         if (need > ws_bytes_) { std::fprintf(stderr, "workspace too small\n"); std::exit(1); }
@@ -453,18 +437,18 @@ static Config parse(int argc, char** argv) {
         else if (a == "--no-normalise") c.normalise = false;
         else if (a == "--compute") {
             const std::string v = next();
-            if (v != "fp32" && v != "bf16" && v != "bf16_operands") { std::fprintf(stderr, "--compute fp32|bf16|bf16_operands\n"); std::exit(1); }
-            c.bf16 = (v == "bf16_operands"); c.store16 = (v == "bf16");
+            if (v != "fp32" && v != "bf16") { std::fprintf(stderr, "--compute fp32|bf16\n"); std::exit(1); }
+            c.store16 = (v == "bf16");
         }
         else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); std::exit(1); }
     }
     if (c.store16 && (c.channels < 8 || (c.channels & (c.channels - 1)))) {
-        std::fprintf(stderr, "--compute bf16 needs --channels 8 * 2^k (16-byte units of bf16 channels); use bf16_operands or fp32\n");
+        std::fprintf(stderr, "--compute bf16 needs --channels 8 * 2^k (16-byte units of bf16 channels); use fp32\n");
         std::exit(1);
     }
     if (c.weights.empty() || c.image.empty() || c.label_out.empty() || (int)c.convs.size() != c.levels) {
         std::fprintf(stderr, "usage: vnet_infer --weights W --image I.npy --label-out L.npy [--prob-out P.npy] --classes K --channels C "
-                             "--levels L --convs a,b,.. --bottom n --patch x,y,z --stride x,y,z --batch b [--compute fp32|bf16|bf16_operands]\n");
+                             "--levels L --convs a,b,.. --bottom n --patch x,y,z --stride x,y,z --batch b [--compute fp32|bf16]\n");
         std::exit(1);
     }
     return c;
@@ -484,7 +468,7 @@ int main(int argc, char** argv) {
     auto vars = load_weights(cfg.weights);
     VNetForward net(cfg, vars, compute);
     const size_t patch_vox = (size_t)P0 * P1 * P2;
-    net.set_arena((size_t)cfg.batch * patch_vox * (cfg.bf16 ? 6 : 4) * (size_t)(cfg.channels * 14 + 64) + ((size_t)64 << 20));
+    net.set_arena((size_t)cfg.batch * patch_vox * 4 * (size_t)(cfg.channels * 14 + 64) + ((size_t)64 << 20));
 
     // patch enumeration, model.py:866-903 (last patch clamped to the border; the last batch is appended twice)
     int num[3]; const int dims[3] = {X, Y, Z};
@@ -544,7 +528,7 @@ int main(int argc, char** argv) {
         if (bi + 1 < batches.size())
             next = std::async(std::launch::async, [&, bi] { HIP_OK(hipEventSynchronize(consumed[(bi + 1) & 1])); crop(bi + 1, (int)((bi + 1) & 1)); });
         HIP_OK(hipStreamWaitEvent(compute, copied[slot], 0));
-        Tensor in{d_in[slot], nullptr, (int)batches[bi].size(), P0, P1, P2, Cin};
+        Tensor in{d_in[slot], (int)batches[bi].size(), P0, P1, P2, Cin};
         Tensor sm = net.forward(in);
         for (size_t p = 0; p < batches[bi].size(); ++p)
             ABI_OK(vnet_accumulate_patch(sm.p + p * patch_vox * K, d_vol, d_cnt, K, P0, P1, P2, batches[bi][p][0], batches[bi][p][1],
@@ -575,6 +559,6 @@ int main(int argc, char** argv) {
     std::printf("vnet_infer: %zu batches (%zu patches of %dx%dx%d), %dx%dx%d volume, %d classes -> %s\n", batches.size(), npatch,
                 P0, P1, P2, X, Y, Z, K, cfg.label_out.c_str());
     std::printf("vnet_infer: sliding window %.3f s = %.1f patches/s (crop + H2D + forward + accumulate, %s)\n", secs, npatch / secs,
-                cfg.store16 ? "bf16 storage" : cfg.bf16 ? "bf16 operands" : "fp32");
+                cfg.store16 ? "bf16 storage" : "fp32");
     return 0;
 }

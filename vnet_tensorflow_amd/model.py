@@ -241,18 +241,23 @@ class image2label(object):
         self.synthetic = T['Data'].get('Synthetic')            # extension: synthetic generator (no NIfTI shipped)
         self.compute_dtype = T.get('ComputeDtype', 'fp32')            # extension: 'bf16' = BASELINE config C5 arithmetic
         # 'fp32_split3' (round 5): fp32 tensors and fp32 accuracy, the 5^3 convolutions on the bf16 matrix pipe (csrc/conv_x3.h)
-        if self.compute_dtype not in ('fp32', 'fp32_split3', 'bf16', 'bf16_operands'):
-            raise SystemExit("Invalid ComputeDtype %r (fp32 | fp32_split3 | bf16 | bf16_operands)" % (self.compute_dtype,))
+        if self.compute_dtype not in ('fp32', 'fp32_split3', 'bf16'):
+            raise SystemExit("Invalid ComputeDtype %r (fp32 | fp32_split3 | bf16; round 2's 'bf16_operands' was retired in round 5: "
+                             "'bf16' is its successor)" % (self.compute_dtype,))
         if self.compute_dtype == 'bf16':
-            # since round 3 'bf16' means bf16 STORAGE (every activation a bf16 tensor; the operand-rounding form of round 2 is
-            # 'bf16_operands'); its kernels move 8-channel units whose count is a power of two: fail HERE, not at the first forward
+            # 'bf16' = bf16 STORAGE (every activation a bf16 tensor); its kernels move 8-channel units whose count is a power of
+            # two: fail HERE, not at the first forward
             nch = int(T.get('Networks', {}).get('NumChannel', 16))
             if nch < 8 or nch & (nch - 1):
                 raise SystemExit("ComputeDtype 'bf16' (bf16 storage) needs Networks.NumChannel = 8 * 2^k, got %d; "
-                                 "'bf16_operands' (fp32 tensors, bf16 operands in the 5^3 convolutions) takes any width" % nch)
+                                 "'fp32' / 'fp32_split3' take any width" % nch)
         self.sync_batch_norm = bool(T.get('SyncBatchNorm', False))   # extension: cross-replica BN statistics
         if 'AllReduceHoldFraction' in T:                               # extension: when the gradient buckets are launched (parallel.py)
             self.allreduce_hold_fraction = float(T['AllReduceHoldFraction'])
+        if 'PrefetchDepth' in T:                                       # extension: input prefetcher of train() (0 = synchronous loader)
+            self.prefetch_depth = int(T['PrefetchDepth'])
+        if 'LoaderThreads' in T:
+            self.loader_threads = int(T['LoaderThreads'])
         self.batch_size = T['BatchSize']
         self.patch_shape = T['PatchShape']
         self.dimension = len(T['PatchShape'])
@@ -383,10 +388,10 @@ class image2label(object):
             parallel.broadcast_parameters(self.flat.data)
             self.optimizer.gscale = 1.0 / self.world
             # launch the bucket all-reduces once this fraction of the gradient bytes exists (parallel.py): keeps the
-            # collective off the 256-CU-planned deep-level kernels; TrainingSetting.AllReduceHoldFraction / VNET_DP_HOLD
+            # collective off the 256-CU-planned deep-level kernels; TrainingSetting.AllReduceHoldFraction
             # (bf16 mode: the backward pass that is left after encoder level 3 is shorter than the all-reduce -> launch when ready)
             default_hold = 0.99 if ops.get_compute_dtype() in ("fp32", "fp32_split3") else 0.0
-            hold = float(os.environ.get("VNET_DP_HOLD", getattr(self, "allreduce_hold_fraction", default_hold)))
+            hold = float(getattr(self, "allreduce_hold_fraction", default_hold))
             # two-pass backward (pass 1: output layer, decoder, bottom level = 81 % of the gradient bytes; pass 2: encoder):
             # the replayed step is then gradients graph 1 -> all-reduce of pass 1's buckets (asynchronous) -> gradients graph 2
             # -> the remaining buckets -> optimiser graph, i.e. the collective travels under the encoder's backward kernels
@@ -433,8 +438,8 @@ class image2label(object):
 
     def _defer_wgrad_reduce(self):
         """One batched reduce of the filter-gradient slabs at the end of the backward pass instead of one per layer -- unless the
-        data-parallel buckets leave from the gradient hooks while backward runs (eager step).  VNET_WGRAD_BATCH=0: off."""
-        if os.environ.get("VNET_WGRAD_BATCH", "1") == "0" or self.device.type != "cuda":
+        data-parallel buckets leave from the gradient hooks while backward runs (eager step)."""
+        if self.device.type != "cuda":
             return False
         return self.sync is None or bool(self.sync.hold_all)
 
@@ -606,8 +611,8 @@ class image2label(object):
             pin = os.environ.get("VNET_DP_MODE")               # segmented | serial | off: no measurement, this one
             if pin in cands or pin in ("segmented", "off"):
                 cands = [pin]
-            self._tuner = parallel.StepModeAutotune(cands, steps=int(os.environ.get("VNET_DP_AUTOTUNE_STEPS", "5")),
-                                                    blocks=int(os.environ.get("VNET_DP_AUTOTUNE_BLOCKS", "3")),
+            self._tuner = parallel.StepModeAutotune(cands, steps=int(getattr(self, "dp_autotune_steps", 5)),
+                                                    blocks=int(getattr(self, "dp_autotune_blocks", 3)),
                                                     sync=self._device_sync)
         return self._tuner
 
@@ -616,7 +621,7 @@ class image2label(object):
             self._graph_stream = torch.cuda.Stream(device=self.device)
             self._step_state = ops.step_state(self.device)
             self._graphs, self._g_shape, self._g_warm = None, None, 0
-        if self._graphs is None and self._g_warm < max(1, int(os.environ.get("VNET_STEP_GRAPH_WARMUP", "2"))):
+        if self._graphs is None and self._g_warm < max(1, int(getattr(self, "step_graph_warmup", 2))):
             # eager steps first: sizes every scratch buffer, builds the packed-filter registry, calibrates the bucket counts
             self._g_warm += 1
             return self._train_step_eager(images, labels, dropout)
@@ -729,8 +734,8 @@ class image2label(object):
         if self.testing:
             test_set = self._dataset(self.test_data_dir, False)
             test_iter = iter(test_set)
-        prefetch = int(os.environ.get("VNET_PREFETCH", getattr(self, "prefetch_depth", 4)))
-        workers = int(os.environ.get("VNET_LOADER_THREADS", getattr(self, "loader_threads", 3)))
+        prefetch = int(getattr(self, "prefetch_depth", 4))
+        workers = int(getattr(self, "loader_threads", 3))
         self.steps_timed, self.seconds_timed = 0, 0.0
 
         first_epoch = self.start_epoch
@@ -861,7 +866,7 @@ class image2label(object):
             return (t.pin_memory() if self.device.type == "cuda" else t), torch.zeros(1, dtype=torch.int32)
 
         from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=int(os.environ.get("VNET_LOADER_THREADS", "3"))) as pool:
+        with ThreadPoolExecutor(max_workers=int(getattr(self, "loader_threads", 3))) as pool:
             def windowed(depth=3):
                 # a bounded window of crop jobs in flight (Executor.map would submit -- and pin -- every patch of the volume at once)
                 from collections import deque

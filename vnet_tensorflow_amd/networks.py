@@ -90,7 +90,7 @@ class VNet(object):
                 store16 = ops.storage_is_bf16() and x.device.type != "meta"
                 if store16 and (self.num_channels < 8 or self.num_channels & (self.num_channels - 1)):
                     raise ops.VnetHipError("ComputeDtype 'bf16' stores activations as bf16 in 16-byte channel units: NumChannel must be "
-                                           "8 * 2^k (got %d); use 'fp32' or 'bf16_operands'" % self.num_channels)
+                                           "8 * 2^k (got %d); use 'fp32' or 'fp32_split3'" % self.num_channels)
                 if input_channels == 1:
                     # tile + BN; the first 5^3 conv then runs on the un-tiled image (layers2.convolution_tiled)
                     x, tiled = L.batch_normalization(x, tile=True, channels=self.num_channels, want_stats=True)

@@ -30,7 +30,8 @@ PACK_FWD_X3, PACK_BWD_X3 = 7, 8
 #                   gradients are torch.bfloat16 tensors, every kernel on them computes in fp32 and rounds once (include/vnet_hip.h,
 #                   `*_b16`); 5^3 AND 2^3 convolutions take bf16 operands; statistics, parameter gradients, logits and loss fp32.
 #                   The ops below dispatch on the tensor dtype, so the mode only decides what the network input is turned into.
-#   "bf16_operands" (round 2): fp32 tensors (+ bf16 shadows), only the 5^3 convolutions round their operands.
+#   (round 2's "bf16_operands" -- fp32 tensors + bf16 shadows, bf16 operands in the 5^3 convolutions only -- was superseded by the
+#   storage mode in round 3 and retired in round 5 together with its `*_x16` / `vnet_conv_*_bf16` entry points.)
 # ---- per-model state (round 4) ---------------------------------------------------------------------------------------------
 # What used to be process globals -- the compute dtype, the parameter-gradient stream and the registry of packed filters -- lives
 # in an OpsContext.  image2label owns one and enters it around everything it runs (model.in_context), so a fp32 and a bf16 model
@@ -98,8 +99,8 @@ PACK_ROUND16 = 16
 
 
 def set_compute_dtype(dtype):
-    if dtype not in ("fp32", "fp32_split3", "bf16", "bf16_operands"):
-        raise VnetHipError("compute dtype must be 'fp32', 'fp32_split3', 'bf16' or 'bf16_operands', got %r" % (dtype,))
+    if dtype not in ("fp32", "fp32_split3", "bf16"):
+        raise VnetHipError("compute dtype must be 'fp32', 'fp32_split3' or 'bf16', got %r" % (dtype,))
     _COMPUTE["dtype"] = "fp32" if dtype in ("fp32", "fp32_split3") else "bf16"
     _COMPUTE["store16"] = dtype == "bf16"
     # "fp32_split3" (round 5, csrc/conv_x3.h): fp32 tensors and fp32 accuracy, but the 5^3 convolutions form every product from six
@@ -271,7 +272,7 @@ def packed_weights(w, mode, taps, I, O):
     return wp
 
 
-_PACK_BOTH = {"on": _os.environ.get("VNET_PACK_BOTH", "1") != "0"}      # (environment: A/B measurements)
+_PACK_BOTH = {"on": True}      # (tests / A-B scripts flip the entry)
 
 
 def repack_registered():
@@ -422,49 +423,6 @@ class _Timed(object):
 
 
 # ---- convolution family ----------------------------------------------------------------------------
-# ---- bf16 shadows (bf16 compute mode) ---------------------------------------------------------------------------------
-# Every input of a bf16-operand 5^3 convolution is written by a batch-norm / dropout kernel (forward) or a batch-norm backward
-# kernel (dy).  Those producers write, behind the fp32 tensor IN THE SAME ALLOCATION, its bf16 image (round-to-nearest-even,
-# the rounding the convolution kernels apply while staging), and the convolutions stage that image instead: half the bytes
-# through L2, no conversion, bit-identical results (include/vnet_hip.h: *_x16).  A tensor carries a shadow iff its storage was
-# made by _alloc_shadowed() (tagged, exactly 6 bytes per element) -- which is only called next to the kernel that fills it.
-def _want_shadow(C):
-    return _COMPUTE["dtype"] == "bf16" and not _COMPUTE["store16"] and _FUSE["bf16_shadow"] and C % 8 == 0
-
-
-def _alloc_shadowed(shape, device):
-    """(fp32 tensor of `shape`, address of the bf16 shadow behind its data)."""
-    n = 1
-    for v in shape:
-        n *= int(v)
-    st = torch.UntypedStorage(n * 6, device=device)
-    st._vnet_shadow = True          # (the storage's Python object lives as long as the storage: the tag travels with every view)
-    y = torch.empty(0, dtype=torch.float32, device=device).set_(st, 0, tuple(int(v) for v in shape))
-    return y, y.data_ptr() + n * 4
-
-
-def with_shadow(t):
-    """Copy of `t` in a shadowed allocation, the shadow filled by torch's own round-to-nearest-even conversion (tests,
-    micro-benchmarks: stands in for a producer kernel)."""
-    y, _ = _alloc_shadowed(t.shape, t.device)
-    y.copy_(t)
-    n = t.numel()
-    sh = torch.empty(0, dtype=torch.bfloat16, device=t.device).set_(y.untyped_storage(), 2 * n, (n,))
-    sh.copy_(t.reshape(-1).to(torch.bfloat16))
-    return y
-
-
-def _shadow_ptr(x):
-    """Address of the bf16 shadow a producer wrote behind x, or None."""
-    if x is None or not _FUSE["bf16_shadow"] or x.dtype != torch.float32 or x.storage_offset() != 0 or not x.is_contiguous():
-        return None
-    n = x.numel()
-    st = x.untyped_storage()
-    if n == 0 or st.nbytes() != n * 6 or not getattr(st, "_vnet_shadow", False):
-        return None
-    return x.data_ptr() + n * 4
-
-
 def _conv_call(ks, stride, up, x0, x1, wp, bias, y0, y1, dims_in, dims_out, kx=0, accum=False, stats=None, res=None):
     L = _lib.lib()
     B = x0.shape[0]
@@ -490,8 +448,8 @@ def _conv_call(ks, stride, up, x0, x1, wp, bias, y0, y1, dims_in, dims_out, kx=0
 
 
 # force: (tests) take the f32x3 kernels for every shape they can run, not only where they pay;  ksplit: the deep levels (few bricks:
-# channel chunks split over workgroups, partial slabs + reduce) take them too (VNET_X3_KSPLIT=0: A/B measurements)
-_X3 = {"force": False, "ksplit": _os.environ.get("VNET_X3_KSPLIT", "1") != "0"}
+# channel chunks split over workgroups, partial slabs + reduce) take them too (`_X3["ksplit"] = False`: A/B measurements)
+_X3 = {"force": False, "ksplit": True}
 
 
 def _x3_ok(C0, C1, Cy0, Cy1, B, dims):
@@ -522,39 +480,8 @@ def _conv_x3_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res=N
                                  _ptr(y0) if accum else None, _ptr(res), _ptr(stats), _ptr(ws), nb, _stream()), "vnet_conv_fwd_x3")
 
 
-def _conv_bf16_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res=None, acc_src=None):
-    """5^3 stride-1 conv with bf16 operands / fp32 accumulation (vnet_conv_fwd_bf16).
-    accum: y0 += conv; acc_src (needs the bf16 shadows): y0 = conv + acc_src, out of place."""
-    L = _lib.lib()
-    B = x0.shape[0]
-    C0, C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
-    Cy0, Cy1 = y0.shape[-1], (y1.shape[-1] if y1 is not None else 0)
-    nb = L.vnet_conv_bf16_ws_bytes(C0 + C1, Cy0 + Cy1, B, *dims)
-    ws = workspace(nb, x0.device) if nb else None
-    nvox = B * dims[0] * dims[1] * dims[2]
-    flops = 2.0 * nvox * 125 * (C0 + C1) * (Cy0 + Cy1)
-    nbytes = 4.0 * nvox * (C0 + C1 + Cy0 + Cy1) + 2.0 * 125 * (C0 + C1) * (Cy0 + Cy1)
-    tag = "conv-bf16 k5 s1 %d^3x%d %d->%d" % (dims[2], B, C0 + C1, Cy0 + Cy1)
-    h0, h1 = _shadow_ptr(x0), _shadow_ptr(x1)
-    with _Timed(tag, flops, nbytes):
-        if h0 is not None and (x1 is None or h1 is not None) and C0 % 8 == 0 and C1 % 8 == 0:
-            acc = _ptr(acc_src) if acc_src is not None else (_ptr(y0) if accum else None)
-            check(L.vnet_conv_fwd_bf16_x16(h0, C0, h1, C1, _ptr(wp), _ptr(bias), _ptr(y0), Cy0, _ptr(y1), Cy1, B, *dims,
-                                           acc, _ptr(res), _ptr(stats), _ptr(ws), nb, _stream()), "vnet_conv_fwd_bf16_x16")
-            return
-        if acc_src is not None:
-            raise VnetHipError("out-of-place accumulation needs the bf16 shadows of the convolution's input")
-        if stats is not None:
-            check(L.vnet_conv_fwd_bf16_stats(_ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias), _ptr(y0), Cy0, B, *dims,
-                                             _ptr(res), _ptr(stats), _ptr(ws), nb, _stream()), "vnet_conv_fwd_bf16_stats")
-            return
-        fn = L.vnet_conv_fwd_bf16_acc if accum else L.vnet_conv_fwd_bf16
-        check(fn(_ptr(x0), C0, _ptr(x1), C1, _ptr(wp), _ptr(bias), _ptr(y0), Cy0, _ptr(y1), Cy1,
-                 B, *dims, _ptr(ws), nb, _stream()), "vnet_conv_fwd_bf16")
-
-
 # ---- bf16-storage convolution calls (include/vnet_hip.h: vnet_conv_fwd_b16, vnet_conv2_fwd_b16, ...) ----------------------------
-_IN4 = {"on": _os.environ.get("VNET_CONV_IN4", "1") != "0"}
+_IN4 = {"on": True}
 
 
 def _conv5_b16_call(x0, x1, wp, bias, y0, y1, dims, accum=False, stats=None, res=None, acc_src=None, cin_real=0):
@@ -616,7 +543,7 @@ def _conv2_b16_call(up, x, wp, bias, y, dims_in, dims_out, accum=False, stats=No
                                    int(bool(accum)), _ptr(stats), _ptr(ws), nb, _stream()), "vnet_conv2_fwd_b16")
 
 
-_DIRECT2 = {"on": _os.environ.get("VNET_CONV2_DIRECT", "1") != "0"}          # (tests / A-B: False = always the generic kernels)
+_DIRECT2 = {"on": True}          # (tests / A-B: False = always the generic kernels)
 
 
 def _conv2_b16(down, x, w, bias, y, dims_fine, dims_coarse, Cf, Cc, accum=False, stats=None):
@@ -705,8 +632,8 @@ _DEFER = {"on": False, "jobs": [], "dy_ptrs": set(), "stream": None}
 # grouped launch of the 5^3 filter gradients of a deferring pass (layers up to 128^3 voxels; measured: 32^3 and below -0.23 ms,
 # all levels -0.33 ms per C5 step) (bf16 storage; include/vnet_hip.h:
 # vnet_conv_wgrad_b16_group).  VNET_WGRAD_GROUP=0: every layer launches its own kernel as it did through round 3.
-_GROUP = {"on": _os.environ.get("VNET_WGRAD_GROUP", "1") != "0", "max_voxels": int(_os.environ.get("VNET_WGRAD_GROUP_MAXVOX", 128 ** 3)),
-          "k2": _os.environ.get("VNET_WGRAD_GROUP_K2", "1") != "0"}
+_GROUP = {"on": _os.environ.get("VNET_WGRAD_GROUP", "1") != "0", "max_voxels": 128 ** 3,
+          "k2": True}
 # (k2: the 2^3 stride-2 filter gradients join too -- -0.05 ms per C5 step.  Round 4 also built the group for fp32 tensors and let the
 #  zero-padded network input join; both measured no gain -- DESIGN 4.5 -- and were removed in round 5)
 
@@ -794,28 +721,6 @@ def _immediate_reduce(immediate):
         yield
     finally:
         L.vnet_wgrad_defer(1, st)
-
-
-def _wgrad_bf16_call(x0, x1, dy, dw, dims, owner=None):
-    """Filter gradient of the 5^3 stride-1 conv with bf16 operands / fp32 accumulation (vnet_conv_wgrad_bf16)."""
-    L = _lib.lib()
-    B = x0.shape[0]
-    C0, C1 = x0.shape[-1], (x1.shape[-1] if x1 is not None else 0)
-    Co = dy.shape[-1]
-    nb = L.vnet_wgrad_bf16_ws_bytes(C0 + C1, Co, B, *dims)
-    ws = _wgrad_workspace(dw, nb, False, owner)
-    nvox = B * dims[0] * dims[1] * dims[2]
-    flops = 2.0 * nvox * 125 * (C0 + C1) * Co
-    nbytes = 4.0 * (nvox * (C0 + C1 + Co) + 125 * (C0 + C1) * Co)
-    tag = _wgrad_tag(True, 5, 0, 1, dims[2], B, C0 + C1, Co)
-    h0, h1, hd = _shadow_ptr(x0), _shadow_ptr(x1), _shadow_ptr(dy)
-    with _Timed(tag, flops, nbytes), _immediate_reduce(owner is None):
-        if h0 is not None and hd is not None and (x1 is None or h1 is not None) and C0 % 8 == 0 and C1 % 8 == 0 and Co % 8 == 0:
-            check(L.vnet_conv_wgrad_bf16_x16(h0, C0, h1, C1, hd, Co, _ptr(dw), B, *dims, _ptr(ws), nb, _stream()),
-                  "vnet_conv_wgrad_bf16_x16")
-            return
-        check(L.vnet_conv_wgrad_bf16(_ptr(x0), C0, _ptr(x1), C1, _ptr(dy), Co, _ptr(dw), B, *dims,
-                                     _ptr(ws), nb, _stream()), "vnet_conv_wgrad_bf16")
 
 
 def _wgrad_x3_ok(C0, C1, Co, B, dims):
@@ -949,9 +854,8 @@ def _slot_target(slot, dy, shape):
 # in exact arithmetic (the fp64 oracle gets ~1e-12).  Inside this context the convolutions take the closed form: the bias
 # gradient is left at exactly 0 in the flat gradient buffer and the 29 column-sum + 29 finalize launches per step are not
 # made.  Stand-alone layers2.convolution (outside the networks) keeps the generic column sum.
-_FUSE = {"zero_bias_grad": False, "bn_stats": _os.environ.get("VNET_BN_STATS", "1") != "0",
-         "bf16_shadow": _os.environ.get("VNET_BF16_SHADOW", "1") != "0",
-         "bn_stats_fp32_direct": _os.environ.get("VNET_BN_STATS_FP32", "1") == "1"}     # (environment: A/B measurements)
+_FUSE = {"zero_bias_grad": False, "bn_stats": True,
+         "bn_stats_fp32_direct": True}
 
 
 def set_epilogue_bn_stats(on, fp32_direct=None):
@@ -960,12 +864,6 @@ def set_epilogue_bn_stats(on, fp32_direct=None):
     _FUSE["bn_stats"] = bool(on)
     if fp32_direct is not None:
         _FUSE["bn_stats_fp32_direct"] = bool(fp32_direct)
-
-
-def set_bf16_shadows(on):
-    """Switch for the bf16 shadows of the activations in bf16 compute mode (on by default; off = the convolutions convert the
-    fp32 tensors while staging; results are bit-identical either way)."""
-    _FUSE["bf16_shadow"] = bool(on)
 
 
 @contextlib.contextmanager
@@ -1002,7 +900,7 @@ class _ConvFn(torch.autograd.Function):
         if b16 and (_is16(x1) != (x1 is not None) or (res is not None and not _is16(res))):
             raise VnetHipError("conv: bf16 and float32 tensors mixed")
         y = torch.empty((B,) + dims_out + (O,), dtype=torch.bfloat16 if b16 else torch.float32, device=x0.device)
-        bf16 = (not up) and ks == 5 and stride == 1 and (_COMPUTE["dtype"] == "bf16" or b16)
+        bf16 = (not up) and ks == 5 and stride == 1 and b16
         if res is not None:
             res = res.contiguous()
         if b16:
@@ -1015,8 +913,6 @@ class _ConvFn(torch.autograd.Function):
             else:
                 _conv5_b16_call(x0, x1, packed_weights(w, PACK_FWD_BF16, 125, I, O), b, y, None, dims_out, stats=stats, res=res,
                                 cin_real=(I if x1 is None and I < x0.shape[-1] else 0))
-        elif bf16:
-            _conv_bf16_call(x0, x1, packed_weights(w, PACK_FWD_BF16, 125, I, O), b, y, None, dims_out, stats=stats, res=res)
         elif up and x1 is None:
             _conv2_b16(False, x0, w, b, y, dims_out, (Di, Hi, Wi), O, I)
         elif ks == 2 and stride == 2 and x1 is None and res is None:
@@ -1100,8 +996,6 @@ class _ConvFn(torch.autograd.Function):
             elif dw is not None:
                 if up:      # dw[a][o][ci] = sum_i dy[2i+a][o] * x[i][ci]  == filter grad of the 2^3 down conv (fine -> coarse)
                     _wgrad_call(2, 2, dy, None, x0, dw, dout, din, owner=sw)
-                elif ctx.bf16:
-                    _wgrad_bf16_call(x0, x1, dy, dw, din, owner=sw)
                 elif ks == 5 and stride == 1 and _wgrad_x3_ok(C0, C1, O, B, din):
                     _wgrad_x3_call(x0, x1, dy, dw, din, owner=sw)
                 else:
@@ -1119,7 +1013,7 @@ class _ConvFn(torch.autograd.Function):
             oop = None
             if (acc is None and x1 is None and ctx.bf16 and slot0 is not None and slot0.first is not None
                     and slot0.first.data_ptr() == dy.data_ptr() and tuple(dy.shape) == tuple(x0.shape)
-                    and (b16 or _shadow_ptr(dy) is not None) and C0 % 8 == 0):
+                    and b16 and C0 % 8 == 0):
                 oop = dy
             if acc is not None and b16 and ks == 5 and stride == 1 and not up and acc.data_ptr() in _DEFER["dy_ptrs"]:
                 # the other gradient of x0 is ALSO the dy of a filter gradient that waits for the grouped launch (a residual block's
@@ -1141,10 +1035,6 @@ class _ConvFn(torch.autograd.Function):
                 _conv2_b16(True, dy, w, None, dx0, dout, din, O, I, accum=accum)
             elif stride == 2:   # backward-data of the down conv = the 2^3 transposed conv with the same filter
                 _conv2_b16(False, dy, w, None, dx0, din, dout, I, O, accum=accum)
-            elif ctx.bf16:
-                _conv_bf16_call(dy, None, packed_weights(w, PACK_BWD_BF16, 125, I, O), None, dx0, dx1, din, accum=accum, acc_src=oop)
-                if oop is not None:
-                    slot0.total = dx0
             elif ks == 5 and _x3_ok(O, 0, C0, C1, B, din):
                 _conv_x3_call(dy, None, packed_weights(w, PACK_BWD_X3, 125, I, O), None, dx0, dx1, din, accum=accum)
             else:
@@ -1279,15 +1169,11 @@ def _epilogue_stats_buffer(bf16, ks, kx, stride, x0, x1, O, dims_out):
             rows = L.vnet_conv_stats_rows(ks, kx, stride, 0, C0 + C1, O, 0, B, *dims_out)
     elif bf16:
         # (the kernels that stage bf16 sources have their own brick shapes: one partial row per brick)
-        if _is16(x0):                         # bf16 storage: the deep-level kernel has its own bricks (csrc/conv_deep.h)
-            rows = L.vnet_conv_b16_stats_rows(C0, C1, O, 0, B, *dims_out)
-        else:
-            x16 = _shadow_ptr(x0) is not None and (x1 is None or _shadow_ptr(x1) is not None) and C0 % 8 == 0 and C1 % 8 == 0
-            rows = (L.vnet_conv_bf16_stats_rows_x16 if x16 else L.vnet_conv_bf16_stats_rows)(C0 + C1, O, 0, C0, C1, B, *dims_out)
+        rows = L.vnet_conv_b16_stats_rows(C0, C1, O, 0, B, *dims_out)     # (the deep-level kernel has its own bricks: csrc/conv_deep.h)
     else:
         # fp32 MFMA kernels: measured (profiles/r02_epilogue_stats.txt) the STATS instantiations lose in their main loop most of
         # what the statistics pass costs (+1..3 % per launch, residual re-read on the input conv): the fused form is worth
-        # 0.07 ms of a 25.7 ms step; VNET_BN_STATS_FP32=0 keeps it to the split-K launches (statistics from the reduce kernel)
+        # 0.07 ms of a 25.7 ms step; `_FUSE["bn_stats_fp32_direct"] = False` keeps it to the split-K launches (statistics from the reduce kernel)
         rows = 0
         if ks == 5 and stride == 1 and kx in (0, 5) and _FUSE["bn_stats_fp32_direct"] and _x3_ok(C0, C1, O, 0, B, dims_out):
             rows = L.vnet_conv_x3_stats_rows(C0 + C1, O, B, *dims_out)        # f32x3 kernel: one row per 2x8x16 brick (or per reduce block)
@@ -1315,18 +1201,12 @@ def conv(x0, w, b, ks, stride=1, x1=None, bn_stats=False, bn_residual=None):
     stats = None
     if bn_stats and _FUSE["bn_stats"]:
         dims_out = tuple(_same_out(int(v), stride) for v in x0.shape[1:4])
-        bf16 = ks == 5 and stride == 1 and (_COMPUTE["dtype"] == "bf16" or _is16(x0))
+        bf16 = ks == 5 and stride == 1 and _is16(x0)
         stats = _epilogue_stats_buffer(bf16, ks, 0, stride, x0, x1, w.shape[-1], dims_out)
-    dy16 = ks == 5 and stride == 1 and _want_shadow(int(w.shape[-1]))
     if stats is None:
-        y = _ConvFn.apply(x0, x1, w, b, ks, stride, False, None)
-        if dy16:
-            y._vnet_dy16 = True            # the batch-norm behind y writes a bf16 shadow of ds (= this convolution's dy)
-        return y
+        return _ConvFn.apply(x0, x1, w, b, ks, stride, False, None)
     y = _ConvFn.apply(x0, x1, w, b, ks, stride, False, None, stats, bn_residual)
     y._vnet_stats = _EpilogueStats(stats, stats.shape[0], bn_residual)
-    if dy16:
-        y._vnet_dy16 = True
     return y
 
 
@@ -1392,10 +1272,10 @@ def _bn_statistics(L, x, r, bcast, M, C, mean, invstd, mm, mv, ws, nb, pre=None,
 
 
 # bf16 storage, tiny tensors (the 8^3 level: <= 512 rows): statistics + finalize + normalise in ONE launch, and reduce + finalize +
-# apply in one (vnet_bn_small_*_b16; VNET_BN_SMALL=0: the streaming kernels everywhere).  Measured (profiles/ab_env.sh, C5 step):
+# apply in one (vnet_bn_small_*_b16; `_SMALL_BN["on"] = False`: the streaming kernels everywhere).  Measured (profiles/ab_env.sh, C5 step):
 # <= 512 rows -0.015 ms, <= 1024 the same, <= 8192 (the 16^3 level too) +0.13 ms -- one workgroup per channel octet uses 16 bytes
 # of every 256-byte row it touches, on 16-32 CUs; the five launch-bound streaming launches on 128+ workgroups are faster there.
-_SMALL_BN = {"on": _os.environ.get("VNET_BN_SMALL", "1") != "0", "rows": int(_os.environ.get("VNET_BN_SMALL_ROWS", "512"))}
+_SMALL_BN = {"on": True, "rows": 512}
 
 
 def _bn_small(M, C, *tensors):
@@ -1409,7 +1289,6 @@ class _BnActFn(torch.autograd.Function):
         L = _lib.lib()
         ctx.slot_r = getattr(r, "_vnet_slot", None)
         pre, r_orig = getattr(x, "_vnet_stats", None), r
-        ctx.dy16 = bool(getattr(x, "_vnet_dy16", False))
         x = x.contiguous()
         r = r.contiguous() if r is not None else None
         C = gamma.numel()
@@ -1443,12 +1322,9 @@ class _BnActFn(torch.autograd.Function):
             check(L.vnet_bn_act_fwd_b16(_ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
                                         act, _ptr(alpha), _ptr(y), _stream()), "vnet_bn_act_fwd_b16")
         else:
-            if _want_shadow(C):
-                y, yh = _alloc_shadowed(x.shape[:-1] + (C,), dev)
-            else:
-                y, yh = torch.empty(x.shape[:-1] + (C,), dtype=torch.float32, device=dev), None
-            check(L.vnet_bn_act_fwd_x16(_ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
-                                        act, _ptr(alpha), _ptr(y), yh, _stream()), "vnet_bn_act_fwd")
+            y = torch.empty(x.shape[:-1] + (C,), dtype=torch.float32, device=dev)
+            check(L.vnet_bn_act_fwd(_ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
+                                    act, _ptr(alpha), _ptr(y), _stream()), "vnet_bn_act_fwd")
         ctx.save_for_backward(x, r, gamma, beta, alpha, mean, invstd)
         ctx.params = (gamma, beta, alpha)
         ctx.cfg = (act, bcast, M, C)
@@ -1468,11 +1344,8 @@ class _BnActFn(torch.autograd.Function):
         dbeta, sbt = _grad_out(bref)
         dalpha, sa = _grad_out(aref) if alpha is not None else (None, None)
         need_ds = ctx.needs_input_grad[0] or (r is not None and ctx.needs_input_grad[1])
-        dsh = None
         if ctx.b16:
             ds = torch.empty(dy.shape, dtype=torch.bfloat16, device=dev) if need_ds else None
-        elif need_ds and ctx.dy16 and not bcast and _want_shadow(C):
-            ds, dsh = _alloc_shadowed(dy.shape, dev)
         else:
             ds = torch.empty(dy.shape, dtype=torch.float32, device=dev) if need_ds else None
         nb = L.vnet_bn_ws_bytes(C)
@@ -1498,13 +1371,6 @@ class _BnActFn(torch.autograd.Function):
                 check(L.vnet_bn_act_bwd_apply_b16(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd),
                                                   _ptr(gamma), _ptr(beta), act, _ptr(alpha), _ptr(sdz), _ptr(sdzx),
                                                   ctx.m_total, None, _ptr(ds), _stream()), "vnet_bn_act_bwd_apply_b16")
-        elif ctx.sync is None and dsh is not None:
-            check(L.vnet_bn_act_bwd_reduce(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd),
-                                           _ptr(gamma), _ptr(beta), act, _ptr(alpha), _ptr(dgamma), _ptr(dbeta),
-                                           _ptr(dalpha), _ptr(ws), nb, _stream()), "vnet_bn_act_bwd_reduce")
-            check(L.vnet_bn_act_bwd_apply_x16(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd),
-                                              _ptr(gamma), _ptr(beta), act, _ptr(alpha), _ptr(dbeta), _ptr(dgamma),
-                                              float(M), None, _ptr(ds), dsh, _stream()), "vnet_bn_act_bwd_apply")
         elif ctx.sync is None:
             check(L.vnet_bn_act_bwd(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd), _ptr(gamma),
                                     _ptr(beta), act, _ptr(alpha), _ptr(dgamma), _ptr(dbeta), _ptr(dalpha), _ptr(ds),
@@ -1518,9 +1384,9 @@ class _BnActFn(torch.autograd.Function):
             if ds is not None:
                 tot = torch.cat([dbeta.reshape(-1), dgamma.reshape(-1)])
                 ctx.sync[0](tot)
-                check(L.vnet_bn_act_bwd_apply_x16(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd),
-                                                  _ptr(gamma), _ptr(beta), act, _ptr(alpha), _ptr(tot), _ptr(tot[C:]),
-                                                  ctx.m_total, None, _ptr(ds), dsh, _stream()), "vnet_bn_act_bwd_apply")
+                check(L.vnet_bn_act_bwd_apply(_ptr(dy), _ptr(x), _ptr(r), int(bcast), M, C, _ptr(mean), _ptr(invstd),
+                                              _ptr(gamma), _ptr(beta), act, _ptr(alpha), _ptr(tot), _ptr(tot[C:]),
+                                              ctx.m_total, None, _ptr(ds), _stream()), "vnet_bn_act_bwd_apply")
         th = getattr(gref, "_vnet_deferred", None)
         if th is not None and sg is not None and sbt is not None:
             del gref._vnet_deferred
@@ -1542,7 +1408,6 @@ class _BnChainFn(torch.autograd.Function):
     def forward(ctx, x, kind, act, alpha, g1, b1, g2, b2, g3, b3, bufs):
         L = _lib.lib()
         pre = getattr(x, "_vnet_stats", None)
-        ctx.dy16 = bool(getattr(x, "_vnet_dy16", False))
         x = x.contiguous()
         C = g1.numel()
         M = x.numel() // C
@@ -1565,12 +1430,9 @@ class _BnChainFn(torch.autograd.Function):
             check(L.vnet_bn_act_fwd_b16(_ptr(x), None, 0, M, C, _ptr(mean), _ptr(invstd), _ptr(ceff), _ptr(deff),
                                         act, _ptr(alpha), _ptr(y), _stream()), "vnet_bn_act_fwd_b16")
         else:
-            if _want_shadow(C):
-                y, yh = _alloc_shadowed(x.shape, dev)
-            else:
-                y, yh = torch.empty(x.shape, dtype=torch.float32, device=dev), None
-            check(L.vnet_bn_act_fwd_x16(_ptr(x), None, 0, M, C, _ptr(mean), _ptr(invstd), _ptr(ceff), _ptr(deff),
-                                        act, _ptr(alpha), _ptr(y), yh, _stream()), "vnet_bn_act_fwd")
+            y = torch.empty(x.shape, dtype=torch.float32, device=dev)
+            check(L.vnet_bn_act_fwd(_ptr(x), None, 0, M, C, _ptr(mean), _ptr(invstd), _ptr(ceff), _ptr(deff),
+                                    act, _ptr(alpha), _ptr(y), _stream()), "vnet_bn_act_fwd")
         ctx.save_for_backward(x, alpha, g1, g2, g3, mean, invstd, ceff, deff)
         ctx.params = (alpha, g1, b1, g2, b2, g3, b3)
         ctx.cfg = (kind, act, M, C)
@@ -1617,13 +1479,10 @@ class _BnChainFn(torch.autograd.Function):
                                               act, _ptr(alpha), _ptr(dDg), _ptr(dCg), ctx.m_total, _ptr(extra), _ptr(dx),
                                               _stream()), "vnet_bn_act_bwd_apply_b16")
         elif ctx.needs_input_grad[0]:
-            if ctx.dy16 and _want_shadow(C):
-                dx, dxh = _alloc_shadowed(dy.shape, dev)
-            else:
-                dx, dxh = torch.empty(dy.shape, dtype=torch.float32, device=dev), None
-            check(L.vnet_bn_act_bwd_apply_x16(_ptr(dy), _ptr(x), None, 0, M, C, _ptr(mean), _ptr(invstd), _ptr(ceff), _ptr(deff),
-                                              act, _ptr(alpha), _ptr(dDg), _ptr(dCg), ctx.m_total, _ptr(extra), _ptr(dx), dxh,
-                                              _stream()), "vnet_bn_act_bwd_apply")
+            dx = torch.empty(dy.shape, dtype=torch.float32, device=dev)
+            check(L.vnet_bn_act_bwd_apply(_ptr(dy), _ptr(x), None, 0, M, C, _ptr(mean), _ptr(invstd), _ptr(ceff), _ptr(deff),
+                                          act, _ptr(alpha), _ptr(dDg), _ptr(dCg), ctx.m_total, _ptr(extra), _ptr(dx),
+                                          _stream()), "vnet_bn_act_bwd_apply")
         g3ret = _grad_ret(dg3, s3) if g3r is not None else None
         b3ret = _grad_ret(db3, t3) if b3r is not None else None
         return (dx, None, None, _grad_ret(dalpha, sa) if alpha is not None else None, _grad_ret(dg1, s1), _grad_ret(db1, t1),
@@ -1873,11 +1732,8 @@ class _DropoutFn(torch.autograd.Function):
             y = torch.empty_like(x)
             check(L.vnet_dropout_fwd_b16(_ptr(x), _ptr(y), _ptr(mask), x.numel(), rate, seed, _ptr(st), _stream()), "vnet_dropout_fwd_b16")
         else:
-            if x.dim() == 5 and _want_shadow(int(x.shape[-1])):
-                y, yh = _alloc_shadowed(x.shape, x.device)
-            else:
-                y, yh = torch.empty(x.shape, dtype=torch.float32, device=x.device), None
-            check(L.vnet_dropout_fwd_x16(_ptr(x), _ptr(y), yh, _ptr(mask), x.numel(), rate, seed, _ptr(st), _stream()), "vnet_dropout_fwd")
+            y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            check(L.vnet_dropout_fwd_dev(_ptr(x), _ptr(y), _ptr(mask), x.numel(), rate, seed, _ptr(st), _stream()), "vnet_dropout_fwd")
         ctx.save_for_backward(mask)
         ctx.rate = rate
         return y
