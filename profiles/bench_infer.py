@@ -30,8 +30,9 @@ with tempfile.TemporaryDirectory() as tmp:
     np.save(v, vol)
     # the Python evaluate path (image2label.evaluate_single_3D): 27 patches + the duplicated last batch = 14 batches of 2
     from vnet_tensorflow_amd import ops
-    for compute in ("fp32", "bf16"):
-        ops.set_compute_dtype(compute)
+    for compute in ("fp32", "fp32_split3", "bf16"):
+        with ops.context(m.ctx):                                  # (round 4: the compute dtype is per-model state)
+            ops.set_compute_dtype(compute)
         m.evaluate_single_3D(vol[:192, :192, :192])               # warm-up
         torch.cuda.synchronize(); t0 = time.perf_counter()
         m.evaluate_single_3D(vol)
@@ -40,7 +41,7 @@ with tempfile.TemporaryDirectory() as tmp:
     ops.set_compute_dtype("fp32")
     del m
     torch.cuda.empty_cache()
-    for compute in ("fp32", "bf16"):
+    for compute in ("fp32", "fp32_split3", "bf16"):
         out = subprocess.run([os.path.join(ROOT, "vnet_tensorflow_amd", "vnet_infer"), "--weights", w, "--image", v,
                               "--label-out", os.path.join(tmp, "lab.npy"), "--classes", "2", "--channels", "16", "--levels", "4",
                               "--convs", "1,2,3,3", "--bottom", "3", "--patch", "128,128,128", "--stride", "64,64,64", "--batch", "2",

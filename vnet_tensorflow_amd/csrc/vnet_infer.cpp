@@ -157,6 +157,7 @@ struct Config {
     int patch[3] = {64, 64, 64}, stride[3] = {64, 64, 64};
     std::string weights, image, label_out, prob_out;
     bool normalise = true;
+    bool split3 = false;     // --compute fp32_split3: fp32 tensors, the 5^3 convolutions on the bf16 matrix pipe (vnet_conv_fwd_x3) where vnet_conv_x3_ok
     bool store16 = false;    // --compute bf16: every activation is a bf16 tensor (BASELINE config C5 as the Python path runs it)
 };
 
@@ -336,6 +337,14 @@ private:
             return y;
         }
         Tensor y = alloc(x0.B, Do, Ho, Wo, Cout);
+        if (cfg.split3 && ks == 5 && stride == 1 && vnet_conv_x3_ok(x0.C, x1 ? x1->C : 0, Cout, 0, x0.B, Do, Ho, Wo) == 1) {
+            // the Python path's rule (ops._x3_ok): exactly split bf16 operands, six products, fp32 accumulate
+            float* wp3 = pack(sc + "/weights", VNET_PACK_FWD_X3, 125, Cin, Cout);
+            if (vnet_conv_x3_ws_bytes(Cin, Cout, x0.B, Do, Ho, Wo) > ws_bytes_) { std::fprintf(stderr, "workspace too small\n"); std::exit(1); }
+            ABI_OK(vnet_conv_fwd_x3(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, wp3, var(sc + "/biases").dev, y.p, Cout, nullptr, 0,
+                                    x0.B, x0.D, x0.H, x0.W, nullptr, nullptr, nullptr, ws_, ws_bytes_, st_));
+            return y;
+        }
         float* wp = pack(sc + "/weights", VNET_PACK_FWD, ks * ks * ks, Cin, Cout);
         size_t need = vnet_conv_ws_bytes(ks, 0, stride, 0, Cin, Cout, x0.B, Do, Ho, Wo);
         if (need > ws_bytes_) { std::fprintf(stderr, "workspace too small\n"); std::exit(1); }
@@ -437,8 +446,8 @@ static Config parse(int argc, char** argv) {
         else if (a == "--no-normalise") c.normalise = false;
         else if (a == "--compute") {
             const std::string v = next();
-            if (v != "fp32" && v != "bf16") { std::fprintf(stderr, "--compute fp32|bf16\n"); std::exit(1); }
-            c.store16 = (v == "bf16");
+            if (v != "fp32" && v != "fp32_split3" && v != "bf16") { std::fprintf(stderr, "--compute fp32|fp32_split3|bf16\n"); std::exit(1); }
+            c.store16 = (v == "bf16"); c.split3 = (v == "fp32_split3");
         }
         else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); std::exit(1); }
     }
@@ -448,7 +457,7 @@ static Config parse(int argc, char** argv) {
     }
     if (c.weights.empty() || c.image.empty() || c.label_out.empty() || (int)c.convs.size() != c.levels) {
         std::fprintf(stderr, "usage: vnet_infer --weights W --image I.npy --label-out L.npy [--prob-out P.npy] --classes K --channels C "
-                             "--levels L --convs a,b,.. --bottom n --patch x,y,z --stride x,y,z --batch b [--compute fp32|bf16]\n");
+                             "--levels L --convs a,b,.. --bottom n --patch x,y,z --stride x,y,z --batch b [--compute fp32|fp32_split3|bf16]\n");
         std::exit(1);
     }
     return c;
@@ -559,6 +568,6 @@ int main(int argc, char** argv) {
     std::printf("vnet_infer: %zu batches (%zu patches of %dx%dx%d), %dx%dx%d volume, %d classes -> %s\n", batches.size(), npatch,
                 P0, P1, P2, X, Y, Z, K, cfg.label_out.c_str());
     std::printf("vnet_infer: sliding window %.3f s = %.1f patches/s (crop + H2D + forward + accumulate, %s)\n", secs, npatch / secs,
-                cfg.store16 ? "bf16 storage" : "fp32");
+                cfg.store16 ? "bf16 storage" : cfg.split3 ? "fp32_split3" : "fp32");
     return 0;
 }
