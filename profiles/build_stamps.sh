@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 T=$(mktemp -d)
-for f in conv_mfma conv_b16 conv2_b16 elementwise input_block; do
+for f in conv_mfma conv_x3 conv_b16 conv2_b16 elementwise input_block; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-result ${DEFS:--DVNET_STAMPS} $EXTRA \
       -Iinclude -c vnet_tensorflow_amd/csrc/$f.hip -o $T/$f.o &
 done

@@ -811,6 +811,14 @@ __global__ void pack_kernel(int mode, const float* __restrict__ w, float* __rest
     }
 }
 
+// s_setprio alternation between the two waves of a SIMD (w, w + 4), as in conv_x3.h: the matrix pipe goes to the OLDER wave whenever
+// both are ready, so the older half of a workgroup reaches the step's common phases (stores, prefetch issue, barrier) early and the
+// younger half finishes alone.  Round 5 (profiles/r05_ab_prio.txt, interleaved A/B on two boxes): 16-cout forward kernel -2.3 %
+// (128^3 32->16: 0.285 -> 0.278 ms), row-reuse filter gradient -1.2 %; the row-pair kernel (a barrier per filter plane) did not
+// move and has none; switching in the middle of the dz-pair phase instead of at its end: no gain.
+#define VNET_PRIO_ALT(cond) do { if (cond) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } while (0)
+#define VNET_PRIO_OFF() __builtin_amdgcn_s_setprio(0)
+
 // all filters of a network in ONE launch (after every optimiser step): blockIdx.y selects the descriptor
 // {w, wp, mode, T, I, O, CQ, NP} (8 x int64 in device memory)
 __global__ void __launch_bounds__(256) pack_batched_kernel(const long long* __restrict__ descs) {
@@ -1807,6 +1815,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             for (int m = 0; m < 4; ++m) accA[m] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         // ---- dz pairs (0,1), (2,3) ----
+        VNET_PRIO_ALT(wave >= 4);                  // the younger half first ...
 #pragma unroll
         for (int zp = 0; zp < 2; ++zp)
 #pragma unroll
@@ -1832,6 +1841,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (more) tile_pack();          // the prefetched tile has long arrived: convert now, 32 fewer live registers from here
                                         // (packing after the first dz pair and letting the second pair's reads hoist: measured 2 % slower)
         // ---- dz = 4: dy pairs (0,1), (2,3) and the single tap dy = 4 ----
+        VNET_PRIO_ALT(wave < 4);                   // ... the older half for the last 60 of a step's 260 MFMAs
 #pragma unroll
         for (int dx = 0; dx < NDX; ++dx) {
             bf16x8 P[6], S[4], A[3];
@@ -1848,6 +1858,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 accA[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2], S[m], accA[m], 0, 0, 0);
             }
         }
+        VNET_PRIO_OFF();
         VNET_STAMP(3);
         if (last) {
             // epilogue: lane holds cout 4g..4g+3 of voxel (vz, vy0 + m, x = j)
@@ -2593,6 +2604,7 @@ __device__ __forceinline__ void wgrad5_bf16_rr_body(const WgradArgs& a, const in
         }
 #pragma unroll 1
         for (int z = 0; z < TZ; ++z) {
+            VNET_PRIO_ALT(((wave >> 2) ^ z) & 1);
             const int zx = z * (IY * IX * 32), zd = z * (TY * TX * 32);
             // one (dz, dx) pair at a time: the window of five row fragments of ONE pair is live (20 registers; all three pairs in
             // lockstep -- A read once per row -- needed 60 and spilled next to the prefetch registers); A is re-read per pair
@@ -2625,6 +2637,7 @@ __device__ __forceinline__ void wgrad5_bf16_rr_body(const WgradArgs& a, const in
             }
         }
     }
+    VNET_PRIO_OFF();
     if constexpr (IN4) {
         // lane holds D[(dz, dy), x offset 4 dxg][j = i = (sx, c)][co]: the tap dx = 4 dxg + sx of modality c (dx <= 4)
 #pragma unroll
