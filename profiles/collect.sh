@@ -10,7 +10,7 @@
 # 5. the per-layer tables of the 5^3 / 2^3 launches (one per leg),
 # 6. the streaming batch-norm passes one kernel at a time (profiles/bench_bn.py).
 # Every step is bounded by `timeout`; python is the program right after `--`.
-OUT=gpurun_out/${1:-prof}; shift
+OUT=gpurun_out/${1:-prof}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p $OUT
 timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err
