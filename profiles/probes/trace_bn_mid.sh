@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE (round 5): the one-launch batch-norm backward this script A/Bs was measured and NOT kept; the kernel and its VNET_BN_MID switch
+# exist only in commit b1cb486's parent experiment (see profiles/r04_bn_mid.txt and DESIGN 4.4) -- at HEAD both legs run the same code.
 # per-grid durations of the batch-norm backward kernels in the C5 step (VNET_BN_MID=1 / 0) under rocprofv3 --kernel-trace
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for v in 1 0; do

@@ -130,14 +130,17 @@ def test_full_size_network_c5_b16_storage(dev):
     got, ref = logits[s].cpu().numpy(), z["logits_sample"]
     # measured in round 4 (profiles/r04_golden_full_errors.txt): logits 2.31e-2, loss 1.5e-6, predictions 98.57 %, gradient 11.2 %
     # (round 3's bounds were 3e-2 / 1e-3 / 0.3: 30 % to three orders of magnitude of slack)
-    assert rel_l2(got, ref) < 2.7e-2, rel_l2(got, ref)
+    # (round 5, ADVICE r4: round 4 had put these ~15 % above ONE measurement of a chaotic quantity -- 2.7e-2 vs 2.31e-2, 0.14 vs 0.112 --
+    #  so that any benign change of a summation order, e.g. of the grouped filter-gradient plan, could trip them; now 1.5x the
+    #  measurement.  The per-layer teacher-forced test below is the tight one.)
+    assert rel_l2(got, ref) < 3.5e-2, rel_l2(got, ref)
     assert abs(loss - float(z["loss"])) < 2e-5, (loss, float(z["loss"]))
     assert (pred[s].cpu().numpy() == z["pred_sample"]).mean() >= 0.98
     errs = _grad_errors(z, net)
     names = list(map(str, z["names"]))
     num = sum((e[1] * float(z["grad_norm"][names.index(e[0])])) ** 2 for e in errs)
     den = sum(float(v) ** 2 for v in z["grad_norm"])
-    assert (num / den) ** 0.5 < 0.14, (num / den) ** 0.5
+    assert (num / den) ** 0.5 < 0.17, (num / den) ** 0.5
 
 
 def test_teacher_forced_layers_c5_b16(dev):

@@ -197,5 +197,17 @@ def test_training_step_gradients_do_not_depend_on_the_grouping(dev, P, monkeypat
     scale = float(gb.abs().max())
     assert float((ga - gb).abs().max()) <= 2e-5 * scale, (float((ga - gb).abs().max()), scale)
     assert max(grouped) >= 10 and min(grouped) == 0, grouped     # one pass collected the 5^3 layers, the other none
+    # byte budget: with a small budget the pass launches its group in several pieces; the same gradients to summation order
+    monkeypatch.setitem(ops._GROUP, "max_bytes", 3 * P ** 3 * 16 * 2)
+    grouped.clear()
+    np.random.seed(9)
+    m = image2label(None, cfg, device=dev, verbose=False)
+    m.read_config(); m.build_model_graph(); m._setup_training()
+    with ops.context(m.ctx):
+        loss = m._compute_gradients(xt, lt, 0.0)
+    torch.cuda.synchronize()
+    assert float(loss) == res[False][0]
+    assert float((m.flat.grad - gb).abs().max()) <= 2e-5 * scale
+    assert len([g for g in grouped if g > 0]) >= 3, grouped         # several partial groups instead of one
 
 

@@ -127,3 +127,39 @@ def test_x3_split_is_exact(dev, split3):
                 got = total[p, lanes, :]
                 bad = np.argwhere(got != want)
                 assert bad.size == 0, (p, hi, half, [(tuple(b), got[tuple(b)], want[tuple(b)]) for b in bad[:4]])
+
+
+def test_backward_runs_in_the_context_of_the_forward(dev):
+    """a backward pass driven from OUTSIDE the model's OpsContext (a user calling loss.backward() after a forward that
+    ran inside it) must take the forward's compute mode, pack registry and streams -- here: a fp32_split3 context, backward called
+    while the default (fp32) context is current; bit-identical to the backward called inside the context, and not the fp32 kernels'
+    bits."""
+    from vnet_tensorflow_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 32, 32, 64, 16, generator=gen).to(dev)          # (256 bricks of 2x8x16: vnet_conv_x3_ok)
+    dy = torch.randn(1, 32, 32, 64, 16, generator=gen).to(dev)
+    w0 = (torch.randn(5, 5, 5, 16, 16, generator=gen) * 0.1).to(dev)
+    b0 = torch.randn(16, generator=gen).to(dev)
+    ctx = ops.OpsContext()
+    with ops.context(ctx):
+        ops.set_compute_dtype("fp32_split3")
+    grads = {}
+    for where in ("outside", "inside", "fp32"):
+        xx, w, b = x.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        if where == "fp32":
+            y = ops.conv(xx, w, b, 5, 1)
+            y.backward(dy)
+        else:
+            with ops.context(ctx):
+                y = ops.conv(xx, w, b, 5, 1)
+                if where == "inside":
+                    y.backward(dy)
+            if where == "outside":
+                assert ops.get_compute_dtype() == "fp32"
+                y.backward(dy)
+        torch.cuda.synchronize()
+        grads[where] = (y.detach().clone(), xx.grad.clone(), w.grad.clone())
+    for a, b_ in zip(grads["outside"], grads["inside"]):
+        assert torch.equal(a, b_)
+    assert not torch.equal(grads["outside"][1], grads["fp32"][1])          # (the f32x3 kernels really ran: other bits than the fp32 MFMA)
+    assert rel_l2(grads["outside"][2].cpu().numpy(), grads["fp32"][2].cpu().numpy()) < 2e-6

@@ -523,6 +523,7 @@ def _wgrad5_b16_call(x0, x1, dy, dw, dims, cin_dw, owner=None):
         # pass ends (vnet_conv_wgrad_b16_group); the tensors stay alive -- and unmodified, see _ConvFn.backward -- until then
         _DEFER["jobs"].append((x0, x1, dy, dw, ws, nb, int(cin_dw), B, tuple(dims), flops, nbytes, 5))
         _DEFER["dy_ptrs"].add(dy.data_ptr())
+        _group_pinned(x0, x1, dy)
         return
     with _Timed(tag, flops, nbytes), _immediate_reduce(owner is None):
         check(L.vnet_conv_wgrad_b16(_ptr(x0), C0, _ptr(x1), C1, _ptr(dy), Co, _ptr(dw), int(cin_dw), B, *dims, _ptr(ws), nb, _stream()),
@@ -592,6 +593,7 @@ def _wgrad2_b16_call(xfine, dycoarse, dw, dims_fine, dims_coarse, owner=None):
         _DEFER["jobs"].append((xfine, None, dycoarse, dw, ws, nb, int(Cin), B, tuple(dims_fine),
                                2.0 * nout * 8 * Cin * Co, 2.0 * nout * (8 * Cin + Co) + 4.0 * 8 * Cin * Co, 2))
         _DEFER["dy_ptrs"].add(dycoarse.data_ptr())
+        _group_pinned(xfine, None, dycoarse)
         return
     with _Timed(tag, 2.0 * nout * 8 * Cin * Co, 2.0 * nout * (8 * Cin + Co) + 4.0 * 8 * Cin * Co), _immediate_reduce(immediate):
         check(L.vnet_conv2_wgrad_b16(_ptr(xfine), Cin, _ptr(dycoarse), Co, _ptr(dw), B, *dims_fine, *dims_coarse, _ptr(ws), nb, _stream()),
@@ -632,7 +634,7 @@ _DEFER = {"on": False, "jobs": [], "dy_ptrs": set(), "stream": None}
 # grouped launch of the 5^3 filter gradients of a deferring pass (layers up to 128^3 voxels; measured: 32^3 and below -0.23 ms,
 # all levels -0.33 ms per C5 step) (bf16 storage; include/vnet_hip.h:
 # vnet_conv_wgrad_b16_group).  VNET_WGRAD_GROUP=0: every layer launches its own kernel as it did through round 3.
-_GROUP = {"on": _os.environ.get("VNET_WGRAD_GROUP", "1") != "0", "max_voxels": 128 ** 3,
+_GROUP = {"on": _os.environ.get("VNET_WGRAD_GROUP", "1") != "0", "max_voxels": 128 ** 3, "max_bytes": 4 << 30,
           "k2": True}
 # (k2: the 2^3 stride-2 filter gradients join too -- -0.05 ms per C5 step.  Round 4 also built the group for fp32 tensors and let the
 #  zero-padded network input join; both measured no gain -- DESIGN 4.5 -- and were removed in round 5)
@@ -645,10 +647,21 @@ def set_wgrad_group(on):
     _GROUP["on"] = bool(on)
 
 
+def _group_pinned(*tensors):
+    """Byte budget of the grouped launch: the activations and gradients of every layer that joins stay alive until the
+    group is launched, where autograd used to release them layer by layer; the footprint grows with the batch size.  Once the
+    tensors waiting exceed `_GROUP["max_bytes"]` the layers collected so far are launched mid-pass (their slabs' reduces still join
+    the one batched flush) and their tensors are let go.  An upper bound: a tensor two layers share is counted twice."""
+    _DEFER["pinned"] = _DEFER.get("pinned", 0) + sum(t.numel() * t.element_size() for t in tensors if t is not None)
+    if _DEFER["pinned"] > _GROUP["max_bytes"]:
+        _flush_wgrad_group()
+
+
 def _flush_wgrad_group(launch=True):
     """Launch the collected filter gradients (the reduces of their slabs join the deferred queue) and let go of their tensors."""
     jobs, _DEFER["jobs"] = _DEFER["jobs"], []
     _DEFER["dy_ptrs"] = set()
+    _DEFER["pinned"] = 0
     if not jobs or not launch:
         return
     _launch_wgrad_group(jobs, "vnet_conv_wgrad_b16_group")
@@ -930,10 +943,18 @@ class _ConvFn(torch.autograd.Function):
         ctx.b16 = b16
         ctx.bias_zero = _FUSE["zero_bias_grad"] and b is not None
         ctx.slots = (slot0, slot1)
+        ctx.opsctx = current_context()
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        # the backward pass runs in the OpsContext of the forward pass (a user-driven loss.backward() outside
+        # model.in_context would otherwise pick the default context's compute mode, stream and pack registry)
+        with context(ctx.opsctx):
+            return _ConvFn._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         x0, x1, w = ctx.saved_tensors
         ks, stride, up, din, dout, C0, C1, I, O = ctx.cfg
         dy = dy.contiguous()
