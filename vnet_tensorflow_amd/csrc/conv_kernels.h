@@ -726,6 +726,7 @@ struct Tuning {
     int group_debug;         // VNET_WGRAD_GROUP_DEBUG: print the group's plan
     int bf16_deep;           // VNET_BF16_DEEP: deep-level bf16 kernel (csrc/conv_deep.h), default 1
     int bf16_deep_target;    // VNET_BF16_DEEP_TARGET: workgroups its K split aims for (default 256)
+    int bf16_c16pp;          // VNET_BF16_C16PP: ping-pong form of the 16-cout bf16 kernel (csrc/conv_c16pp.h) where it applies, default 1
     int x3_nb2;              // VNET_X3_NB2: f32x3 convolution, two 16-cout blocks per item where the layer allows (default 1)
     int f32_small;           // VNET_F32_SMALL: fp32 5^3 convolutions on volumes narrower than 16: 0 = 8x8x8 bricks / 8 waves (rounds 1-4),
                              // 1 = 4x8x8 bricks / 4 waves (two workgroups per CU), 2 (default) = ... and 4x4x4 bricks for volumes <= 4^3
@@ -2745,6 +2746,14 @@ bool conv_bf16_use_c16(int Cin, int Cout, int C0, int C1, int Cy0, int Cy1, int 
     return (long)B * ceil_div(D, 4) * ceil_div(H, 8) * ceil_div(W, 16) >= 256;
 }
 
+// ping-pong form (conv_c16pp.h): bf16 tensors in and out, one or two 16-channel chunks, not the x-im2col input layer
+// (Cin >= 16: the zero-padded network input -- 8 channels -- keeps the c16 kernel with or without its x-im2col form, so that the
+//  number of statistics rows stays a function of the shape alone)
+bool conv_bf16_use_c16pp(int Cin, int Cout, int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W) {
+    if (tuning().bf16_c16pp == 0 || Cin < 16 || (C0 & 7) || (C1 & 7)) return false;
+    return conv_bf16_use_c16(Cin, Cout, C0, C1, Cy0, Cy1, B, D, H, W);
+}
+
 // row-pair kernel: whole 32-cout blocks, vector-aligned outputs, >= 256 (brick of 4x16x16, cout block) items
 bool conv_bf16_use_r32(int Cout, int Cy0, int Cy1, int B, int D, int H, int W) {
 #ifdef VNET_PLAN_ENV
@@ -2829,6 +2838,9 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
     hipLaunchKernelGGL(k, grid, dim3(512), lds, st, a);
     return (int)hipGetLastError();
 }
+}  // namespace
+#include "conv_c16pp.h"
+namespace {
 // kernel choice of the bf16-operand 5^3 convolution (HS: bf16 sources, O16: bf16 outputs); -1 = launched, nothing to reduce
 template <bool HS, bool O16 = false>
 int conv_fwd_bf16_go(ConvArgs& a, const Bf16Plan& p, int nslab, int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W, hipStream_t st) {
@@ -2838,6 +2850,23 @@ int conv_fwd_bf16_go(ConvArgs& a, const Bf16Plan& p, int nslab, int C0, int C1, 
         a.nbz = ceil_div(D, 4); a.nby = ceil_div(H, 8); a.nbx = ceil_div(W, 16);
         const size_t lds = (size_t)GC::TILE_BYTES + 65 * 1024 + 64 * 16 + 8 * 32 * 4;
         if constexpr (HS && O16) {
+            if (!a.in4 && conv_bf16_use_c16pp(a.Cin, a.Cout, C0, C1, Cy0, Cy1, B, D, H, W)) {
+                // filter out of LDS, two 4-wave workgroups per CU (conv_c16pp.h): the same 4x8x16 bricks
+                const int grid = 2 * (device_cus() / 8) * 8;
+                if (a.stats) {
+                    auto k = conv5_bf16_c16pp_kernel<true>;
+                    static unsigned long long attr_done = 0;
+                    if (int ae = ensure_lds(k, PP_LDS, attr_done)) return ae;
+                    hipLaunchKernelGGL(k, dim3(grid), dim3(256), PP_LDS, st, a);
+                } else {
+                    auto k = conv5_bf16_c16pp_kernel<false>;
+                    static unsigned long long attr_done = 0;
+                    if (int ae = ensure_lds(k, PP_LDS, attr_done)) return ae;
+                    hipLaunchKernelGGL(k, dim3(grid), dim3(256), PP_LDS, st, a);
+                }
+                VNET_LAUNCH_CHECK();
+                return -1;
+            }
             if (a.in4) {              // the multi-modality network input: x-im2col in LDS, 2.5x fewer MFMAs
                 if (a.stats) {
                     auto k = conv5_bf16_c16_kernel<4, 8, 16, true, true, true, true>;

@@ -30,7 +30,7 @@ static Tuning tuning_from_env() {
     t.group_rounds = g ? atof(g) : 2.0;
     t.group_debug = getenv("VNET_WGRAD_GROUP_DEBUG") ? 1 : 0;
     t.bf16_deep = geti("VNET_BF16_DEEP", 1); t.bf16_deep_target = geti("VNET_BF16_DEEP_TARGET", 256);
-    t.f32_small = geti("VNET_F32_SMALL", 2); t.x3_nb2 = geti("VNET_X3_NB2", 1);
+    t.f32_small = geti("VNET_F32_SMALL", 2); t.x3_nb2 = geti("VNET_X3_NB2", 1); t.bf16_c16pp = geti("VNET_BF16_C16PP", 1);
     return t;
 }
 Tuning& tuning() { static Tuning t = tuning_from_env(); return t; }
@@ -49,6 +49,7 @@ double* option_slot(const char* name, int** ip) {
     else if (!strcmp(name, "BF16_DEEP_TARGET")) *ip = &t.bf16_deep_target;
     else if (!strcmp(name, "F32_SMALL")) *ip = &t.f32_small;
     else if (!strcmp(name, "X3_NB2")) *ip = &t.x3_nb2;
+    else if (!strcmp(name, "BF16_C16PP")) *ip = &t.bf16_c16pp;
     else if (!strcmp(name, "WGRAD_GROUP_ROUNDS")) return &t.group_rounds;
     return nullptr;
 }
