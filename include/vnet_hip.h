@@ -62,7 +62,7 @@ const char* vnet_version(void);
 
 /* Tuning options: read ONCE from the environment (VNET_<NAME>, first use), never on a launch path; afterwards only through
  * vnet_set_option(name, value) -> previous value (NaN: unknown name).  Names: WGRAD_ZS, WGRAD_RR, CONV_IN4, WGRAD_GROUP_ROUNDS,
- * WGRAD_GROUP_DEBUG, BF16_DEEP, BF16_DEEP_TARGET, F32_SMALL, X3_NB2 ("Switches"). */
+ * WGRAD_GROUP_DEBUG, BF16_DEEP, BF16_DEEP_TARGET, BF16_C16PP, F32_SMALL, X3_NB2 ("Switches"). */
 double vnet_set_option(const char* name, double value);
 double vnet_get_option(const char* name);
 
