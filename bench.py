@@ -411,7 +411,7 @@ def measure(args, patch, batch, channels, classes, compute, rank, local, world):
                 tper = ent.get("per_kernel")                      # forward / backward-data / filter gradient, each per launch
                 tsrc = "profiles/%s: rocprofv3 --pmc passes of this command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), not this run" % os.path.basename(pmc)
         peak = PEAK_BF16_TFLOPS if bf16 else (PEAK_F32X3_TFLOPS if x3 else PEAK_FP32_TFLOPS)
-        kname = ("conv5_bf16_c16_kernel (fwd 32->16) + conv5_bf16_r32_kernel (bwd-data 16->32) + wgrad5_bf16_rr_kernel (row-reuse filter gradient), bf16 tensors in and out" if bf16
+        kname = ("conv5_bf16_c16pp_kernel (fwd 32->16: filter L2 -> VGPR, two workgroups per CU) + conv5_bf16_r32_kernel (bwd-data 16->32) + wgrad5_bf16_rr_kernel (row-reuse filter gradient), bf16 tensors in and out" if bf16
                  else "conv5_x3_kernel (fwd 32->16, bwd-data 16->32) + wgrad5_x3_kernel: fp32 tensors, six v_mfma_f32_16x16x32_bf16 per product of "
                       "exactly split operands; peak = 2500 / 6 TF/s fp32-equivalent" if x3
                  else "conv_kernel<5,1,4,8,8,4,4,{1,2}> (fwd 32->16, bwd-data 16->32) + wgrad_kernel<5,1,4,4,16,1,16>")

@@ -35,7 +35,9 @@ FAMILIES = {
                      ("wgrad", "wgrad5_x3_kernel", None, "longest")]),
     # C5, bf16 storage: forward with statistics 16->16, 32->16 = the second launch of the plain 16-cout kernel (the 4->16 input conv is
     # the x-im2col instantiation); backward-data 16->32 and the stand-alone filter gradient are the first launches of their kernels
-    "bf16": ("c5", [("fwd", "conv5_bf16_c16_kernel<4, 8, 16, true, true, true, false>", None, 1),
+    # (round 5: forward 16->16 / 32->16 with statistics take conv5_bf16_c16pp_kernel<true> -- persistent grid, the 4->16 input conv stays on the
+    #  x-im2col instantiation of the c16 kernel: the 32->16 launch is the LONGEST of its kernel in a step)
+    "bf16": ("c5", [("fwd", "conv5_bf16_c16pp_kernel<true>", None, "longest"),
                     ("bwd", "conv5_bf16_r32_kernel<false, true>", None, 0),
                     ("wgrad", "wgrad5_bf16_rr_kernel<4, false>", None, 0)]),
 }
