@@ -530,3 +530,28 @@ def test_row_reuse_filter_gradient(dev, shape, monkeypatch, lib_option):
     check_close("rr wgrad %s" % (shape,), got["2"], dw_ex, 2e-6)
     check_close("generic wgrad %s" % (shape,), got["0"], dw_ex, 2e-6)
     assert not torch.equal(got["2"], got["0"]) or C0 + C1 <= 16, "the row-reuse kernel did not run (identical bits)"
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 32, 64, 16, 0, 16),      # one chunk
+                                   (1, 30, 50, 70, 16, 16, 16),     # two sources = two chunks, ragged bricks
+                                   (2, 16, 32, 32, 32, 0, 8)])      # batch 2, 8 output channels
+def test_c16pp_kernel_is_bit_identical_to_the_c16_kernel(dev, shape, lib_option):
+    """csrc/conv_c16pp.h (round 5: filter fragments L2 -> VGPR, two 4-wave workgroups per CU, a wave owns 8 rows) keeps, per accumulator,
+    the order of additions of conv5_bf16_c16_kernel: forward output, epilogue statistics to summation order, accumulate mode and the
+    backward-data results are the SAME BITS with option BF16_C16PP = 0 / 1."""
+    from vnet_tensorflow_amd import ops
+    B, D, H, W, C0, C1, Co = shape
+    x0, x1, w, b, dy = _conv5_inputs(shape, sum(shape) + 3)
+    res = {}
+    for pp in (1, 0):
+        lib_option("BF16_C16PP", pp)
+        tx0 = g16(x0, dev).requires_grad_(True)
+        tx1 = g16(x1, dev).requires_grad_(True) if C1 else None
+        tw, tb = g(w, dev).requires_grad_(True), g(b, dev).requires_grad_(True)
+        y = ops.conv(tx0, tw, tb, 5, 1, x1=tx1, bn_stats=True)
+        st = y._vnet_stats.partial.double().sum(0)
+        y.backward(g16(dy, dev))
+        torch.cuda.synchronize()
+        res[pp] = (y.detach().clone(), st, tx0.grad.clone(), tw.grad.clone())
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-6, atol=1e-3)       # (per-brick rows summed in another order across waves)
