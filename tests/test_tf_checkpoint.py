@@ -1,0 +1,118 @@
+"""CPU: the TensorFlow checkpoint (tensor bundle, tf.train.Saver V2) reader / writer of vnet_tensorflow_amd/tf_checkpoint.py -- the format
+the reference saves and restores with (model.py:689-699, 758-764, 806-808).  TensorFlow cannot be installed here: the format is pinned by
+published known answers (CRC-32C check value, leveldb's CRC mask, the table magic), hand-assembled bytes and the module's own round trip --
+NOT by a file TensorFlow wrote (parity unpinned by the reference)."""
+import struct
+
+import numpy as np
+import pytest
+
+from vnet_tensorflow_amd import tf_checkpoint as T
+
+
+def test_crc32c_known_answers():
+    assert T.crc32c(b"123456789") == 0xe3069283                      # the CRC-32C check value (RFC 3720 appendix B.4 / iSCSI)
+    assert T.crc32c(b"\x00" * 32) == 0x8a9136aa and T.crc32c(b"\xff" * 32) == 0x62a8ab43      # RFC 3720 B.4 test patterns
+    assert T.crc32c(bytes(range(32))) == 0x46dd794e
+    assert T.crc32c(b"hello world") == T.crc32c(b" world", T.crc32c(b"hello"))               # incremental form
+    for c in (0, 1, 0xe3069283, 0xffffffff):
+        assert T.unmask_crc(T.mask_crc(c)) == c
+    assert T.mask_crc(0) == 0xa282ead8                                 # leveldb crc32c.h: rotate right by 15, add kMaskDelta
+
+
+def test_hand_assembled_block_and_entry():
+    # a block of three entries with prefix compression (restart interval 16 -> one restart): keys "ab", "abc", "b"
+    blk = bytes([0, 2, 1]) + b"ab" + b"x" + bytes([2, 1, 1]) + b"c" + b"y" + bytes([0, 1, 2]) + b"b" + b"zz" + struct.pack("<II", 0, 1)
+    assert list(T._block_entries(blk)) == [(b"ab", b"x"), (b"abc", b"y"), (b"b", b"zz")]
+    assert T._build_block([(b"ab", b"x"), (b"abc", b"y"), (b"b", b"zz")], 16) == blk
+    # BundleEntryProto: dtype DT_FLOAT (1), shape [2, 3], offset 24, size 24, crc32c 0x01020304 (fixed32, field 6)
+    e = bytes([0x08, 1, 0x12, 8, 0x12, 2, 0x08, 2, 0x12, 2, 0x08, 3, 0x20, 24, 0x28, 24, 0x35, 4, 3, 2, 1])
+    assert T._entry_proto(1, (2, 3), 24, 24, 0x01020304) == e
+    p = T._parse_entry(e)
+    assert (p["dtype"], p["shape"], p["offset"], p["size"], p["crc32c"]) == (1, [2, 3], 24, 24, 0x01020304)
+    # varints: 300 = ac 02
+    assert T._put_varint(300) == b"\xac\x02" and T._get_varint(b"\xac\x02", 0) == (300, 2)
+
+
+def _state(rng, n=40):
+    t = {}
+    for i in range(n):
+        scope = "vnet/encoder/level_%d/conv_%d" % (i % 4 + 1, i // 4)
+        t[scope + "/weights"] = rng.standard_normal((5, 5, 5, 2 + i % 3, 3)).astype(np.float32)
+        t[scope + "/weights/Adam"] = rng.standard_normal(t[scope + "/weights"].shape).astype(np.float32)
+        t[scope + "/weights/Adam_1"] = np.abs(rng.standard_normal(t[scope + "/weights"].shape)).astype(np.float32)
+        t[scope + "/biases"] = rng.standard_normal(3).astype(np.float32)
+    t["beta1_power"] = np.float32(0.9 ** 8)
+    t["beta2_power"] = np.float32(0.999 ** 8)
+    t["global_step"] = np.int64(7)
+    t["start_epoch"] = np.array([2], dtype=np.int32)
+    t["empty"] = np.zeros((0, 4), dtype=np.float32)
+    return t
+
+
+def test_round_trip_and_file_structure(tmp_path):
+    rng = np.random.default_rng(0)
+    t = _state(rng)
+    prefix = str(tmp_path / "ck" / "checkpoint-7")
+    T.write(prefix, t, block_size=512)                                  # small blocks: several data blocks, prefix compression across 16-entry runs
+    idx = open(prefix + ".index", "rb").read()
+    assert struct.unpack("<Q", idx[-8:])[0] == 0xdb4775248b80fb57 and len(idx) > 48
+    got = T.read(prefix, verify="all")
+    assert sorted(got) == sorted(t)
+    for k in t:
+        assert got[k].dtype == np.asarray(t[k]).dtype and got[k].shape == np.asarray(t[k]).shape and np.array_equal(got[k], t[k]), k
+    lv = T.list_variables(prefix)
+    assert list(lv) == sorted(t, key=lambda s: s.encode()) and lv["global_step"] == (np.int64, ())
+    # tensors lie back to back in key order in the data file
+    data = open(prefix + ".data-00000-of-00001", "rb").read()
+    assert len(data) == sum(np.asarray(v).nbytes for v in t.values())
+    # a flipped byte in a tensor / in the index is caught
+    bad = bytearray(data); bad[10] ^= 1
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(bad))
+    with pytest.raises(ValueError, match="checksum"):
+        T.read(prefix, verify="all")
+    open(prefix + ".data-00000-of-00001", "wb").write(data)
+    bad = bytearray(idx); bad[5] ^= 1
+    open(prefix + ".index", "wb").write(bytes(bad))
+    with pytest.raises(ValueError, match="checksum"):
+        T.read(prefix)
+    open(prefix + ".index", "wb").write(idx[:-1] + b"\x00")
+    with pytest.raises(ValueError, match="magic"):
+        T.read(prefix)
+
+
+def test_training_state_of_the_reference(tmp_path):
+    rng = np.random.default_rng(1)
+    t = _state(rng, 8)
+    names = [k for k in t if k.endswith(("weights", "biases"))]
+    variables, opt, gs, ep = T.split_training_state(t, names)
+    assert sorted(variables) == sorted(names) and gs == 7 and ep == 2
+    assert opt["kind"] == "adam" and opt["t"] == 7 and sorted(opt["m"]) == sorted(n for n in names if n.endswith("weights"))
+    with pytest.raises(KeyError):
+        T.split_training_state(t, names + ["vnet/missing/weights"])
+
+
+def test_model_round_trip_through_the_reference_format(tmp_path):
+    """image2label.save_tf_checkpoint -> load_tf_checkpoint on a second model: variables, moving statistics, Adam slots, global_step."""
+    import torch
+    from vnet_tensorflow_amd.model import image2label
+    from tests.test_host import _config
+    cfg = _config(tmp_path)
+    a = image2label(None, cfg, device="cpu", verbose=False)
+    a.read_config(); a.build_model_graph(); a._setup_training()
+    with torch.no_grad():
+        a.optimizer.m.normal_(); a.optimizer.v.uniform_(); a.optimizer.t = 11
+    a.global_step, a.start_epoch = 123, 4
+    prefix = a.save_tf_checkpoint(str(tmp_path / "tfck" / "checkpoint-123"))
+    np.random.seed(99)
+    b = image2label(None, cfg, device="cpu", verbose=False)
+    b.read_config(); b.build_model_graph(); b._setup_training()
+    b.load_tf_checkpoint(prefix, verify="all")
+    sa, sb = a.network.state_dict(), b.network.state_dict()
+    assert list(sa) == list(sb) and all(torch.equal(sa[k], sb[k]) for k in sa)
+    assert b.global_step == 123 and b.start_epoch == 4 and b.optimizer.t == 11
+    for n, off, p in zip(a.flat.names, a.flat.offsets, a.flat.params):
+        sl = slice(off, off + p.numel())
+        assert torch.equal(a.optimizer.m[sl], b.optimizer.m[sl]) and torch.equal(a.optimizer.v[sl], b.optimizer.v[sl]), n
+    names = T.list_variables(prefix)
+    assert "global_step" in names and "beta1_power" in names and any(k.endswith("/Adam_1") for k in names)

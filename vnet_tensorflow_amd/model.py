@@ -699,6 +699,59 @@ class image2label(object):
             self.optimizer.load_state_dict(ck["optimizer"])
         return path
 
+    @in_context
+    def load_tf_checkpoint(self, prefix, with_optimizer=True, verify="small"):
+        """Restore from a checkpoint the REFERENCE wrote (`tf.train.Saver`, model.py:689-699, 762, 806: `<ckpt_dir>/checkpoint-<step>` =
+        `.index` + `.data-00000-of-00001`): the network's variables by their TF names, global_step, start_epoch and -- when the
+        configured optimiser matches -- the Adam (`<var>/Adam`, `<var>/Adam_1`, beta1_power) or Momentum (`<var>/Momentum`) slots.
+        tf_checkpoint.py restates the file format; no TensorFlow needed."""
+        from . import tf_checkpoint as tfc
+        names = list(self.network.state_dict().keys())
+        tensors = tfc.read(prefix, verify=verify)
+        variables, opt, gs, ep = tfc.split_training_state(tensors, names)
+        self.network.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in variables.items()})
+        ops.invalidate_packed()
+        if self.device is not None and self.device.type == "cuda":
+            ops.repack_registered()
+        self.global_step, self.start_epoch = gs, ep
+        if with_optimizer and opt is not None and getattr(self, "optimizer", None) is not None:
+            flat, o = self.flat, self.optimizer
+
+            def fill(dst, table):
+                with torch.no_grad():
+                    for n, off, p in zip(flat.names, flat.offsets, flat.params):
+                        if n in table:
+                            dst[off:off + p.numel()].copy_(torch.from_numpy(np.ascontiguousarray(table[n], dtype=np.float32)).reshape(-1).to(dst.device))
+            if opt["kind"] == "adam" and hasattr(o, "m"):
+                fill(o.m, opt["m"]); fill(o.v, opt["v"]); o.t = opt["t"]
+            elif opt["kind"] == "momentum" and hasattr(o, "acc"):
+                fill(o.acc, opt["acc"])
+        return prefix
+
+    def save_tf_checkpoint(self, prefix=None):
+        """Write the training state in the reference's own checkpoint format (what its `saver.restore` reads): variables, optimiser
+        slots, global_step, start_epoch.  Pure-Python CRC-32C: a full-width network (176 MB) takes minutes."""
+        from . import tf_checkpoint as tfc
+        if prefix is None:
+            prefix = "%s-%d" % (self._ckpt_prefix(), self.global_step)
+        out = {k: v.detach().cpu().numpy() for k, v in self.network.state_dict().items()}
+        o = getattr(self, "optimizer", None)
+        if o is not None:
+            for n, off, p in zip(self.flat.names, self.flat.offsets, self.flat.params):
+                sl = slice(off, off + p.numel())
+                if hasattr(o, "m"):
+                    out[n + "/Adam"] = o.m[sl].view(p.shape).cpu().numpy()
+                    out[n + "/Adam_1"] = o.v[sl].view(p.shape).cpu().numpy()
+                elif hasattr(o, "acc"):
+                    out[n + "/Momentum"] = o.acc[sl].view(p.shape).cpu().numpy()
+            if hasattr(o, "m"):
+                out["beta1_power"] = np.float32(o.b1 ** (o.t + 1))          # (TF keeps beta^(t+1): the power the NEXT step will use)
+                out["beta2_power"] = np.float32(o.b2 ** (o.t + 1))
+        out["global_step"] = np.int64(self.global_step)
+        out["start_epoch"] = np.array([self.start_epoch], dtype=np.int32)
+        tfc.write(prefix, out)
+        return prefix
+
     def _dataset(self, data_dir, train):
         tf = None
         if self.training_pipeline:
