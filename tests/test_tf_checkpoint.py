@@ -114,5 +114,14 @@ def test_model_round_trip_through_the_reference_format(tmp_path):
     for n, off, p in zip(a.flat.names, a.flat.offsets, a.flat.params):
         sl = slice(off, off + p.numel())
         assert torch.equal(a.optimizer.m[sl], b.optimizer.m[sl]) and torch.equal(a.optimizer.v[sl], b.optimizer.v[sl]), n
+    # ... and load_checkpoint() finds the reference's files through `checkpoint-latest` (model.py:696-699) on its own
+    import os
+    c = image2label(None, cfg, device="cpu", verbose=False)
+    c.read_config(); c.build_model_graph(); c._setup_training()
+    c.ckpt_dir = str(tmp_path / "tfck")
+    with open(os.path.join(c.ckpt_dir, "checkpoint-latest"), "w") as f:
+        f.write('model_checkpoint_path: "checkpoint-123"\nall_model_checkpoint_paths: "checkpoint-123"\n')
+    c.load_checkpoint()
+    assert c.global_step == 123 and all(torch.equal(sa[k], c.network.state_dict()[k]) for k in sa)
     names = T.list_variables(prefix)
     assert "global_step" in names and "beta1_power" in names and any(k.endswith("/Adam_1") for k in names)

@@ -685,6 +685,9 @@ class image2label(object):
         if path is None:
             with open(self._ckpt_prefix() + "-latest") as f:
                 path = os.path.join(self.ckpt_dir, f.readline().split('"')[1])
+        if os.path.exists(path + ".index") and not os.path.isfile(path):
+            # a checkpoint the REFERENCE wrote (tf.train.Saver: <prefix>.index + .data-*): the same names, another container
+            return self.load_tf_checkpoint(path, with_optimizer=with_optimizer)
         ck = torch.load(path, map_location="cpu", weights_only=True)      # tensors, ints and a list of names only
         self.network.load_state_dict(ck["variables"])
         ops.invalidate_packed()
