@@ -534,7 +534,8 @@ def test_row_reuse_filter_gradient(dev, shape, monkeypatch, lib_option):
 
 @pytest.mark.parametrize("shape", [(1, 16, 32, 64, 16, 0, 16),      # one chunk
                                    (1, 30, 50, 70, 16, 16, 16),     # two sources = two chunks, ragged bricks
-                                   (2, 16, 32, 32, 32, 0, 8)])      # batch 2, 8 output channels
+                                   (2, 16, 32, 32, 32, 0, 8),       # batch 2, 8 output channels
+                                   (1, 32, 64, 64, 48, 0, 16)])     # three chunks
 def test_c16pp_kernel_is_bit_identical_to_the_c16_kernel(dev, shape, lib_option):
     """csrc/conv_c16pp.h (round 5: filter fragments L2 -> VGPR, two 4-wave workgroups per CU, a wave owns 8 rows) keeps, per accumulator,
     the order of additions of conv5_bf16_c16_kernel: forward output, epilogue statistics to summation order, accumulate mode and the
