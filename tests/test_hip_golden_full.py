@@ -21,7 +21,7 @@ import pytest
 import torch
 
 from oracle import vnet_oracle as O
-from tests.golden.make_golden_full import CASES, SAMPLE, STRIDE, sample_indices
+from tests.golden.make_golden_full import CASES, SAMPLE, STRIDE, WEIGHT_SEED, sample_indices
 from tests.util import g, rel_l2
 
 pytestmark = pytest.mark.gpu
@@ -32,7 +32,7 @@ def _run_case(dev, case, compute=None):
     from vnet_tensorflow_amd import networks, ops
     fname, P, B, cin, K, seed, rounding = CASES[case]
     z = np.load(os.path.join(GOLD, fname))
-    store = O.ParamStore(rng=np.random.default_rng(42))
+    store = O.ParamStore(rng=np.random.default_rng(WEIGHT_SEED[case]))
     ref_net = O.VNetOracle(K, 0.0, 16, 4, (1, 2, 3, 3), 3, "prelu", "networks", store)
     ref_net.GetNetwork(np.zeros((1, 16, 16, 16, cin)))             # creates the variables in the fixture's order
     assert list(store.vars.keys()) == [str(n) for n in z["names"]]

@@ -42,8 +42,8 @@ def _state(rng, n=40):
         t[scope + "/weights/Adam"] = rng.standard_normal(t[scope + "/weights"].shape).astype(np.float32)
         t[scope + "/weights/Adam_1"] = np.abs(rng.standard_normal(t[scope + "/weights"].shape)).astype(np.float32)
         t[scope + "/biases"] = rng.standard_normal(3).astype(np.float32)
-    t["beta1_power"] = np.float32(0.9 ** 8)
-    t["beta2_power"] = np.float32(0.999 ** 8)
+    t["training/beta1_power"] = np.float32(0.9 ** 8)          # (the reference builds its optimiser under tf.name_scope("training"))
+    t["training/beta2_power"] = np.float32(0.999 ** 8)
     t["global_step"] = np.int64(7)
     t["start_epoch"] = np.array([2], dtype=np.int32)
     t["empty"] = np.zeros((0, 4), dtype=np.float32)
@@ -90,6 +90,20 @@ def test_training_state_of_the_reference(tmp_path):
     assert opt["kind"] == "adam" and opt["t"] == 7 and sorted(opt["m"]) == sorted(n for n in names if n.endswith("weights"))
     with pytest.raises(KeyError):
         T.split_training_state(t, names + ["vnet/missing/weights"])
+    # the un-scoped key is accepted too; Adam's t comes from global_step (minimize increments it once per apply), so a long
+    # run -- float32 0.9^(t+1) is denormal near t ~ 830 and exactly 0 past ~ 987 -- does not restart the bias correction at t = 0
+    u = dict(t); u["beta1_power"] = u.pop("training/beta1_power"); u["beta2_power"] = u.pop("training/beta2_power")
+    assert T.split_training_state(u, names)[1]["t"] == 7
+    for steps in (1500, 200000):
+        u = dict(t); u["global_step"] = np.int64(steps)
+        u["training/beta1_power"] = np.float32(0.9) ** np.float32(steps + 1)
+        assert float(u["training/beta1_power"]) < 1e-38
+        assert T.split_training_state(u, names)[1]["t"] == steps
+    u = dict(t); u["global_step"] = np.int64(400)                    # a beta1_power that contradicts global_step is an error, not a guess
+    with pytest.raises(ValueError, match="global_step"):
+        T.split_training_state(u, names)
+    u = dict(t); del u["global_step"]                                # no global_step: fall back to the power
+    assert T.split_training_state(u, names)[1]["t"] == 7
 
 
 def test_model_round_trip_through_the_reference_format(tmp_path):
@@ -101,7 +115,7 @@ def test_model_round_trip_through_the_reference_format(tmp_path):
     a = image2label(None, cfg, device="cpu", verbose=False)
     a.read_config(); a.build_model_graph(); a._setup_training()
     with torch.no_grad():
-        a.optimizer.m.normal_(); a.optimizer.v.uniform_(); a.optimizer.t = 11
+        a.optimizer.m.normal_(); a.optimizer.v.uniform_(); a.optimizer.t = 123          # (= global_step: minimize increments it once per apply)
     a.global_step, a.start_epoch = 123, 4
     prefix = a.save_tf_checkpoint(str(tmp_path / "tfck" / "checkpoint-123"))
     np.random.seed(99)
@@ -110,7 +124,7 @@ def test_model_round_trip_through_the_reference_format(tmp_path):
     b.load_tf_checkpoint(prefix, verify="all")
     sa, sb = a.network.state_dict(), b.network.state_dict()
     assert list(sa) == list(sb) and all(torch.equal(sa[k], sb[k]) for k in sa)
-    assert b.global_step == 123 and b.start_epoch == 4 and b.optimizer.t == 11
+    assert b.global_step == 123 and b.start_epoch == 4 and b.optimizer.t == 123
     for n, off, p in zip(a.flat.names, a.flat.offsets, a.flat.params):
         sl = slice(off, off + p.numel())
         assert torch.equal(a.optimizer.m[sl], b.optimizer.m[sl]) and torch.equal(a.optimizer.v[sl], b.optimizer.v[sl]), n
@@ -119,9 +133,8 @@ def test_model_round_trip_through_the_reference_format(tmp_path):
     c = image2label(None, cfg, device="cpu", verbose=False)
     c.read_config(); c.build_model_graph(); c._setup_training()
     c.ckpt_dir = str(tmp_path / "tfck")
-    with open(os.path.join(c.ckpt_dir, "checkpoint-latest"), "w") as f:
-        f.write('model_checkpoint_path: "checkpoint-123"\nall_model_checkpoint_paths: "checkpoint-123"\n')
+    assert 'model_checkpoint_path: "checkpoint-123"' in open(os.path.join(c.ckpt_dir, "checkpoint-latest")).read()   # written by save_tf_checkpoint
     c.load_checkpoint()
     assert c.global_step == 123 and all(torch.equal(sa[k], c.network.state_dict()[k]) for k in sa)
     names = T.list_variables(prefix)
-    assert "global_step" in names and "beta1_power" in names and any(k.endswith("/Adam_1") for k in names)
+    assert "global_step" in names and "training/beta1_power" in names and any(k.endswith("/Adam_1") for k in names)

@@ -135,6 +135,8 @@ def set_option(name, value):
     prev = lib().vnet_set_option(name.encode(), float(value))
     if prev != prev:
         raise VnetHipError("unknown library option %r" % (name,))
+    for c in _MEMOS:                      # the planners read the options (F32_SMALL, BF16_DEEP, X3_*): memoised size queries are stale
+        c.clear()
     return prev
 
 
@@ -177,8 +179,12 @@ def lib():
     return _lib
 
 
+_MEMOS = []
+
+
 def _memo(fn, opts=None, L=None):
     cache = {}
+    _MEMOS.append(cache)
 
     def cached(*args):
         key = args if opts is None else args + tuple(L.vnet_get_option(o) for o in opts)

@@ -748,11 +748,17 @@ class image2label(object):
                 elif hasattr(o, "acc"):
                     out[n + "/Momentum"] = o.acc[sl].view(p.shape).cpu().numpy()
             if hasattr(o, "m"):
-                out["beta1_power"] = np.float32(o.b1 ** (o.t + 1))          # (TF keeps beta^(t+1): the power the NEXT step will use)
-                out["beta2_power"] = np.float32(o.b2 ** (o.t + 1))
+                # TF keeps beta^(t+1) (the power the NEXT step will use) in tf.Variables created under the reference's
+                # tf.name_scope("training") (model.py:647-662): `training/beta1_power`, which is what its saver.restore looks up
+                out["training/beta1_power"] = np.float32(o.b1 ** (o.t + 1))
+                out["training/beta2_power"] = np.float32(o.b2 ** (o.t + 1))
         out["global_step"] = np.int64(self.global_step)
         out["start_epoch"] = np.array([self.start_epoch], dtype=np.int32)
         tfc.write(prefix, out)
+        # the state file tf.train.latest_checkpoint(ckpt_dir, latest_filename="checkpoint-latest") reads (model.py:696-699)
+        base = os.path.basename(prefix)
+        with open(os.path.join(os.path.dirname(os.path.abspath(prefix)), "checkpoint-latest"), "w") as f:
+            f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (base, base))
         return prefix
 
     def _dataset(self, data_dir, train):

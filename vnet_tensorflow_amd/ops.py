@@ -1196,7 +1196,9 @@ def _epilogue_stats_buffer(bf16, ks, kx, stride, x0, x1, O, dims_out):
         # what the statistics pass costs (+1..3 % per launch, residual re-read on the input conv): the fused form is worth
         # 0.07 ms of a 25.7 ms step; `_FUSE["bn_stats_fp32_direct"] = False` keeps it to the split-K launches (statistics from the reduce kernel)
         rows = 0
-        if ks == 5 and stride == 1 and kx in (0, 5) and _FUSE["bn_stats_fp32_direct"] and _x3_ok(C0, C1, O, 0, B, dims_out):
+        # (NOT conditional on bn_stats_fp32_direct -- _ConvFn.forward takes the f32x3 kernel whenever _x3_ok, and the buffer
+        #  must have that kernel's row count whatever the fp32-MFMA switch says)
+        if ks == 5 and stride == 1 and kx in (0, 5) and _x3_ok(C0, C1, O, 0, B, dims_out):
             rows = L.vnet_conv_x3_stats_rows(C0 + C1, O, B, *dims_out)        # f32x3 kernel: one row per 2x8x16 brick (or per reduce block)
         if ks == 2 and stride == 2 and x1 is None and _DIRECT2["on"]:
             rows = L.vnet_conv2_direct_stats_rows(C0, O, B, *dims_out)        # the LDS-free direct kernel (levels 1-2): one row per workgroup

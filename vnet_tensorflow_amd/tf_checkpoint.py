@@ -313,7 +313,7 @@ def write(prefix, tensors, block_size=4096, restart_interval=16):
 def split_training_state(tensors, variable_names, beta1=0.9):
     """Sort the tensors of a reference checkpoint into (variables, optimiser state, global_step, start_epoch).
     variable_names: the network's variables (trainable and moving statistics, SURVEY B.1 names).  Optimiser state: for
-    tf.train.AdamOptimizer {"kind": "adam", "m": {name: array}, "v": {...}, "t": steps taken (beta1_power = beta1^(t+1))}; for
+    tf.train.AdamOptimizer {"kind": "adam", "m": {name: array}, "v": {...}, "t": steps taken (= global_step; `training/beta1_power` = beta1^(t+1) cross-checks it)}; for
     tf.train.MomentumOptimizer {"kind": "momentum", "acc": {...}}; None if the checkpoint holds no slots."""
     names = set(variable_names)
     missing = [n for n in variable_names if n not in tensors]
@@ -324,15 +324,27 @@ def split_training_state(tensors, variable_names, beta1=0.9):
     v = {n[:-len("/Adam_1")]: a for n, a in tensors.items() if n.endswith("/Adam_1") and n[:-len("/Adam_1")] in names}
     acc = {n[:-len("/Momentum")]: a for n, a in tensors.items() if n.endswith("/Momentum") and n[:-len("/Momentum")] in names}
     opt = None
+    gs = int(np.asarray(tensors["global_step"]).reshape(-1)[0]) if "global_step" in tensors else 0
     if m and v:
-        t = 0
-        if "beta1_power" in tensors:
-            p = float(np.asarray(tensors["beta1_power"]).reshape(-1)[0])
-            # tf.train.AdamOptimizer initialises beta1_power to beta1 and multiplies it by beta1 after every apply: beta1^(t+1) after t steps
-            t = max(int(round(np.log(p) / np.log(beta1))) - 1, 0) if 0.0 < p < 1.0 else 0
+        # Adam's step count.  The reference calls optimizer.minimize(loss, global_step=...) inside tf.name_scope("training")
+        # (model.py:647-662): minimize increments global_step once per apply, so t = global_step; the non-slot accumulators are
+        # tf.Variables, which honour the name scope: `training/beta1_power` (a bare `beta1_power` from an un-scoped graph is accepted
+        # too).  beta1_power = beta1^(t+1) is only a CROSS-CHECK, and only while it is a normal float32: 0.9^(t+1) goes denormal near
+        # t ~ 830 and is exactly 0 past t ~ 987, where log(beta1_power) says nothing.
+        t = gs
+        key = next((k for k in ("training/beta1_power", "beta1_power") if k in tensors), None)
+        if key is None:
+            key = next((k for k in sorted(tensors) if k.endswith("/beta1_power")), None)
+        if key is not None:
+            p = float(np.asarray(tensors[key]).reshape(-1)[0])
+            if 1e-30 < p < 1.0:
+                tp = max(int(round(np.log(p) / np.log(beta1))) - 1, 0)
+                if "global_step" not in tensors:
+                    t = tp
+                elif abs(tp - gs) > max(2, gs // 100):
+                    raise ValueError("checkpoint: %s = %g says %d Adam steps, global_step says %d" % (key, p, tp, gs))
         opt = {"kind": "adam", "m": m, "v": v, "t": t}
     elif acc:
         opt = {"kind": "momentum", "acc": acc}
-    gs = int(np.asarray(tensors["global_step"]).reshape(-1)[0]) if "global_step" in tensors else 0
     ep = int(np.asarray(tensors["start_epoch"]).reshape(-1)[0]) if "start_epoch" in tensors else 0
     return variables, opt, gs, ep
