@@ -367,3 +367,102 @@ def test_world8_two_pass_exchange_on_the_full_width_layout(tmp_path):
     assert all(r["launched_p1"] == r["p1"] and 0 < len(r["p1"]) < r["nb"] for r in rs)
     assert len({r["choice"] for r in rs}) == 1 and all(r["times"] == rs[0]["times"] for r in rs)
     assert rs[0]["choice"] == "serial"            # 'off' is slow on rank 5, 'segmented' on some ranks: max over ranks decides
+
+
+# ---- round 6: bf16 gradient buckets with fp32 accumulation, and a step-length-aware preferred mode --------------
+def _bf16_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from vnet_tensorflow_amd import optim, parallel
+    parallel.init_from_env("gloo")
+    g = torch.Generator().manual_seed(5)
+    shapes = [("a/weights", (37, 11)), ("a/biases", (11,)), ("b/weights", (11, 129)), ("b/biases", (129,)), ("c/weights", (1000,))]
+    params = [(n, torch.nn.Parameter(torch.randn(s, generator=g))) for n, s in shapes]
+    res = {}
+    for dt in ("fp32", "bf16"):
+        flat = optim.FlatParams(params)
+        sync = parallel.BucketedGradAllReduce(flat, bucket_bytes=1500, comm_dtype=dt)       # several buckets, sizes not multiples of world
+        sync.hold_all = True
+        gr = torch.Generator().manual_seed(1000 + rank)
+        # gradients of very different magnitudes per variable, as a network's are
+        scale = torch.ones(flat.numel)
+        for i, (off, p) in enumerate(zip(flat.offsets, flat.params)):
+            scale[off:off + p.numel()] = 10.0 ** (i - 2)
+        flat.grad.copy_(torch.randn(flat.numel, generator=gr) * scale)
+        mine = flat.grad.clone()
+        sync.begin_step()
+        sync.reduce_all()
+        res[dt] = (flat.grad.clone(), sync.comm_bytes, sync.exposed_seconds())
+        res["mine"] = mine
+        sync.remove()
+    torch.save(res, os.path.join(out, "b%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bf16_gradient_buckets_accumulate_in_fp32(tmp_path, world):
+    """GradCommDtype 'bf16': bf16 on the links, fp32 accumulation on receipt.  Every rank ends with the SAME bits; the result is
+    RNE_bf16(sum_r RNE_bf16(g_r)) with the sum taken in fp32 in rank order -- computed here independently; against the fp32
+    all-reduce the difference is two roundings (bf16's unit roundoff is 2^-8: <= 2^-7 of sum_r |g_r| per element, far inside it in the norm); half the link bytes."""
+    mp.spawn(_bf16_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(tmp_path / ("b%d.pt" % r)) for r in range(world)]
+    for r in rs[1:]:
+        assert torch.equal(r["bf16"][0], rs[0]["bf16"][0]) and torch.equal(r["fp32"][0], rs[0]["fp32"][0])
+    # (the "mine" stored last is the bf16 leg's input = the fp32 leg's: same seed)
+    parts = [r["mine"] for r in rs]
+    acc = parts[0].to(torch.bfloat16).to(torch.float32)
+    for p in parts[1:]:
+        acc = acc + p.to(torch.bfloat16).to(torch.float32)
+    want = acc.to(torch.bfloat16).to(torch.float32)
+    got, ref = rs[0]["bf16"][0], rs[0]["fp32"][0]
+    assert torch.equal(got, want)
+    mag = sum(p.abs() for p in parts)
+    assert bool(((got - ref).abs() <= 2.0 ** -7 * mag + 1e-30).all())
+    assert float((got - ref).norm() / ref.norm()) < 4e-3
+    assert 0.45 < rs[0]["bf16"][1] / rs[0]["fp32"][1] < 0.56                    # half the bytes (+ padding to a multiple of world)
+    assert rs[0]["bf16"][2] is not None and rs[0]["bf16"][2] > 0.0
+
+
+def test_bf16_gradient_exchange_is_opt_in_and_needs_the_bf16_mode(tmp_path):
+    from vnet_tensorflow_amd.model import image2label
+    from tests.test_host import _config
+    cfg = _config(tmp_path)
+    m = image2label(None, cfg, device="cpu", verbose=False)
+    m.read_config()
+    assert m.grad_comm_dtype == "fp32"
+    cfg["TrainingSetting"]["GradCommDtype"] = "bf16"
+    with pytest.raises(SystemExit, match="ComputeDtype"):
+        image2label(None, cfg, device="cpu", verbose=False).read_config()
+    cfg["TrainingSetting"]["ComputeDtype"] = "bf16"
+    cfg["TrainingSetting"]["Networks"]["NumChannel"] = 8
+    m = image2label(None, cfg, device="cpu", verbose=False)
+    m.read_config()
+    assert m.grad_comm_dtype == "bf16"
+
+
+def test_step_mode_autotune_preference_follows_the_exposed_all_reduce():
+    """'serial' is the default only while its exposed all-reduce is a small share of the step (<= 5 %).  A 25 ms fp32 step with
+    1 ms of all-reduce keeps it (segmented 1.7 % faster: inside the margin); a 5.3 ms bf16 step with the same 1 ms exposed (19 %)
+    prefers the overlapped replay even when it measures the SAME or up to 2 % slower -- and still takes 'serial' when serial is
+    more than 2 % faster than every overlapped mode."""
+    from vnet_tensorflow_amd import parallel
+
+    def run(costs, exposed):
+        now = [0.0]
+        t = parallel.StepModeAutotune(["segmented", "serial", "off"], steps=2, blocks=3, clock=lambda: now[0], exposed=lambda: exposed)
+        while t.choice is None:
+            m = t.mode()
+            t.before()
+            now[0] += costs[m]
+            t.after()
+        return t
+    t = run({"segmented": 0.02458, "serial": 0.0250, "off": 0.0400}, 0.0010)
+    assert t.choice == "serial" and t.preferred == "serial" and abs(t.exposed_fraction - 0.04) < 1e-9
+    t = run({"segmented": 0.00535, "serial": 0.0053, "off": 0.0090}, 0.0010)
+    assert t.choice == "segmented" and t.preferred == "segmented" and t.exposed_fraction > 0.18
+    t = run({"segmented": 0.0060, "serial": 0.0053, "off": 0.0090}, 0.0010)          # overlap hurts the kernels more than it hides
+    assert t.choice == "serial" and t.preferred == "segmented"
+    t = run({"segmented": 0.0060, "serial": 0.0059, "off": 0.0052}, 0.0010)          # the eager enqueue is the fastest overlapped mode
+    assert t.choice == "off" and t.preferred == "off"
+    t = run({"segmented": 0.0250, "serial": 0.0250, "off": 0.0400}, None)             # no measurement: round 5's behaviour
+    assert t.choice == "serial" and t.exposed_fraction == 0.0

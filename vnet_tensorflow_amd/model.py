@@ -252,6 +252,13 @@ class image2label(object):
                 raise SystemExit("ComputeDtype 'bf16' (bf16 storage) needs Networks.NumChannel = 8 * 2^k, got %d; "
                                  "'fp32' / 'fp32_split3' take any width" % nch)
         self.sync_batch_norm = bool(T.get('SyncBatchNorm', False))   # extension: cross-replica BN statistics
+        # extension (round 6, opt-in): gradient buckets travel as bf16 -- half the bytes over xGMI -- and are accumulated in fp32
+        # on receipt (parallel.BucketedGradAllReduce); only with ComputeDtype 'bf16', whose gradients come from bf16 tensors anyway
+        self.grad_comm_dtype = T.get('GradCommDtype', 'fp32')
+        if self.grad_comm_dtype not in ('fp32', 'bf16'):
+            raise SystemExit("Invalid GradCommDtype %r (fp32 | bf16)" % (self.grad_comm_dtype,))
+        if self.grad_comm_dtype == 'bf16' and self.compute_dtype != 'bf16':
+            raise SystemExit("GradCommDtype 'bf16' needs ComputeDtype 'bf16' (the fp32 modes keep fp32 gradients on the links)")
         if 'AllReduceHoldFraction' in T:                               # extension: when the gradient buckets are launched (parallel.py)
             self.allreduce_hold_fraction = float(T['AllReduceHoldFraction'])
         if 'PrefetchDepth' in T:                                       # extension: input prefetcher of train() (0 = synchronous loader)
@@ -402,7 +409,8 @@ class image2label(object):
                               and len(head) < len(names) and head == list(range(len(head))))
             self.sync = parallel.BucketedGradAllReduce(self.flat, hold_fraction=hold, force=force,
                                                        bucket_bytes=int(os.environ.get("VNET_DP_BUCKET_BYTES", 32 << 20)),
-                                                       phase1_last=(head[-1] if self._two_pass else None))
+                                                       phase1_last=(head[-1] if self._two_pass else None),
+                                                       comm_dtype=getattr(self, "grad_comm_dtype", "fp32"))
             if getattr(self, "sync_batch_norm", False):
                 # single-device BatchSize = world x per-rank batch semantics of the reference (networks.py:319);
                 # the default (per-replica statistics) equals the reference run on each rank's batch alone
@@ -613,7 +621,8 @@ class image2label(object):
                 cands = [pin]
             self._tuner = parallel.StepModeAutotune(cands, steps=int(getattr(self, "dp_autotune_steps", 5)),
                                                     blocks=int(getattr(self, "dp_autotune_blocks", 3)),
-                                                    sync=self._device_sync)
+                                                    sync=self._device_sync,
+                                                    exposed=(self.sync.exposed_seconds if self.sync is not None else None))
         return self._tuner
 
     def _train_step_graph(self, mode, images, labels, dropout):

@@ -43,8 +43,16 @@ def broadcast_parameters(flat_data, src=0, group=None):
 class BucketedGradAllReduce(object):
     """All-reduces `flat.grad` bucket by bucket as soon as every variable of a bucket has its gradient."""
 
-    def __init__(self, flat, bucket_bytes=32 << 20, group=None, overlap=True, force=False, hold_fraction=0.0, phase1_last=None):
+    def __init__(self, flat, bucket_bytes=32 << 20, group=None, overlap=True, force=False, hold_fraction=0.0, phase1_last=None,
+                 comm_dtype="fp32"):
         """`force`: run the collective path even in a group of one (lets a 1-GPU box exercise RCCL itself).
+        `comm_dtype`: "fp32" (default) -- a sum all-reduce of the fp32 bucket; "bf16" (opt-in, TrainingSetting.GradCommDtype with
+        ComputeDtype "bf16": everything else of that mode is bf16 already and at a 5 ms step the fp32 all-reduce of 175.8 MB is the
+        largest exposed cost) -- HALF the bytes on the links, fp32 ACCUMULATION on receipt: every rank rounds
+        its bucket to bf16 (RNE), an all-to-all hands rank r the r-th 1/N slice of every rank's bucket, rank r adds the N slices
+        in fp32 in rank order (deterministic, independent of the link topology), rounds the sum to bf16 once and an all-gather
+        returns the slices; the fp32 master gradient (flat.grad) receives the bf16 sums.  Two roundings per element (2^-8 relative each)
+        against none for "fp32"; same traffic as a bf16 ring all-reduce, without its N - 1 bf16 additions along the ring.
         `hold_fraction`: ready buckets are held back until this fraction of the gradient bytes is ready, then all of
         them go out back to back (0 = every bucket as soon as it is ready).  V-Net produces 98 % of its gradient bytes
         (decoder, bottom level, encoder level 4/3) while the backward pass is in the 32^3...8^3 levels, whose kernels are
@@ -54,6 +62,11 @@ class BucketedGradAllReduce(object):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())
         self.hold_fraction = float(hold_fraction)
+        if comm_dtype not in ("fp32", "bf16"):
+            raise ValueError("comm_dtype %r (fp32 | bf16)" % (comm_dtype,))
+        self.comm_dtype = comm_dtype
+        self.comm_bytes = 0              # bytes this rank SENDS over the links in the current step (ring all-reduce resp. all-to-all + all-gather)
+        self._exposed = None             # (start, end) of the last reduce_all(): the all-reduce nothing overlaps (StepModeAutotune)
         # a bucket boundary exactly where the cumulative bytes cross hold_fraction, so the launch point does not depend
         # on where the size-driven cuts happen to fall (without it the 0.99 threshold of the V-Net layout is only crossed
         # by the LAST bucket and nothing overlaps backward)
@@ -105,6 +118,18 @@ class BucketedGradAllReduce(object):
         self._ready_bytes = 0
         self._held = []
         self.launch_log = []
+        self.comm_bytes = 0
+
+    def exposed_seconds(self):
+        """Duration of the last reduce_all() -- every bucket's all-reduce after backward with nothing to hide under ('serial' step
+        mode): HIP events on the compute stream around launch + wait (synchronises), wall clock on CPU.  None if there was none."""
+        if self._exposed is None:
+            return None
+        a, b = self._exposed
+        if isinstance(a, float):
+            return b - a
+        b.synchronize()
+        return a.elapsed_time(b) * 1e-3
 
     def reduce_prefix(self):
         """Two-pass backward (model.train_step, segmented graphs): all-reduce the buckets the first pass completed, on the
@@ -136,6 +161,12 @@ class BucketedGradAllReduce(object):
         'segmented' mode).  Leaves the event calibration untouched."""
         if not self.active:
             return
+        import time
+        if self.is_cuda:
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+        else:
+            t0 = time.perf_counter()
         self._launched = [False] * len(self.buckets)
         self._handles = []
         self.launch_log = []
@@ -146,6 +177,11 @@ class BucketedGradAllReduce(object):
         if self.overlap:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._handles = []
+        if self.is_cuda:
+            t1.record()
+        else:
+            t1 = time.perf_counter()
+        self._exposed = (t0, t1)
 
     def _make_hook(self, pi):
         def hook(param):
@@ -191,11 +227,41 @@ class BucketedGradAllReduce(object):
             if pg is not None:
                 self.comm_stream.wait_stream(pg)
             with torch.cuda.stream(self.comm_stream):
-                self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._all_reduce(view)
         else:
             if pg is not None:
                 torch.cuda.current_stream().wait_stream(pg)
+            self._all_reduce(view)
+
+    def _all_reduce(self, view):
+        """Sum `view` (a slice of the flat fp32 gradient) over the ranks, in place, on the current stream."""
+        if self.comm_dtype == "fp32":
+            self.comm_bytes += 2 * (self.world - 1) * 4 * view.numel() // max(self.world, 1)       # reduce-scatter + all-gather halves of a ring
             self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        # bf16 on the links, fp32 accumulation on receipt (see __init__).  Stream-ordered: each collective is enqueued behind the
+        # previous one on this stream (async_op=False does not block the host with RCCL; gloo on CPU tensors is synchronous anyway).
+        W, n = self.world, view.numel()
+        chunk = -(-n // W)
+        send = torch.zeros(W * chunk, dtype=torch.bfloat16, device=view.device)
+        send[:n].copy_(view)                                        # RNE fp32 -> bf16
+        if W == 1:
+            view.copy_(send[:n])
+            return
+        recv = torch.empty(W * chunk, dtype=torch.bfloat16, device=view.device)
+        dist.all_to_all_single(recv, send, group=self.group)         # slice r of every rank's bucket -> rank r
+        part = recv.view(W, chunk)
+        acc = part[0].to(torch.float32)
+        for r in range(1, W):                                       # fixed rank order: bit-identical on every run and every rank
+            acc += part[r]
+        mine = acc.to(torch.bfloat16)
+        full = torch.empty(W * chunk, dtype=torch.bfloat16, device=view.device)
+        dist.all_gather_into_tensor(full, mine, group=self.group)
+        view.copy_(full[:n])
+        self.comm_bytes += 2 * (W - 1) * 2 * chunk                  # (W - 1) slices out in the all-to-all, the own slice to W - 1 peers in the all-gather
+        if view.is_cuda:
+            for t in (send, recv, full, mine):
+                t.record_stream(torch.cuda.current_stream())
 
     def finish(self):
         """Flush buckets that are still pending (calibration step; variables that never receive a gradient such as
@@ -238,13 +304,24 @@ class StepModeAutotune(object):
     the mode whose time is the easiest to predict) is kept unless another candidate's median is more than `margin` (2 %) faster.
     Usage per step:  mode = tuner.mode();  tuner.before();  <run the step in that mode>;  tuner.after()."""
 
-    def __init__(self, candidates, steps=5, group=None, sync=None, clock=None, blocks=3, prefer="serial", margin=0.02):
+    def __init__(self, candidates, steps=5, group=None, sync=None, clock=None, blocks=3, prefer="serial", margin=0.02,
+                 exposed=None, exposed_threshold=0.05, overlapped=("segmented", "off")):
+        """`exposed`: callable -> seconds the last 'serial' step spent in its all-reduce with nothing overlapping it (or None);
+        sampled at the end of every 'serial' block.  Round 6: the preference is STEP-LENGTH-AWARE -- 'serial'
+        is the default only while that exposed time stays below `exposed_threshold` (5 %) of its step (fp32 128^3: <= 2.5 ms of
+        25 ms can be borderline, fp32_split3 16 ms and bf16 5.3 ms are not: there 1-2.5 ms is 20-45 % of the step); above it
+        the preferred mode is the fastest OVERLAPPED candidate (`overlapped`, in that order of preference when they tie within the
+        margin), and 'serial' has to beat it by more than `margin` to be chosen."""
         import time
         self.candidates, self.steps, self.group = list(candidates), int(steps), group
         self.blocks = max(1, int(blocks))
         self.prefer, self.margin = prefer, float(margin)
         self.sync = sync if sync is not None else (lambda: None)          # device synchronisation
         self.clock = clock if clock is not None else time.perf_counter
+        self.exposed, self.exposed_threshold, self.overlapped = exposed, float(exposed_threshold), tuple(overlapped)
+        self.exposed_samples = []                                         # seconds per 'serial' step in the exposed all-reduce
+        self.exposed_fraction = None
+        self.preferred = prefer
         self.samples = [[] for _ in self.candidates]                      # per candidate: seconds per step of each block
         self.times, self._i, self._n, self._t0 = [], 0, 0, None
         self.choice = self.candidates[0] if len(self.candidates) == 1 else None
@@ -281,13 +358,30 @@ class StepModeAutotune(object):
             dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
             t = t.to(dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        cur = self.candidates[self._i % len(self.candidates)]
         self.samples[self._i % len(self.candidates)].append(float(t.item()) / self.steps)
+        if cur == "serial" and self.exposed is not None:
+            e = self.exposed()
+            e = torch.tensor([float(e) if e is not None else 0.0], dtype=torch.float64)
+            if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+                e = e.to(t.device)
+                dist.all_reduce(e, op=dist.ReduceOp.MAX, group=self.group)     # every rank decides on the same number
+            self.exposed_samples.append(float(e.item()))
         self._i, self._n = self._i + 1, 0
         if self._i == len(self.candidates) * self.blocks:
             self.times = [self._median(v) for v in self.samples]
             best = min(range(len(self.times)), key=lambda k: (self.times[k], k))
-            if self.prefer in self.candidates:
-                k = self.candidates.index(self.prefer)
+            prefer = self.prefer
+            if prefer == "serial" and "serial" in self.candidates and self.exposed_samples:
+                ks = self.candidates.index("serial")
+                self.exposed_fraction = self._median(self.exposed_samples) / max(self.times[ks], 1e-12)
+                if self.exposed_fraction > self.exposed_threshold:
+                    over = [c for c in self.overlapped if c in self.candidates]
+                    if over:                     # the exposed all-reduce is a real share of this step: prefer hiding it
+                        prefer = min(over, key=lambda c: (self.times[self.candidates.index(c)], over.index(c)))
+            self.preferred = prefer
+            if prefer in self.candidates:
+                k = self.candidates.index(prefer)
                 if self.times[best] >= (1.0 - self.margin) * self.times[k]:
                     best = k                     # nobody beats the preferred mode by more than the margin
             self.choice = self.candidates[best]
