@@ -63,6 +63,11 @@ int main() {
     clear(); for (int k = 0; k < 4; ++k) { a[k] = 1.f; b[k] = 0.25f * U; } report("c=1 + 4 x 0.25 ulp (exact: +1 ulp)", 1.f, a, b);
     clear(); a[0] = 1.f; b[0] = 1.f; for (int k = 1; k < 32; ++k) { a[k] = 1.5f; b[k] = 0.25f * U; } report("c=0, p0=1 + 31 x 0.375 ulp (exact 11.625 ulp)", 0.f, a, b);
     clear(); a[0] = 1.f; b[0] = 1.f; for (int k = 1; k < 4; ++k) { a[k] = 1.5f; b[k] = 0.25f * U; } report("c=0, p0=1 + 3 x 0.375 ulp (exact 1.125 ulp)", 0.f, a, b);
+    // floor or truncation toward zero?  small NEGATIVE products next to a large positive one, and the mirror image
+    clear(); a[0] = 1.f; b[0] = 1.f; for (int k = 1; k < 4; ++k) { a[k] = -1.5f; b[k] = 0.25f * U; } report("c=0, p0=+1, 3 x -0.375 ulp (RTZ: +1.125 err, floor: -0.375)", 0.f, a, b);
+    clear(); a[0] = -1.f; b[0] = 1.f; for (int k = 1; k < 4; ++k) { a[k] = 1.5f; b[k] = 0.25f * U; } report("c=0, p0=-1, 3 x +0.375 ulp (RTZ: -1.125 err, floor: -1.125)", 0.f, a, b);
+    clear(); a[0] = -1.f; b[0] = 1.f; for (int k = 1; k < 4; ++k) { a[k] = -1.5f; b[k] = 0.25f * U; } report("c=0, p0=-1, 3 x -0.375 ulp (RTZ: +1.125 err, floor: -0.375)", 0.f, a, b);
+    clear(); a[0] = 1.f; b[0] = 1.f; for (int k = 1; k < 8; ++k) { a[k] = -1.25f; b[k] = 0.125f * U; } report("c=0, p0=+1, 7 x -0.156 ulp (floor: each -> -0.5 ulp)", 0.f, a, b);
     for (int sh = 20; sh <= 48; sh += 4) {
         char nm[96]; snprintf(nm, sizeof nm, "c=0: 2^%d - 2^%d + 30 x 1.0 (internal width: exact 30)", sh, sh);
         clear(); a[0] = std::ldexp(1.f, sh / 2); b[0] = std::ldexp(1.f, sh - sh / 2); a[1] = -a[0]; b[1] = b[0];

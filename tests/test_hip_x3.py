@@ -166,17 +166,27 @@ def test_backward_runs_in_the_context_of_the_forward(dev):
 
 
 # ---- round 6 (VERDICT r5 next #1 b, c): the gates for reporting fp32_split3 as the fp32 number ---------------------------------------
+# Shape of the A/B: 16 x 32 x 64 voxels, 32 -> 32 channels = 256 (brick, cout block) work items for BOTH kernels, i.e. the accumulation
+# structure of the bench sizes: every output is ONE chain of 4000 products (the fp32 MFMA kernel: 1000 v_mfma_f32_16x16x4_f32 in a row;
+# f32x3: four waves x ~195 v_mfma_f32_16x16x32_bf16 each, met once in LDS).  On smaller volumes the fp32-MFMA planner splits K over up to
+# ten partial slabs (plan_conv: nsplit x nz) and the slab-wise summation makes THAT launch more accurate than either kernel is at
+# 128^3 -- measured on 6 x 16 x 32: `spread` forward 1.65e-7 (ten slabs) against 2.5e-7 (f32x3) -- which says something about
+# split-K, not about the two arithmetics.
+X3_AB_SHAPE = (1, 16, 32, 64, 32, 32)
+
+
 def _adversarial_case(kind, rng):
-    """(x [B,D,H,W,C], w [5,5,5,C,Co], dy scale) of operands chosen to hurt a split-operand product.
+    """(x [B,D,H,W,C], w [5,5,5,C,Co]) of operands chosen to hurt a split-operand product.
     raw:     intensities 0..255 with mean >> std, un-normalised (what a first 16-channel layer would see if the pipeline skipped
              its normalisation): the h piece carries almost everything, the information is in m and l;
-    cancel:  alternating-sign filter on a smooth input: the 2000-term sum cancels to ~1e-3 of its terms' magnitude, so every
+    cancel:  alternating-sign filter on a smooth input: the 4000-term sum cancels to ~1e-3 of its terms' magnitude, so every
              absolute product error is amplified ~1000x in the result;
     spread:  magnitudes spread over 2^+-20 in both operands, independently per ELEMENT (the pieces' exponents are all over the place,
-             also inside the 8 consecutive channels one lane feeds to an MFMA);
+             also inside the 8 consecutive channels one lane feeds to an MFMA, whose products the bf16 instruction adds in a 24-bit
+             window below the largest of them: profiles/r06_mfma_round_probe.txt);
     spread_vox: the same 2^+-20 spread per VOXEL of x and per (tap, cout) of w -- the 8 channels of a lane share a scale;
-    tiny_m:  operands that are bf16-representable plus a 2^-17 perturbation: m = 0 or one ulp-of-l, the (h, l) products decide."""
-    B, D, H, W, C, Co = 1, 6, 16, 32, 32, 32
+    tiny_m:  operands that are bf16-representable plus a 2^-17 perturbation: m is a single bit, l = 0."""
+    B, D, H, W, C, Co = X3_AB_SHAPE
     if kind == "raw":
         x = np.clip(np.rint(180.0 + 6.0 * rng.standard_normal((B, D, H, W, C))), 0, 255)
         w = rng.standard_normal((5, 5, 5, C, Co)) * 0.02
@@ -204,27 +214,20 @@ def _adversarial_case(kind, rng):
     return f(x), f(w)
 
 
-# measured ratios (profiles/r06_x3_adversarial.txt); `spread` is the ONE class where f32x3 is worse than the fp32 MFMA: see the docstring
-X3_AB_RATIO = {"raw": 1.25, "cancel": 1.25, "tiny_m": 1.25, "spread_vox": 1.25, "spread": 1.75}
-
-
 @pytest.mark.parametrize("kind", ["raw", "cancel", "spread", "spread_vox", "tiny_m"])
 def test_x3_not_worse_than_fp32_mfma_on_adversarial_operands(dev, kind):
     """A/B against float64 (VERDICT r5 next #1b): the SAME operands through the fp32-MFMA kernels (v_mfma_f32_16x16x4_f32) and through
     the f32x3 kernels, forward + backward-data + filter gradient; the f32x3 error (rel-L2 vs the numpy-fp64 oracle) must not exceed
-    1.25 x the fp32 MFMA's on any of them.  (Both are also held to an absolute 2e-6 x the conditioning of the case: the `cancel` sum
-    loses three digits by construction -- its yardstick is sum |x||w|, not |sum x w|.)
-
-    KNOWN EXCEPTION, stated on the bench line and in DESIGN 4.8: `spread` (every element of both operands with its own random exponent
-    in 2^+-20) -- forward 2.5e-7 against 1.65e-7 = 1.5 x (both about two fp32 roundings; bound here 1.75 x and 3e-7 absolute).  Mechanism
-    (profiles/r06_mfma_round_probe.txt): v_mfma_f32_16x16x32_bf16 adds the 8 products of one lane (8 consecutive channels of one tap)
-    in a fixed-point window of 24 bits below the LARGEST of them, truncating toward zero, before the groups and the accumulator meet
-    (c = 0, p0 = 1, three more products of 0.375 ulp each: result 1.0, exact 1 + 1.125 ulp); v_mfma_f32_16x16x4_f32 rounds to nearest
-    after every product.  With iid exponents inside a lane's 8 channels that truncation is the larger error; when the 8 channels of
-    a voxel share a scale (`spread_vox`, and every tensor a network produces) no product bit falls out of the window."""
-    from vnet_tensorflow_amd import ops
+    1.25 x the fp32 MFMA's on any of them (measured ratios: profiles/r06_x3_adversarial.txt).  Both are also held to an absolute
+    2e-6 x the conditioning of the case: the `cancel` sum loses three digits by construction -- its yardstick is sum |x||w|, not
+    |sum x w|."""
+    from vnet_tensorflow_amd import _lib, ops
     rng = np.random.default_rng({"raw": 1, "cancel": 2, "spread": 3, "tiny_m": 4, "spread_vox": 5}[kind])
     x, w = _adversarial_case(kind, rng)
+    B, D, H, W, C, Co = X3_AB_SHAPE
+    L = _lib.lib()
+    # the premise of the shape: neither kernel splits K (no partial slabs, no reduce launch)
+    assert L.vnet_conv_ws_bytes(5, 0, 1, 0, C, Co, B, D, H, W) == 0 and L.vnet_conv_x3_ws_bytes(C, Co, B, D, H, W) == 0
     y_ref = O.conv_nd_fwd(x, w, 1)
     dy = rng.standard_normal(y_ref.shape)
     if kind == "spread":
@@ -236,9 +239,10 @@ def test_x3_not_worse_than_fp32_mfma_on_adversarial_operands(dev, kind):
     # conditioning: |x| * |w| against |x * w| (1 for benign operands)
     cond = float(np.linalg.norm(O.conv_nd_fwd(np.abs(x), np.abs(w), 1)) / np.linalg.norm(y_ref))
     errs = {}
+    assert L.vnet_conv_x3_ok(C, 0, Co, 0, B, D, H, W) == 1            # the product's own dispatch takes the f32x3 convolution here
     for mode in ("fp32", "fp32_split3"):
         ops.set_compute_dtype(mode)
-        ops._X3["force"] = mode == "fp32_split3"
+        ops._X3["force"] = mode == "fp32_split3"      # (the filter gradient asks for >= 4 bricks per workgroup before it pays: force it, 2 here)
         try:
             tx, tw = g(x, dev).requires_grad_(True), g(w, dev).requires_grad_(True)
             ops.profile_start()
@@ -251,13 +255,11 @@ def test_x3_not_worse_than_fp32_mfma_on_adversarial_operands(dev, kind):
         finally:
             ops._X3["force"] = False
             ops.set_compute_dtype("fp32")
-    print("adversarial %-7s cond %.1e  fp32 MFMA fwd/dx/dw %.2e %.2e %.2e | f32x3 %.2e %.2e %.2e" % ((kind, cond) + errs["fp32"] + errs["fp32_split3"]))
-    bad = [(what, e3, e32, e3 / e32) for what, e32, e3 in zip(("fwd", "dx", "dw"), errs["fp32"], errs["fp32_split3"])
-           if e3 > X3_AB_RATIO[kind] * e32 + 1e-9]
+    print("adversarial %-10s cond %.1e  fp32 MFMA fwd/dx/dw %.2e %.2e %.2e | f32x3 %.2e %.2e %.2e | ratio %.2f %.2f %.2f" %
+          ((kind, cond) + errs["fp32"] + errs["fp32_split3"] + tuple(b / a for a, b in zip(errs["fp32"], errs["fp32_split3"]))))
+    bad = [(what, e3, e32, e3 / e32) for what, e32, e3 in zip(("fwd", "dx", "dw"), errs["fp32"], errs["fp32_split3"]) if e3 > 1.25 * e32 + 1e-9]
     assert not bad, (kind, bad)
     assert errs["fp32_split3"][0] <= 2e-6 * max(cond, 1.0), (errs, cond)
-    if kind == "spread":
-        assert max(errs["fp32_split3"]) <= 3e-7, errs
 
 
 def test_x3_non_finite_operands(dev, split3):
@@ -298,3 +300,37 @@ def test_x3_non_finite_operands(dev, split3):
     assert np.isfinite(yb).all()
     # (w = k 2^-10 is a single piece; the three products h w, m w, l w are exact and meet in two fp32 additions: within one ulp)
     np.testing.assert_allclose(yb[0, 3, 8, 16, :].astype(np.float64), np.float64(big) * wb[2, 2, 2, 2, :].astype(np.float64), rtol=1.2e-7)
+
+
+def test_filter_gradient_long_chains_carry_no_offset(dev):
+    """Round 6: over the 10^5..10^6 voxels of a filter gradient the bf16 matrix instruction's one-sided accumulation error adds up
+    to an OFFSET -- before the sign alternation of wgrad5_x3_kernel: mean error -7.9e-7 of rms |dw| on this very case (N(0,1)
+    operands, 32 x 64 x 128 voxels, 16 -> 16; 256 workgroups x 4 bricks), rel-L2 9.3e-7 against the fp32 MFMA's 5.7e-7, and growing
+    with the volume (profiles/r06_x3_wgrad_taps.txt).  The per-kernel tests above use volumes too small to see it and the 128^3
+    crop test feeds a gradient supported on a 10^3 block.  Pinned here for BOTH fp32 modes: no offset (|mean error| <= 2.5e-7 of rms
+    |dw|: measured +1.0e-7 / +7e-10), f32x3 rel-L2 <= 1.25 x the fp32 MFMA's (measured 0.86 x), both <= 1e-6."""
+    from vnet_tensorflow_amd import ops
+    D, H, W, C, Co = 32, 64, 128, 16, 16
+    rng = np.random.default_rng(3)
+    f = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    x, dy = f(rng.standard_normal((1, D, H, W, C))), f(rng.standard_normal((1, D, H, W, Co)))
+    w = f(rng.standard_normal((5, 5, 5, C, Co)) * 0.1)
+    _, dw_ref = O.conv_nd_bwd(x, w, dy, 1, need_dx=False)
+    rms = float(np.sqrt((dw_ref ** 2).mean()))
+    res = {}
+    for mode in ("fp32", "fp32_split3"):
+        ops.set_compute_dtype(mode)
+        try:
+            tx, tw = g(x, dev), g(w, dev).requires_grad_(True)
+            ops.profile_start()
+            ops.conv(tx, tw, None, 5, 1).backward(g(dy, dev))
+            recs = ops.profile_stop()
+            assert any(r[0].startswith("wgrad-x3") for r in recs) == (mode == "fp32_split3"), [r[0] for r in recs]   # the product's own dispatch
+            got = tw.grad.cpu().numpy().astype(np.float64)
+            res[mode] = (rel_l2(got, dw_ref), float((got - dw_ref).mean()) / rms)
+        finally:
+            ops.set_compute_dtype("fp32")
+    print("long-chain dw: fp32 MFMA rel-L2 %.2e offset %+.2e | f32x3 rel-L2 %.2e offset %+.2e" % (res["fp32"] + res["fp32_split3"]))
+    for mode, (e, off) in res.items():
+        assert e < 1e-6 and abs(off) < 2.5e-7, (mode, e, off)
+    assert res["fp32_split3"][0] <= 1.25 * res["fp32"][0], res

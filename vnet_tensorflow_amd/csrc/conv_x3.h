@@ -473,7 +473,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             pd[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](const bool neg) {
         const int r0 = tid / XT::COLS, col = tid - r0 * XT::COLS;
         if (r0 < XT::RPI) {
             unsigned char* base = xt + (col >> 2) * 32 + (col & 3) * 8;
@@ -494,7 +494,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             const int v = q >> 2, cq = q & 3;
             const int vx = v & 15, row = v >> 4;
             u32x2 h, m, l;
-            x3_split4(pd[k], h, m, l);
+            // (odd bricks: -dy.  The split is symmetric -- RNE -- so the pieces of -v are the negated pieces of v, exactly.)
+            const float4 dv = neg ? make_float4(-pd[k].x, -pd[k].y, -pd[k].z, -pd[k].w) : pd[k];
+            x3_split4(dv, h, m, l);
             unsigned char* dst = dyt + (row * 16 + (vx ^ ((row & 1) << 2))) * 32 + cq * 8;
             *reinterpret_cast<u32x2*>(dst) = h;
             *reinterpret_cast<u32x2*>(dst + XW_DPB) = m;
@@ -502,15 +504,30 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
     };
 
+    // SIGN ALTERNATION (round 6).  The accumulation of v_mfma_f32_16x16x32_bf16 is not sign-symmetric: over long chains its results
+    // sit BELOW the exact sum by an amount that grows with the number of instructions -- measured on this kernel (N(0,1) operands,
+    // 32 x 64 x 128 voxels, 16 -> 16): mean error -7.9e-7 of rms |dw|, the same for every tap, i.e. almost all of the kernel's 9.3e-7
+    // rel-L2 against the fp32 MFMA's 5.7e-7, and 1.7e-6 against 4.9e-7 at 64 x 128 x 128 (profiles/r06_x3_wgrad_taps.txt,
+    // r06_x3_adversarial_chain.txt; the single-instruction probe profiles/r06_mfma_round_probe.txt shows the in-lane 24-bit window,
+    // which truncates toward zero -- the one-sided part is below what one instruction reveals).  Whatever its seat, it does not
+    // follow the sign of the operands: every other brick therefore runs NEGATED -- -dy goes into LDS (exact: the split is symmetric)
+    // and the accumulators change sign at the brick boundary (exact) -- so consecutive, statistically equal bricks carry the offset
+    // with opposite signs.  After: mean +1.0e-7, rel-L2 4.9e-7 (0.86 x the fp32 MFMA's); results stay deterministic.
+    bool neg = false;
     if (split < a.nbrick) issue(split);
     for (int brick = split; brick < a.nbrick; brick += a.nsplit) {
         __syncthreads();                               // every wave is done reading the previous tiles
-        commit();
+        commit(neg);
         __syncthreads();
         if (brick + a.nsplit < a.nbrick) {
             issue(brick + a.nsplit);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (brick != split) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[t] = -acc[t];
+        }
+        neg = !neg;
 #pragma unroll 1
         for (int zz = 0; zz < X3_TZ; ++zz) {
             // (priority alternation between the two waves of a SIMD, as in the convolution kernel: the matrix pipe goes to the older wave
@@ -565,6 +582,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
     }
     __builtin_amdgcn_s_setprio(0);
+    if (!neg) {                                        // (`neg` was toggled after the last brick: false = that brick ran negated)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = -acc[t];
+    }
     // lane holds dW[tap][ci = chunk*16 + i][co = co0 + 4*g + {0..3}]
 #pragma unroll
     for (int t = 0; t < 16; ++t) {

@@ -243,24 +243,28 @@ class BucketedGradAllReduce(object):
         # previous one on this stream (async_op=False does not block the host with RCCL; gloo on CPU tensors is synchronous anyway).
         W, n = self.world, view.numel()
         chunk = -(-n // W)
+        dev = view.device
+        if view.is_cuda and dist.get_backend(self.group) == "gloo":
+            dev = torch.device("cpu")                               # test hook (several ranks on one GPU over gloo): gloo has no device all-to-all
         send = torch.zeros(W * chunk, dtype=torch.bfloat16, device=view.device)
         send[:n].copy_(view)                                        # RNE fp32 -> bf16
         if W == 1:
             view.copy_(send[:n])
             return
-        recv = torch.empty(W * chunk, dtype=torch.bfloat16, device=view.device)
+        send = send.to(dev)
+        recv = torch.empty(W * chunk, dtype=torch.bfloat16, device=dev)
         dist.all_to_all_single(recv, send, group=self.group)         # slice r of every rank's bucket -> rank r
         part = recv.view(W, chunk)
         acc = part[0].to(torch.float32)
         for r in range(1, W):                                       # fixed rank order: bit-identical on every run and every rank
             acc += part[r]
         mine = acc.to(torch.bfloat16)
-        full = torch.empty(W * chunk, dtype=torch.bfloat16, device=view.device)
+        full = torch.empty(W * chunk, dtype=torch.bfloat16, device=dev)
         dist.all_gather_into_tensor(full, mine, group=self.group)
         view.copy_(full[:n])
         self.comm_bytes += 2 * (W - 1) * 2 * chunk                  # (W - 1) slices out in the all-to-all, the own slice to W - 1 peers in the all-gather
-        if view.is_cuda:
-            for t in (send, recv, full, mine):
+        for t in (send, recv, full, mine):
+            if t.is_cuda:
                 t.record_stream(torch.cuda.current_stream())
 
     def finish(self):
