@@ -1,9 +1,9 @@
 #!/bin/bash
 # Compiles every translation unit of libvnet_hip.so to gfx950 ISA (hipcc cross-compiles without a GPU) and reads the code-object
 # metadata of each kernel: fails (exit 1) when a convolution kernel (conv* / wgrad*) executes scratch instructions between its first and last MFMA or
-# spills more than 8 VGPRs (a private segment with no scratch instruction is the frame of SGPRs spilled into VGPR lanes: reported, not failed).  Usage: bash profiles/check_isa.sh [outfile]   (default: profiles/r05_check_isa.txt)
+# spills more than 8 VGPRs (a private segment with no scratch instruction is the frame of SGPRs spilled into VGPR lanes: reported, not failed).  Usage: bash profiles/check_isa.sh [outfile]   (default: profiles/r06_check_isa.txt)
 cd "$(dirname "$0")/../vnet_tensorflow_amd/csrc"
-OUT=${1:-../../profiles/r05_check_isa.txt}
+OUT=${1:-../../profiles/r06_check_isa.txt}
 TMP=$(mktemp -d)
 for f in conv_mfma conv_x3 conv_b16 conv2_b16 elementwise input_block; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-function -Wno-unused-result -S --cuda-device-only $f.hip -o $TMP/$f.s 2>/dev/null &

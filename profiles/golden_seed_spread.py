@@ -18,7 +18,7 @@ GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 table = {}
 print("%-6s %-12s %10s %10s %10s %10s %10s %10s  %s" % ("case", "mode", "worst", "median", "head", "norm", "vector", "loss err", "worst tensor"))
 for cfg in ("c3", "c2"):
-    for s in range(5):
+    for s in range(10):
         case = cfg if s == 0 else "%ss%d" % (cfg, s)
         if not os.path.exists(os.path.join(GOLD, CASES[case][0])):
             print("%-6s (fixture missing)" % case)

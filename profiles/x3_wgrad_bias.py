@@ -14,7 +14,7 @@ from tests.util import g, rel_l2  # noqa: E402
 from vnet_tensorflow_amd import ops  # noqa: E402
 
 dev = torch.device("cuda", 0)
-D, H, W, C, Co = 32, 64, 128, 16, 16
+D, H, W, C, Co = 32, 64, 128, int(os.environ.get("X3_C", 16)), int(os.environ.get("X3_C", 16))
 f = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
 for kind in ("benign", "x spread", "dy spread", "both spread", "both spread 2^+-8", "both spread, per row"):
     rng = np.random.default_rng(3)

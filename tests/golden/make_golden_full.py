@@ -41,7 +41,10 @@ WEIGHT_SEED = {"c3": 42, "c2": 42, "c5s": 42}
 # round 6 (VERDICT r5 next #1a): a SEED SPREAD of the two fp32 fixtures -- four more (weight seed, input seed) draws each, so that the
 # whole-network gradient bound of tests/test_hip_golden_full.py is set from ten samples of a chaotic quantity instead of two
 # (profiles/r06_golden_seed_spread.txt).  Same recipe, same stored quantities; files under tests/golden/spread/.
-for _s in range(1, 5):
+# (first pass: draws 1-4.  c3's max-over-five came out at 1.34 x the fp32 mode's because of ONE draw -- draw 0, 1.27e-2 -- while the mean of
+#  the per-draw worst, the medians and the whole-vector error were at or below the fp32 mode's; draws 5-9 were added BEFORE looking at
+#  them, to report max-over-ten per config and pooled, whatever they say.)
+for _s in range(1, 10):
     CASES["c3s%d" % _s] = ("spread/c3_128cube_s%d.npz" % _s, 128, 1, 1, 2, 1000 + 17 * _s, None)
     CASES["c2s%d" % _s] = ("spread/c2_64cube_b2_s%d.npz" % _s, 64, 2, 1, 2, 3000 + 17 * _s, None)
     WEIGHT_SEED["c3s%d" % _s] = WEIGHT_SEED["c2s%d" % _s] = 42 + 101 * _s
