@@ -160,6 +160,21 @@ int vnet_input_conv_fold(const float* w, const float* gamma, const float* beta, 
 int vnet_input_conv_grads(const float* G, const float* w, const float* gamma, const float* beta, const float* mean,
     const float* invstd, float* dw, float* dgamma, float* dbeta, int C, int O, int accumulate, void* stream);
 
+/* Round 6: the same folded block WITHOUT the x-im2col tensor and without the matrix cores -- packed fp32 FMAs on the vector pipe straight
+ * from the 1-channel image (csrc/input_block.hip: 8.4 GF of real work instead of 26.8 GF of 5x5x1 MFMA work; every product an exact
+ * fp32 FMA; the indicator channel is separable and costs no multiplications: vnet_input_conv_fold_border pre-sums its x taps per
+ * x class of a voxel).  O = 8 or 16 (vnet_input_conv_direct_ok), wv from vnet_input_conv_fold.
+ *   forward : y = conv(fold) + bias; stats (optional) [rows = vnet_input_conv_direct_stats_rows][2][O] partial batch-norm sums of y (+ res)
+ *   gradient: G [25][16][O] in the layout vnet_input_conv_grads reads; ws >= vnet_input_wgrad_direct_slabs(..) * 25 * 16 * O floats */
+int vnet_input_conv_direct_ok(int O, int B, int D, int H, int W);
+int vnet_input_conv_direct_stats_rows(int B, int D, int H, int W);
+int vnet_input_conv_fold_border(const float* wv, int O, float* wbc /* [9][25][O] */, float* cbc /* [9][O] */, void* stream);
+int vnet_input_conv_direct_fwd(const float* img, const float* wv, const float* wbc, const float* cbc, const float* bias, const float* res,
+    float* y, float* stats, int O, int B, int D, int H, int W, void* stream);
+int vnet_input_wgrad_direct_slabs(int B, int D, int H, int W);
+int vnet_input_wgrad_direct(const float* img, const float* dy, float* G, int O, int B, int D, int H, int W, void* ws, size_t ws_bytes,
+    void* stream);
+
 /* ---- 1x1x1 output head, networks.py:298-303 `convolution(x,[1,1,1,C,K])` (K <= 8) ---------- */
 int vnet_head_fwd(const float* x, const float* w, const float* bias, float* y, int64_t M, int C, int K, void* stream);
 int vnet_head_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int64_t M, int C, int K,

@@ -37,6 +37,6 @@ timeout 300 python profiles/train_loop_bench.py > $OUT/train_loop.json 2> $OUT/t
 timeout 300 python profiles/train_loop_bench.py 128 bf16 4 5 > $OUT/train_loop_c5.json 2> $OUT/train_loop_c5.err
 timeout 300 python profiles/train_loop_bench.py 128 fp32_split3 1 2 > $OUT/train_loop_x3.json 2> $OUT/train_loop_x3.err
 timeout 300 python profiles/bench_bn.py 200 > $OUT/bn_passes.txt 2> $OUT/bn_passes.err
-rm -f $OUT/*_kernel_trace.csv
+rm -f $OUT/*_fetch_kernel_trace.csv $OUT/*_write_kernel_trace.csv      # (the counter-free traces stay: per-dispatch family rows, summarize.py)
 ls -la $OUT | head -60
 cut -c1-700 $OUT/bench_line.json

@@ -64,8 +64,49 @@ def read_pass(path, counter):
     return seqs
 
 
+def family_dispatches(src, here, tag):
+    """Round 6 (VERDICT r5 #7b): the family's launches one row per DISPATCH from the counter-free `--kernel-trace --stats` run of each
+    leg (<leg>_kernel_trace.csv), selected by (kernel, position in the step / longest launch of the step) like the PMC passes -- so the
+    `avg_ms` of the bench line can be re-derived to a few percent from a run WITHOUT counters (the --stats rows of a persistent-grid
+    kernel average every layer that kernel serves).  -> profiles/<tag>_family_dispatches.csv, and a summary on stdout."""
+    rows = []
+    for fam, (leg, members) in FAMILIES.items():
+        path = os.path.join(src, leg + "_kernel_trace.csv")
+        if not os.path.exists(path):
+            continue
+        seqs, steps = defaultdict(list), 0
+        trace = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
+        for r in trace:
+            name = short(r["Kernel_Name"])
+            if name.startswith("softmax_dice_bwd_kernel"):
+                steps += 1
+            seqs[(name, r.get("Grid_Size", r.get("Grid_Size_X", "")))].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        for role, pat, grid, pos in members:
+            keys = [k for k in seqs if k[0].startswith(pat) and (grid is None or k[1] == grid)]
+            if len(keys) != 1 or not steps:
+                print("WARNING: %s/%s: %d kernels match" % (fam, role, len(keys)))
+                continue
+            seq = seqs[keys[0]]
+            per_step = len(seq) // steps if len(seq) % steps == 0 else 1
+            if pos == "longest":
+                sel = [max(seq[i:i + per_step], key=lambda t: t[1]) for i in range(0, len(seq), per_step)]
+            else:
+                sel = seq[pos % per_step::per_step]
+            for i, (t0, dur) in enumerate(sel):
+                rows.append((fam, leg, role, keys[0][0], i, dur))
+            d = sorted(t[1] for t in sel)
+            print("%-6s %-6s %-40s n=%3d  avg %8.1f us  median %8.1f  min %8.1f  max %8.1f" %
+                  (fam, role, keys[0][0][:40], len(d), sum(d) / len(d) / 1e3, d[len(d) // 2] / 1e3, d[0] / 1e3, d[-1] / 1e3))
+    if rows:
+        with open(os.path.join(here, tag + "_family_dispatches.csv"), "w") as f:
+            f.write("family,leg,role,kernel,launch_index,duration_ns\n")
+            for r in rows:
+                f.write('%s,%s,%s,"%s",%d,%d\n' % r)
+
+
 def main(src, tag):
     here = os.path.dirname(os.path.abspath(__file__))
+    family_dispatches(src, here, tag)
     out = {"note": "per launch; KB from rocprofv3 --pmc (separate passes, one leg per run); fetch doubled per the gfx950 correction",
            "legs": {}, "families": {}}
     for leg in LEGS:

@@ -11,8 +11,9 @@ layer upstream inherits it.  MEASURED against these same fixtures (profiles/r02_
     stock PyTorch-CPU fp32 (oneDNN, torch autograd; profiles/golden_full_errors_cpu.py), C2: filters max 5.0e-3 / median
     3.8e-3, per-channel vectors max 5.2e-3 / median 3.7e-3;   HIP path, C2: filters 6.9e-3 / 2.8e-3, vectors 9.6e-3 / 2.9e-3;
     HIP path, C3: filters 5.8e-3 / 5.2e-3, vectors 6.7e-3 / 4.6e-3.
-The test therefore holds every tensor to 1.5e-2, the median over tensors to 6e-3 and the whole gradient vector to 8e-3
-(rel-L2 on the stored seeded sample of <= 2048 elements per tensor), plus norm agreement 5e-3; the loss head and logits
+The test therefore holds every tensor to 1.5e-2, the median over tensors to 6e-3 and the whole gradient vector to 1.5e-3
+(rel-L2 on the stored seeded sample of <= 2048 elements per tensor), plus norm agreement 5e-3 -- one set of bounds for both fp32
+modes, from a ten-draw seed spread (FULL_BOUNDS below, profiles/r06_golden_seed_spread.txt); the loss head and logits
 stay at the BASELINE tolerances.  Weights and inputs come from the recipe the fixture was made with."""
 import os
 
@@ -82,11 +83,20 @@ def _grad_errors(z, net):
     return out
 
 
-@pytest.mark.parametrize("case,compute", [("c3", "fp32"), ("c2", "fp32"), ("c3", "fp32_split3"), ("c2", "fp32_split3")])
+# Gradient bounds of the full-size fp32 fixtures -- ONE set for both fp32 modes (VERDICT r5 next #1a), set from the committed seed spread
+# profiles/r06_golden_seed_spread.txt (ten (weight seed, input seed) draws per config x {fp32, fp32_split3}; the largest value seen in
+# either mode, and the bound):   per-tensor sampled rel-L2 1.27e-2 -> 1.5e-2;  first-8-elements error 1.07e-2 -> 1.25e-2;  norm 2.9e-3 ->
+# 5e-3;  median over tensors 5.1e-3 -> 6e-3;  whole gradient vector 7.7e-4 -> 1.5e-3 (rounds 2-5: 8e-3).
+FULL_BOUNDS = {"tensor": 1.5e-2, "head": 1.25e-2, "norm": 5e-3, "median": 6e-3, "vector": 1.5e-3}
+
+
+@pytest.mark.parametrize("compute", ["fp32", "fp32_split3"])
+@pytest.mark.parametrize("case", ["c3", "c2", "c3s1", "c2s1", "c3s2", "c2s2"])
 def test_full_size_network_fp32(dev, case, compute):
-    """BASELINE configs[2]/[3] (128^3, B=1 -- the exact BENCH workload) and configs[1] (64^3, B=2) at full width; and the same
-    fixtures at the SAME bounds with ComputeDtype fp32_split3 (round 5: the 5^3 convolutions of the levels with enough bricks form
-    their products from six bf16 products of exactly split operands, csrc/conv_x3.h)."""
+    """BASELINE configs[2]/[3] (128^3, B=1 -- the exact BENCH workload) and configs[1] (64^3, B=2) at full width, three draws each
+    (fixture + two of the seed spread; profiles/golden_seed_spread.py runs all ten), in both fp32 modes at the SAME bounds:
+    ComputeDtype fp32 (v_mfma_f32_16x16x4_f32) and fp32_split3 (the 5^3 convolutions form their products from six bf16 products of
+    exactly split operands, csrc/conv_x3.h)."""
     z, net, logits, loss, sm, pred, lab, K = _run_case(dev, case, compute)
     s = (slice(None),) + (slice(None, None, STRIDE),) * 3
     got = logits[s].cpu().numpy()
@@ -104,18 +114,13 @@ def test_full_size_network_fp32(dev, case, compute):
     errs = _grad_errors(z, net)
     assert len(errs) > 100
     worst = sorted(errs, key=lambda e: -e[1])[:5]
-    # per-tensor bound: fp32 MFMA kernels 1.2e-2 (measured worst 7.3e-3 on c3, 9.7e-3 on c2: profiles/r04_golden_full_errors.txt);
-    # fp32_split3 1.5e-2, the bound of rounds 2-3 (measured, profiles/r05_golden_full_errors.txt: c3 worst 1.27e-2 -- the four
-    # bottom-level tensors, medians 5.6e-3 / 4.8e-3 as with the fp32 MFMA -- and c2 worst 2.6e-3, medians 1.6e-3, i.e. 3-4x BELOW the
-    # fp32 MFMA kernels on that fixture: the same rounding-noise class, a different sample of it; per kernel both are held to 2e-6)
-    tb = 1.5e-2 if compute == "fp32_split3" else 1.2e-2
     for n, e_sample, e_norm, e_head, e_sum in errs:
-        assert e_sample < tb and e_norm < 5e-3 and e_head < (1.2e-2 if compute == "fp32_split3" else 5e-3), (n, e_sample, e_norm, e_head, worst)
-    assert np.median([e[1] for e in errs]) < 6e-3, np.median([e[1] for e in errs])
+        assert e_sample < FULL_BOUNDS["tensor"] and e_norm < FULL_BOUNDS["norm"] and e_head < FULL_BOUNDS["head"], (n, e_sample, e_norm, e_head, worst)
+    assert np.median([e[1] for e in errs]) < FULL_BOUNDS["median"], np.median([e[1] for e in errs])
     names = list(map(str, z["names"]))
     num = sum((e[1] * float(z["grad_norm"][names.index(e[0])])) ** 2 for e in errs)
     den = sum(float(v) ** 2 for v in z["grad_norm"])
-    assert (num / den) ** 0.5 < 8e-3, (num / den) ** 0.5
+    assert (num / den) ** 0.5 < FULL_BOUNDS["vector"], (num / den) ** 0.5
 
 
 def test_full_size_network_c5_b16_storage(dev):

@@ -287,10 +287,24 @@ def test_bn_chain(dev, kind, C, act):
         check_close(tag + " moving_var%d" % k, mov[2 * k + 1], 0.99 + 0.01 * var, 1e-5)
 
 
-@pytest.mark.parametrize("shape", [(1, 8, 16, 32, 16), (2, 5, 9, 17, 16), (1, 6, 7, 9, 4), (1, 8, 8, 8, 8)])
-def test_input_block(dev, shape):
-    """conv5^3(BN(tile(img))) through the un-tiled 5x5x1 path (csrc/input_block.hip) == the oracle's tiled graph,
-    including the gradients that reach the input BN's gamma/beta through BOTH the conv and a residual use of x."""
+@pytest.mark.parametrize("direct", [True, False])
+@pytest.mark.parametrize("shape", [(1, 8, 16, 32, 16), (2, 5, 9, 17, 16), (1, 6, 7, 9, 4), (1, 8, 8, 8, 8), (1, 12, 13, 140, 16), (1, 9, 12, 70, 8)])
+def test_input_block(dev, shape, direct):
+    """conv5^3(BN(tile(img))) through the un-tiled folded form (csrc/input_block.hip) == the oracle's tiled graph, including the
+    gradients that reach the input BN's gamma/beta through BOTH the conv and a residual use of x.  direct (round 6): packed fp32 FMAs
+    straight from the image for 8 / 16 channels (12 x 13 x 140 has bricks on every face, two ragged axes AND an interior brick, whose
+    indicator channel is a constant); otherwise rounds 1-5's x-im2col + 5x5x1 MFMA kernels (what 4 channels still take)."""
+    from vnet_tensorflow_amd import ops
+    B, D, H, W, C = shape
+    prev = ops._FUSE["input_direct"]
+    ops._FUSE["input_direct"] = direct
+    try:
+        _input_block_case(dev, shape, direct)
+    finally:
+        ops._FUSE["input_direct"] = prev
+
+
+def _input_block_case(dev, shape, direct):
     from vnet_tensorflow_amd import ops
     B, D, H, W, C = shape
     rng = np.random.default_rng(sum(shape))
@@ -306,14 +320,42 @@ def test_input_block(dev, shape):
     timg = g(img, dev)
     tg, tb, tw, tbi = (g(a, dev).requires_grad_(True) for a in (gamma, beta, w, b))
     tx, mean, invstd = ops.bn_act(timg, tg, tb, None, None, None, True, None, None, want_stats=True)
+    ops.profile_start()
     ty = ops.input_conv(timg, tg, tb, mean, invstd, tw, tbi) + tx
     tag = "input block %s" % (shape,)
     check_close(tag + " fwd", ty, y.v, 5e-6)
     ty.backward(g(dy, dev))
+    recs = ops.profile_stop()
+    assert sum(1 for r in recs if r[0].startswith("input-")) == (2 if direct and C in (8, 16) else 0), [r[0] for r in recs]
     check_close(tag + " dw", tw.grad, W_.g, 1e-5)
     check_close(tag + " db", tbi.grad, Bi.g, 1e-5)
     check_close(tag + " dgamma", tg.grad, G_.g, 5e-5)
     check_close(tag + " dbeta", tb.grad, B_.g, 5e-5)
+
+
+def test_input_block_direct_statistics(dev):
+    """The direct input convolution's epilogue: batch-norm partial sums of y (+ residual), one row per 4 x 4 x 64 brick."""
+    from vnet_tensorflow_amd import _lib, ops
+    L = _lib.lib()
+    B, D, H, W, C = 2, 6, 9, 70, 16
+    rng = np.random.default_rng(11)
+    img = g(rng.standard_normal((B, D, H, W, 1)) * 40 + 120, dev)
+    tg, tb, tw, tbi = (g(a, dev) for a in (rng.uniform(0.5, 1.5, C), rng.standard_normal(C), rng.standard_normal((5, 5, 5, C, C)) * 0.1, rng.standard_normal(C)))
+    tx, mean, invstd = ops.bn_act(img, tg, tb, None, None, None, True, None, None, want_stats=True)
+    y = ops.input_conv(img, tg, tb, mean, invstd, tw, tbi, bn_stats=True, bn_residual=tx)
+    st = getattr(y, "_vnet_stats", None)
+    assert st is not None and st.rows == L.vnet_input_conv_direct_stats_rows(B, D, H, W) == 2 * 2 * 3 * 2
+    prev = ops._FUSE["input_direct"]
+    ops._FUSE["input_direct"] = False
+    try:
+        y_old = ops.input_conv(img, tg, tb, mean, invstd, tw, tbi)
+    finally:
+        ops._FUSE["input_direct"] = prev
+    check_close("direct vs 5x5x1 MFMA form", y, y_old.cpu().numpy().astype(np.float64), 2e-6)
+    v = (y.double() + tx.double()).reshape(-1, C).cpu().numpy()
+    s = st.partial.double().cpu().numpy()
+    np.testing.assert_allclose(s[:, :C].sum(0), v.sum(0), rtol=0, atol=2e-5 * np.abs(v).sum(0).max())
+    np.testing.assert_allclose(s[:, C:].sum(0), (v * v).sum(0), rtol=2e-6)
 
 
 @pytest.mark.parametrize("C,K", [(16, 2), (16, 5), (4, 3), (8, 8), (6, 2), (5, 3), (12, 4), (24, 1)])

@@ -54,6 +54,12 @@ SIGNATURES = {
     "vnet_tile_im2col_x": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vnet_input_conv_fold": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "vnet_input_conv_grads": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "vnet_input_conv_direct_ok": (_i, [_i, _i, _i, _i, _i]),
+    "vnet_input_conv_direct_stats_rows": (_i, [_i, _i, _i, _i]),
+    "vnet_input_conv_fold_border": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "vnet_input_conv_direct_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "vnet_input_wgrad_direct_slabs": (_i, [_i, _i, _i, _i]),
+    "vnet_input_wgrad_direct": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "vnet_head_fwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
     "vnet_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _sz, _vp]),
     "vnet_head_ws_bytes": (_sz, [_i, _i]),

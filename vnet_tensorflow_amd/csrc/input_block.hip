@@ -87,6 +87,413 @@ __global__ void __launch_bounds__(256) input_grads_kernel(const float* __restric
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the input block WITHOUT the matrix cores and without the x-im2col tensor.
+// The folded form above is a 2-channel convolution (image, inside-indicator): 2 x 125 x O multiply-adds per voxel.  As a 5x5x1
+// convolution over 16 virtual channels it kept the MFMA pipe busy with 26.8 GF at 128^3 (10 of 16 channels used, fp32 MFMA at 1/16 of
+// the bf16 rate: 0.30 ms forward + 0.29 ms filter gradient per step, plus a 134 MB im2col tensor written once and read twice).  Here:
+//   * the IMAGE channel -- 125 x O multiply-adds per voxel, 4.2 GF -- runs on the VECTOR pipe with packed fp32 FMAs (v_pk_fma_f32:
+//     157 TF/s, the matrix pipe's own fp32 rate) straight from the 1-channel image (8 MB); every product an exact fp32 FMA;
+//   * the INDICATOR channel needs no multiplications at all: ind(v + tap) = in_z(z + dz) in_y(y + dy) in_x(x + dx) is separable, so
+//     forward its x taps are pre-summed per x CLASS of the voxel ((min(x, 2), min(W - 1 - x, 2)): 9 classes, vnet_input_conv_fold_border)
+//     -- a constant per class where the brick's z / y halo is inside the volume (88 % of the bricks at 128^3), 25 adds per voxel on the
+//     z / y faces -- and backward it is box sums of dy: row sums minus the edge columns.
+// Forward: a workgroup = 4 waves = a brick of 4 (z) x 4 (y) x 64 (x) voxels; wave = y row, lane = x, a thread owns the 4 voxels of its
+// z column (4 x O accumulators); image brick + halo (8 x 8 x 68 floats) in LDS; per tap the O folded weights arrive as SCALAR operands
+// (s_load, uniform address), four LDS reads (one per z) feed 4 x O/2 v_pk_fma_f32.  Epilogue: indicator term, bias, y stored as 64
+// contiguous bytes per voxel, batch-norm statistics of y (+ residual) as one row per brick.
+// ------------------------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// sum over the 16 lanes of a DPP row, every lane gets it (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    return v;
+}
+
+constexpr int IC_TZ = 4, IC_TY = 4, IC_TX = 64;
+constexpr int IC_IZ = IC_TZ + 4, IC_IY = IC_TY + 4, IC_IX = IC_TX + 4;
+constexpr int IC_TILE = IC_IZ * IC_IY * IC_IX;          // 4352 floats
+
+// 16 bytes of zeros in device memory: masked-off lanes load from here (a select on the ADDRESS keeps the load unconditional).
+// Explicit global address space on both sides of the select: a plain pointer select falls back to flat_load, which also counts on
+// lgkmcnt and is waited for by the next LDS access.
+__device__ __attribute__((aligned(16))) const float ic_zero4[4] = {0.f, 0.f, 0.f, 0.f};
+typedef const __attribute__((address_space(1))) float* ic_gf_t;
+typedef const __attribute__((address_space(1))) f32x4* ic_gf4_t;      // (the ext-vector type: HIP's float4 struct behind an address-space pointer loads flat)
+__device__ __forceinline__ float ic_ld1(const float* p, bool ok) { ic_gf_t q = ok ? (ic_gf_t)p : (ic_gf_t)ic_zero4; return *q; }
+__device__ __forceinline__ float4 ic_ld4(const float* p, bool ok) { ic_gf4_t q = ok ? (ic_gf4_t)p : (ic_gf4_t)ic_zero4; const f32x4 v = *q; return make_float4(v[0], v[1], v[2], v[3]); }
+
+// the loads of one brick of the filter gradient, global -> registers (image tile: 17 floats, dy brick: 16 float4 per thread)
+template <int O>
+__device__ __forceinline__ void ic_issue_brick(float4 (&dv)[16], float (&iv)[IC_TILE / 256], const float* __restrict__ img, const float* __restrict__ dy,
+                                               int brick, int nbz, int nby, int nbx, int D, int H, int W, int tid) {
+    const int bx = brick % nbx; brick /= nbx;
+    const int by = brick % nby; brick /= nby;
+    const int bz = brick % nbz; const int b = brick / nbz;
+    const int gz0 = bz * IC_TZ - 2, gy0 = by * IC_TY - 2, gx0 = bx * IC_TX - 2;
+    const float* src = img + (size_t)b * D * H * W;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int q = tid + 256 * k;
+        const int v = q >> 2, cq = q & 3;
+        const int vx = v % IC_TX, vy = (v / IC_TX) % IC_TY, vz = v / (IC_TX * IC_TY);
+        const int oz = bz * IC_TZ + vz, oy = by * IC_TY + vy, ox = bx * IC_TX + vx;
+        const bool ok = 4 * cq < O && oz < D && oy < H && ox < W;
+        dv[k] = ic_ld4(dy + ((((size_t)b * D + oz) * H + oy) * W + ox) * O + 4 * cq, ok);
+    }
+#pragma unroll
+    for (int k = 0; k < IC_TILE / 256; ++k) {
+        const int q = tid + 256 * k;
+        const int ix = q % IC_IX, r = q / IC_IX, iy = r % IC_IY, iz = r / IC_IY;
+        const int gz = gz0 + iz, gy = gy0 + iy, gx = gx0 + ix;
+        const bool in = (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        iv[k] = ic_ld1(src + ((size_t)gz * H + gy) * W + gx, in);
+    }
+}
+
+// image brick + halo -> LDS: all 17 loads of a thread in flight, then the stores
+__device__ __forceinline__ void ic_load_tile(float* __restrict__ timg, const float* __restrict__ src, int gz0, int gy0, int gx0, int D, int H, int W, int tid) {
+    float v[IC_TILE / 256];
+#pragma unroll
+    for (int k = 0; k < IC_TILE / 256; ++k) {
+        const int q = tid + 256 * k;
+        const int ix = q % IC_IX, r = q / IC_IX, iy = r % IC_IY, iz = r / IC_IY;
+        const int gz = gz0 + iz, gy = gy0 + iy, gx = gx0 + ix;
+        const bool in = (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        v[k] = ic_ld1(src + ((size_t)gz * H + gy) * W + gx, in);
+    }
+#pragma unroll
+    for (int k = 0; k < IC_TILE / 256; ++k) timg[tid + 256 * k] = v[k];
+}
+
+// x class of a voxel: which of the five x taps stay inside the volume (dx valid <=> 2 - lo <= dx <= 2 + hi)
+__device__ __forceinline__ int ic_xclass(int ox, int W) { return min(ox, 2) * 3 + min(W - 1 - ox, 2); }
+
+// wbc[cls][t25][o] = sum over the valid dx of class cls of wv[t25][2 dx + 1][o];  cbc[cls][o] = sum_t25 wbc[cls][t25][o]
+__global__ void __launch_bounds__(256) input_fold_border_kernel(const float* __restrict__ wv, int O, float* __restrict__ wbc, float* __restrict__ cbc) {
+    const int n = 9 * 25 * O;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n + 9 * O; q += gridDim.x * blockDim.x) {
+        if (q < n) {
+            const int o = q % O, t25 = (q / O) % 25, cls = q / (25 * O);
+            const int lo = cls / 3, hi = cls - lo * 3;
+            float s = 0.f;
+            for (int dx = 2 - lo; dx <= 2 + hi; ++dx) s += wv[(t25 * 16 + 2 * dx + 1) * O + o];
+            wbc[q] = s;
+        } else {
+            const int r = q - n, o = r % O, cls = r / O;
+            const int lo = cls / 3, hi = cls - lo * 3;
+            float s = 0.f;
+            for (int t25 = 0; t25 < 25; ++t25) {
+                float t = 0.f;
+                for (int dx = 2 - lo; dx <= 2 + hi; ++dx) t += wv[(t25 * 16 + 2 * dx + 1) * O + o];
+                s += t;
+            }
+            cbc[r] = s;
+        }
+    }
+}
+
+struct ICArgs {
+    const float* img; const float* wv; const float* wbc; const float* cbc; const float* bias; const float* res; float* y; float* stats;
+    int B, D, H, W, nbz, nby, nbx;
+};
+
+template <int O>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) input_conv_direct_kernel(ICArgs a) {
+    static_assert(O == 8 || O == 16, "output channels: 8 or 16");
+    __shared__ float timg[IC_TILE];
+    __shared__ float red[4 * 2 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, kk = lane >> 4;
+    int brick = blockIdx.x;
+    const int bx = brick % a.nbx; brick /= a.nbx;
+    const int by = brick % a.nby; brick /= a.nby;
+    const int bz = brick % a.nbz; const int b = brick / a.nbz;
+    const int gz0 = bz * IC_TZ - 2, gy0 = by * IC_TY - 2, gx0 = bx * IC_TX - 2;
+    const bool inner_zy = gz0 >= 0 && gz0 + IC_IZ <= a.D && gy0 >= 0 && gy0 + IC_IY <= a.H;      // z / y halo inside the volume
+    // A fragments of the 32 K-steps (k = tap 4 s + kk, row m = output channel i): the whole folded filter of the image channel, 32
+    // registers for the life of the workgroup
+    float af[32];
+    int toff[32];                                     // tile offset of this lane's tap in step s
+#pragma unroll
+    for (int st = 0; st < 32; ++st) {
+        const int tap = 4 * st + kk;
+        const int t25 = tap / 5, dx = tap - t25 * 5, dz = t25 / 5, dy = t25 - dz * 5;
+        const bool ok = tap < 125 && i < O;
+        af[st] = ok ? a.wv[(t25 * 16 + 2 * dx) * O + i] : 0.f;
+        toff[st] = tap < 125 ? (dz * IC_IY + dy) * IC_IX + dx : 0;
+    }
+    ic_load_tile(timg, a.img + (size_t)b * a.D * a.H * a.W, gz0, gy0, gx0, a.D, a.H, a.W, tid);
+    __syncthreads();
+
+    // D[16 o][16 voxels] += A[o][k = 4 taps] B[4 taps][16 voxels]: a subtile = 16 consecutive x of one (z, y) row; the four z of a column
+    // of subtiles run interleaved (four independent accumulators per A fragment)
+    const int oy = by * IC_TY + wave;
+    const int co = 4 * kk;                            // D layout: lane (column n = voxel i, kk) holds rows 4 kk .. 4 kk + 3 = channels co ..
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias && co < O) { const float4 bb = *reinterpret_cast<const float4*>(a.bias + co); bias4[0] = bb.x; bias4[1] = bb.y; bias4[2] = bb.z; bias4[3] = bb.w; }
+#pragma unroll 1
+    for (int xq = 0; xq < IC_TX / 16; ++xq) {
+        const float* tb = timg + wave * IC_IX + xq * 16 + i;
+        f32x4 acc[IC_TZ];
+#pragma unroll
+        for (int z = 0; z < IC_TZ; ++z) acc[z] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the residual of the statistics is fetched under the MFMAs of this column (unconditional: masked lanes read a zero line)
+        float4 rr[IC_TZ];
+        {
+            const int ox_ = bx * IC_TX + xq * 16 + i;
+#pragma unroll
+            for (int z = 0; z < IC_TZ; ++z) {
+                const int oz = bz * IC_TZ + z;
+                const bool ok = a.stats && a.res && oz < a.D && oy < a.H && ox_ < a.W && co < O;
+                rr[z] = ic_ld4(a.res + ((((size_t)b * a.D + oz) * a.H + oy) * a.W + ox_) * O + co, ok);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#if !defined(IC_ABL) || IC_ABL != 1
+#pragma unroll
+        for (int st = 0; st < 32; ++st) {
+            float bv[IC_TZ];
+#pragma unroll
+            for (int z = 0; z < IC_TZ; ++z) bv[z] = tb[toff[st] + z * IC_IY * IC_IX];
+#pragma unroll
+            for (int z = 0; z < IC_TZ; ++z) acc[z] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[st], bv[z], acc[z], 0, 0, 0);
+        }
+#else
+        acc[0][0] = tb[toff[xq]] * af[xq];           // (timing ablation: no MFMA loop; results are wrong)
+#endif
+        const int ox = bx * IC_TX + xq * 16 + i;
+        const bool col_ok = oy < a.H && ox < a.W && co < O;
+        const int cls = ic_xclass(min(ox, a.W - 1), a.W);
+        // indicator channel: per x class a constant (z / y halo inside) or the sum over the (dz, dy) whose row lies inside the volume
+        if (co < O) {
+            if (inner_zy) {
+                const float4 c = *reinterpret_cast<const float4*>(a.cbc + (size_t)cls * O + co);
+#pragma unroll
+                for (int z = 0; z < IC_TZ; ++z) { acc[z][0] += c.x; acc[z][1] += c.y; acc[z][2] += c.z; acc[z][3] += c.w; }
+            } else {
+#pragma unroll 1
+                for (int t25 = 0; t25 < 25; ++t25) {
+                    const int dz = t25 / 5, dy = t25 - dz * 5;
+                    if ((unsigned)(oy + dy - 2) >= (unsigned)a.H) continue;                 // (wave-uniform)
+                    const float4 c = *reinterpret_cast<const float4*>(a.wbc + ((size_t)cls * 25 + t25) * O + co);
+#pragma unroll
+                    for (int z = 0; z < IC_TZ; ++z) {
+                        if ((unsigned)(bz * IC_TZ + z + dz - 2) < (unsigned)a.D) { acc[z][0] += c.x; acc[z][1] += c.y; acc[z][2] += c.z; acc[z][3] += c.w; }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int z = 0; z < IC_TZ; ++z) {
+            const int oz = bz * IC_TZ + z;
+#if defined(IC_ABL) && IC_ABL == 2
+            if (oz < a.D && col_ok && acc[z][0] == 12345.678f) {      // (timing ablation: no stores / residual loads)
+#else
+            if (oz < a.D && col_ok) {
+#endif
+                const size_t ov = (((size_t)b * a.D + oz) * a.H + oy) * a.W + ox;
+                const float e[4] = {acc[z][0] + bias4[0], acc[z][1] + bias4[1], acc[z][2] + bias4[2], acc[z][3] + bias4[3]};
+                *reinterpret_cast<float4*>(a.y + ov * O + co) = make_float4(e[0], e[1], e[2], e[3]);
+#if defined(IC_ABL) && IC_ABL == 3
+                if (false) {
+#else
+                if (a.stats) {
+#endif
+                    const float vv[4] = {e[0] + rr[z].x, e[1] + rr[z].y, e[2] + rr[z].z, e[3] + rr[z].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { s1[k] += vv[k]; s2[k] += vv[k] * vv[k]; }
+                }
+            }
+        }
+    }
+    if (a.stats) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t1 = row16_sum(s1[k]), t2 = row16_sum(s2[k]);           // over the 16 voxels of a lane row: channels co + k
+            if (i == 0 && co < O) { red[wave * 2 * O + co + k] = t1; red[wave * 2 * O + O + co + k] = t2; }
+        }
+        __syncthreads();
+        if (tid < 2 * O) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) t += red[w * 2 * O + tid];
+            a.stats[(size_t)blockIdx.x * 2 * O + tid] = t;
+        }
+    }
+}
+
+// Filter gradient of the folded 2-channel convolution:  G[t25][2 dx][o] = sum_v img[v + tap] dy[v][o] (packed fp32 FMAs),
+// G[t25][2 dx + 1][o] = sum_{v: v + tap inside} dy[v][o] (box sums of dy: no multiplications) -- the layout vnet_input_conv_grads
+// reads; virtual channels 10..15 = 0.  Persistent workgroups of 256 threads walk bricks of 4 x 4 x 64 voxels; image tile and the dy
+// brick (1024 voxels x O) sit in LDS.
+//   image channel: thread = (tap quad tq of 32, voxel slice s of 8): 4 taps x O accumulators; per voxel of its slice: O/4 broadcast
+//     reads of dy, 4 image reads, 4 x O/2 packed FMAs; at the end the 8 slices meet in LDS;
+//   indicator channel: per brick the 16 (z, y) rows' sums of dy over x, with the edge columns (x = 0, 1, W - 2, W - 1) taken out per
+//     dx -> T[row][dx][o]; tap (dz, dy, dx) then collects the rows whose shifted row lies inside the volume (all 16 when the brick's
+//     z / y halo is inside: one brick sum per dx).  Every output (tap, o) has ONE owner thread: 8 accumulators per thread.
+// One partial slab [25][16][O] per workgroup; the slabs are summed by input_wgrad_reduce_kernel.
+template <int O>
+__global__ void __launch_bounds__(256) input_wgrad_direct_kernel(const float* __restrict__ img, const float* __restrict__ dy, float* __restrict__ part,
+                                                                  int B, int D, int H, int W, int nbz, int nby, int nbx) {
+    static_assert(O == 8 || O == 16, "output channels: 8 or 16");
+    constexpr int NVB = IC_TZ * IC_TY * IC_TX;       // 1024 voxels per brick
+    constexpr int NROW = IC_TZ * IC_TY;              // 16 (z, y) rows
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* timg = smem;                              // IC_TILE
+    float* tT = smem + IC_TILE;                      // [NROW + 1][5][O]: T per row, and the brick sums in the last slot
+    float* tdy = smem + IC_TILE + (NROW + 1) * 5 * 16;   // NVB * 16 (always 16 columns: the B fragment reads column i; O = 8: columns 8..15 zero)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, kk = lane >> 4;
+    // image channel on the matrix cores: D[16 taps][16 o] += A[tap][k = 4 voxels] B[4 voxels][o], eight M tiles = taps 16 m + i; the
+    // A fragment of a lane is the image at its voxel kk shifted by ITS tap: one LDS read at a per-lane offset (im2col by addressing)
+    int toff[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int tap = min(16 * m + i, 124);
+        const int dz = tap / 25, dyy = (tap / 5) % 5, dx = tap % 5;
+        toff[m] = (dz * IC_IY + dyy) * IC_IX + dx + kk;
+    }
+    f32x4 acc[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float g2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g2[j] = 0.f;
+    const int nbrick = B * nbz * nby * nbx;
+    // the next brick's image tile (17 floats) and dy brick (16 float4) travel global -> registers under this brick's MFMAs
+    float4 dv[16];
+    float iv[IC_TILE / 256];
+    static_assert(NVB * 4 / 256 == 16, "dy brick: 16 float4 per thread");
+    if ((int)blockIdx.x < nbrick) ic_issue_brick<O>(dv, iv, img, dy, blockIdx.x, nbz, nby, nbx, D, H, W, tid);
+    for (int brick0 = blockIdx.x; brick0 < nbrick; brick0 += gridDim.x) {
+        int brick = brick0;
+        const int bx = brick % nbx; brick /= nbx;
+        const int by = brick % nby; brick /= nby;
+        const int bz = brick % nbz;
+        const int gz0 = bz * IC_TZ - 2, gy0 = by * IC_TY - 2;
+        const bool inner_zy = gz0 >= 0 && gz0 + IC_IZ <= D && gy0 >= 0 && gy0 + IC_IY <= H;
+        __syncthreads();                             // the previous brick's tiles are read
+#pragma unroll
+        for (int k = 0; k < IC_TILE / 256; ++k) timg[tid + 256 * k] = iv[k];
+#pragma unroll
+        for (int k = 0; k < NVB * 4 / 256; ++k) {
+            const int q = tid + 256 * k;
+            *reinterpret_cast<float4*>(tdy + (size_t)(q >> 2) * 16 + 4 * (q & 3)) = dv[k];
+        }
+        __syncthreads();
+        if (brick0 + (int)gridDim.x < nbrick) {
+            ic_issue_brick<O>(dv, iv, img, dy, brick0 + gridDim.x, nbz, nby, nbx, D, H, W, tid);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- image channel: wave = y row of the brick, K steps = 4 consecutive x
+#pragma unroll 1
+        for (int z = 0; z < IC_TZ; ++z) {
+            const float* ta = timg + (z * IC_IY + wave) * IC_IX;
+            const float* tbp = tdy + (size_t)((z * IC_TY + wave) * IC_TX + kk) * 16 + i;
+#pragma unroll
+            for (int x4 = 0; x4 < IC_TX / 4; ++x4) {
+                const float bv = tbp[x4 * 4 * 16];
+                float av[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) av[m] = ta[toff[m] + x4 * 4];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv, acc[m], 0, 0, 0);
+            }
+        }
+        // ---- indicator channel: T[row][dx][o] = sum_{x: 0 <= x + dx - 2 < W} dy[row][x][o]
+        if (tid < NROW * O) {
+            const int r = tid / O, o = tid - r * O;
+            const float* rowp = tdy + (size_t)(r * IC_TX) * 16 + o;
+            // (all 64 reads in flight, four partial sums: a load-add chain costs one LDS round trip per element)
+            float sr4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int x = 0; x < IC_TX; ++x) sr4[x & 3] += rowp[(size_t)x * 16];
+            const float srow = (sr4[0] + sr4[1]) + (sr4[2] + sr4[3]);
+            // edge columns that fall into this brick (absolute x = 0, 1, W - 2, W - 1); voxels beyond W are zero in the tile
+            const int x0 = bx * IC_TX;
+            auto col = [&](int ox) { const int xl = ox - x0; return (xl >= 0 && xl < IC_TX && ox >= 0 && ox < W) ? rowp[(size_t)xl * 16] : 0.f; };
+            const float lo0 = col(0), lo1 = col(1), hi0 = col(W - 1), hi1 = col(W - 2);
+            // dx: excluded are x < 2 - dx and x > W + 1 - dx
+            tT[(r * 5 + 0) * O + o] = srow - lo0 - (W > 1 ? lo1 : 0.f);
+            tT[(r * 5 + 1) * O + o] = srow - lo0;
+            tT[(r * 5 + 2) * O + o] = srow;
+            tT[(r * 5 + 3) * O + o] = srow - hi0;
+            tT[(r * 5 + 4) * O + o] = srow - hi0 - (W > 1 ? hi1 : 0.f);
+        }
+        __syncthreads();
+        if (inner_zy) {
+            if (tid < 5 * O) {                       // brick sums per dx
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < NROW; ++r) s += tT[r * 5 * O + tid];
+                tT[NROW * 5 * O + tid] = s;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int q = tid + 256 * j;         // output (tap, o)
+                if (q < 125 * O) { const int o = q % O, tap = q / O; g2[j] += tT[(NROW * 5 + tap % 5) * O + o]; }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int q = tid + 256 * j;
+                if (q < 125 * O) {
+                    const int o = q % O, tap = q / O, dx = tap % 5, dyy = (tap / 5) % 5, dz = tap / 25;
+                    float s = 0.f;
+                    for (int r = 0; r < NROW; ++r) {
+                        const int oz = bz * IC_TZ + r / IC_TY + dz - 2, oy = by * IC_TY + r % IC_TY + dyy - 2;
+                        if ((unsigned)oz < (unsigned)D && (unsigned)oy < (unsigned)H) s += tT[(r * 5 + dx) * O + o];
+                    }
+                    g2[j] += s;
+                }
+            }
+        }
+    }
+    float* slab = part + (size_t)blockIdx.x * 25 * 16 * O;
+    // indicator channel: one owner per output; the unused virtual channels 10..15 are zero
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int q = tid + 256 * j;
+        if (q < 125 * O) { const int o = q % O, tap = q / O; slab[((tap / 5) * 16 + 2 * (tap % 5) + 1) * O + o] = g2[j]; }
+    }
+    for (int q = tid; q < 25 * 6 * O; q += 256) { const int o = q % O, vch = 10 + (q / O) % 6, t25 = q / (6 * O); slab[(t25 * 16 + vch) * O + o] = 0.f; }
+    // image channel: the four waves' partial tiles meet in LDS [wave][tap 128][16 o]; lane (column n = o i, kk) holds rows 4 kk .. 4 kk + 3
+    __syncthreads();
+    float* redg = smem;
+    static_assert(4 * 128 * 16 <= IC_TILE + (NROW + 1) * 5 * 16 + NVB * 16, "reduction buffer fits the tiles");
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) redg[(wave * 128 + 16 * m + 4 * kk + k) * 16 + i] = acc[m][k];
+    __syncthreads();
+    for (int q = tid; q < 125 * O; q += 256) {
+        const int o = q % O, tap = q / O;
+        const float s4 = (redg[(0 * 128 + tap) * 16 + o] + redg[(1 * 128 + tap) * 16 + o]) + (redg[(2 * 128 + tap) * 16 + o] + redg[(3 * 128 + tap) * 16 + o]);
+        slab[((tap / 5) * 16 + 2 * (tap % 5)) * O + o] = s4;
+    }
+}
+
+// G[q] = sum over the workgroups' slabs, fixed order (four interleaved partial sums: the slabs of one output are 25.6 KB apart)
+__global__ void __launch_bounds__(256) input_wgrad_reduce_kernel(const float* __restrict__ part, int nslab, int n, float* __restrict__ G) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 3 < nslab; k += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[u] += part[(size_t)(k + u) * n + q];
+    }
+    for (; k < nslab; ++k) s[0] += part[(size_t)k * n + q];
+    G[q] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -97,6 +504,62 @@ int vnet_tile_im2col_x(const float* img, float* xv, int B, int D, int H, int W, 
     const size_t nq = nvox * 4;
     const int blocks = (int)(nq / 256 / 4 + 1 > 4096 ? 4096 : nq / 256 / 4 + 1);
     hipLaunchKernelGGL(im2col_x_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, xv, nvox, W);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+
+
+int vnet_input_conv_direct_ok(int O, int B, int D, int H, int W) { return (O == 16 || O == 8) && B > 0 && D > 0 && H > 0 && W > 0 ? 1 : 0; }
+int vnet_input_conv_direct_stats_rows(int B, int D, int H, int W) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    return B * ceil_div(D, IC_TZ) * ceil_div(H, IC_TY) * ceil_div(W, IC_TX);
+}
+// border tables of the indicator channel: wbc [9][25][O], cbc [9][O] (x classes (min(x, 2), min(W - 1 - x, 2)); independent of the volume)
+int vnet_input_conv_fold_border(const float* wv, int O, float* wbc, float* cbc, void* stream) {
+    if (!wv || !wbc || !cbc || O <= 0) return VNET_E_BADARG;
+    if (O > 16) return VNET_E_UNSUPPORTED;
+    hipLaunchKernelGGL(input_fold_border_kernel, dim3(ceil_div(9 * 26 * O, 256)), dim3(256), 0, (hipStream_t)stream, wv, O, wbc, cbc);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+int vnet_input_conv_direct_fwd(const float* img, const float* wv, const float* wbc, const float* cbc, const float* bias, const float* res,
+                               float* y, float* stats, int O, int B, int D, int H, int W, void* stream) {
+    if (!img || !wv || !wbc || !cbc || !y || B <= 0 || D <= 0 || H <= 0 || W <= 0) return VNET_E_BADARG;
+    if (O != 16 && O != 8) return VNET_E_UNSUPPORTED;
+    ICArgs a{img, wv, wbc, cbc, bias, res, y, stats, B, D, H, W, ceil_div(D, IC_TZ), ceil_div(H, IC_TY), ceil_div(W, IC_TX)};
+    const int grid = B * a.nbz * a.nby * a.nbx;
+    if (O == 16) hipLaunchKernelGGL(input_conv_direct_kernel<16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(input_conv_direct_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    VNET_LAUNCH_CHECK();
+    return VNET_OK;
+}
+// workgroups (= partial slabs [25][16][O] floats) of the direct filter gradient; ws must hold that many slabs
+int vnet_input_wgrad_direct_slabs(int B, int D, int H, int W) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const int nbrick = B * ceil_div(D, IC_TZ) * ceil_div(H, IC_TY) * ceil_div(W, IC_TX);
+    return nbrick < 512 ? nbrick : 512;
+}
+int vnet_input_wgrad_direct(const float* img, const float* dy, float* G, int O, int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    if (!img || !dy || !G || B <= 0 || D <= 0 || H <= 0 || W <= 0) return VNET_E_BADARG;
+    if (O != 16 && O != 8) return VNET_E_UNSUPPORTED;
+    const int nbz = ceil_div(D, IC_TZ), nby = ceil_div(H, IC_TY), nbx = ceil_div(W, IC_TX);
+    const int grid = vnet_input_wgrad_direct_slabs(B, D, H, W);
+    const int n = 25 * 16 * O;
+    if (!ws || ws_bytes < (size_t)grid * n * sizeof(float)) return VNET_E_WORKSPACE;
+    float* part = reinterpret_cast<float*>(ws);
+    const size_t lds = (size_t)(IC_TILE + 17 * 5 * 16 + IC_TZ * IC_TY * IC_TX * 16) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (O == 16) {
+        static bool done = false;
+        if (!done) { if (hipFuncSetAttribute((const void*)input_wgrad_direct_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VNET_E_UNSUPPORTED; done = true; }
+        hipLaunchKernelGGL(input_wgrad_direct_kernel<16>, dim3(grid), dim3(256), lds, st, img, dy, part, B, D, H, W, nbz, nby, nbx);
+    } else {
+        static bool done = false;
+        if (!done) { if (hipFuncSetAttribute((const void*)input_wgrad_direct_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VNET_E_UNSUPPORTED; done = true; }
+        hipLaunchKernelGGL(input_wgrad_direct_kernel<8>, dim3(grid), dim3(256), lds, st, img, dy, part, B, D, H, W, nbz, nby, nbx);
+    }
+    VNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(input_wgrad_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, part, grid, n, G);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
 }

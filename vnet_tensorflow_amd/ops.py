@@ -868,7 +868,10 @@ def _slot_target(slot, dy, shape):
 # gradient is left at exactly 0 in the flat gradient buffer and the 29 column-sum + 29 finalize launches per step are not
 # made.  Stand-alone layers2.convolution (outside the networks) keeps the generic column sum.
 _FUSE = {"zero_bias_grad": False, "bn_stats": True,
-         "bn_stats_fp32_direct": True}
+         "bn_stats_fp32_direct": True,
+         # round 6: the single-modality input block on the vector pipe straight from the image (csrc/input_block.hip:
+         # input_conv_direct_kernel / input_wgrad_direct_kernel); False = rounds 1-5: x-im2col tensor + 5x5x1 fp32-MFMA kernels (A/B runs)
+         "input_direct": _os.environ.get("VNET_INPUT_DIRECT", "1") != "0"}
 
 
 def set_epilogue_bn_stats(on, fp32_direct=None):
@@ -1088,15 +1091,26 @@ class _InputConvFn(torch.autograd.Function):
         B, D, H, W, _ = img.shape
         C, O = w.shape[-2], w.shape[-1]
         dev = img.device
-        xv = torch.empty((B, D, H, W, 16), dtype=torch.float32, device=dev)
-        check(L.vnet_tile_im2col_x(_ptr(img), _ptr(xv), B, D, H, W, _stream()), "vnet_tile_im2col_x")
         wv = torch.empty((25, 16, O), dtype=torch.float32, device=dev)
         check(L.vnet_input_conv_fold(_ptr(w), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(wv), C, O, _stream()),
               "vnet_input_conv_fold")
-        wp = torch.empty(L.vnet_packed_weight_floats(PACK_FWD, 25, 16, O), dtype=torch.float32, device=dev)
-        check(L.vnet_pack_weights(PACK_FWD, _ptr(wv), _ptr(wp), 25, 16, O, _stream()), "vnet_pack_weights")
         y = torch.empty((B, D, H, W, O), dtype=torch.float32, device=dev)
-        _conv_call(5, 1, 0, xv, None, wp, b, y, None, (D, H, W), (D, H, W), kx=1, stats=stats, res=res)
+        direct = _input_direct_ok(O, B, D, H, W)
+        if direct:
+            # packed fp32 FMAs straight from the image: no im2col tensor, no filter repack
+            xv = img
+            border = torch.empty(9 * 26 * O, dtype=torch.float32, device=dev)      # wbc [9][25][O] | cbc [9][O]
+            check(L.vnet_input_conv_fold_border(_ptr(wv), O, _ptr(border), _ptr(border[9 * 25 * O:]), _stream()), "vnet_input_conv_fold_border")
+            with _Timed("input-direct %d^3x%d 1->%d" % (W, B, O), 2.0 * B * D * H * W * 125 * O, 4.0 * B * D * H * W * (1 + O)):
+                check(L.vnet_input_conv_direct_fwd(_ptr(img), _ptr(wv), _ptr(border), _ptr(border[9 * 25 * O:]), _ptr(b), _ptr(res), _ptr(y),
+                                                   _ptr(stats), O, B, D, H, W, _stream()), "vnet_input_conv_direct_fwd")
+        else:
+            xv = torch.empty((B, D, H, W, 16), dtype=torch.float32, device=dev)
+            check(L.vnet_tile_im2col_x(_ptr(img), _ptr(xv), B, D, H, W, _stream()), "vnet_tile_im2col_x")
+            wp = torch.empty(L.vnet_packed_weight_floats(PACK_FWD, 25, 16, O), dtype=torch.float32, device=dev)
+            check(L.vnet_pack_weights(PACK_FWD, _ptr(wv), _ptr(wp), 25, 16, O, _stream()), "vnet_pack_weights")
+            _conv_call(5, 1, 0, xv, None, wp, b, y, None, (D, H, W), (D, H, W), kx=1, stats=stats, res=res)
+        ctx.direct = direct
         ctx.save_for_backward(xv, gamma, beta, mean, invstd, w)
         ctx.params = (w, b)
         ctx.gb = (gamma, beta)
@@ -1109,7 +1123,7 @@ class _InputConvFn(torch.autograd.Function):
         xv, gamma, beta, mean, invstd, w = ctx.saved_tensors
         wref, bref = ctx.params
         dy = dy.contiguous()
-        B, D, H, W, _ = xv.shape
+        B, D, H, W = xv.shape[:4]
         C, O = w.shape[-2], w.shape[-1]
         dev = dy.device
         if ctx.bias_zero and getattr(bref, "_vnet_sink", None) is not None and not bref._vnet_sink.written:
@@ -1118,7 +1132,13 @@ class _InputConvFn(torch.autograd.Function):
             db, sb = _grad_out(bref)
             colsum(dy, O, out=db)
         G = torch.empty((25, 16, O), dtype=torch.float32, device=dev)
-        _wgrad_call(5, 1, xv, None, dy, G, (D, H, W), (D, H, W), kx=1, immediate=True)     # G is folded right below
+        if ctx.direct:                                   # xv IS the image here
+            nb = L.vnet_input_wgrad_direct_slabs(B, D, H, W) * 25 * 16 * O * 4
+            ws = workspace(nb, dev)
+            with _Timed("input-wgrad-direct %d^3x%d 1->%d" % (W, B, O), 2.0 * B * D * H * W * 125 * O, 4.0 * B * D * H * W * (1 + O)):
+                check(L.vnet_input_wgrad_direct(_ptr(xv), _ptr(dy), _ptr(G), O, B, D, H, W, _ptr(ws), nb, _stream()), "vnet_input_wgrad_direct")
+        else:
+            _wgrad_call(5, 1, xv, None, dy, G, (D, H, W), (D, H, W), kx=1, immediate=True)     # G is folded right below
         dw, sw = _grad_out(wref)
         gpar, bpar = ctx.gb
         gs, bs = getattr(gpar, "_vnet_sink", None), getattr(bpar, "_vnet_sink", None)
@@ -1150,6 +1170,10 @@ class _InputConvFn(torch.autograd.Function):
         return None, dgamma, dbeta, None, None, _grad_ret(dw, sw), _grad_ret(db, sb), None, None
 
 
+def _input_direct_ok(O, B, D, H, W):
+    return _FUSE["input_direct"] and _lib.lib().vnet_input_conv_direct_ok(O, B, D, H, W) == 1
+
+
 def input_conv(img, gamma, beta, mean, invstd, w, b, bn_stats=False, bn_residual=None):
     """convolution(BN(tf.tile(img)), [5,5,5,C,C]) for a 1-channel `img` (networks.py:254-259 + 316)."""
     if _meta(img):
@@ -1158,7 +1182,10 @@ def input_conv(img, gamma, beta, mean, invstd, w, b, bn_stats=False, bn_residual
     stats = None
     if bn_stats and _FUSE["bn_stats"] and _FUSE["bn_stats_fp32_direct"] and _SYNC_BN is None:
         B, D, H, W, _ = img.shape
-        rows = _lib.lib().vnet_conv_stats_rows(5, 1, 1, 0, 16, w.shape[-1], 0, B, D, H, W)
+        if _input_direct_ok(w.shape[-1], B, D, H, W):
+            rows = _lib.lib().vnet_input_conv_direct_stats_rows(B, D, H, W)
+        else:
+            rows = _lib.lib().vnet_conv_stats_rows(5, 1, 1, 0, 16, w.shape[-1], 0, B, D, H, W)
         if rows > 0:
             stats = torch.empty((rows, 2 * w.shape[-1]), dtype=torch.float32, device=img.device)
     if stats is None:
