@@ -127,27 +127,36 @@ typedef const __attribute__((address_space(1))) f32x4* ic_gf4_t;      // (the ex
 __device__ __forceinline__ float ic_ld1(const float* p, bool ok) { ic_gf_t q = ok ? (ic_gf_t)p : (ic_gf_t)ic_zero4; return *q; }
 __device__ __forceinline__ float4 ic_ld4(const float* p, bool ok) { ic_gf4_t q = ok ? (ic_gf4_t)p : (ic_gf4_t)ic_zero4; const f32x4 v = *q; return make_float4(v[0], v[1], v[2], v[3]); }
 
-// the loads of one brick of the filter gradient, global -> registers (image tile: 17 floats, dy brick: 16 float4 per thread)
+// The filter gradient walks bricks of IW_TZ = 2 planes (512 voxels): image tile 6 x 8 x 68 floats + dy brick 32 KB + the row sums =
+// 49 KB of LDS, so three workgroups share a CU and one's loads / commits / indicator sums run under another's MFMAs (with the forward
+// kernel's 4-plane brick -- 87 KB, one workgroup per CU -- every phase of a brick was exposed).
+constexpr int IW_TZ = 2, IW_IZ = IW_TZ + 4;
+constexpr int IW_TILE = IW_IZ * IC_IY * IC_IX;          // 3264 floats
+constexpr int IW_NVB = IW_TZ * IC_TY * IC_TX;           // 512 voxels
+constexpr int IW_NI = (IW_TILE + 255) / 256;            // 13 image loads per thread
+constexpr int IW_ND = IW_NVB * 4 / 256;                 // 8 float4 of dy per thread
+
+// the loads of one brick of the filter gradient, global -> registers
 template <int O>
-__device__ __forceinline__ void ic_issue_brick(float4 (&dv)[16], float (&iv)[IC_TILE / 256], const float* __restrict__ img, const float* __restrict__ dy,
+__device__ __forceinline__ void ic_issue_brick(float4 (&dv)[IW_ND], float (&iv)[IW_NI], const float* __restrict__ img, const float* __restrict__ dy,
                                                int brick, int nbz, int nby, int nbx, int D, int H, int W, int tid) {
     const int bx = brick % nbx; brick /= nbx;
     const int by = brick % nby; brick /= nby;
     const int bz = brick % nbz; const int b = brick / nbz;
-    const int gz0 = bz * IC_TZ - 2, gy0 = by * IC_TY - 2, gx0 = bx * IC_TX - 2;
+    const int gz0 = bz * IW_TZ - 2, gy0 = by * IC_TY - 2, gx0 = bx * IC_TX - 2;
     const float* src = img + (size_t)b * D * H * W;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < IW_ND; ++k) {
         const int q = tid + 256 * k;
         const int v = q >> 2, cq = q & 3;
         const int vx = v % IC_TX, vy = (v / IC_TX) % IC_TY, vz = v / (IC_TX * IC_TY);
-        const int oz = bz * IC_TZ + vz, oy = by * IC_TY + vy, ox = bx * IC_TX + vx;
+        const int oz = bz * IW_TZ + vz, oy = by * IC_TY + vy, ox = bx * IC_TX + vx;
         const bool ok = 4 * cq < O && oz < D && oy < H && ox < W;
         dv[k] = ic_ld4(dy + ((((size_t)b * D + oz) * H + oy) * W + ox) * O + 4 * cq, ok);
     }
 #pragma unroll
-    for (int k = 0; k < IC_TILE / 256; ++k) {
-        const int q = tid + 256 * k;
+    for (int k = 0; k < IW_NI; ++k) {
+        const int q = min(tid + 256 * k, IW_TILE - 1);
         const int ix = q % IC_IX, r = q / IC_IX, iy = r % IC_IY, iz = r / IC_IY;
         const int gz = gz0 + iz, gy = gy0 + iy, gx = gx0 + ix;
         const bool in = (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
@@ -339,15 +348,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 //     z / y halo is inside: one brick sum per dx).  Every output (tap, o) has ONE owner thread: 8 accumulators per thread.
 // One partial slab [25][16][O] per workgroup; the slabs are summed by input_wgrad_reduce_kernel.
 template <int O>
-__global__ void __launch_bounds__(256) input_wgrad_direct_kernel(const float* __restrict__ img, const float* __restrict__ dy, float* __restrict__ part,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) input_wgrad_direct_kernel(const float* __restrict__ img, const float* __restrict__ dy, float* __restrict__ part,
                                                                   int B, int D, int H, int W, int nbz, int nby, int nbx) {
     static_assert(O == 8 || O == 16, "output channels: 8 or 16");
-    constexpr int NVB = IC_TZ * IC_TY * IC_TX;       // 1024 voxels per brick
-    constexpr int NROW = IC_TZ * IC_TY;              // 16 (z, y) rows
+    constexpr int NVB = IW_NVB;                       // 512 voxels per brick
+    constexpr int NROW = IW_TZ * IC_TY;              // 8 (z, y) rows
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* timg = smem;                              // IC_TILE
-    float* tT = smem + IC_TILE;                      // [NROW + 1][5][O]: T per row, and the brick sums in the last slot
-    float* tdy = smem + IC_TILE + (NROW + 1) * 5 * 16;   // NVB * 16 (always 16 columns: the B fragment reads column i; O = 8: columns 8..15 zero)
+    float* timg = smem;                              // IW_TILE
+    float* tT = smem + IW_TILE;                      // [NROW + 1][5][O]: T per row, and the brick sums in the last slot
+    float* tdy = smem + IW_TILE + (NROW + 1) * 5 * 16;   // NVB * 16 (always 16 columns: the B fragment reads column i; O = 8: columns 8..15 zero)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, kk = lane >> 4;
     // image channel on the matrix cores: D[16 taps][16 o] += A[tap][k = 4 voxels] B[4 voxels][o], eight M tiles = taps 16 m + i; the
@@ -367,22 +376,21 @@ __global__ void __launch_bounds__(256) input_wgrad_direct_kernel(const float* __
     for (int j = 0; j < 8; ++j) g2[j] = 0.f;
     const int nbrick = B * nbz * nby * nbx;
     // the next brick's image tile (17 floats) and dy brick (16 float4) travel global -> registers under this brick's MFMAs
-    float4 dv[16];
-    float iv[IC_TILE / 256];
-    static_assert(NVB * 4 / 256 == 16, "dy brick: 16 float4 per thread");
+    float4 dv[IW_ND];
+    float iv[IW_NI];
     if ((int)blockIdx.x < nbrick) ic_issue_brick<O>(dv, iv, img, dy, blockIdx.x, nbz, nby, nbx, D, H, W, tid);
     for (int brick0 = blockIdx.x; brick0 < nbrick; brick0 += gridDim.x) {
         int brick = brick0;
         const int bx = brick % nbx; brick /= nbx;
         const int by = brick % nby; brick /= nby;
         const int bz = brick % nbz;
-        const int gz0 = bz * IC_TZ - 2, gy0 = by * IC_TY - 2;
-        const bool inner_zy = gz0 >= 0 && gz0 + IC_IZ <= D && gy0 >= 0 && gy0 + IC_IY <= H;
+        const int gz0 = bz * IW_TZ - 2, gy0 = by * IC_TY - 2;
+        const bool inner_zy = gz0 >= 0 && gz0 + IW_IZ <= D && gy0 >= 0 && gy0 + IC_IY <= H;
         __syncthreads();                             // the previous brick's tiles are read
 #pragma unroll
-        for (int k = 0; k < IC_TILE / 256; ++k) timg[tid + 256 * k] = iv[k];
+        for (int k = 0; k < IW_NI; ++k) if (tid + 256 * k < IW_TILE) timg[tid + 256 * k] = iv[k];
 #pragma unroll
-        for (int k = 0; k < NVB * 4 / 256; ++k) {
+        for (int k = 0; k < IW_ND; ++k) {
             const int q = tid + 256 * k;
             *reinterpret_cast<float4*>(tdy + (size_t)(q >> 2) * 16 + 4 * (q & 3)) = dv[k];
         }
@@ -393,10 +401,10 @@ __global__ void __launch_bounds__(256) input_wgrad_direct_kernel(const float* __
         }
         // ---- image channel: wave = y row of the brick, K steps = 4 consecutive x
 #pragma unroll 1
-        for (int z = 0; z < IC_TZ; ++z) {
+        for (int z = 0; z < IW_TZ; ++z) {
             const float* ta = timg + (z * IC_IY + wave) * IC_IX;
             const float* tbp = tdy + (size_t)((z * IC_TY + wave) * IC_TX + kk) * 16 + i;
-#pragma unroll
+#pragma unroll 4
             for (int x4 = 0; x4 < IC_TX / 4; ++x4) {
                 const float bv = tbp[x4 * 4 * 16];
                 float av[8];
@@ -448,7 +456,7 @@ __global__ void __launch_bounds__(256) input_wgrad_direct_kernel(const float* __
                     const int o = q % O, tap = q / O, dx = tap % 5, dyy = (tap / 5) % 5, dz = tap / 25;
                     float s = 0.f;
                     for (int r = 0; r < NROW; ++r) {
-                        const int oz = bz * IC_TZ + r / IC_TY + dz - 2, oy = by * IC_TY + r % IC_TY + dyy - 2;
+                        const int oz = bz * IW_TZ + r / IC_TY + dz - 2, oy = by * IC_TY + r % IC_TY + dyy - 2;
                         if ((unsigned)oz < (unsigned)D && (unsigned)oy < (unsigned)H) s += tT[(r * 5 + dx) * O + o];
                     }
                     g2[j] += s;
@@ -467,7 +475,7 @@ __global__ void __launch_bounds__(256) input_wgrad_direct_kernel(const float* __
     // image channel: the four waves' partial tiles meet in LDS [wave][tap 128][16 o]; lane (column n = o i, kk) holds rows 4 kk .. 4 kk + 3
     __syncthreads();
     float* redg = smem;
-    static_assert(4 * 128 * 16 <= IC_TILE + (NROW + 1) * 5 * 16 + NVB * 16, "reduction buffer fits the tiles");
+    static_assert(4 * 128 * 16 <= IW_TILE + (NROW + 1) * 5 * 16 + NVB * 16, "reduction buffer fits the tiles");
 #pragma unroll
     for (int m = 0; m < 8; ++m)
 #pragma unroll
@@ -534,20 +542,26 @@ int vnet_input_conv_direct_fwd(const float* img, const float* wv, const float* w
     return VNET_OK;
 }
 // workgroups (= partial slabs [25][16][O] floats) of the direct filter gradient; ws must hold that many slabs
+static int device_cus_ib() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    return n;
+}
 int vnet_input_wgrad_direct_slabs(int B, int D, int H, int W) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    const int nbrick = B * ceil_div(D, IC_TZ) * ceil_div(H, IC_TY) * ceil_div(W, IC_TX);
-    return nbrick < 512 ? nbrick : 512;
+    const int nbrick = B * ceil_div(D, IW_TZ) * ceil_div(H, IC_TY) * ceil_div(W, IC_TX);
+    const int cap = 2 * device_cus_ib();              // two workgroups per CU (49 KB of LDS each; 256 registers per lane)
+    return nbrick < cap ? nbrick : cap;
 }
 int vnet_input_wgrad_direct(const float* img, const float* dy, float* G, int O, int B, int D, int H, int W, void* ws, size_t ws_bytes, void* stream) {
     if (!img || !dy || !G || B <= 0 || D <= 0 || H <= 0 || W <= 0) return VNET_E_BADARG;
     if (O != 16 && O != 8) return VNET_E_UNSUPPORTED;
-    const int nbz = ceil_div(D, IC_TZ), nby = ceil_div(H, IC_TY), nbx = ceil_div(W, IC_TX);
+    const int nbz = ceil_div(D, IW_TZ), nby = ceil_div(H, IC_TY), nbx = ceil_div(W, IC_TX);
     const int grid = vnet_input_wgrad_direct_slabs(B, D, H, W);
     const int n = 25 * 16 * O;
     if (!ws || ws_bytes < (size_t)grid * n * sizeof(float)) return VNET_E_WORKSPACE;
     float* part = reinterpret_cast<float*>(ws);
-    const size_t lds = (size_t)(IC_TILE + 17 * 5 * 16 + IC_TZ * IC_TY * IC_TX * 16) * sizeof(float);
+    const size_t lds = (size_t)(IW_TILE + (IW_TZ * IC_TY + 1) * 5 * 16 + IW_NVB * 16) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (O == 16) {
         static bool done = false;
