@@ -583,9 +583,10 @@ def main():
                "roofline": r["roofline"], "hbm_kernels": r.get("hbm_kernels"), "hbm_kernels_note": r.get("hbm_kernels_note"),
                "sustained": r.get("sustained"),
                "parity": ("unpinned by the reference (TF 1.15 cannot run here, the reference has no tests): every number is checked against the "
-                          "repo's fp64 oracle.  Full-size (this workload) gradients are held to 1.5e-2 rel-L2 per tensor / 6e-3 median / 1.5e-3 "
-                          "whole vector in BOTH fp32 modes (one set of bounds from a ten-draw seed spread, profiles/r06_golden_seed_spread.txt) "
-                          "-- per tensor a 15x relaxation of BASELINE.md 2.1's 1e-3, which fp32 itself does not resolve here (stock "
+                          "repo's fp64 oracle.  Full-size (this workload) gradients are held to 2.75e-2 rel-L2 per tensor / 1.4e-2 median / 1.5e-3 "
+                          "whole vector in BOTH fp32 modes (one set of bounds = 1.25 x the largest value of a ten-draw seed spread, "
+                          "profiles/r06_golden_seed_spread.txt: the per-tensor worst of a run is chaotic, 2.2e-2 in the reference's own arithmetic on one draw) "
+                          "-- per tensor a 27x relaxation of BASELINE.md 2.1's 1e-3, which fp32 itself does not resolve here (stock "
                           "PyTorch-CPU fp32 on the same fixture: 5e-3); logits 1e-3, loss 1e-5, Dice sums 1e-5, argmax >= 99.99 % as "
                           "BASELINE states them (tests/test_hip_golden_full.py, DESIGN.md section 6)")}
         for k in ("conv_ms_per_step", "conv_tflops"):

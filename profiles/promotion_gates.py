@@ -19,7 +19,7 @@ gates, failed = {}, []
 txt = open(os.path.join(HERE, "r06_golden_seed_spread.txt")).read()
 rows = {}
 for line in txt.splitlines():
-    m = re.match(r"^(c[23])(s\d+)?\s+(fp32|fp32_split3)\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)", line)
+    m = re.match(r"^(c[23])(s\d+)?\s+(fp32|fp32_split3)\s+(\d\S+)\s+(\d\S+)\s+(\d\S+)\s+(\d\S+)\s+(\d\S+)", line)
     if m:
         rows.setdefault((m.group(1), m.group(3)), []).append([float(m.group(k)) for k in range(4, 9)])
 a = {}
@@ -35,7 +35,11 @@ all3 = [r[0] for cfg in ("c3", "c2") for r in rows[(cfg, "fp32_split3")]]
 a["pooled"] = {"draws": len(all3), "ratio": round(max(all3) / max(all32), 3)}
 ok_a = all(a[c]["ratio"] <= 1.25 for c in ("c3", "c2"))
 gates["a_seed_spread"] = {"pass": ok_a, "rule": "per config: max-over-seeds of the worst per-tensor gradient error, fp32_split3 <= 1.25 x fp32",
-                          "evidence": "profiles/r06_golden_seed_spread.txt", "measured": a}
+                          "evidence": "profiles/r06_golden_seed_spread.txt", "measured": a,
+                          "history": "first pass, five draws, kernels of the start of round 6: c3 1.34 (one draw: fp32_split3 1.27e-2 vs fp32 9.5e-3), "
+                                     "c2 1.09; draws 5-9 were registered before they were computed (tests/golden/make_golden_full.py); this record: "
+                                     "ten draws on the final kernels.  The per-run worst is chaotic (see the header of the evidence file); "
+                                     "medians and whole-vector errors favour fp32_split3 in both configs"}
 if not ok_a:
     failed.append("a")
 
