@@ -13,17 +13,17 @@
 OUT=gpurun_out/${1:-prof}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p $OUT
-timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err
+[ -n "$LEGS" ] || timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err
 COMMON="--no-cpu-baseline --no-sustained --no-c5 --no-c2 --no-x3"
 leg_args() {
   case $1 in
-    fp32) echo "--gpus 1 $COMMON" ;;
+    fp32) echo "--gpus 1 --compute fp32 $COMMON" ;;
     x3)   echo "--gpus 1 --compute fp32_split3 $COMMON" ;;
     c5)   echo "--gpus 1 --compute bf16 --channels 4 --classes 5 $COMMON" ;;
     c2)   echo "--gpus 1 --patch 64 --batch 2 $COMMON" ;;
   esac
 }
-for LEG in fp32 x3 c5 c2; do
+for LEG in ${LEGS:-fp32 x3 c5 c2}; do
   A=$(leg_args $LEG)
   BENCH_NO_HBM_TABLE=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${LEG} -- python bench.py $A --steps 20 --warmup 5 > $OUT/${LEG}_stats.log 2>&1
   if [ $LEG != c2 ]; then
@@ -33,6 +33,7 @@ for LEG in fp32 x3 c5 c2; do
   BENCH_NO_HBM_TABLE=1 BENCH_KERNEL_TABLE=1 timeout 600 python bench.py $A --steps 10 > /dev/null 2> $OUT/${LEG}_layer_table.err
   grep "^#" $OUT/${LEG}_layer_table.err > $OUT/${LEG}_layer_table.txt
 done
+[ -n "$LEGS" ] && exit 0      # (LEGS="fp32" bash profiles/collect.sh <dir>: re-run only those legs' rocprofv3 passes)
 timeout 300 python profiles/train_loop_bench.py > $OUT/train_loop.json 2> $OUT/train_loop.err
 timeout 300 python profiles/train_loop_bench.py 128 bf16 4 5 > $OUT/train_loop_c5.json 2> $OUT/train_loop_c5.err
 timeout 300 python profiles/train_loop_bench.py 128 fp32_split3 1 2 > $OUT/train_loop_x3.json 2> $OUT/train_loop_x3.err

@@ -80,7 +80,8 @@ def family_dispatches(src, here, tag):
             name = short(r["Kernel_Name"])
             if name.startswith("softmax_dice_bwd_kernel"):
                 steps += 1
-            seqs[(name, r.get("Grid_Size", r.get("Grid_Size_X", "")))].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+            grid = r.get("Grid_Size") or str(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]))      # (the trace has X / Y / Z)
+            seqs[(name, grid)].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
         for role, pat, grid, pos in members:
             keys = [k for k in seqs if k[0].startswith(pat) and (grid is None or k[1] == grid)]
             if len(keys) != 1 or not steps:
@@ -137,9 +138,10 @@ def main(src, tag):
             e["hbm_bytes_per_launch"] = e.get("hbm_read_bytes", 0.0) + e.get("hbm_write_bytes", 0.0)
             kern["%s grid=%s" % (name, grid)] = e
         out["legs"][leg] = kern
-        # training steps of this run: the once-per-step kernel
-        any_seq = next(iter(seqs.values()))
-        nsteps = sum(len(v) for k, v in any_seq.items() if k[0].startswith("softmax_dice_bwd_kernel"))
+        # training steps of each pass: the once-per-step kernel (round 6: PER PASS -- the eager steps that run while rocm-smi is read
+        # make the step count of two passes differ)
+        steps_of = {c: sum(len(v) for k, v in sq.items() if k[0].startswith("softmax_dice_bwd_kernel")) for c, sq in seqs.items()}
+        nsteps = min(steps_of.values())
         for fam, (fleg, members) in FAMILIES.items():
             if fleg != leg:
                 continue
@@ -148,6 +150,7 @@ def main(src, tag):
                 e = {}
                 for counter, sq in seqs.items():
                     keys = [k for k in sq if k[0].startswith(pat) and (grid is None or k[1] == grid)]
+                    nsteps = steps_of[counter]
                     if len(keys) != 1 or not nsteps:
                         continue
                     seq = sq[keys[0]]
@@ -172,7 +175,7 @@ def main(src, tag):
                                         "hbm_bytes_per_launch": round(rd + wr), "avg_us_profiled": round(e["avg_us_profiled"], 1)}
                     used.append(e["kernel"])
             if len(per_kernel) == len(members):
-                out["families"][fam] = {"leg": leg, "steps_profiled": nsteps, "kernels": used, "per_kernel": per_kernel,
+                out["families"][fam] = {"leg": leg, "steps_profiled": min(steps_of.values()), "kernels": used, "per_kernel": per_kernel,
                                         "hbm_bytes_per_launch": round(sum(v["hbm_bytes_per_launch"] for v in per_kernel.values()) / len(per_kernel))}
             else:
                 print("WARNING: family %s incomplete: %s" % (fam, sorted(per_kernel)))
