@@ -619,7 +619,8 @@ class image2label(object):
             pin = os.environ.get("VNET_DP_MODE")               # segmented | serial | off: no measurement, this one
             if pin in cands or pin in ("segmented", "off"):
                 cands = [pin]
-            self._tuner = parallel.StepModeAutotune(cands, steps=int(getattr(self, "dp_autotune_steps", 5)),
+            # (VNET_DP_AUTOTUNE_STEPS: steps per block, default 5 -- tests whose all-reduce crosses the host over gloo take 1)
+            self._tuner = parallel.StepModeAutotune(cands, steps=int(os.environ.get("VNET_DP_AUTOTUNE_STEPS", getattr(self, "dp_autotune_steps", 5))),
                                                     blocks=int(getattr(self, "dp_autotune_blocks", 3)),
                                                     sync=self._device_sync,
                                                     exposed=(self.sync.exposed_seconds if self.sync is not None else None))
