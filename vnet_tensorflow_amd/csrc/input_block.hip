@@ -183,26 +183,26 @@ __device__ __forceinline__ void ic_load_tile(float* __restrict__ timg, const flo
 __device__ __forceinline__ int ic_xclass(int ox, int W) { return min(ox, 2) * 3 + min(W - 1 - ox, 2); }
 
 // wbc[cls][t25][o] = sum over the valid dx of class cls of wv[t25][2 dx + 1][o];  cbc[cls][o] = sum_t25 wbc[cls][t25][o]
+// (one workgroup per class; the sums of the 25 rows go through LDS: a thread that walks all 125 taps alone costs 19 us of load latency)
 __global__ void __launch_bounds__(256) input_fold_border_kernel(const float* __restrict__ wv, int O, float* __restrict__ wbc, float* __restrict__ cbc) {
-    const int n = 9 * 25 * O;
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n + 9 * O; q += gridDim.x * blockDim.x) {
-        if (q < n) {
-            const int o = q % O, t25 = (q / O) % 25, cls = q / (25 * O);
-            const int lo = cls / 3, hi = cls - lo * 3;
-            float s = 0.f;
-            for (int dx = 2 - lo; dx <= 2 + hi; ++dx) s += wv[(t25 * 16 + 2 * dx + 1) * O + o];
-            wbc[q] = s;
-        } else {
-            const int r = q - n, o = r % O, cls = r / O;
-            const int lo = cls / 3, hi = cls - lo * 3;
-            float s = 0.f;
-            for (int t25 = 0; t25 < 25; ++t25) {
-                float t = 0.f;
-                for (int dx = 2 - lo; dx <= 2 + hi; ++dx) t += wv[(t25 * 16 + 2 * dx + 1) * O + o];
-                s += t;
-            }
-            cbc[r] = s;
-        }
+    __shared__ float row[25 * 16];
+    const int cls = blockIdx.x, lo = cls / 3, hi = cls - lo * 3;
+    for (int q = threadIdx.x; q < 25 * O; q += 256) {
+        const int o = q % O, t25 = q / O;
+        float t[5];
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) t[dx] = wv[(t25 * 16 + 2 * dx + 1) * O + o];
+        float s = 0.f;
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) if (dx >= 2 - lo && dx <= 2 + hi) s += t[dx];
+        wbc[(size_t)cls * 25 * O + q] = s;
+        row[q] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < O) {
+        float s = 0.f;
+        for (int t25 = 0; t25 < 25; ++t25) s += row[t25 * O + threadIdx.x];
+        cbc[cls * O + threadIdx.x] = s;
     }
 }
 
@@ -488,18 +488,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 }
 
-// G[q] = sum over the workgroups' slabs, fixed order (four interleaved partial sums: the slabs of one output are 25.6 KB apart)
+// G[q] = sum over the workgroups' slabs, fixed order: a block = 32 outputs x 8 slab groups (group g takes slabs g, g + 8, ...: up to 64
+// loads per thread, sixteen in flight), the groups meet in LDS.  (One thread per output walking all 512 slabs: 41 us of load latency.)
 __global__ void __launch_bounds__(256) input_wgrad_reduce_kernel(const float* __restrict__ part, int nslab, int n, float* __restrict__ G) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
+    __shared__ float sh[8][32];
+    const int ql = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int q = blockIdx.x * 32 + ql;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 3 < nslab; k += 4) {
+    if (q < n) {
+        int k = grp;
+        for (; k + 24 < nslab; k += 32) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s[u] += part[(size_t)(k + u) * n + q];
+            for (int u = 0; u < 4; ++u) s[u] += part[(size_t)(k + 8 * u) * n + q];
+        }
+        for (; k < nslab; k += 8) s[0] += part[(size_t)k * n + q];
     }
-    for (; k < nslab; ++k) s[0] += part[(size_t)k * n + q];
-    G[q] = (s[0] + s[1]) + (s[2] + s[3]);
+    sh[grp][ql] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (grp == 0 && q < n) G[q] = ((sh[0][ql] + sh[1][ql]) + (sh[2][ql] + sh[3][ql])) + ((sh[4][ql] + sh[5][ql]) + (sh[6][ql] + sh[7][ql]));
 }
 
 }  // namespace
@@ -526,7 +532,7 @@ int vnet_input_conv_direct_stats_rows(int B, int D, int H, int W) {
 int vnet_input_conv_fold_border(const float* wv, int O, float* wbc, float* cbc, void* stream) {
     if (!wv || !wbc || !cbc || O <= 0) return VNET_E_BADARG;
     if (O > 16) return VNET_E_UNSUPPORTED;
-    hipLaunchKernelGGL(input_fold_border_kernel, dim3(ceil_div(9 * 26 * O, 256)), dim3(256), 0, (hipStream_t)stream, wv, O, wbc, cbc);
+    hipLaunchKernelGGL(input_fold_border_kernel, dim3(9), dim3(256), 0, (hipStream_t)stream, wv, O, wbc, cbc);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
 }
@@ -573,7 +579,7 @@ int vnet_input_wgrad_direct(const float* img, const float* dy, float* G, int O, 
         hipLaunchKernelGGL(input_wgrad_direct_kernel<8>, dim3(grid), dim3(256), lds, st, img, dy, part, B, D, H, W, nbz, nby, nbx);
     }
     VNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(input_wgrad_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, part, grid, n, G);
+    hipLaunchKernelGGL(input_wgrad_reduce_kernel, dim3(ceil_div(n, 32)), dim3(256), 0, st, part, grid, n, G);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
 }
