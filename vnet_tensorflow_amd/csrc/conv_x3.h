@@ -529,17 +529,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         __syncthreads();                               // every wave is done reading the previous tiles
         commit(neg);
         __syncthreads();
-        if (brick + a.nsplit < a.nbrick) {
-            issue(brick + a.nsplit);
-            __builtin_amdgcn_sched_barrier(0);
-        }
         if (brick != split) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[t] = -acc[t];
         }
         neg = !neg;
-#pragma unroll 1
-        for (int zz = 0; zz < X3_TZ; ++zz) {
+        auto plane = [&](const int zz) {
             // (priority alternation between the two waves of a SIMD, as in the convolution kernel: the matrix pipe goes to the older wave
             //  whenever both are ready, so without it waves 0-3 finish a brick early and waves 4-7 finish it alone at a single wave's rate)
             if ((wave >> 2) ^ zz) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
@@ -589,7 +584,17 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-        }
+        };
+        static_assert(X3_TZ == 2, "two planes per brick");
+        plane(0);
+        // The next brick's loads go out BETWEEN the two planes (round 6), not right behind the barrier: there both waves of a SIMD spend
+        // their first ~1.2 K cycles on the 14 loads' address arithmetic with the matrix pipe idle; here the other wave of the SIMD is
+        // multiplying.  Unconditional (past the end: this brick again): a branch around an issue merges two vmcnt states and hipcc
+        // then waits for the younger one.
+        __builtin_amdgcn_sched_barrier(0);
+        issue(brick + a.nsplit < a.nbrick ? brick + a.nsplit : brick);
+        __builtin_amdgcn_sched_barrier(0);
+        plane(1);
     }
     __builtin_amdgcn_s_setprio(0);
     if (!neg) {                                        // (`neg` was toggled after the last brick: false = that brick ran negated)
