@@ -2599,12 +2599,7 @@ __device__ __forceinline__ void wgrad5_bf16_rr_body(const WgradArgs& a, const in
             for (int k = 0; k < DPER; ++k) *reinterpret_cast<u32x4*>(dyt + (size_t)(tid + k * 512) * 16) = hd[k];
         }
         __syncthreads();
-        if (brick + a.nsplit < a.nbrick) {
-            issue(brick + a.nsplit);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll 1
-        for (int z = 0; z < TZ; ++z) {
+        auto plane = [&](const int z) {
             VNET_PRIO_ALT(((wave >> 2) ^ z) & 1);
             const int zx = z * (IY * IX * 32), zd = z * (TY * TX * 32);
             // one (dz, dx) pair at a time: the window of five row fragments of ONE pair is live (20 registers; all three pairs in
@@ -2636,7 +2631,15 @@ __device__ __forceinline__ void wgrad5_bf16_rr_body(const WgradArgs& a, const in
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-        }
+        };
+        // The next brick's loads go out behind the FIRST plane (round 6, as in wgrad5_x3_kernel), not right behind the barrier, where both
+        // waves of a SIMD did their address arithmetic at the same time with the matrix pipe idle.  Unconditional: past the end, this brick again.
+        plane(0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(brick + a.nsplit < a.nbrick ? brick + a.nsplit : brick);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int z = 1; z < TZ; ++z) plane(z);
     }
     VNET_PRIO_OFF();
     if constexpr (IN4) {
