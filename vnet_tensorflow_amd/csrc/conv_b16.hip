@@ -127,7 +127,7 @@ static int conv_fwd_b16_impl(const void* x0, int C0, const void* x1, int C1, con
         if (!ws || ws_bytes < need) return VNET_E_WORKSPACE;
         a.part = reinterpret_cast<float*>(ws); a.part_stride = nvox * a.CoutP;
     }
-    const int e = dp.use ? launch_conv_deep(a, dp, st) : conv_fwd_bf16_go<true, true>(a, p, nslab, C0, C1, Cy0, Cy1, B, D, H, W, st);
+    const int e = dp.use ? launch_conv_deep(a, dp, st) : conv_fwd_bf16_go(a, p, nslab, C0, C1, Cy0, Cy1, B, D, H, W, st);
     if (e == -1) return VNET_OK;
     if (e) return e;
     if (nslab > 1) {
@@ -202,11 +202,11 @@ int vnet_conv_wgrad_b16(const void* x0, int C0, const void* x1, int C1, const vo
         return VNET_OK;
     }
     if (p.small) {
-        e = p.ns == 2 ? launch_wgrad_bf16<4, 8, 8, 2, 8, true>(a, p.nsplit, p.ncob, p.ntg, st)
-                      : launch_wgrad_bf16<4, 8, 8, 1, 16, true>(a, p.nsplit, p.ncob, p.ntg, st);
+        e = p.ns == 2 ? launch_wgrad_bf16<4, 8, 8, 2, 8>(a, p.nsplit, p.ncob, p.ntg, st)
+                      : launch_wgrad_bf16<4, 8, 8, 1, 16>(a, p.nsplit, p.ncob, p.ntg, st);
     } else {
-        e = p.ns == 2 ? launch_wgrad_bf16<4, 4, 16, 2, 8, true>(a, p.nsplit, p.ncob, p.ntg, st)
-                      : launch_wgrad_bf16<4, 4, 16, 1, 16, true>(a, p.nsplit, p.ncob, p.ntg, st);
+        e = p.ns == 2 ? launch_wgrad_bf16<4, 4, 16, 2, 8>(a, p.nsplit, p.ncob, p.ntg, st)
+                      : launch_wgrad_bf16<4, 4, 16, 1, 16>(a, p.nsplit, p.ncob, p.ntg, st);
     }
     if (e) return e;
     if (direct) return VNET_OK;
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(512) wgrad5_b16_group_kernel(WgradGroup g) {
     const int ny = (a.CinP / 16) * a.ncob;
     switch (q.fam) {
         case WG_RR: wgrad5_bf16_rr_body<4, false>(a, split, rest); break;
-        case WG_S16: wgrad5_bf16_body<4, 4, 16, 2, 8, true>(a, split, rest % ny, rest / ny); break;
+        case WG_S16: wgrad5_bf16_body<4, 4, 16, 2, 8>(a, split, rest % ny, rest / ny); break;
         case WG_ZS32: wgrad5_b16_zs_body<32>(a, split, rest); break;
         case WG_ZS16: wgrad5_b16_zs_body<16>(a, split, rest); break;
         case WG_ZS8: wgrad5_b16_zs_body<8>(a, split, rest); break;
@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(512) wgrad5_b16_group_kernel(WgradGroup g) {
         case WG_K2_W4: wgrad_body<2, 2, 2, 4, 16, 4, 1, 2, true>(a, split, rest, 0); break;
         case WG_K2_S2: wgrad_body<2, 2, 2, 8, 8, 2, 1, 2, true>(a, split, rest, 0); break;
         case WG_K2_S4: wgrad_body<2, 2, 2, 8, 8, 4, 1, 2, true>(a, split, rest, 0); break;
-        default: wgrad5_bf16_body<4, 8, 8, 2, 8, true>(a, split, rest % ny, rest / ny); break;
+        default: wgrad5_bf16_body<4, 8, 8, 2, 8>(a, split, rest % ny, rest / ny); break;
     }
 }
 

@@ -77,7 +77,7 @@ __device__ __forceinline__ void stats_row_write(const float* red, float* __restr
     }
 }
 
-// bf16-storage mode (O16 / IO16 instantiations): y0 / y1 / accsrc / res of ConvArgs then point at bf16 tensors (same NDHWC
+// bf16-storage mode (the bf16 5^3 kernels and the IO16 instantiations): y0 / y1 / accsrc / res of ConvArgs then point at bf16 tensors (same NDHWC
 // indexing, 2-byte elements).  One lane's 4 consecutive output channels `co..co+3` of voxel `ov` (bias already added):
 // optional accumulation onto the stored gradient, ONE rounding (RNE), statistics of the ROUNDED values (+ residual) -- the
 // batch-norm behind normalises exactly the tensor that is stored -- and an 8-byte store.
@@ -1262,23 +1262,7 @@ __device__ __forceinline__ void bf16_w_commit(u32x4* wl, const u32x4 (&wreg)[WPE
         wl[idx < WUNITS ? idx : WUNITS] = wreg[k];          // WUNITS = one spare 16-byte dump slot behind the slab
     }
 }
-// brick (+halo) of one 16-channel chunk: fp32 NDHWC -> two bf16 planes [cin half][voxel][8]
-template <typename G, typename XT, int K0, int KN>
-__device__ __forceinline__ void bf16_tile_commit(unsigned char* tile, unsigned char* dump, const float4 (&v)[KN], int tid) {
-    const int r0 = tid / XT::COLS, col = tid - r0 * XT::COLS;
-    const int ix = col >> 2, cq = col & 3;
-    unsigned char* base = tile + (cq >> 1) * G::PLANE + ix * 16 + (cq & 1) * 8;
-#pragma unroll
-    for (int k = 0; k < KN; ++k) {
-        const int row = r0 + (K0 + k) * XT::RPI;
-        const bool ok = r0 < XT::RPI && row < XT::ROWS;
-        // select on the ADDRESS, not a branch around the store: a branch would pull the global load of v[k] inside it
-        // and every load would then wait for the previous one
-        unsigned char* dst = ok ? base + row * (G::IX * 16) : dump;
-        *reinterpret_cast<uint2*>(dst) = make_uint2(pk_bf16(v[k].x, v[k].y), pk_bf16(v[k].z, v[k].w));
-    }
-}
-
+// brick (+halo) of one 16-channel chunk, bf16 source: 16-byte units as they sit in LDS, two planes [cin half][voxel][8]
 template <typename G, typename XH, int K0, int KN>
 __device__ __forceinline__ void bf16_tile_commit_h(unsigned char* tile, unsigned char* dump, const u32x4 (&v)[KN], int tid) {
     const int r0 = tid / XH::COLS, col = tid - r0 * XH::COLS;
@@ -1291,9 +1275,10 @@ __device__ __forceinline__ void bf16_tile_commit_h(unsigned char* tile, unsigned
     }
 }
 
-// H: x0 / x1 point at bf16 shadows of the activations (same NDHWC indexing, 2-byte elements)
-// O16: bf16-storage mode -- the outputs (and the accumulate source / residual) are bf16 tensors (epilogue4_b16)
-template <int TZ, int TY, int TX, int NSB, int WAVES, bool STATS = false, bool H = false, bool O16 = false>
+// bf16-storage mode (round 3; the only form since round 5 retired the fp32-source / fp32-output instantiations, whose template paths were
+// deleted in round 6): x0 / x1 are bf16 tensors (same NDHWC indexing, 2-byte elements), and so are the outputs, the accumulate source and
+// the residual (epilogue_b16_batch)
+template <int TZ, int TY, int TX, int NSB, int WAVES, bool STATS = false>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) conv5_bf16_kernel(ConvArgs a) {
     using G = Bf16Geom<TZ, TY, TX>;
     constexpr int MS = 2, NT = WAVES * 64;
@@ -1352,56 +1337,17 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
 
     const int gz0 = bz * TZ - 2, gy0 = by * TY - 2, gx0 = bx * TX - 2;
     const u32x4* wg = reinterpret_cast<const u32x4*>(a.wp);
-    using XT = XTile<G::IZ, G::IY, G::IX, NT>;
 
     u32x4 wreg[WPER];
     unsigned char* dump = smem + G::TILE_BYTES + WUNITS * 16 + (tid & 63) * 16;       // per-lane slot for masked-off stores
     auto wsrc = [&](int chunk, int dz) { return wg + ((size_t)(chunk * 125 + dz * 25) * ncob + cob0) * 64; };
     auto stage_tile = [&](int chunk) {
-        if constexpr (H) {
-            using XH = XTileH<G::IZ, G::IY, G::IX, NT>;
-            u32x4 v[XH::PER];
-            XH::template issue_part<0, XH::PER>(v, reinterpret_cast<const unsigned short*>(a.x0), reinterpret_cast<const unsigned short*>(a.x1),
-                                                a.C0, a.C1, chunk, b, gz0, gy0, gx0, a.Di, a.Hi, a.Wi, tid);
-            __builtin_amdgcn_sched_barrier(0);
-            bf16_tile_commit_h<G, XH, 0, XH::PER>(tile, dump, v, tid);
-        } else if (a.vec_in) {
-            // four batches: a quarter of the staging registers (round 4: with two, the fp32-source instantiations of this
-            // legacy bf16_operands path spilled up to 78 VGPRs -- profiles/check_isa.sh; the staging here is synchronous anyway)
-            constexpr int Q0 = XT::PER / 4, Q1 = XT::PER / 2, Q2 = (3 * XT::PER) / 4;
-#define VNET_STAGE_BATCH(K0, K1)                                                                                        \
-            if constexpr ((K1) > (K0)) {                                                                                \
-                float4 v[(K1) - (K0)];                                                                                  \
-                XT::template issue_part<(K0), (K1) - (K0)>(v, a.x0, a.x1, a.C0, a.C1, chunk, b, gz0, gy0, gx0, a.Di, a.Hi, a.Wi, tid); \
-                __builtin_amdgcn_sched_barrier(0);                                                                      \
-                bf16_tile_commit<G, XT, (K0), (K1) - (K0)>(tile, dump, v, tid);                                         \
-                __builtin_amdgcn_sched_barrier(0);                                                                      \
-            }
-            VNET_STAGE_BATCH(0, Q0)
-            VNET_STAGE_BATCH(Q0, Q1)
-            VNET_STAGE_BATCH(Q1, Q2)
-            VNET_STAGE_BATCH(Q2, XT::PER)
-#undef VNET_STAGE_BATCH
-        } else {
-            const int Cin = a.C0 + a.C1;
-            for (int q = tid; q < G::NV * 4; q += NT) {       // channel counts that are not multiples of 4
-                const int vox = q >> 2, cq = q & 3;
-                const int ix = vox % G::IX, iy = (vox / G::IX) % G::IY, iz = vox / (G::IX * G::IY);
-                const int gz = gz0 + iz, gy = gy0 + iy, gx = gx0 + ix;
-                const int c = chunk * 16 + cq * 4;
-                float e[4] = {0.f, 0.f, 0.f, 0.f};
-                if ((unsigned)gz < (unsigned)a.Di && (unsigned)gy < (unsigned)a.Hi && (unsigned)gx < (unsigned)a.Wi && c < Cin) {
-                    const size_t gv = ((size_t)(b * a.Di + gz) * a.Hi + gy) * a.Wi + gx;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int ck = c + k;
-                        if (ck < Cin) e[k] = (ck < a.C0) ? a.x0[gv * a.C0 + ck] : a.x1[gv * a.C1 + (ck - a.C0)];
-                    }
-                }
-                *reinterpret_cast<uint2*>(tile + (cq >> 1) * G::PLANE + vox * 16 + (cq & 1) * 8) =
-                    make_uint2(pk_bf16(e[0], e[1]), pk_bf16(e[2], e[3]));
-            }
-        }
+        using XH = XTileH<G::IZ, G::IY, G::IX, NT>;
+        u32x4 v[XH::PER];
+        XH::template issue_part<0, XH::PER>(v, reinterpret_cast<const unsigned short*>(a.x0), reinterpret_cast<const unsigned short*>(a.x1),
+                                            a.C0, a.C1, chunk, b, gz0, gy0, gx0, a.Di, a.Hi, a.Wi, tid);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16_tile_commit_h<G, XH, 0, XH::PER>(tile, dump, v, tid);
     };
 
     if (c_begin < c_end) {
@@ -1466,7 +1412,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int k = 0; k < 4; ++k) s1[n][g][k] = s2[n][g][k] = 0.f;
-    if constexpr (O16) {
+    {
         if (!a.part) {
             // bf16 outputs, no split-K: the four channel groups of a voxel and cout block as one batch (epilogue_b16_batch)
 #pragma unroll
@@ -1509,55 +1455,23 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
             }
         }
     }
+    if (a.part) {                              // split K: the raw fp32 partial sums; bias / accumulate / rounding / statistics belong to the reduce
 #pragma unroll
-    for (int m = 0; m < MS; ++m) {
-        if (O16 && !a.part) break;
-        const int v = (wave * MS + m) * 32 + q32;
-        const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
-        const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
-        if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
-        const size_t ov = ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+        for (int m = 0; m < MS; ++m) {
+            const int v = (wave * MS + m) * 32 + q32;
+            const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+            const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
+            if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
+            const size_t ov = ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
 #pragma unroll
-        for (int n = 0; n < NSB; ++n)
+            for (int n = 0; n < NSB; ++n)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = co0 + n * 32 + g * 8 + half * 4;
-                float e[4] = {acc[m][n][g * 4], acc[m][n][g * 4 + 1], acc[m][n][g * 4 + 2], acc[m][n][g * 4 + 3]};
-                if (a.part) {
-                    *reinterpret_cast<float4*>(a.part + blockIdx.z * a.part_stride + ov * a.CoutP + co) = make_float4(e[0], e[1], e[2], e[3]);
-                    continue;
+                for (int g = 0; g < 4; ++g) {
+                    const int co = co0 + n * 32 + g * 8 + half * 4;
+                    *reinterpret_cast<float4*>(a.part + blockIdx.z * a.part_stride + ov * a.CoutP + co) =
+                        make_float4(acc[m][n][g * 4], acc[m][n][g * 4 + 1], acc[m][n][g * 4 + 2], acc[m][n][g * 4 + 3]);
                 }
-                if (co >= a.Cout) continue;
-                if constexpr (O16) {
-                    if (a.bias) { e[0] += a.bias[co]; e[1] += a.bias[co + 1]; e[2] += a.bias[co + 2]; e[3] += a.bias[co + 3]; }
-                    epilogue4_b16<STATS>(a, ov, co, e, s1[STATS ? n : 0][g], s2[STATS ? n : 0][g]);
-                    continue;
-                }
-                if (a.vec_out && co + 3 < a.Cout) {
-                    if (a.bias) { e[0] += a.bias[co]; e[1] += a.bias[co + 1]; e[2] += a.bias[co + 2]; e[3] += a.bias[co + 3]; }
-                    if constexpr (STATS) {
-                        float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (a.res) rr = *reinterpret_cast<const float4*>(a.res + ov * a.Cout + co);
-                        const float vv[4] = {e[0] + rr.x, e[1] + rr.y, e[2] + rr.z, e[3] + rr.w};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) { s1[n][g][k] += vv[k]; s2[n][g][k] += vv[k] * vv[k]; }
-                    }
-                    float* p = (co < a.Cy0) ? a.y0 + ov * a.Cy0 + co : a.y1 + ov * a.Cy1 + (co - a.Cy0);
-                    if (a.accum) {
-                        const float4 old = *reinterpret_cast<const float4*>(a.accsrc ? a.accsrc + ov * a.Cy0 + co : p);
-                        e[0] += old.x; e[1] += old.y; e[2] += old.z; e[3] += old.w;
-                    }
-                    *reinterpret_cast<float4*>(p) = make_float4(e[0], e[1], e[2], e[3]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int ck = co + k;
-                        if (ck >= a.Cout) break;
-                        float* dst = (ck < a.Cy0) ? a.y0 + ov * a.Cy0 + ck : a.y1 + ov * a.Cy1 + (ck - a.Cy0);
-                        *dst = e[k] + (a.bias ? a.bias[ck] : 0.f) + (a.accum ? (a.accsrc ? a.accsrc[ov * a.Cy0 + ck] : *dst) : 0.f);
-                    }
-                }
-            }
+        }
     }
     if constexpr (STATS) if (!a.part) {
         // the 32 lanes of a half hold the same channels for 32 voxels: butterfly over p32, then across waves via LDS
@@ -1601,11 +1515,11 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
 // times modality c = 0..3 (an x-im2col done while the tile is committed to LDS: every loaded voxel's 8 bytes go to the four
 // units (x - sx, slot sx)), so one MFMA covers the taps dx = 0..3 of a (dz pair, dy) and a second one, at x offset 4, the tap
 // dx = 4 (its other twelve K-channels meet zero weights): 26 filter fragments and 104 MFMAs per 4 rows instead of 65 and 260.
-template <int TZ, int TY, int TX, bool STATS = false, bool H = false, bool O16 = false, bool IN4 = false>
+// (bf16 tensors in and out: the fp32-source / fp32-output template paths of rounds 2-4 were deleted in round 6)
+template <int TZ, int TY, int TX, bool STATS = false, bool IN4 = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv5_bf16_c16_kernel(ConvArgs a) {
     using G = Bf16Geom<TZ, TY, TX>;
     static_assert(TZ == 4 && TY == 8 && TX == 16, "8 waves x 4 rows of 16 voxels");
-    static_assert(!IN4 || H, "IN4 stages bf16 sources");
     constexpr int NDX = IN4 ? 2 : 5, XSTEP = IN4 ? 4 : 1;                 // x groups of a (dz pair, dy) and their tile offset
     constexpr int NT = 512, NFRAG = IN4 ? 26 : 65, FUNITS = NFRAG * 64, FPER = (FUNITS + NT - 1) / NT;
     constexpr int ROWB = G::IX * 16, PLANEB = G::IY * G::IX * 16;       // bytes per tile row / per tile z-plane (one cin half)
@@ -1633,7 +1547,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int nmine = (b_hi - b_lo - slot + G8 - 1) / G8;                // bricks b_lo + slot + i * G8
     if (b_lo + slot >= b_hi) return;
     const int nch = a.nchunks;
-    using XT = XTile<G::IZ, G::IY, G::IX, NT>;
     const u32x4* wg = reinterpret_cast<const u32x4*>(a.wp);
 
     auto brick_origin = [&](int i, int& b, int& bz, int& by, int& bx) {
@@ -1702,41 +1615,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         bi = 2 * q + (second ? 1 : 0); ch = r < 2 ? cf : 1 - cf; first = r < 2; last = r >= 2; swap = (r == 1 || r == 3);
     };
     using XH = XTileH<G::IZ, G::IY, G::IX, NT>;
-    // fp32 sources (the round-2 bf16_operands path without shadows): the prefetch goes in two halves through ONE half-sized
-    // register set -- first half at the head of the step, packed to bf16 half-way, when the second half is issued into the same
-    // registers; that one is packed at the commit.  (Round 4: with the whole fp32 tile in flight, 64 + 32 registers, these two
-    // instantiations spilled 7 / 19 VGPRs: profiles/check_isa.sh.)
-    constexpr int HP = H ? 1 : (XT::PER + 1) / 2, HQ = H ? 1 : XT::PER - HP;
-    float4 v[HP];
-    u32x2 pk[H ? 1 : XT::PER];          // (native vector type: arrays of HIP's uint2 struct are not scalarised)
-    u32x4 hv[H ? XH::PER : 1];           // H: the prefetched tile as it will sit in LDS
-    int p_b = 0, p_z = 0, p_y = 0, p_x = 0, p_ch = 0;      // (fp32 sources) origin of the tile in flight, for its second half
+    u32x4 hv[XH::PER];                   // the prefetched tile as it will sit in LDS
     auto tile_issue = [&](int bi, int ch) {
         int b, bz, by, bx;
         brick_origin(bi, b, bz, by, bx);
-        if constexpr (H)
-            XH::template issue_part<0, XH::PER>(hv, reinterpret_cast<const unsigned short*>(a.x0), reinterpret_cast<const unsigned short*>(a.x1),
-                                                a.C0, a.C1, ch, b, bz * TZ - 2, by * TY - 2, bx * TX - 2, a.Di, a.Hi, a.Wi, tid);
-        else {
-            p_b = b; p_z = bz * TZ - 2; p_y = by * TY - 2; p_x = bx * TX - 2; p_ch = ch;
-            XT::template issue_part<0, HP>(v, a.x0, a.x1, a.C0, a.C1, ch, b, p_z, p_y, p_x, a.Di, a.Hi, a.Wi, tid);
-        }
-    };
-    auto tile_pack = [&]() {            // fp32 -> bf16 (RNE) in registers; then the second half of the tile takes the registers
-        if constexpr (!H) {
-#pragma unroll
-            for (int k = 0; k < HP; ++k) pk[k] = u32x2{pk_bf16(v[k].x, v[k].y), pk_bf16(v[k].z, v[k].w)};
-            if constexpr (HQ > 0) {
-                float4 (&v2)[HQ] = *reinterpret_cast<float4 (*)[HQ]>(&v[0]);
-                XT::template issue_part<HP, HQ>(v2, a.x0, a.x1, a.C0, a.C1, p_ch, p_b, p_z, p_y, p_x, a.Di, a.Hi, a.Wi, tid);
-            }
-        }
-    };
-    auto tile_pack2 = [&]() {
-        if constexpr (!H) {
-#pragma unroll
-            for (int k = 0; k < HQ; ++k) pk[HP + k] = u32x2{pk_bf16(v[k].x, v[k].y), pk_bf16(v[k].z, v[k].w)};
-        }
+        XH::template issue_part<0, XH::PER>(hv, reinterpret_cast<const unsigned short*>(a.x0), reinterpret_cast<const unsigned short*>(a.x1),
+                                            a.C0, a.C1, ch, b, bz * TZ - 2, by * TY - 2, bx * TX - 2, a.Di, a.Hi, a.Wi, tid);
     };
     auto tile_commit = [&]() {
         if constexpr (IN4) {
@@ -1756,19 +1640,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     *reinterpret_cast<uint2*>(ok && xp >= 0 ? dst : dump) = v8;
                 }
             }
-        } else if constexpr (H) {
-            bf16_tile_commit_h<G, XH, 0, XH::PER>(tile, dump, hv, tid);
         } else {
-            tile_pack2();
-            const int r0 = tid / XT::COLS, col = tid - r0 * XT::COLS;
-            const int ix = col >> 2, cq = col & 3;
-            unsigned char* base = tile + (cq >> 1) * G::PLANE + ix * 16 + (cq & 1) * 8;
-#pragma unroll
-            for (int k = 0; k < XT::PER; ++k) {
-                const int row = r0 + k * XT::RPI;
-                const bool ok = r0 < XT::RPI && row < XT::ROWS;
-                *reinterpret_cast<u32x2*>(ok ? base + row * (G::IX * 16) : dump) = pk[k];
-            }
+            bf16_tile_commit_h<G, XH, 0, XH::PER>(tile, dump, hv, tid);
         }
     };
 
@@ -1782,7 +1655,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     filter_issue(ch);
     tile_issue(bi, ch);
     filter_commit();
-    tile_pack();
     tile_commit();
     __syncthreads();
 
@@ -1839,7 +1711,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                                                        // already cover the read latency
             }
         VNET_STAMP(2);
-        if (more) tile_pack();          // the prefetched tile has long arrived: convert now, 32 fewer live registers from here
                                         // (packing after the first dz pair and letting the second pair's reads hoist: measured 2 % slower)
         // ---- dz = 4: dy pairs (0,1), (2,3) and the single tap dy = 4 ----
         VNET_PRIO_ALT(wave < 4);                   // ... the older half for the last 60 of a step's 260 MFMAs
@@ -1867,7 +1738,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             brick_origin(bi, b, bz, by, bx);
             const int oz = bz * TZ + vz, ox = bx * TX + j, co = 4 * g;
             float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (O16) {
+            {
                 const bool colok = oz < a.Do && ox < a.Wo && co < a.Cout;
                 size_t ovs[4]; int cos[4]; bool oks[4]; float e[4][4];
 #pragma unroll
@@ -1888,27 +1759,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                             for (int k = 0; k < 4; ++k) { s1[k] += e[m][k]; s2[k] += e[m][k] * e[m][k]; }
                         }
                 }
-            }
-#pragma unroll
-            for (int m = 0; m < (O16 ? 0 : 4); ++m) {
-                const int oy = by * TY + vy0 + m;
-                if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo || co >= a.Cout) continue;
-                const size_t ov = ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
-                float e[4] = {accA[m][0], accA[m][1], accA[m][2], accA[m][3]};
-                e[0] += bias4[0]; e[1] += bias4[1]; e[2] += bias4[2]; e[3] += bias4[3];
-                if constexpr (STATS) {
-                    float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (a.res) rr = *reinterpret_cast<const float4*>(a.res + ov * a.Cout + co);
-                    const float vv[4] = {e[0] + rr.x, e[1] + rr.y, e[2] + rr.z, e[3] + rr.w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { s1[k] += vv[k]; s2[k] += vv[k] * vv[k]; }
-                }
-                float* p = (co < a.Cy0) ? a.y0 + ov * a.Cy0 + co : a.y1 + ov * a.Cy1 + (co - a.Cy0);
-                if (a.accum) {
-                    const float4 old = *reinterpret_cast<const float4*>(a.accsrc ? a.accsrc + ov * a.Cy0 + co : p);
-                    e[0] += old.x; e[1] += old.y; e[2] += old.z; e[3] += old.w;
-                }
-                *reinterpret_cast<float4*>(p) = make_float4(e[0], e[1], e[2], e[3]);
             }
             if constexpr (STATS) {
 #pragma unroll
@@ -1944,7 +1794,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 // workgroups walk (brick, cout block) items, the next tile is prefetched global -> registers during the MFMAs, and the filter
 // streams through TWO LDS plane buffers (one dz plane of one cout block each, 25 KB): one barrier per plane instead of two.
 // ------------------------------------------------------------------------------------------
-template <bool STATS = false, bool O16 = false>
+// (bf16 tensors in and out: the fp32-output template path was deleted in round 6)
+template <bool STATS = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv5_bf16_r32_kernel(ConvArgs a) {
     constexpr int TZ = 4, TY = 16, TX = 16, NT = 512;
     using G = Bf16Geom<TZ, TY, TX>;
@@ -2065,7 +1916,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) s1[g][k] = s2[g][k] = 0.f;
-            if constexpr (O16) {
+            {
                 // bf16 outputs (round 3).  (1) every load of the epilogue -- bias, the other gradient in accumulate mode, the
                 // residual of the statistics -- is in flight before the first use; (2) the packed results of channel groups
                 // (g, g+1) are exchanged between lanes L and L+32 (v_permlane32_swap), after which a lane holds 8 consecutive
@@ -2163,32 +2014,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     }
                 }
             }
-#pragma unroll
-            for (int m = 0; m < (O16 ? 0 : 4); ++m) {
-                const int oy = by * TY + vy0 + 2 * m + (q32 >> 4);
-                if (oz >= a.Do || oy >= a.Ho || ox >= a.Wo) continue;
-                const size_t ov = ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int co = co0 + g * 8 + half * 4;
-                    if (co >= a.Cout) continue;
-                    float e[4] = {acc[m][g * 4], acc[m][g * 4 + 1], acc[m][g * 4 + 2], acc[m][g * 4 + 3]};
-                    if (a.bias) { e[0] += a.bias[co]; e[1] += a.bias[co + 1]; e[2] += a.bias[co + 2]; e[3] += a.bias[co + 3]; }
-                    if constexpr (STATS) {
-                        float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (a.res) rr = *reinterpret_cast<const float4*>(a.res + ov * a.Cout + co);
-                        const float vv[4] = {e[0] + rr.x, e[1] + rr.y, e[2] + rr.z, e[3] + rr.w};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) { s1[g][k] += vv[k]; s2[g][k] += vv[k] * vv[k]; }
-                    }
-                    float* p = (co < a.Cy0) ? a.y0 + ov * a.Cy0 + co : a.y1 + ov * a.Cy1 + (co - a.Cy0);
-                    if (a.accum) {
-                        const float4 old = *reinterpret_cast<const float4*>(a.accsrc ? a.accsrc + ov * a.Cy0 + co : p);
-                        e[0] += old.x; e[1] += old.y; e[2] += old.z; e[3] += old.w;
-                    }
-                    *reinterpret_cast<float4*>(p) = make_float4(e[0], e[1], e[2], e[3]);
-                }
-            }
             if constexpr (STATS) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -2248,17 +2073,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p, int off) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TZ, int TY, int TX, int NS, int TW, bool H = false>
+// (x and dy are bf16 tensors: the fp32-source template path of rounds 2-4 was deleted in round 6)
+template <int TZ, int TY, int TX, int NS, int TW>
 __device__ __forceinline__ void wgrad5_bf16_body(const WgradArgs& a, const int bid_x, const int bid_y, const int bid_z) {
     using G = TileGeom<5, 1, TZ, TY, TX, 5>;
-    using XT = XTile<G::IZ, G::IY, G::IX, 512>;
     using XH = XTileH<G::IZ, G::IY, G::IX, 512>;
-    constexpr int NQH = TZ * TY * TX * NS * 2, PERH = (NQH + 511) / 512;     // H: 16-byte units (voxel, cout block, half) of the dy brick
+    constexpr int NQH = TZ * TY * TX * NS * 2, PERH = (NQH + 511) / 512;     // 16-byte units (voxel, cout block, half) of the dy brick
     constexpr int NV = TZ * TY * TX, T3 = 125;
     constexpr int TXP = TX + 4;                                  // dy row pitch (voxels): same bank argument as the x tile
     constexpr int XBYTES = G::NVOX_IN * 32;
     constexpr int DYPLANE = TZ * TY * TXP * 32;
-    constexpr int NQD = NV * NS * 4, PERD = (NQD + 511) / 512;
     static_assert(NV % 32 == 0 && (TX == 16 || TX == 8), "k-steps are 32 voxels: 2 rows of 16 or 4 rows of 8");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xt = smem;
@@ -2290,11 +2114,8 @@ __device__ __forceinline__ void wgrad5_bf16_body(const WgradArgs& a, const int b
 #pragma unroll
         for (int n = 0; n < NS; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const bool pre = H || (a.vec_in && a.vec_dy);
-    float4 px[H ? 1 : XT::PER];
-    float4 pd[H ? 1 : PERD];
-    u32x4 hx[H ? XH::PER : 1];
-    u32x4 hd[H ? PERH : 1];
+    u32x4 hx[XH::PER];
+    u32x4 hd[PERH];
 
     auto brick_coords = [&](int brick, int& b, int& bz, int& by, int& bx) {
         bx = brick % a.nbx; brick /= a.nbx;
@@ -2304,111 +2125,41 @@ __device__ __forceinline__ void wgrad5_bf16_body(const WgradArgs& a, const int b
     auto issue = [&](int brick) {
         int b, bz, by, bx;
         brick_coords(brick, b, bz, by, bx);
-        if constexpr (H) {
-            XH::template issue_part<0, XH::PER>(hx, reinterpret_cast<const unsigned short*>(a.x0), reinterpret_cast<const unsigned short*>(a.x1),
-                                                a.C0, a.C1, chunk, b, bz * TZ - 2, by * TY - 2, bx * TX - 2, a.Di, a.Hi, a.Wi, tid);
-            const unsigned short* dyh = reinterpret_cast<const unsigned short*>(a.dy);
+        XH::template issue_part<0, XH::PER>(hx, reinterpret_cast<const unsigned short*>(a.x0), reinterpret_cast<const unsigned short*>(a.x1),
+                                            a.C0, a.C1, chunk, b, bz * TZ - 2, by * TY - 2, bx * TX - 2, a.Di, a.Hi, a.Wi, tid);
+        const unsigned short* dyh = reinterpret_cast<const unsigned short*>(a.dy);
 #pragma unroll
-            for (int k = 0; k < PERH; ++k) {
-                const int q = tid + k * 512;
-                const int v = q / (NS * 2), cu = q - v * (NS * 2);
-                const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
-                const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
-                const int c = co0 + cu * 8;
-                const bool ok = q < NQH && oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout;
-                const size_t ov = ok ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
-                hd[k] = load16_or_zero(dyh + ov * a.Cout + (ok ? c : 0), ok);
-            }
-        } else {
-            XT::issue(px, a.x0, a.x1, a.C0, a.C1, chunk, b, bz * TZ - 2, by * TY - 2, bx * TX - 2, a.Di, a.Hi, a.Wi, tid);
-#pragma unroll
-            for (int k = 0; k < PERD; ++k) {
-                const int q = tid + k * 512;
-                const int v = q / (NS * 4), cq = q - v * (NS * 4);
-                const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
-                const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
-                const int c = co0 + cq * 4;
-                const bool ok = q < NQD && oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout;
-                const size_t ov = ok ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
-                const float4 t = *reinterpret_cast<const float4*>(a.dy + ov * a.Cout + (ok ? c : 0));
-                pd[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+        for (int k = 0; k < PERH; ++k) {
+            const int q = tid + k * 512;
+            const int v = q / (NS * 2), cu = q - v * (NS * 2);
+            const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+            const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
+            const int c = co0 + cu * 8;
+            const bool ok = q < NQH && oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout;
+            const size_t ov = ok ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
+            hd[k] = load16_or_zero(dyh + ov * a.Cout + (ok ? c : 0), ok);
         }
-    };
-    auto dy_addr = [&](int q) -> unsigned char* {
-        const int v = q / (NS * 4), cq = q - v * (NS * 4);
-        const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
-        return dyt + (cq >> 2) * DYPLANE + (((vz * TY + vy) * TXP + vx) * 32) + (cq & 3) * 8;
     };
 
-    if (pre && split < a.nbrick) issue(split);
+    if (split < a.nbrick) issue(split);
     for (int brick = split; brick < a.nbrick; brick += a.nsplit) {
         __syncthreads();
-        if constexpr (H) {
-            const int r0 = tid / XH::COLS, col = tid - r0 * XH::COLS;
+        const int r0 = tid / XH::COLS, col = tid - r0 * XH::COLS;
 #pragma unroll
-            for (int k = 0; k < XH::PER; ++k) {
-                const int row = r0 + k * XH::RPI;
-                if (r0 < XH::RPI && row < XH::ROWS)
-                    *reinterpret_cast<u32x4*>(xt + (row * G::IX + (col >> 1)) * 32 + (col & 1) * 16) = hx[k];
-            }
+        for (int k = 0; k < XH::PER; ++k) {
+            const int row = r0 + k * XH::RPI;
+            if (r0 < XH::RPI && row < XH::ROWS)
+                *reinterpret_cast<u32x4*>(xt + (row * G::IX + (col >> 1)) * 32 + (col & 1) * 16) = hx[k];
+        }
 #pragma unroll
-            for (int k = 0; k < PERH; ++k) {
-                const int q = tid + k * 512;
-                const int v = q / (NS * 2), cu = q - v * (NS * 2);
-                const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
-                if (q < NQH) *reinterpret_cast<u32x4*>(dyt + (cu >> 1) * DYPLANE + (((vz * TY + vy) * TXP + vx) * 32) + (cu & 1) * 16) = hd[k];
-            }
-        } else if (pre) {
-            const int r0 = tid / XT::COLS, col = tid - r0 * XT::COLS;
-#pragma unroll
-            for (int k = 0; k < XT::PER; ++k) {
-                const int row = r0 + k * XT::RPI;
-                if (r0 < XT::RPI && row < XT::ROWS)
-                    *reinterpret_cast<uint2*>(xt + (row * G::IX + (col >> 2)) * 32 + (col & 3) * 8) =
-                        make_uint2(pk_bf16(px[k].x, px[k].y), pk_bf16(px[k].z, px[k].w));
-            }
-#pragma unroll
-            for (int k = 0; k < PERD; ++k) {
-                const int q = tid + k * 512;
-                if (q < NQD) *reinterpret_cast<uint2*>(dy_addr(q)) = make_uint2(pk_bf16(pd[k].x, pd[k].y), pk_bf16(pd[k].z, pd[k].w));
-            }
-        } else {
-            int b, bz, by, bx;
-            brick_coords(brick, b, bz, by, bx);
-            const int Cin = a.C0 + a.C1;
-            for (int q = tid; q < G::NVOX_IN * 4; q += 512) {
-                const int vox = q >> 2, cq = q & 3;
-                const int ix = vox % G::IX, iy = (vox / G::IX) % G::IY, iz = vox / (G::IX * G::IY);
-                const int gz = bz * TZ - 2 + iz, gy = by * TY - 2 + iy, gxx = bx * TX - 2 + ix;
-                const int c = chunk * 16 + cq * 4;
-                float e[4] = {0.f, 0.f, 0.f, 0.f};
-                if ((unsigned)gz < (unsigned)a.Di && (unsigned)gy < (unsigned)a.Hi && (unsigned)gxx < (unsigned)a.Wi && c < Cin) {
-                    const size_t gv = ((size_t)(b * a.Di + gz) * a.Hi + gy) * a.Wi + gxx;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int ck = c + k;
-                        if (ck < Cin) e[k] = (ck < a.C0) ? a.x0[gv * a.C0 + ck] : a.x1[gv * a.C1 + (ck - a.C0)];
-                    }
-                }
-                *reinterpret_cast<uint2*>(xt + vox * 32 + cq * 8) = make_uint2(pk_bf16(e[0], e[1]), pk_bf16(e[2], e[3]));
-            }
-            for (int q = tid; q < NQD; q += 512) {
-                const int v = q / (NS * 4), cq = q - v * (NS * 4);
-                const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
-                const int oz = bz * TZ + vz, oy = by * TY + vy, ox = bx * TX + vx;
-                const int c = co0 + cq * 4;
-                float e[4] = {0.f, 0.f, 0.f, 0.f};
-                if (oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout) {
-                    const float* p = a.dy + (((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.Cout + c;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) if (c + k < a.Cout) e[k] = p[k];
-                }
-                *reinterpret_cast<uint2*>(dy_addr(q)) = make_uint2(pk_bf16(e[0], e[1]), pk_bf16(e[2], e[3]));
-            }
+        for (int k = 0; k < PERH; ++k) {
+            const int q = tid + k * 512;
+            const int v = q / (NS * 2), cu = q - v * (NS * 2);
+            const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
+            if (q < NQH) *reinterpret_cast<u32x4*>(dyt + (cu >> 1) * DYPLANE + (((vz * TY + vy) * TXP + vx) * 32) + (cu & 1) * 16) = hd[k];
         }
         __syncthreads();
-        if (pre && brick + a.nsplit < a.nbrick) {
+        if (brick + a.nsplit < a.nbrick) {
             issue(brick + a.nsplit);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -2459,9 +2210,9 @@ __device__ __forceinline__ void wgrad5_bf16_body(const WgradArgs& a, const int b
     }
 }
 
-template <int TZ, int TY, int TX, int NS, int TW, bool H = false>
+template <int TZ, int TY, int TX, int NS, int TW>
 __global__ void __launch_bounds__(512) wgrad5_bf16_kernel(WgradArgs a) {
-    wgrad5_bf16_body<TZ, TY, TX, NS, TW, H>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+    wgrad5_bf16_body<TZ, TY, TX, NS, TW>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2687,11 +2438,11 @@ int launch_wgrad_bf16_rr(const WgradArgs& a, int nsplit, int ncob, hipStream_t s
     return (int)hipGetLastError();
 }
 
-template <int TZ, int TY, int TX, int NS, int TW, bool H = false>
+template <int TZ, int TY, int TX, int NS, int TW>
 int launch_wgrad_bf16(const WgradArgs& a, int nsplit, int ncob, int ntg, hipStream_t st) {
     using G = TileGeom<5, 1, TZ, TY, TX, 5>;
     const size_t lds = (size_t)G::NVOX_IN * 32 + (size_t)NS * TZ * TY * (TX + 4) * 32;
-    auto k = wgrad5_bf16_kernel<TZ, TY, TX, NS, TW, H>;
+    auto k = wgrad5_bf16_kernel<TZ, TY, TX, NS, TW>;
     static unsigned long long attr_done = 0;
     if (int ae = ensure_lds(k, lds, attr_done)) return ae;
     dim3 grid(nsplit, (a.CinP / 16) * ncob, ntg);
@@ -2767,27 +2518,19 @@ bool conv_bf16_use_r32(int Cout, int Cy0, int Cy1, int B, int D, int H, int W) {
     return (long)B * ceil_div(D, 4) * ceil_div(H, 16) * ceil_div(W, 16) * (Cout / 32) >= 256;
 }
 
-template <int TZ, int TY, int TX, int WAVES, bool STATS = false, bool H = false, bool O16 = false>
+template <int TZ, int TY, int TX, int WAVES, bool STATS = false>
 int launch_conv_bf16(const ConvArgs& a, const Bf16Plan& p, hipStream_t st) {
     using G = Bf16Geom<TZ, TY, TX>;
     dim3 grid(a.B * p.nbz * p.nby * p.nbx, p.ncobg, p.nsplit * p.nz), block(WAVES * 64);
 #define VNET_GO(NSBV)                                                                             \
     {                                                                                             \
-        auto k = conv5_bf16_kernel<TZ, TY, TX, NSBV, WAVES, STATS, H, O16>;                       \
+        auto k = conv5_bf16_kernel<TZ, TY, TX, NSBV, WAVES, STATS>;                       \
         const size_t lds = (size_t)G::TILE_BYTES + (size_t)25 * NSBV * 1024 + 16 + 64 * 16;       \
         static unsigned long long attr_done = 0;                                                  \
         if (int ae = ensure_lds(k, lds, attr_done)) return ae;                                    \
         hipLaunchKernelGGL(k, grid, block, lds, st, a);                                           \
     }
-    if constexpr (!H) {
-        // fp32 sources (the round-2 bf16_operands path without shadows): one cout block per workgroup only -- the two-block
-        // instantiations spilled 2..78 VGPRs next to the fp32 staging registers (profiles/check_isa.sh).  Every output still sums
-        // its products in the same order, so the results do not change.
-        grid.y = p.ncobg * p.nsb;
-        VNET_GO(1)
-    } else {
-        if (p.nsb == 2) VNET_GO(2) else VNET_GO(1)
-    }
+    if (p.nsb == 2) VNET_GO(2) else VNET_GO(1)
 #undef VNET_GO
     return (int)hipGetLastError();
 }
@@ -2844,15 +2587,14 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
 }  // namespace
 #include "conv_c16pp.h"
 namespace {
-// kernel choice of the bf16-operand 5^3 convolution (HS: bf16 sources, O16: bf16 outputs); -1 = launched, nothing to reduce
-template <bool HS, bool O16 = false>
-int conv_fwd_bf16_go(ConvArgs& a, const Bf16Plan& p, int nslab, int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W, hipStream_t st) {
+// kernel choice of the bf16-storage 5^3 convolution (bf16 tensors in and out); -1 = launched, nothing to reduce
+inline int conv_fwd_bf16_go(ConvArgs& a, const Bf16Plan& p, int nslab, int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W, hipStream_t st) {
     if (conv_bf16_use_c16(a.Cin, a.Cout, C0, C1, Cy0, Cy1, B, D, H, W)) {
         // 16 output channels at a size with enough bricks for one persistent workgroup per CU: no padding to 32 cout
         using GC = Bf16Geom<4, 8, 16>;
         a.nbz = ceil_div(D, 4); a.nby = ceil_div(H, 8); a.nbx = ceil_div(W, 16);
         const size_t lds = (size_t)GC::TILE_BYTES + 65 * 1024 + 64 * 16 + 8 * 32 * 4;
-        if constexpr (HS && O16) {
+        {
             if (!a.in4 && conv_bf16_use_c16pp(a.Cin, a.Cout, C0, C1, Cy0, Cy1, B, D, H, W)) {
                 // filter out of LDS, two 4-wave workgroups per CU (conv_c16pp.h): the same 4x8x16 bricks
                 const int grid = 2 * (device_cus() / 8) * 8;
@@ -2872,12 +2614,12 @@ int conv_fwd_bf16_go(ConvArgs& a, const Bf16Plan& p, int nslab, int C0, int C1, 
             }
             if (a.in4) {              // the multi-modality network input: x-im2col in LDS, 2.5x fewer MFMAs
                 if (a.stats) {
-                    auto k = conv5_bf16_c16_kernel<4, 8, 16, true, true, true, true>;
+                    auto k = conv5_bf16_c16_kernel<4, 8, 16, true, true>;
                     static unsigned long long attr_done = 0;
                     if (int ae = ensure_lds(k, lds, attr_done)) return ae;
                     hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, st, a);
                 } else {
-                    auto k = conv5_bf16_c16_kernel<4, 8, 16, false, true, true, true>;
+                    auto k = conv5_bf16_c16_kernel<4, 8, 16, false, true>;
                     static unsigned long long attr_done = 0;
                     if (int ae = ensure_lds(k, lds, attr_done)) return ae;
                     hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, st, a);
@@ -2887,12 +2629,12 @@ int conv_fwd_bf16_go(ConvArgs& a, const Bf16Plan& p, int nslab, int C0, int C1, 
             }
         }
         if (a.stats) {
-            auto k = conv5_bf16_c16_kernel<4, 8, 16, true, HS, O16>;
+            auto k = conv5_bf16_c16_kernel<4, 8, 16, true>;
             static unsigned long long attr_done = 0;
             if (int ae = ensure_lds(k, lds, attr_done)) return ae;
             hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, st, a);
         } else {
-            auto k = conv5_bf16_c16_kernel<4, 8, 16, false, HS, O16>;
+            auto k = conv5_bf16_c16_kernel<4, 8, 16, false>;
             static unsigned long long attr_done = 0;
             if (int ae = ensure_lds(k, lds, attr_done)) return ae;
             hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, st, a);
@@ -2900,19 +2642,19 @@ int conv_fwd_bf16_go(ConvArgs& a, const Bf16Plan& p, int nslab, int C0, int C1, 
         VNET_LAUNCH_CHECK();
         return -1;            // done, no reduce
     }
-    if constexpr (HS) {
+    {
         if (conv_bf16_use_r32(a.Cout, Cy0, Cy1, B, D, H, W) && nslab == 1) {
             // 32-cout blocks, many bricks, bf16 shadows: the row-pair kernel (11 B + 5 A fragments per 20 MFMAs)
             using GR = Bf16Geom<4, 16, 16>;
             a.nbz = ceil_div(D, 4); a.nby = ceil_div(H, 16); a.nbx = ceil_div(W, 16);
             const size_t lds = (size_t)GR::TILE_BYTES + 2 * (25 * 1024 + 16) + 64 * 16 + 16 * 64 * 4;
             if (a.stats) {
-                auto k = conv5_bf16_r32_kernel<true, O16>;
+                auto k = conv5_bf16_r32_kernel<true>;
                 static unsigned long long attr_done = 0;
                 if (int ae = ensure_lds(k, lds, attr_done)) return ae;
                 hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, st, a);
             } else {
-                auto k = conv5_bf16_r32_kernel<false, O16>;
+                auto k = conv5_bf16_r32_kernel<false>;
                 static unsigned long long attr_done = 0;
                 if (int ae = ensure_lds(k, lds, attr_done)) return ae;
                 hipLaunchKernelGGL(k, dim3(256), dim3(512), lds, st, a);
@@ -2922,10 +2664,10 @@ int conv_fwd_bf16_go(ConvArgs& a, const Bf16Plan& p, int nslab, int C0, int C1, 
         }
     }
     return (a.stats && nslab == 1)
-         ? (p.small ? launch_conv_bf16<8, 8, 8, 8, true, HS, O16>(a, p, st)
-            : p.half ? launch_conv_bf16<4, 8, 8, 4, true, HS, O16>(a, p, st) : launch_conv_bf16<4, 8, 16, 8, true, HS, O16>(a, p, st))
-         : (p.small ? launch_conv_bf16<8, 8, 8, 8, false, HS, O16>(a, p, st)
-            : p.half ? launch_conv_bf16<4, 8, 8, 4, false, HS, O16>(a, p, st) : launch_conv_bf16<4, 8, 16, 8, false, HS, O16>(a, p, st));
+         ? (p.small ? launch_conv_bf16<8, 8, 8, 8, true>(a, p, st)
+            : p.half ? launch_conv_bf16<4, 8, 8, 4, true>(a, p, st) : launch_conv_bf16<4, 8, 16, 8, true>(a, p, st))
+         : (p.small ? launch_conv_bf16<8, 8, 8, 8, false>(a, p, st)
+            : p.half ? launch_conv_bf16<4, 8, 8, 4, false>(a, p, st) : launch_conv_bf16<4, 8, 16, 8, false>(a, p, st));
 }
 
 }  // namespace
