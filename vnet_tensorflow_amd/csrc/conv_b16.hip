@@ -127,7 +127,7 @@ static int conv_fwd_b16_impl(const void* x0, int C0, const void* x1, int C1, con
         if (!ws || ws_bytes < need) return VNET_E_WORKSPACE;
         a.part = reinterpret_cast<float*>(ws); a.part_stride = nvox * a.CoutP;
     }
-    const int e = dp.use ? launch_conv_deep(a, dp, st) : conv_fwd_bf16_go(a, p, nslab, C0, C1, Cy0, Cy1, B, D, H, W, st);
+    const int e = dp.use ? launch_conv_deep(a, dp, st) : conv_fwd_bf16_go<>(a, p, nslab, C0, C1, Cy0, Cy1, B, D, H, W, st);
     if (e == -1) return VNET_OK;
     if (e) return e;
     if (nslab > 1) {

@@ -2588,7 +2588,9 @@ int launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
 #include "conv_c16pp.h"
 namespace {
 // kernel choice of the bf16-storage 5^3 convolution (bf16 tensors in and out); -1 = launched, nothing to reduce
-inline int conv_fwd_bf16_go(ConvArgs& a, const Bf16Plan& p, int nslab, int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W, hipStream_t st) {
+// (a template so that only the translation unit that calls it instantiates the kernels)
+template <int UNIT = 0>
+int conv_fwd_bf16_go(ConvArgs& a, const Bf16Plan& p, int nslab, int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W, hipStream_t st) {
     if (conv_bf16_use_c16(a.Cin, a.Cout, C0, C1, Cy0, Cy1, B, D, H, W)) {
         // 16 output channels at a size with enough bricks for one persistent workgroup per CU: no padding to 32 cout
         using GC = Bf16Geom<4, 8, 16>;
