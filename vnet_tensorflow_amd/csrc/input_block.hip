@@ -488,24 +488,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 }
 
-// G[q] = sum over the workgroups' slabs, fixed order: a block = 32 outputs x 8 slab groups (group g takes slabs g, g + 8, ...: up to 64
-// loads per thread, sixteen in flight), the groups meet in LDS.  (One thread per output walking all 512 slabs: 41 us of load latency.)
+// G[q] = sum over the workgroups' slabs in a FIXED association: four interleaved partial sums (slabs k = u mod 4, in increasing order; the
+// leftover slabs of a count that is no multiple of 4 go to partial 0), then (s0 + s1) + (s2 + s3).  A block = 64 outputs x the 4 partial
+// sums, one thread each with sixteen loads in flight; the partials meet in LDS.  (One thread per output walking all 512 slabs alone: 41 us
+// of load latency; the association is the one of that first version, so the results are bit-identical to it.)
 __global__ void __launch_bounds__(256) input_wgrad_reduce_kernel(const float* __restrict__ part, int nslab, int n, float* __restrict__ G) {
-    __shared__ float sh[8][32];
-    const int ql = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int q = blockIdx.x * 32 + ql;
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    __shared__ float sh[4][64];
+    const int ql = threadIdx.x & 63, u = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + ql;
+    float s = 0.f;
     if (q < n) {
-        int k = grp;
-        for (; k + 24 < nslab; k += 32) {
+        const int nmain = nslab & ~3;
+        int k = u;
+        for (; k + 60 < nmain; k += 64) {
+            float t[16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) s[u] += part[(size_t)(k + 8 * u) * n + q];
+            for (int j = 0; j < 16; ++j) t[j] = part[(size_t)(k + 4 * j) * n + q];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s += t[j];
         }
-        for (; k < nslab; k += 8) s[0] += part[(size_t)k * n + q];
+        for (; k < nmain; k += 4) s += part[(size_t)k * n + q];
+        if (u == 0) for (k = nmain; k < nslab; ++k) s += part[(size_t)k * n + q];
     }
-    sh[grp][ql] = (s[0] + s[1]) + (s[2] + s[3]);
+    sh[u][ql] = s;
     __syncthreads();
-    if (grp == 0 && q < n) G[q] = ((sh[0][ql] + sh[1][ql]) + (sh[2][ql] + sh[3][ql])) + ((sh[4][ql] + sh[5][ql]) + (sh[6][ql] + sh[7][ql]));
+    if (u == 0 && q < n) G[q] = (sh[0][ql] + sh[1][ql]) + (sh[2][ql] + sh[3][ql]);
 }
 
 }  // namespace
@@ -579,7 +586,7 @@ int vnet_input_wgrad_direct(const float* img, const float* dy, float* G, int O, 
         hipLaunchKernelGGL(input_wgrad_direct_kernel<8>, dim3(grid), dim3(256), lds, st, img, dy, part, B, D, H, W, nbz, nby, nbx);
     }
     VNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(input_wgrad_reduce_kernel, dim3(ceil_div(n, 32)), dim3(256), 0, st, part, grid, n, G);
+    hipLaunchKernelGGL(input_wgrad_reduce_kernel, dim3(ceil_div(n, 64)), dim3(256), 0, st, part, grid, n, G);
     VNET_LAUNCH_CHECK();
     return VNET_OK;
 }
