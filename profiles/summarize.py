@@ -38,7 +38,7 @@ FAMILIES = {
     # (round 5: forward 16->16 / 32->16 with statistics take conv5_bf16_c16pp_kernel<true> -- persistent grid, the 4->16 input conv stays on the
     #  x-im2col instantiation of the c16 kernel: the 32->16 launch is the LONGEST of its kernel in a step)
     "bf16": ("c5", [("fwd", "conv5_bf16_c16pp_kernel<true>", None, "longest"),
-                    ("bwd", "conv5_bf16_r32_kernel<false, true>", None, 0),
+                    ("bwd", "conv5_bf16_r32_kernel<false", None, 0),       # (round 6: the O16 template argument is gone)
                     ("wgrad", "wgrad5_bf16_rr_kernel<4, false>", None, 0)]),
 }
 
