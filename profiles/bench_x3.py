@@ -1,5 +1,5 @@
 """Micro-benchmark of the f32x3 convolution kernel against the fp32-MFMA kernel on the shapes VERDICT r4 #1 names.
-python profiles/bench_x3.py [reps]"""
+python profiles/bench_x3.py [reps] [P,ci,co ...]      (e.g. 50 8,256,256 16,128,128: the deep levels)"""
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -7,7 +7,7 @@ from vnet_tensorflow_amd import ops
 
 dev = torch.device("cuda", 0)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-shapes = [(128, 32, 16), (128, 16, 32), (128, 16, 16), (64, 32, 32), (64, 64, 32), (64, 32, 64), (32, 64, 64), (32, 128, 64), (32, 64, 128)]
+shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[2:]] or [(128, 32, 16), (128, 16, 32), (128, 16, 16), (64, 32, 32), (64, 64, 32), (64, 32, 64), (32, 64, 64), (32, 128, 64), (32, 64, 128)]
 for P, ci, co in shapes:
     x = torch.randn(1, P, P, P, ci, device=dev)
     w = (torch.randn(5, 5, 5, ci, co, device=dev) * 0.05).requires_grad_(False)

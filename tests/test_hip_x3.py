@@ -30,6 +30,12 @@ def split3():
     (1, 2, 8, 40, 48, 0, 32),      # three chunks, ragged x
     (1, 8, 8, 16, 128, 0, 32),     # few items, eight chunks: the chunks split over four workgroups per item (partial slabs + reduce)
     (1, 4, 16, 16, 32, 32, 32),    # K split with two sources
+    # volumes exactly 8 wide (the 8^3 level): the narrow brick 4 x 8 x 8 -- lanes 8..15 of a column block are the plane two further
+    (1, 8, 8, 8, 32, 0, 32),       # whole bricks, two chunks (the second runs negated), two cout blocks
+    (2, 6, 10, 8, 16, 16, 48),     # ragged depth and height, two sources, batch 2
+    (1, 3, 5, 8, 16, 0, 16),       # smaller than one brick
+    (1, 8, 8, 8, 128, 0, 64),      # eight chunks split over four workgroups per item (partial slabs + reduce)
+    (1, 9, 8, 8, 48, 0, 16),       # three chunks, a last brick with one plane
 ])
 def test_conv5_x3(dev, split3, shape):
     ops = split3
@@ -73,12 +79,14 @@ def test_x3_wide_dynamic_range(dev, split3):
     assert rel_l2(y.cpu().numpy(), y_ref) < 2e-6
 
 
-def test_x3_epilogue_statistics_accumulate_and_residual(dev, split3):
-    """The batch-norm partial sums of the epilogue (rows per 2x8x16 brick), the residual in front of them, and y += conv."""
+@pytest.mark.parametrize("W", [20, 8])
+def test_x3_epilogue_statistics_accumulate_and_residual(dev, split3, W):
+    """The batch-norm partial sums of the epilogue (rows per 2x8x16 brick; per 4x8x8 brick in a volume 8 wide), the residual in front of
+    them, and y += conv."""
     ops = split3
     from vnet_tensorflow_amd import _lib
     L = _lib.lib()
-    B, D, H, W, C, Co = 1, 5, 9, 20, 32, 32
+    B, D, H, C, Co = 1, 5, 9, 32, 32
     rng = np.random.default_rng(3)
     x = rng.standard_normal((B, D, H, W, C)); w = rng.standard_normal((5, 5, 5, C, Co)) * 0.1
     b = rng.standard_normal(Co); r = rng.standard_normal((B, D, H, W, Co)); y_old = rng.standard_normal((B, D, H, W, Co))
@@ -86,7 +94,7 @@ def test_x3_epilogue_statistics_accumulate_and_residual(dev, split3):
     tx, tw, tb, tr = g(x, dev), g(w, dev), g(b, dev), g(r, dev)
     wp = ops.packed_weights(tw, ops.PACK_FWD_X3, 125, C, Co)
     rows = L.vnet_conv_x3_stats_rows(C, Co, B, D, H, W)
-    assert rows == 3 * 2 * 2
+    assert rows == (3 * 2 * 2 if W == 20 else 2 * 2 * 1)
     stats = torch.full((rows, 2 * Co), float("nan"), device=dev)
     y = torch.empty((B, D, H, W, Co), device=dev)
     ops._conv_x3_call(tx, None, wp, tb, y, None, (D, H, W), stats=stats, res=tr)

@@ -31,11 +31,29 @@ namespace {
 constexpr int X3_TZ = 2, X3_TY = 8, X3_TX = 16;
 constexpr int X3_IZ = X3_TZ + 4, X3_IY = X3_TY + 4, X3_IX = X3_TX + 4;
 constexpr int X3_NV = X3_IZ * X3_IY * X3_IX;             // 1440 tile voxels
-constexpr int X3_PLANEB = X3_NV * 16;                    // one (piece, cin half) plane: 23040 B (a multiple of 256: bank-neutral)
-constexpr int X3_PIECEB = 2 * X3_PLANEB;
-constexpr int X3_TILEB = 3 * X3_PIECEB;                  // 138240
-constexpr int X3_ROWB = X3_IX * 16, X3_ZB = X3_IY * X3_IX * 16;
-constexpr int X3_LDS = X3_TILEB + 2 * 8 * 32 * 4;        // + epilogue statistics [NB <= 2][8 waves][32]
+
+// Tile geometry of the convolution kernel.
+//   W8 = false: brick 2 x 8 x 16, tile 6 x 12 x 20 voxels; the 16 voxels of an MFMA column block are 16 consecutive x.
+//   W8 = true (round 6: volumes exactly 8 voxels wide -- the 8^3 level): brick 4 x 8 x 8.  The 16 voxels of a column block are
+//     8 x of plane z and the same 8 x of plane z + 2: lanes 8..15 read the tile two planes further.  Everything else -- tap pairs,
+//     K split over the waves, y-sliding reuse, the reduction -- is the same code on other constants.  Tile 8 x 12 x 12 voxels; the plane
+//     pitch carries 64 bytes of padding so that the two 8-lane halves of a ds_read_b128 service group (lanes 0-3 | 12-15 | 20-27) sit
+//     128 bytes apart modulo 256: conflict-free like the contiguous 16-lane row of the wide brick.
+template <bool W8>
+struct X3G {
+    static constexpr int TZ = W8 ? 4 : 2;
+    static constexpr int IZ = TZ + 4, IY = X3_IY, IX = W8 ? 12 : X3_IX;
+    static constexpr int ROWB = IX * 16;
+    static constexpr int ZB = IY * ROWB + (W8 ? 64 : 0);
+    static constexpr int PLANEB = IZ * ZB;               // one (piece, cin half) plane: 23040 B / 18944 B (multiples of 256: bank-neutral)
+    static constexpr int PIECEB = 2 * PLANEB;
+    static constexpr int TILEB = 3 * PIECEB;             // 138240 / 113664
+    static constexpr int LDS = TILEB + 2 * 8 * 32 * 4;   // + epilogue statistics [NB <= 2][8 waves][32]
+    static constexpr int SPER = W8 ? 8 : 12;             // staging loads per thread and tile
+};
+static_assert(X3G<false>::PLANEB == X3_NV * 16 && X3G<false>::PLANEB % 256 == 0 && X3G<true>::PLANEB % 256 == 0, "tile planes");
+static_assert((2 * X3G<true>::ZB) % 256 == 128, "lanes 8..15 of the narrow brick: the other half of the 256-byte bank row");
+constexpr int X3_LDS = X3G<false>::LDS;
 
 // Compile-time loop: body(std::integral_constant<int, k>) for k = 0 .. N - 1.  NOT `#pragma unroll`: when hipcc's IndVarSimplify visits
 // a not-yet-unrolled loop it sinks every side-effect-free instruction of the loop's preheader that the loop does not use to behind the
@@ -67,10 +85,11 @@ __device__ __forceinline__ void x3_load_a1(bf16x8 (&A)[3], const u32x4* __restri
     });
 }
 
+template <typename G>
 __device__ __forceinline__ void x3_read_b(bf16x8 (&B)[3], const unsigned char* p) {
     B[0] = *reinterpret_cast<const bf16x8*>(p);
-    B[1] = *reinterpret_cast<const bf16x8*>(p + X3_PIECEB);
-    B[2] = *reinterpret_cast<const bf16x8*>(p + 2 * X3_PIECEB);
+    B[1] = *reinterpret_cast<const bf16x8*>(p + G::PIECEB);
+    B[2] = *reinterpret_cast<const bf16x8*>(p + 2 * G::PIECEB);
 }
 
 // the six products of one (A pair, B row): piece indices (A, B); small terms first
@@ -80,15 +99,15 @@ __device__ __forceinline__ void x3_read_b(bf16x8 (&B)[3], const unsigned char* p
 // taps (dz pair, dy = DY0 .. DY0 + NDY - 1, dx) on the 8 output rows of this wave's plane: tile rows jr = DY0 .. DY0 + NDY + 6, row jr
 // feeds output row m = jr - dy.  bz: lane base + plane pair + dx.
 // (A0: index of the first of the NDY pairs in A -- slices of a larger register array without a cast, which would send it to scratch)
-template <int DY0, int NDY, int A0 = 0, int NA = NDY>
+template <typename G, int DY0, int NDY, int A0 = 0, int NA = NDY>
 __device__ __forceinline__ void x3_zrows(f32x4 (&acc)[8], const unsigned char* bz, const bf16x8 (&A)[NA][3]) {
     constexpr int J0 = DY0, J1 = DY0 + NDY + 7;
     bf16x8 Bn[3];
-    x3_read_b(Bn, bz + J0 * X3_ROWB);
+    x3_read_b<G>(Bn, bz + J0 * G::ROWB);
     x3_for<J1 - J0>([&](auto JI) {
         constexpr int jr = J0 + decltype(JI)::value;
         bf16x8 B[3] = {Bn[0], Bn[1], Bn[2]};
-        if constexpr (jr + 1 < J1) x3_read_b(Bn, bz + (jr + 1) * X3_ROWB);
+        if constexpr (jr + 1 < J1) x3_read_b<G>(Bn, bz + (jr + 1) * G::ROWB);
         __builtin_amdgcn_sched_barrier(0);
         x3_for<6 * NDY>([&](auto KI) {
             constexpr int k = decltype(KI)::value / NDY, d = decltype(KI)::value % NDY, m = jr - DY0 - d;
@@ -100,14 +119,14 @@ __device__ __forceinline__ void x3_zrows(f32x4 (&acc)[8], const unsigned char* b
 }
 
 // plane dz = 4 of column dx: pairs (dy 0|1), (dy 2|3) from row-pair fragments (lanes 32..63 one row further): A[A0], A[A0 + 1]
-template <int A0, int NA>
+template <typename G, int A0, int NA>
 __device__ __forceinline__ void x3_yrows_pairs(f32x4 (&acc)[8], const unsigned char* by, const bf16x8 (&A)[NA][3]) {
     bf16x8 Bn[3];
-    x3_read_b(Bn, by);
+    x3_read_b<G>(Bn, by);
     x3_for<10>([&](auto KI) {                       // row pair (k | k + 1): output row k with q = 0, row k - 2 with q = 1
         constexpr int k = decltype(KI)::value;
         bf16x8 B[3] = {Bn[0], Bn[1], Bn[2]};
-        if constexpr (k + 1 < 10) x3_read_b(Bn, by + (k + 1) * X3_ROWB);
+        if constexpr (k + 1 < 10) x3_read_b<G>(Bn, by + (k + 1) * G::ROWB);
         __builtin_amdgcn_sched_barrier(0);
         x3_for<6>([&](auto TI) {
             constexpr int t = decltype(TI)::value;
@@ -118,14 +137,14 @@ __device__ __forceinline__ void x3_yrows_pairs(f32x4 (&acc)[8], const unsigned c
     });
 }
 // tap (4, 4, dx) alone (the filter's second half is zero): single rows m + 4, both lane halves read the same row: A[A0]
-template <int A0, int NA>
+template <typename G, int A0, int NA>
 __device__ __forceinline__ void x3_yrows_single(f32x4 (&acc)[8], const unsigned char* b0, const bf16x8 (&A)[NA][3]) {
     bf16x8 Bn[3];
-    x3_read_b(Bn, b0 + 4 * X3_ROWB);
+    x3_read_b<G>(Bn, b0 + 4 * G::ROWB);
     x3_for<8>([&](auto MI) {
         constexpr int m = decltype(MI)::value;
         bf16x8 B[3] = {Bn[0], Bn[1], Bn[2]};
-        if constexpr (m + 1 < 8) x3_read_b(Bn, b0 + (m + 5) * X3_ROWB);
+        if constexpr (m + 1 < 8) x3_read_b<G>(Bn, b0 + (m + 5) * G::ROWB);
         __builtin_amdgcn_sched_barrier(0);
         x3_for<6>([&](auto TI) {
             constexpr int t = decltype(TI)::value;
@@ -138,24 +157,27 @@ __device__ __forceinline__ void x3_yrows_single(f32x4 (&acc)[8], const unsigned 
 // NB: 16-cout blocks per item (1 or 2).  With two, a step runs the four pieces twice on the SAME tile -- once per block, one block's
 // accumulators and filter fragments at a time -- so the tile commit, its two barriers and the item's reduction are paid once per
 // 2 x 6240 MFMAs instead of once per 6240.
-template <bool STATS, int NB>
+template <bool STATS, int NB, bool W8 = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv5_x3_kernel(ConvArgs a) {
     constexpr int NT = 512;
-    using XT = XTile<X3_IZ, X3_IY, X3_IX, NT>;
-    static_assert(XT::PER * XT::RPI == XT::ROWS, "every staging pass covers whole tile rows");
+    using G = X3G<W8>;
+    using XT = XTile<X3_IZ, X3_IY, X3_IX, NT>;              // (staging shape of the wide brick)
+    static_assert(XT::PER * XT::RPI == XT::ROWS && XT::PER == X3G<false>::SPER, "every staging pass covers whole tile rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* tile = smem;
     float* red = reinterpret_cast<float*>(smem);                              // after an item's K loop: [8 waves][NB][8 rows][64 lanes][4]
-    float* sred = reinterpret_cast<float*>(smem + X3_TILEB);                  // [8 waves][2 x 16] epilogue statistics
+    float* sred = reinterpret_cast<float*>(smem + G::TILEB);                  // [8 waves][2 x 16] epilogue statistics
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4, half = g & 1, hi = g >> 1;
     const int grp = wave >> 2, kw = wave & 3;
 
-    const int base0 = half * X3_PLANEB + ((grp * X3_IY) * X3_IX + j) * 16;
-    const unsigned char* bZ = tile + base0 + hi * X3_ZB;                      // taps (dz, dz + 1)
-    const unsigned char* bY = tile + base0 + hi * X3_ROWB + 4 * X3_ZB;        // taps (4, dy), (4, dy + 1)
-    const unsigned char* b0 = tile + base0 + 4 * X3_ZB;                       // tap (4, 4)
+    // (narrow brick: lanes 8..15 of a column block are the plane two further)
+    const int base0 = W8 ? half * G::PLANEB + (grp + 2 * (j >> 3)) * G::ZB + (j & 7) * 16
+                         : half * G::PLANEB + ((grp * G::IY) * G::IX + j) * 16;
+    const unsigned char* bZ = tile + base0 + hi * G::ZB;                      // taps (dz, dz + 1)
+    const unsigned char* bY = tile + base0 + hi * G::ROWB + 4 * G::ZB;        // taps (4, dy), (4, dy + 1)
+    const unsigned char* b0 = tile + base0 + 4 * G::ZB;                       // tap (4, 4)
 
     const int ncob = a.CoutP >> 4, ncobg = ncob / NB;                         // 16-cout blocks; groups of NB blocks = items per brick
     const int nbrick = a.B * a.nbz * a.nby * a.nbx;
@@ -184,12 +206,16 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     // element offset; out-of-volume units load a device zero line -- a select on the ADDRESS: a select on the data makes hipcc wait
     // for the whole tile right where it was issued (s_memtime stamps: 4 K cycles in front of every step's first MFMA).
     typedef const __attribute__((address_space(1))) f32x4* gf4_t;
-    f32x4 pv[XT::PER];
+    f32x4 pv[G::SPER];
     // (480 threads cover the 6 x 80 columns of a pass; the last 32 repeat the work of the 32 threads one row block before them -- same
     //  loads, same stores -- instead of being masked: a per-row select on the store address is loop-invariant, and hipcc hoists all 36
     //  of them out of the step loop and spills them)
-    const int stid = tid < XT::RPI * XT::COLS ? tid : tid - XT::COLS;
-    const int sr0 = stid / XT::COLS, scol = stid - sr0 * XT::COLS;
+    // Narrow brick: only the 8 x 4 (x, channel quad) columns inside the volume are staged (the x halo of a volume exactly 8 wide is
+    // zero for every brick: written once per item, zero_halo below); a pass is one whole tile plane = 12 rows x 32 columns = 384 threads,
+    // the last 128 repeat the 128 in front of them; pass k is plane k.
+    const int stid = W8 ? (tid < 384 ? tid : tid - 128) : (tid < XT::RPI * XT::COLS ? tid : tid - XT::COLS);
+    constexpr int SCOLS = W8 ? 32 : XT::COLS;
+    const int sr0 = stid / SCOLS, scol = stid - sr0 * SCOLS;
     const int six = scol >> 2, scq = scol & 3;
     auto tile_issue = [&](int step) {
         const int it = step / nch, ch = ((i_lo + slot + it * G8) % nks) * nch + (step - it * nch);
@@ -199,21 +225,36 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         const bool first = c0 < a.C0;
         const int cs = first ? a.C0 : a.C1;
         const float* src = (first ? a.x0 + c0 : a.x1 + (c0 - a.C0)) + (size_t)b * a.Di * a.Hi * a.Wi * cs;
-        const int gz0 = bz * X3_TZ - 2, gy = by * X3_TY - 2 + sr0, gx = bx * X3_TX - 2 + six;
-        const bool xok = (unsigned)gx < (unsigned)a.Wi;
-        const bool yok0 = xok && (unsigned)gy < (unsigned)a.Hi, yok1 = xok && (unsigned)(gy + 6) < (unsigned)a.Hi;
-        const int rs = a.Wi * cs;
-        const int off0 = (gy * a.Wi + gx) * cs + scq * 4;
-        x3_for<XT::PER>([&](auto KI) {
-            constexpr int k = decltype(KI)::value;
-            const int gz = gz0 + (k >> 1);
-            const bool ok = ((k & 1) ? yok1 : yok0) && (unsigned)gz < (unsigned)a.Di;
-            const int off = off0 + gz * a.Hi * rs + (k & 1) * 6 * rs;
-            gf4_t p = ok ? (gf4_t)(src + off) : (gf4_t)(vnet_zero_line);
-            pv[k] = *p;
-        });
+        if constexpr (W8) {
+            const int gz0 = bz * G::TZ - 2, gy = by * X3_TY - 2 + sr0;
+            const bool yok = (unsigned)gy < (unsigned)a.Hi;
+            const int rs = a.Wi * cs;
+            const int off0 = (gy * a.Wi + six) * cs + scq * 4;
+            x3_for<G::SPER>([&](auto KI) {
+                constexpr int k = decltype(KI)::value;
+                const int gz = gz0 + k;
+                const bool ok = yok && (unsigned)gz < (unsigned)a.Di;
+                const int off = off0 + gz * a.Hi * rs;
+                gf4_t p = ok ? (gf4_t)(src + off) : (gf4_t)(vnet_zero_line);
+                pv[k] = *p;
+            });
+        } else {
+            const int gz0 = bz * X3_TZ - 2, gy = by * X3_TY - 2 + sr0, gx = bx * X3_TX - 2 + six;
+            const bool xok = (unsigned)gx < (unsigned)a.Wi;
+            const bool yok0 = xok && (unsigned)gy < (unsigned)a.Hi, yok1 = xok && (unsigned)(gy + 6) < (unsigned)a.Hi;
+            const int rs = a.Wi * cs;
+            const int off0 = (gy * a.Wi + gx) * cs + scq * 4;
+            x3_for<XT::PER>([&](auto KI) {
+                constexpr int k = decltype(KI)::value;
+                const int gz = gz0 + (k >> 1);
+                const bool ok = ((k & 1) ? yok1 : yok0) && (unsigned)gz < (unsigned)a.Di;
+                const int off = off0 + gz * a.Hi * rs + (k & 1) * 6 * rs;
+                gf4_t p = ok ? (gf4_t)(src + off) : (gf4_t)(vnet_zero_line);
+                pv[k] = *p;
+            });
+        }
     };
-    const unsigned cbase = (unsigned)((scq >> 1) * X3_PLANEB + six * 16 + (scq & 1) * 8 + sr0 * X3_ROWB);
+    const unsigned cbase = (unsigned)((scq >> 1) * G::PLANEB + (six + (W8 ? 2 : 0)) * 16 + (scq & 1) * 8 + sr0 * G::ROWB);
     // sgn: 0, or 0x80000000 for the tiles of the odd chunks of an item (SIGN ALTERNATION, see the step loop)
     auto tile_commit = [&](const unsigned sgn) {
         // (opaque per call: the 36 store addresses depend only on the thread, hipcc would otherwise compute them once in front of the
@@ -221,17 +262,33 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         unsigned cb = cbase;
         asm volatile("" : "+v"(cb));
         unsigned char* base = tile + cb;
-        x3_for<XT::PER>([&](auto KI) {
+        x3_for<G::SPER>([&](auto KI) {
             constexpr int k = decltype(KI)::value;
             u32x2 h, m, l;
             x3_split4(make_float4(__uint_as_float(__float_as_uint(pv[k][0]) ^ sgn), __uint_as_float(__float_as_uint(pv[k][1]) ^ sgn),
                                   __uint_as_float(__float_as_uint(pv[k][2]) ^ sgn), __uint_as_float(__float_as_uint(pv[k][3]) ^ sgn)), h, m, l);
-            unsigned char* dst = base + k * XT::RPI * X3_ROWB;
+            unsigned char* dst = base + k * (W8 ? G::ZB : XT::RPI * G::ROWB);
             *reinterpret_cast<u32x2*>(dst) = h;
-            *reinterpret_cast<u32x2*>(dst + X3_PIECEB) = m;
-            *reinterpret_cast<u32x2*>(dst + 2 * X3_PIECEB) = l;
+            *reinterpret_cast<u32x2*>(dst + G::PIECEB) = m;
+            *reinterpret_cast<u32x2*>(dst + 2 * G::PIECEB) = l;
         });
     };
+    // narrow brick: the four x-halo columns (0, 1, 10, 11) of the 96 rows x 2 cin halves x 3 pieces.  They are never staged, but the
+    // item's reduction runs through the head of the tile space: rewritten at the start and after every reduction (addresses disjoint
+    // from the commit's, so both share one barrier interval)
+    auto zero_halo = [&]() {
+        if constexpr (W8) {
+            int t0 = tid;
+            asm volatile("" : "+v"(t0));
+#pragma unroll 1
+            for (int q = t0; q < 3 * 2 * 96 * 4; q += NT) {
+                const int c = q & 3, row = (q >> 2) % 96, ph = q / (96 * 4);
+                const int iz = row / 12, iy = row - iz * 12;
+                *reinterpret_cast<u32x4*>(tile + ph * G::PLANEB + iz * G::ZB + iy * G::ROWB + (c < 2 ? c : c + 8) * 16) = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    zero_halo();
     tile_issue(0);
     tile_commit(0u);
     __syncthreads();
@@ -267,12 +324,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             if (grp) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
             x3_load_a<5>(A, wbase, wc + (unsigned)(kc * 5) * astride, astride, lane);               // (dz 0|1, dx = kc)
             __builtin_amdgcn_sched_barrier(0);
-            x3_zrows<0, 5>(acc[nb], bZ + kc * 16, A);
+            x3_zrows<G, 0, 5>(acc[nb], bZ + kc * 16, A);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (nb == 0) VNET_STAMP(1);
             x3_load_a<5>(A, wbase, wc + (unsigned)(25 + kc * 5) * astride, astride, lane);          // (dz 2|3, dx = kc)
             __builtin_amdgcn_sched_barrier(0);
-            x3_zrows<0, 5>(acc[nb], bZ + 2 * X3_ZB + kc * 16, A);
+            x3_zrows<G, 0, 5>(acc[nb], bZ + 2 * G::ZB + kc * 16, A);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (nb == 0) VNET_STAMP(2);
             x3_load_a1(A[0], wbase, wc + (unsigned)(50 + kc * 3) * astride, lane);                  // (dz 4, dx = kc)
@@ -285,9 +342,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             // that its 48 registers are live for two pieces only; unconditional: a branch around an issue merges two vmcnt states
             if constexpr (nb == NB - 1) tile_issue(min(step + 1, nsteps - 1));
             __builtin_amdgcn_sched_barrier(0);
-            x3_yrows_pairs<0, 5>(acc[nb], bY + kc * 16, A);
-            x3_yrows_single<2, 5>(acc[nb], b0 + kc * 16, A);
-            if (kc == 3) x3_yrows_single<3, 5>(acc[nb], b0 + 4 * 16, A);
+            x3_yrows_pairs<G, 0, 5>(acc[nb], bY + kc * 16, A);
+            x3_yrows_single<G, 2, 5>(acc[nb], b0 + kc * 16, A);
+            if (kc == 3) x3_yrows_single<G, 3, 5>(acc[nb], b0 + 4 * 16, A);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (nb == 0) VNET_STAMP(3);
             // the column dx = 4 in four parts (3 / 3 / 3 / 3 + 1 pairs): pairs 20-22 | 23, 24, 45 | 46-48 | 49, 62, 63 (+ 64 above)
@@ -301,15 +358,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
             __builtin_amdgcn_sched_barrier(0);
             if (kc == 0) {
-                x3_zrows<0, 3, 0, 5>(acc[nb], bZ + 4 * 16, A);
+                x3_zrows<G, 0, 3, 0, 5>(acc[nb], bZ + 4 * 16, A);
             } else if (kc == 1) {
-                x3_zrows<3, 2, 0, 5>(acc[nb], bZ + 4 * 16, A);
-                x3_zrows<0, 1, 2, 5>(acc[nb], bZ + 2 * X3_ZB + 4 * 16, A);
+                x3_zrows<G, 3, 2, 0, 5>(acc[nb], bZ + 4 * 16, A);
+                x3_zrows<G, 0, 1, 2, 5>(acc[nb], bZ + 2 * G::ZB + 4 * 16, A);
             } else if (kc == 2) {
-                x3_zrows<1, 3, 0, 5>(acc[nb], bZ + 2 * X3_ZB + 4 * 16, A);
+                x3_zrows<G, 1, 3, 0, 5>(acc[nb], bZ + 2 * G::ZB + 4 * 16, A);
             } else {
-                x3_zrows<4, 1, 0, 5>(acc[nb], bZ + 2 * X3_ZB + 4 * 16, A);
-                x3_yrows_pairs<1, 5>(acc[nb], bY + 4 * 16, A);
+                x3_zrows<G, 4, 1, 0, 5>(acc[nb], bZ + 2 * G::ZB + 4 * 16, A);
+                x3_yrows_pairs<G, 1, 5>(acc[nb], bY + 4 * 16, A);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -343,7 +400,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 bias4[0] = bb.x; bias4[1] = bb.y; bias4[2] = bb.z; bias4[3] = bb.w;
             }
             float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-            const int oz = bz * X3_TZ + grp, ox = bx * X3_TX + j;
+            const int oz = W8 ? bz * G::TZ + grp + 2 * (j >> 3) : bz * X3_TZ + grp, ox = W8 ? (j & 7) : bx * X3_TX + j;
             x3_for<2>([&](auto TI) {
                 constexpr int t = decltype(TI)::value;
                 const int oy = by * X3_TY + 2 * kw + t;
@@ -387,6 +444,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         }
         VNET_STAMP(6);
+        if (last) zero_halo();
         if (more) tile_commit(((last ? 0 : lc + 1) & 1) ? 0x80000000u : 0u);
         VNET_STAMP(7);
         __syncthreads();
@@ -408,10 +466,22 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 // 30 MFMAs.  The 25th column (4, 4) gives one tap to each of the waves 0..4.  One (16 cin, 16 cout) block per workgroup, bricks
 // split over nsplit workgroups, next brick's tiles prefetched global -> registers under the MFMAs, partial slabs + the usual reduce.
 // ------------------------------------------------------------------------------------------------------------------------------
-constexpr int XW_XPB = X3_NV * 32;                    // one piece of the x tile: 46080 B
-constexpr int XW_DPB = X3_TZ * X3_TY * X3_TX * 32;    // one piece of the dy tile: 8192 B
-constexpr int XW_LDS = 3 * XW_XPB + 3 * XW_DPB;       // 162816 of 163840
-constexpr int XW_XROW = X3_IX * 32, XW_XPLANE = X3_IY * X3_IX * 32;
+// Tile geometry of the filter-gradient kernel.  W8 (volumes exactly 8 wide, brick 4 x 8 x 8): the k-step's two x halves (lane groups
+// 2, 3) are the planes z + 2 instead of the columns x + 8 -- an x tile of 8 x 12 x 12 voxels; in the dy tile a 16-slot row holds the
+// 8 voxels of plane z and the 8 of plane z + 2, so only the staging coordinates differ there.
+template <bool W8>
+struct XWG {
+    static constexpr int TZ = W8 ? 4 : 2;
+    static constexpr int IZ = TZ + 4, IX = W8 ? 12 : X3_IX;
+    static constexpr int XROW = IX * 32, XPLANE = X3_IY * XROW;      // row pitch 640 / 384 B: both 128 mod 256 (see below)
+    static constexpr int XPB = IZ * XPLANE;                          // one piece of the x tile: 46080 / 36864 B
+    static constexpr int DPB = 2 * X3_TY * 16 * 32;                  // one piece of the dy tile: 8192 B
+    static constexpr int LDS = 3 * XPB + 3 * DPB;                    // 162816 (of 163840) / 135168
+    static constexpr int XHALF = W8 ? 2 * XPLANE : 8 * 32;           // lane groups 2, 3
+    static constexpr int XPER = W8 ? 8 : 12;                         // staging loads per thread and x tile
+};
+static_assert(XWG<false>::XROW % 256 == 128 && XWG<true>::XROW % 256 == 128, "row pairs of a k-step on disjoint banks");
+constexpr int XW_LDS = XWG<false>::LDS;
 
 // three-piece fragment: 2 transpose reads per piece (voxels +0..3 at lo, +4..7 at hi)
 __device__ __forceinline__ void xw_frag(bf16x8 (&F)[3], const unsigned char* lo, const unsigned char* hi, int pieceb) {
@@ -430,9 +500,13 @@ __device__ __forceinline__ void xw_mfma6(f32x4& acc, const bf16x8 (&A)[3], const
     for (int k = 0; k < 6; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[X3_PROD_A(k)], B[X3_PROD_B(k)], acc, 0, 0, 0);
 }
 
+template <bool W8>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) wgrad5_x3_kernel(WgradArgs a) {
     constexpr int NT = 512;
-    using XT = XTile<X3_IZ, X3_IY, X3_IX, NT>;
+    using G = XWG<W8>;
+    constexpr int XW_XPB = G::XPB, XW_DPB = G::DPB, XW_XROW = G::XROW, XW_XPLANE = G::XPLANE;
+    using XT = XTile<X3_IZ, X3_IY, X3_IX, NT>;              // (staging shape of the wide brick)
+    static_assert(XT::PER == XWG<false>::XPER, "staging passes of the wide brick");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xt = smem;
     unsigned char* dyt = smem + 3 * XW_XPB;
@@ -443,7 +517,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int chunk = blockIdx.y / a.ncob, cob = blockIdx.y - chunk * a.ncob;
     const int co0 = cob * 16;
 
-    const int lane_x = (((g & 1) * X3_IX + (g >> 1) * 8) + (i >> 2)) * 32 + (i & 3) * 8;
+    const int lane_x = W8 ? ((g & 1) * G::IX + (i >> 2)) * 32 + (g >> 1) * G::XHALF + (i & 3) * 8
+                            : (((g & 1) * X3_IX + (g >> 1) * 8) + (i >> 2)) * 32 + (i & 3) * 8;
     const unsigned char* pb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -460,7 +535,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float4 px[XT::PER], pd[2];
+    float4 px[G::XPER], pd[2];
     auto brick_coords = [&](int brick, int& b, int& bz, int& by, int& bx) {
         bx = brick % a.nbx; brick /= a.nbx;
         by = brick % a.nby; brick /= a.nby;
@@ -469,13 +544,34 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     auto issue = [&](int brick) {
         int b, bz, by, bx;
         brick_coords(brick, b, bz, by, bx);
-        XT::template issue_part<0, XT::PER>(px, a.x0, a.x1, a.C0, a.C1, chunk, b, bz * X3_TZ - 2, by * X3_TY - 2, bx * X3_TX - 2, a.Di, a.Hi, a.Wi, tid);
+        if constexpr (W8) {
+            // only the 8 x 4 (x, channel quad) columns inside the volume (its x halo is zero for every brick: written once, below);
+            // a pass is one tile plane = 12 rows x 32 columns = 384 threads, the last 128 repeat the 128 in front of them
+            const int stid = tid < 384 ? tid : tid - 128;
+            const int iy = stid >> 5, col = stid & 31;
+            const int c = chunk * 16 + (col & 3) * 4;
+            const bool first = c < a.C0;
+            const int cs = first ? a.C0 : a.C1;
+            const float* src = (first ? a.x0 + c : a.x1 + (c - a.C0)) + (size_t)b * a.Di * a.Hi * a.Wi * cs;
+            const int gz0 = bz * G::TZ - 2, gy = by * X3_TY - 2 + iy;
+            const bool yok = (unsigned)gy < (unsigned)a.Hi;
+            const int rs = a.Wi * cs, off0 = (gy * a.Wi + (col >> 2)) * cs;
+#pragma unroll
+            for (int k = 0; k < G::XPER; ++k) {
+                const int gz = gz0 + k;
+                const bool ok = yok && (unsigned)gz < (unsigned)a.Di;
+                const float4 t = *reinterpret_cast<const float4*>(src + (ok ? off0 + gz * a.Hi * rs : 0));
+                px[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            XT::template issue_part<0, XT::PER>(px, a.x0, a.x1, a.C0, a.C1, chunk, b, bz * X3_TZ - 2, by * X3_TY - 2, bx * X3_TX - 2, a.Di, a.Hi, a.Wi, tid);
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int q = tid + k * NT;
             const int v = q >> 2, cq = q & 3;
             const int vx = v & 15, vy = (v >> 4) & 7, vz = v >> 7;
-            const int oz = bz * X3_TZ + vz, oy = by * X3_TY + vy, ox = bx * X3_TX + vx;
+            const int oz = W8 ? bz * G::TZ + vz + 2 * (vx >> 3) : bz * X3_TZ + vz, oy = by * X3_TY + vy, ox = W8 ? (vx & 7) : bx * X3_TX + vx;
             const int c = co0 + cq * 4;
             const bool ok = oz < a.Do && oy < a.Ho && ox < a.Wo && c < a.Cout;
             const size_t ov = ok ? ((size_t)(b * a.Do + oz) * a.Ho + oy) * a.Wo + ox : 0;
@@ -484,6 +580,19 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
     };
     auto commit = [&](const bool neg) {
+        if constexpr (W8) {
+            const int stid = tid < 384 ? tid : tid - 128;
+            unsigned char* base = xt + (stid >> 5) * XW_XROW + (((stid & 31) >> 2) + 2) * 32 + (stid & 3) * 8;
+#pragma unroll
+            for (int k = 0; k < G::XPER; ++k) {
+                u32x2 h, m, l;
+                x3_split4(px[k], h, m, l);
+                unsigned char* dst = base + k * XW_XPLANE;
+                *reinterpret_cast<u32x2*>(dst) = h;
+                *reinterpret_cast<u32x2*>(dst + XW_XPB) = m;
+                *reinterpret_cast<u32x2*>(dst + 2 * XW_XPB) = l;
+            }
+        } else {
         const int r0 = tid / XT::COLS, col = tid - r0 * XT::COLS;
         if (r0 < XT::RPI) {
             unsigned char* base = xt + (col >> 2) * 32 + (col & 3) * 8;
@@ -497,6 +606,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 *reinterpret_cast<u32x2*>(dst + XW_XPB) = m;
                 *reinterpret_cast<u32x2*>(dst + 2 * XW_XPB) = l;
             }
+        }
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -524,6 +634,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     // and the accumulators change sign at the brick boundary (exact) -- so consecutive, statistically equal bricks carry the offset
     // with opposite signs.  After: mean +1.0e-7, rel-L2 4.9e-7 (0.86 x the fp32 MFMA's); results stay deterministic.
     bool neg = false;
+    if constexpr (W8) {                                // the x halo columns (0, 1, 10, 11) of every tile row: zero, never staged
+        for (int q = tid; q < 3 * G::IZ * X3_IY * 4 * 2; q += NT) {
+            const int hf = q & 1, c = (q >> 1) & 3, row = (q >> 3) % (G::IZ * X3_IY), piece = q / (8 * G::IZ * X3_IY);
+            *reinterpret_cast<u32x4*>(xt + piece * XW_XPB + row * XW_XROW + (c < 2 ? c : c + 8) * 32 + hf * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
     if (split < a.nbrick) issue(split);
     for (int brick = split; brick < a.nbrick; brick += a.nsplit) {
         __syncthreads();                               // every wave is done reading the previous tiles
@@ -585,7 +701,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
             }
         };
-        static_assert(X3_TZ == 2, "two planes per brick");
         plane(0);
         // The next brick's loads go out BETWEEN the two planes (round 6), not right behind the barrier: there both waves of a SIMD spend
         // their first ~1.2 K cycles on the 14 loads' address arithmetic with the matrix pipe idle; here the other wave of the SIMD is
@@ -613,19 +728,23 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 }
 
+// bricks of a volume: 2 x 8 x 16, or 4 x 8 x 8 where the volume is exactly 8 wide (X3G<true>)
+inline int x3_conv_nbz(int D, int W) { return W == 8 ? ceil_div(D, X3G<true>::TZ) : ceil_div(D, X3_TZ); }
+inline int x3_conv_bricks(int B, int D, int H, int W) { return B * x3_conv_nbz(D, W) * ceil_div(H, X3_TY) * ceil_div(W, X3_TX); }
 struct X3WgradPlan { int nbz, nby, nbx, nbrick, nsplit, nblk; };
 inline X3WgradPlan x3_plan_wgrad(int Cin, int Cout, int B, int D, int H, int W) {
     X3WgradPlan p{};
-    p.nbz = ceil_div(D, X3_TZ); p.nby = ceil_div(H, X3_TY); p.nbx = ceil_div(W, X3_TX);
+    p.nbz = x3_conv_nbz(D, W); p.nby = ceil_div(H, X3_TY); p.nbx = ceil_div(W, X3_TX);
     p.nbrick = B * p.nbz * p.nby * p.nbx;
     p.nblk = (Cin / 16) * (Cout / 16);
     p.nsplit = max(1, min(p.nbrick, ceil_div(256, p.nblk)));
     return p;
 }
 inline bool x3_wgrad_ok(int C0, int C1, int Cout, int B, int D, int H, int W) {
-    if (C0 <= 0 || Cout <= 0 || (C0 & 15) || (C1 & 15) || (Cout & 15) || W < 16) return false;
+    if (C0 <= 0 || Cout <= 0 || (C0 & 15) || (C1 & 15) || (Cout & 15) || (W < 16 && W != 8)) return false;
     const X3WgradPlan p = x3_plan_wgrad(C0 + C1, Cout, B, D, H, W);
-    return p.nbrick >= 4 * p.nsplit;                   // at least four bricks per workgroup: the first tile load is exposed
+    // at least four bricks per workgroup: the first tile load is exposed (two of the narrow brick's, which are twice as deep)
+    return p.nbrick >= (W == 8 ? 2 : 4) * p.nsplit;
 }
 
 // does the f32x3 kernel take this 5^3 stride-1 problem?  (whole 16-channel blocks on both sides, rows of >= 16 voxels, and enough
@@ -634,9 +753,9 @@ inline bool x3_wgrad_ok(int C0, int C1, int Cout, int B, int D, int H, int W) {
 struct X3Plan { int ok, nks, cps; long items; };
 inline X3Plan x3_plan_conv(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W) {
     X3Plan p{0, 1, 0, 0};
-    if (C0 <= 0 || Cy0 <= 0 || (C0 & 15) || (C1 & 15) || (Cy0 & 15) || (Cy1 & 15) || W < 16) return p;
+    if (C0 <= 0 || Cy0 <= 0 || (C0 & 15) || (C1 & 15) || (Cy0 & 15) || (Cy1 & 15) || (W < 16 && W != 8)) return p;
     const int nch = (C0 + C1) / 16;
-    p.items = (long)B * ceil_div(D, X3_TZ) * ceil_div(H, X3_TY) * ceil_div(W, X3_TX) * ((Cy0 + Cy1) / 16);
+    p.items = (long)x3_conv_bricks(B, D, H, W) * ((Cy0 + Cy1) / 16);
     p.cps = nch;
     while (p.items * p.nks < 256 && p.cps % 2 == 0 && p.cps >= 4) { p.nks *= 2; p.cps /= 2; }      // at least two chunks per item
     p.ok = p.items * p.nks >= 192;

@@ -13,7 +13,7 @@ int vnet_conv_x3_ok(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W
     return x3_conv_ok(C0, C1, Cy0, Cy1, B, D, H, W) ? 1 : 0;
 }
 
-// rows of the epilogue-statistics buffer [rows][2][Cout]: one per 2x8x16 brick, or (K-split launches) one per block of the reduce
+// rows of the epilogue-statistics buffer [rows][2][Cout]: one per brick (2x8x16; 4x8x8 in volumes 8 wide), or (K-split launches) one per block of the reduce
 int vnet_conv_x3_stats_rows(int Cin, int Cout, int B, int D, int H, int W) {
     if (Cin <= 0 || Cout <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     const X3Plan p = x3_plan_conv(Cin, 0, Cout, 0, B, D, H, W);
@@ -22,7 +22,7 @@ int vnet_conv_x3_stats_rows(int Cin, int Cout, int B, int D, int H, int W) {
         const size_t total = (size_t)B * D * H * W * Cout;
         return (int)min((size_t)2048, (total + 255) / 256);
     }
-    return B * ceil_div(D, X3_TZ) * ceil_div(H, X3_TY) * ceil_div(W, X3_TX);
+    return x3_conv_bricks(B, D, H, W);
 }
 
 size_t vnet_conv_x3_ws_bytes(int Cin, int Cout, int B, int D, int H, int W) {
@@ -46,7 +46,7 @@ int vnet_conv_fwd_x3(const float* x0, int C0, const float* x1, int C1, const voi
     a.y0 = y0; a.y1 = y1; a.Cy0 = Cy0; a.Cy1 = Cy1; a.Cout = Cy0 + Cy1;
     a.B = B; a.Di = D; a.Hi = H; a.Wi = W; a.Do = D; a.Ho = H; a.Wo = W;
     a.nchunks = a.Cin / 16; a.CQ = a.nchunks * 4; a.CoutP = a.Cout;
-    a.nbz = ceil_div(D, X3_TZ); a.nby = ceil_div(H, X3_TY); a.nbx = ceil_div(W, X3_TX);
+    a.nbz = x3_conv_nbz(D, W); a.nby = ceil_div(H, X3_TY); a.nbx = ceil_div(W, X3_TX);
     a.pad = 2; a.padx = 2; a.vec_in = 1; a.vec_out = 1;
     a.accum = acc ? 1 : 0; a.accsrc = (acc && acc != y0) ? acc : nullptr;
     a.res = res; a.stats = stats;
@@ -63,16 +63,17 @@ int vnet_conv_fwd_x3(const float* x0, int C0, const float* x1, int C1, const voi
     hipStream_t st = (hipStream_t)stream;
     const int grid = x3_grid();
     // two 16-cout blocks per item where the layer has them and still fills the chip twice (a block pair never straddles y0 / y1)
-    const bool nb2 = (a.Cout % 32 == 0) && (Cy0 % 32 == 0) && p.items * p.nks >= 4 * (long)grid && tuning().x3_nb2 != 0;
-#define VNET_X3_GO(STATSV, NBV)                                                          \
+    const bool w8 = W == 8;                            // the narrow brick (X3G<true>): one cout block per item
+    const bool nb2 = !w8 && (a.Cout % 32 == 0) && (Cy0 % 32 == 0) && p.items * p.nks >= 4 * (long)grid && tuning().x3_nb2 != 0;
+#define VNET_X3_GO(STATSV, NBV, W8V)                                                     \
     {                                                                                    \
-        auto k = conv5_x3_kernel<STATSV, NBV>;                                           \
+        auto k = conv5_x3_kernel<STATSV, NBV, W8V>;                                      \
         static unsigned long long attr_done = 0;                                         \
-        if (int ae = ensure_lds(k, X3_LDS, attr_done)) return ae;                        \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(512), X3_LDS, st, a);                     \
+        if (int ae = ensure_lds(k, X3G<W8V>::LDS, attr_done)) return ae;                 \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), X3G<W8V>::LDS, st, a);              \
     }
-    if (stats && p.nks == 1) { if (nb2) VNET_X3_GO(true, 2) else VNET_X3_GO(true, 1) }
-    else { if (nb2) VNET_X3_GO(false, 2) else VNET_X3_GO(false, 1) }
+    if (stats && p.nks == 1) { if (w8) VNET_X3_GO(true, 1, true) else if (nb2) VNET_X3_GO(true, 2, false) else VNET_X3_GO(true, 1, false) }
+    else { if (w8) VNET_X3_GO(false, 1, true) else if (nb2) VNET_X3_GO(false, 2, false) else VNET_X3_GO(false, 1, false) }
 #undef VNET_X3_GO
     VNET_LAUNCH_CHECK();
     if (p.nks > 1) {
@@ -112,10 +113,17 @@ int vnet_conv_wgrad_x3(const float* x0, int C0, const float* x1, int C1, const f
     const bool direct = p.nsplit == 1;                 // one slab: the slab IS dw (TF layout [tap][Cin][Cout])
     if (!direct && (!ws || ws_bytes < need)) return VNET_E_WORKSPACE;
     a.part = direct ? dw : reinterpret_cast<float*>(ws);
-    auto k = wgrad5_x3_kernel;
-    static unsigned long long attr_done = 0;
-    if (int ae = ensure_lds(k, XW_LDS, attr_done)) return ae;
-    hipLaunchKernelGGL(k, dim3(p.nsplit, p.nblk), dim3(512), XW_LDS, st, a);
+    if (W == 8) {                                      // the narrow brick (XWG<true>)
+        auto k = wgrad5_x3_kernel<true>;
+        static unsigned long long attr_done = 0;
+        if (int ae = ensure_lds(k, XWG<true>::LDS, attr_done)) return ae;
+        hipLaunchKernelGGL(k, dim3(p.nsplit, p.nblk), dim3(512), XWG<true>::LDS, st, a);
+    } else {
+        auto k = wgrad5_x3_kernel<false>;
+        static unsigned long long attr_done = 0;
+        if (int ae = ensure_lds(k, XW_LDS, attr_done)) return ae;
+        hipLaunchKernelGGL(k, dim3(p.nsplit, p.nblk), dim3(512), XW_LDS, st, a);
+    }
     VNET_LAUNCH_CHECK();
     if (direct) return VNET_OK;
     launch_wgrad_reduce(a.part, p.nsplit, 125, a.CinP, a.CoutP, a.Cin, Cout, dw, st);
