@@ -66,6 +66,22 @@ def test_conv5_x3(dev, split3, shape):
     check_close(tag + " dw", tw.grad, dw_ref, 2e-6)
 
 
+def test_x3_two_cout_blocks_per_item_is_bit_identical(dev, split3):
+    """`X3_NB2` (two 16-cout blocks per item: the tile commit and its barriers paid once per pair) changes the schedule, not the sums."""
+    ops = split3
+    from vnet_tensorflow_amd import _lib
+    torch.manual_seed(3)
+    x = torch.randn(1, 32, 32, 32, 64, device=dev); w = torch.randn(5, 5, 5, 64, 64, device=dev) * 0.05; b = torch.randn(64, device=dev)
+    ys = []
+    try:
+        for v in (0, 1):
+            _lib.set_option("X3_NB2", v)
+            ys.append(ops.conv(x, w, b, 5, 1))
+    finally:
+        _lib.set_option("X3_NB2", 1)
+    assert torch.equal(ys[0], ys[1])
+
+
 def test_x3_wide_dynamic_range(dev, split3):
     """The split is exact whatever the magnitudes: operands spread over 2^+-20 -- the result keeps fp32 accuracy (a bf16 or a
     two-piece product would be off by 2^-9 / 2^-17)."""
