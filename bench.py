@@ -162,8 +162,11 @@ def latest_pmc():
 def smi_sample():
     """One reading of shader clock and power from rocm-smi while the GPU is busy (None if it cannot be read)."""
     import subprocess
+    # (a clean environment for the child: under `rocprofv3 --pmc` LD_PRELOAD carries the profiler, which would initialise the GPU in
+    #  rocm-smi's `#!/usr/bin/env python3` hop -- an exec from a GPU-initialised process, which the GPU boxes refuse)
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "ROCTX"))}
     try:
-        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=30).stdout
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=30, env=env).stdout
         card = json.loads(out)
         card = card.get("card0", next(iter(card.values())))
         sclk = power = None
