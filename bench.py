@@ -147,9 +147,9 @@ def promotion():
 
 
 X3_ARITHMETIC = ("fp32 tensors everywhere (activations, gradients, batch-norm, loss, optimiser); every product of the 5^3 convolutions "
-                 "(forward, backward-data, filter gradient; levels with rows >= 16 voxels) = 6 v_mfma_f32_16x16x32_bf16 products of exactly "
-                 "split operands (x = h + m + l, 3 x 8 significant bits, no remainder); fp32 accumulate; the 8^3 level, the 1-channel input "
-                 "block and the 2^3 convolutions on v_mfma_f32_16x16x4_f32")
+                 "(forward, backward-data, filter gradient; every level, 128^3 .. 8^3) = 6 v_mfma_f32_16x16x32_bf16 products of exactly "
+                 "split operands (x = h + m + l, 3 x 8 significant bits, no remainder); fp32 accumulate; the 1-channel input "
+                 "block, the 2^3 stride-2 convolutions and the 1^3 head on v_mfma_f32_16x16x4_f32")
 
 
 def latest_pmc():

@@ -112,7 +112,8 @@ int vnet_conv_fwd_stats(int ks, int kx, int stride, const float* x0, int C0, con
  * and a product is the fp32 sum of six bf16 products (hh, hm, mh, mm, hl, lh; dropped terms < 2^-24 of the product).  Not
  * bit-identical to the fp32 MFMA kernels; held to the same 2e-6 against the fp64 oracle.  wp: VNET_PACK_FWD_X3 (forward) /
  * VNET_PACK_BWD_X3 (backward-data: C0 / Cy0, Cy1 are the backward problem's).  Channel counts % 16 (else VNET_E_UNSUPPORTED);
- * vnet_conv_x3_ok: the kernel is the better choice for the shape.  acc: NULL, y0 (y0 += conv) or another tensor of y0's shape
+ * vnet_conv_x3_ok: the kernel is the better choice for the shape (rows of >= 16 voxels -- 2 x 8 x 16 bricks -- or, round 6, volumes
+ * exactly 8 wide -- 4 x 8 x 8 bricks; any other width runs on the wide brick with idle columns).  acc: NULL, y0 (y0 += conv) or another tensor of y0's shape
  * (Cy1 == 0) added out of place.  res / stats as vnet_conv_fwd_stats, rows = vnet_conv_x3_stats_rows.  ws >= vnet_conv_x3_ws_bytes. */
 int vnet_conv_x3_ok(int C0, int C1, int Cy0, int Cy1, int B, int D, int H, int W);
 int vnet_conv_x3_stats_rows(int Cin, int Cout, int B, int D, int H, int W);
