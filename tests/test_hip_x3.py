@@ -127,23 +127,25 @@ def test_x3_epilogue_statistics_accumulate_and_residual(dev, split3, W):
 
 def test_x3_split_is_exact(dev, split3):
     """h + m + l == w EXACTLY (8 + 8 + 8 significant bits; the remainders are formed by v_dot2c_f32_bf16): read the three pieces back
-    from the packed filter image [k chunk][pair 65][n block][piece 3][64 lanes][8 k] and add them in float64."""
+    from the packed filter image [k chunk][pair 63][n block][piece 3][64 lanes][8 k] and add them in float64."""
     ops = split3
     rng = np.random.default_rng(12)
     I = O = 16
     w = (rng.standard_normal((5, 5, 5, I, O)) * np.exp2(rng.integers(-30, 31, (5, 5, 5, I, O)))).astype(np.float32)
     w.reshape(-1)[:7] = [0.0, -0.0, 1.0, -1.0, 3.0e38, 1.0e-30, 2.0 ** -100]      # (not within 2^24 of the smallest normal: the last piece would be denormal)
     tw = g(w, dev)
-    img = ops.packed_weights(tw, ops.PACK_FWD_X3, 125, I, O).cpu().numpy().view(np.uint16).reshape(65, 3, 64, 8)
+    img = ops.packed_weights(tw, ops.PACK_FWD_X3, 125, I, O).cpu().numpy().view(np.uint16).reshape(63, 3, 64, 8)
     f = (img.astype(np.uint32) << 16).view(np.float32).astype(np.float64)        # bf16 -> float
     total = f.sum(1)                                                             # [pair][lane][8 k]
     w3 = w.reshape(125, I, O).astype(np.float64)
-    for p in range(65):
+    for p in range(63):
         for hi in range(2):
-            if p < 50:
+            if p < 50:                                   # (dz, dz + 1) x dy x dx
                 zp, r = divmod(p, 25); dx, dy = divmod(r, 5); dz = 2 * zp + hi; valid = True
-            else:
-                dx, q = divmod(p - 50, 3); dz = 4; dy = 2 * q + hi; valid = not (q == 2 and hi)
+            elif p < 60:                                 # plane 4: (dy, dy + 1) for dy = 0, 2
+                dx, q = divmod(p - 50, 2); dz = 4; dy = 2 * q + hi; valid = True
+            else:                                        # row (4, 4): (dx, dx + 1) for dx = 0, 2; (4, 4, 4) alone
+                dz = dy = 4; dx = 2 * (p - 60) + hi; valid = not (p == 62 and hi)
             tap = (dz * 5 + dy) * 5 + dx if valid else None
             for half in range(2):
                 lanes = np.arange(16) + 16 * (half + 2 * hi)

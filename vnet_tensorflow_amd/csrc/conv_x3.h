@@ -10,13 +10,15 @@
 //
 // Kernel (forward and, with the flipped / transposed filter image, backward-data):
 //   * D[16 cout][16 voxels] per MFMA, K = 32 = a PAIR of taps x 16 cin (pairs as in the bf16 16-cout kernel: (dz, dz+1) for
-//     dz = 0, 2 -> a tile-plane offset for lanes 32..63; dz = 4: (dy, dy+1) -> a tile-row offset; (4,4,dx) alone) = 65 pairs per chunk;
+//     dz = 0, 2 -> a tile-plane offset for lanes 32..63; dz = 4: (dy, dy+1) -> a tile-row offset; row (4,4): (dx, dx+1) -> a tile-column
+//     offset, (4,4,4) alone) = 63 pairs per chunk;
 //   * brick 2 x 8 x 16 output voxels x 16 cout per item, persistent 8-wave workgroups (one per CU) walk (brick, cout block) items;
 //     the brick + halo of one 16-cin chunk is split while it is committed and sits in LDS as three bf16 images
 //     [piece][cin half][voxel][8 cin] (138 KB): a B fragment is one ds_read_b128 per piece, lane base + compile-time offset;
 //   * the two z-planes of the brick go to two groups of four waves; the four waves of a group hold the SAME 8 output rows (32
-//     accumulator registers) and split K: wave kw owns the tap column dx = kw (13 pairs) and a quarter of the column dx = 4
-//     (16 / 16 / 16 / 17 pairs, rotated by chunk).  So every filter fragment is fetched by exactly two waves of the workgroup,
+//     accumulator registers) and split K: wave kw owns the tap column dx = kw (12 pairs), a quarter of the column dx = 4 and
+//     one of the three pairs of the row (4,4) (16 / 16 / 15 / 16 pairs, rotated by chunk; round 5 had 65 pairs, 16 / 16 / 16 / 17, and the
+//     wave with 17 set the pace of every chunk).  So every filter fragment is fetched by exactly two waves of the workgroup,
 //     straight from L2 into VGPRs (3 KB per pair, ~16 B/clk/CU) and never touches LDS;
 //   * y-sliding reuse: a wave walks the tile rows j of a (dz pair, dx) once and feeds row j to the output rows m = j - dy of
 //     every dy it owns: 12 row fragments (x3 pieces) for 40 (row, dy) steps = 240 MFMAs: 0.15 KB of LDS reads per MFMA;
@@ -136,7 +138,8 @@ __device__ __forceinline__ void x3_yrows_pairs(f32x4 (&acc)[8], const unsigned c
         __builtin_amdgcn_sched_barrier(0);
     });
 }
-// tap (4, 4, dx) alone (the filter's second half is zero): single rows m + 4, both lane halves read the same row: A[A0]
+// row (4, 4): single rows m + 4.  Called with the base b0: tap (4, 4, dx) alone (the filter's second half is zero, both lane halves read
+// the same column); with bX: the taps (4, 4, dx), (4, 4, dx + 1) (lanes 32..63 one column further): A[A0]
 template <typename G, int A0, int NA>
 __device__ __forceinline__ void x3_yrows_single(f32x4 (&acc)[8], const unsigned char* b0, const bf16x8 (&A)[NA][3]) {
     bf16x8 Bn[3];
@@ -177,7 +180,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                          : half * G::PLANEB + ((grp * G::IY) * G::IX + j) * 16;
     const unsigned char* bZ = tile + base0 + hi * G::ZB;                      // taps (dz, dz + 1)
     const unsigned char* bY = tile + base0 + hi * G::ROWB + 4 * G::ZB;        // taps (4, dy), (4, dy + 1)
-    const unsigned char* b0 = tile + base0 + 4 * G::ZB;                       // tap (4, 4)
+    const unsigned char* b0 = tile + base0 + 4 * G::ZB;                       // tap (4, 4, dx) alone
+    const unsigned char* bX = b0 + hi * 16;                                   // taps (4, 4, dx), (4, 4, dx + 1)
 
     const int ncob = a.CoutP >> 4, ncobg = ncob / NB;                         // 16-cout blocks; groups of NB blocks = items per brick
     const int nbrick = a.B * a.nbz * a.nby * a.nbx;
@@ -332,10 +336,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             x3_zrows<G, 0, 5>(acc[nb], bZ + 2 * G::ZB + kc * 16, A);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (nb == 0) VNET_STAMP(2);
-            x3_load_a1(A[0], wbase, wc + (unsigned)(50 + kc * 3) * astride, lane);                  // (dz 4, dx = kc)
-            x3_load_a1(A[1], wbase, wc + (unsigned)(51 + kc * 3) * astride, lane);
-            x3_load_a1(A[2], wbase, wc + (unsigned)(52 + kc * 3) * astride, lane);
-            x3_load_a1(A[3], wbase, wc + 64u * astride, lane);                                     // tap (4, 4, 4): goes with kc == 3
+            x3_load_a1(A[0], wbase, wc + (unsigned)(50 + kc * 2) * astride, lane);                  // (dz 4, dy 0|1, dx = kc)
+            x3_load_a1(A[1], wbase, wc + (unsigned)(51 + kc * 2) * astride, lane);                  // (dz 4, dy 2|3, dx = kc)
+            x3_load_a1(A[2], wbase, wc + (unsigned)(60 + (kc & 1)) * astride, lane);                // taps (4, 4, 0|1) with kc == 0, (4, 4, 2|3) with kc == 1
+            x3_load_a1(A[3], wbase, wc + 62u * astride, lane);                                     // tap (4, 4, 4): goes with kc == 3
             __builtin_amdgcn_sched_barrier(0);
             if (grp) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
             // the next tile's loads go out in the LAST pass, behind this piece's filter loads (vmcnt counts in order) and late enough
@@ -343,15 +347,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             if constexpr (nb == NB - 1) tile_issue(min(step + 1, nsteps - 1));
             __builtin_amdgcn_sched_barrier(0);
             x3_yrows_pairs<G, 0, 5>(acc[nb], bY + kc * 16, A);
-            x3_yrows_single<G, 2, 5>(acc[nb], b0 + kc * 16, A);
+            if (kc < 2) x3_yrows_single<G, 2, 5>(acc[nb], bX + kc * 32, A);          // columns (0|1) / (2|3) of row (4, 4)
             if (kc == 3) x3_yrows_single<G, 3, 5>(acc[nb], b0 + 4 * 16, A);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (nb == 0) VNET_STAMP(3);
-            // the column dx = 4 in four parts (3 / 3 / 3 / 3 + 1 pairs): pairs 20-22 | 23, 24, 45 | 46-48 | 49, 62, 63 (+ 64 above)
+            // the column dx = 4 in four parts (3 / 3 / 3 / 3 + 1 pairs): pairs 20-22 | 23, 24, 45 | 46-48 | 49, 58, 59 (+ 62 above)
             {
                 const int p0 = kc == 0 ? 20 : kc == 1 ? 23 : kc == 2 ? 46 : 49;
-                const int p1 = kc == 0 ? 21 : kc == 1 ? 24 : kc == 2 ? 47 : 62;
-                const int p2 = kc == 0 ? 22 : kc == 1 ? 45 : kc == 2 ? 48 : 63;
+                const int p1 = kc == 0 ? 21 : kc == 1 ? 24 : kc == 2 ? 47 : 58;
+                const int p2 = kc == 0 ? 22 : kc == 1 ? 45 : kc == 2 ? 48 : 59;
                 x3_load_a1(A[0], wbase, wc + (unsigned)p0 * astride, lane);
                 x3_load_a1(A[1], wbase, wc + (unsigned)p1 * astride, lane);
                 x3_load_a1(A[2], wbase, wc + (unsigned)p2 * astride, lane);

@@ -1,7 +1,7 @@
 // x3_pack.h -- filter images of the f32x3 convolution kernels (conv_x3.h): included by conv_kernels.h inside its anonymous
 // namespace (after bf_lo / bf_hi), so that the batched repack (pack_batched_kernel) can emit them too.
 #pragma once
-constexpr int X3_NPAIR = 65;             // tap pairs per 16-channel chunk (125 taps: 62 pairs + one single)
+constexpr int X3_NPAIR = 63;             // tap pairs per 16-channel chunk (125 taps: 62 pairs + one single)
 
 // exact three-way split of four fp32 values into packed bf16 pairs
 __device__ __forceinline__ void x3_split4(const float4 v, u32x2& h, u32x2& m, u32x2& l) {
@@ -12,16 +12,21 @@ __device__ __forceinline__ void x3_split4(const float4 v, u32x2& h, u32x2& m, u3
     l = u32x2{pk_bf16(s0, s1), pk_bf16(s2, s3)};
 }
 
-// tap (dz, dy, dx) of half `hi` of pair p; false: the empty half of the last pair of a column
+// tap (dz, dy, dx) of half `hi` of pair p; false: the empty half of the last pair.
+//   p =  0 .. 49: (dz, dz + 1) for dz = 0, 2:  p = 25 (dz / 2) + 5 dx + dy
+//   p = 50 .. 59: plane dz = 4, (dy, dy + 1) for dy = 0, 2:  p = 50 + 2 dx + dy / 2
+//   p = 60, 61  : row (4, 4), (dx, dx + 1) for dx = 0, 2  (round 6; before, every (4, 4, dx) was a pair with an empty half: 65 pairs,
+//                 and the wave that got 17 of them set the pace of every chunk);  p = 62: (4, 4, 4) alone
 __host__ __device__ __forceinline__ bool x3_pair_tap(int p, int hi, int& dz, int& dy, int& dx) {
     if (p < 50) { const int zp = p / 25, r = p - zp * 25; dx = r / 5; dy = r - dx * 5; dz = 2 * zp + hi; return true; }
-    const int r = p - 50; dx = r / 3; const int q = r - dx * 3; dz = 4; dy = 2 * q + hi;
-    if (q == 2 && hi) { dy = 4; return false; }
-    return true;
+    dz = 4;
+    if (p < 60) { const int r = p - 50; dx = r / 2; dy = 2 * (r - dx * 2) + hi; return true; }
+    dy = 4; dx = 2 * (p - 60) + hi;
+    return !(p == 62 && hi);
 }
 
 // one 16-byte unit (8 consecutive k of one n) of the three filter images:
-//   image [k chunk 16][pair 65][n block 16][piece 3][64 lanes][8 k];  lane = (n % 16) + 16 * (k half + 2 * pair half)
+//   image [k chunk 16][pair 63][n block 16][piece 3][64 lanes][8 k];  lane = (n % 16) + 16 * (k half + 2 * pair half)
 //   FWD: k = ci, n = co;  BWD: k = co, n = ci at the flipped tap  (the backward-data convolution)
 __device__ __forceinline__ void x3_pack_unit(bool bwd, const float* __restrict__ w, u32x4* __restrict__ out, int I, int O, int ncob, uint32_t u) {
     const uint32_t lane = u & 63;
