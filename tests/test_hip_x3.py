@@ -30,6 +30,7 @@ def split3():
     (1, 2, 8, 40, 48, 0, 32),      # three chunks, ragged x
     (1, 8, 8, 16, 128, 0, 32),     # few items, eight chunks: the chunks split over four workgroups per item (partial slabs + reduce)
     (1, 4, 16, 16, 32, 32, 32),    # K split with two sources
+    (1, 32, 32, 64, 16, 16, 16),   # backward-data into two 16-channel destinations with TWO cout blocks per item: the pair straddles them
     # volumes exactly 8 wide (the 8^3 level): the narrow brick 4 x 8 x 8 -- lanes 8..15 of a column block are the plane two further
     (1, 8, 8, 8, 32, 0, 32),       # whole bricks, two chunks (the second runs negated), two cout blocks
     (2, 6, 10, 8, 16, 16, 48),     # ragged depth and height, two sources, batch 2

@@ -62,10 +62,10 @@ int vnet_conv_fwd_x3(const float* x0, int C0, const float* x1, int C1, const voi
     }
     hipStream_t st = (hipStream_t)stream;
     const int grid = x3_grid();
-    // two 16-cout blocks per item where the layer has them and the pairs are still one round of the chip (a block pair never straddles
-    // y0 / y1).  Round 6: from 2 x grid single-block items on (was 4 x): 32^3 64->64 0.149 -> 0.140 ms, 128->64 0.275 -> 0.263
+    // two 16-cout blocks per item where the layer has them and the pairs are still one round of the chip (a pair may straddle
+    // y0 / y1 -- each block finds its own destination: the backward-data launch of a 2C -> C layer with C = 16).  Round 6: from 2 x grid single-block items on (was 4 x): 32^3 64->64 0.149 -> 0.140 ms, 128->64 0.275 -> 0.263
     const bool w8 = W == 8;                            // the narrow brick (X3G<true>): one cout block per item
-    const bool nb2 = !w8 && (a.Cout % 32 == 0) && (Cy0 % 32 == 0) && p.items * p.nks >= 2 * (long)grid && tuning().x3_nb2 != 0;
+    const bool nb2 = !w8 && (a.Cout % 32 == 0) && p.items * p.nks >= 2 * (long)grid && tuning().x3_nb2 != 0;
 #define VNET_X3_GO(STATSV, NBV, W8V)                                                     \
     {                                                                                    \
         auto k = conv5_x3_kernel<STATSV, NBV, W8V>;                                      \
