@@ -29,9 +29,10 @@ FAMILIES = {
     # fp32_split3: persistent kernels (grid = CUs x 512 whatever the problem), and the plain instantiation serves the K-split forward
     # launches of the 16^3 level as well as every backward-data launch: a member is the LONGEST launch of its kernel in a step -- the
     # 128^3 launches of dec1/conv_1 (268 GF each) take twice as long as any other layer's
-    # (<STATS, NB>: dec1/conv_1 has 16 output channels forward and two 16-channel destinations backward: one cout block per item)
+    # (<STATS, NB, W8>: dec1/conv_1 has 16 output channels forward: one cout block per item; backward-data its two 16-channel destinations
+    #  are a pair of cout blocks since round 6)
     "f32x3": ("x3", [("fwd", "conv5_x3_kernel<true, 1, false>", None, "longest"),
-                     ("bwd", "conv5_x3_kernel<false, 1, false>", None, "longest"),
+                     ("bwd", "conv5_x3_kernel<false, 2, false>", None, "longest"),
                      ("wgrad", "wgrad5_x3_kernel<false>", None, "longest")]),
     # C5, bf16 storage: forward with statistics 16->16, 32->16 = the second launch of the plain 16-cout kernel (the 4->16 input conv is
     # the x-im2col instantiation); backward-data 16->32 and the stand-alone filter gradient are the first launches of their kernels
