@@ -44,9 +44,10 @@ extern "C" {
 #define VNET_PACK_BOTH_BF16 5  /* the bf16 pair of a 5^3 filter */
 
 /* f32x3 filter images for vnet_conv_fwd_x3: every weight split exactly into three bf16 pieces (h, m, l),
- * [k chunk 16][tap pair 65][n block 16][piece 3][64 lanes][8 k] (csrc/conv_x3.h) */
+ * [k chunk 16][tap pair 63][n block 16][piece 3][64 lanes][8 k] (csrc/conv_x3.h, x3_pack.h: x3_pair_tap) */
 #define VNET_PACK_FWD_X3 7     /* conv forward (k = ci, n = co)                                              */
 #define VNET_PACK_BWD_X3 8     /* conv backward-data (flipped taps, k = co, n = ci)                          */
+#define VNET_PACK_BOTH_X3 9    /* vnet_pack_weights_batched only, like VNET_PACK_BOTH: both f32x3 images of a 5^3 filter  */
 
 /* or-ed into VNET_PACK_FWD / _BWD / _UP: the fp32 image holds the filter ROUNDED to bf16 (bf16-storage mode of the 2^3 convs) */
 #define VNET_PACK_ROUND_BF16 16

@@ -1,9 +1,11 @@
 #!/bin/bash
-# interleaved A/B of one environment switch on the C5 step inside ONE gpurun call:  bash profiles/ab_env.sh VAR A B [mode cin K]
-VAR=$1; A=$2; B=$3; MODE=${4:-bf16}; CIN=${5:-4}; K=${6:-5}
+# interleaved A/B of whole training steps (graph replay, profiles/step_only.py) between two settings of ONE environment variable:
+#   bash profiles/ab_env.sh <VAR> "<value> <value> ..." <compute> [channels classes] [steps]
+cd "$GRAFT_REPO_ROOT"
+VAR=$1; VALS=$2; COMPUTE=${3:-fp32_split3}; CH=${4:-1}; K=${5:-2}; STEPS=${6:-60}
 for rep in 1 2 3; do
-  for v in $A $B; do
-    printf "%s=%-4s " $VAR $v
-    env $VAR=$v python profiles/step_only.py 60 $MODE $CIN $K | tail -1
+  for v in $VALS; do
+    printf "%-24s %-12s " "$VAR=$v" "$COMPUTE"
+    env $VAR=$v timeout 300 python profiles/step_only.py $STEPS $COMPUTE $CH $K 2>&1 | tail -1
   done
 done

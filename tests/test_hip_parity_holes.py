@@ -261,15 +261,16 @@ def test_batch_norm_statistics_from_the_conv_epilogue(dev, mode, ks, stride, sha
 
 
 @pytest.mark.parametrize("taps,I,O", [(125, 16, 16), (125, 32, 16), (125, 4, 16), (125, 24, 40), (8, 16, 32), (125, 6, 10),
-                                      (125, 32, 32), (125, 64, 32), (125, 32, 96)])      # whole 32-channel blocks: both bf16 images from one read
+                                      (125, 32, 32), (125, 64, 32), (125, 32, 96)])      # whole 32-channel blocks: both bf16 / fp32 / f32x3 images from one read
 def test_batched_filter_repack_equals_single_pack(dev, taps, I, O):
     """The one-launch repack of every registered filter (after each optimiser step) must produce, bit for bit, the images
-    the single-filter packer produces -- all five layouts (fp32 forward / backward-data / transposed, bf16 forward / backward)."""
+    the single-filter packer produces -- all layouts (fp32 forward / backward-data / transposed, bf16 forward / backward, f32x3 forward /
+    backward: the three exactly split bf16 pieces)."""
     from vnet_tensorflow_amd import ops
     ks = 5 if taps == 125 else 2
     gen = torch.Generator().manual_seed(taps + I + O)
     w = torch.nn.Parameter(torch.randn(ks, ks, ks, I, O, generator=gen).to(dev))
-    modes = [ops.PACK_FWD, ops.PACK_BWD] + ([ops.PACK_FWD_BF16, ops.PACK_BWD_BF16] if taps == 125 else [])
+    modes = [ops.PACK_FWD, ops.PACK_BWD] + ([ops.PACK_FWD_BF16, ops.PACK_BWD_BF16, ops.PACK_FWD_X3, ops.PACK_BWD_X3] if taps == 125 else [])
     ops.clear_pack_registry()
     try:
         single = {m: ops.packed_weights(w, m, taps, I, O).clone() for m in modes}          # registers (w, mode) and packs one by one

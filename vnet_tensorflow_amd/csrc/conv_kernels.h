@@ -835,6 +835,54 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const long long* __re
             x3_pack_unit(mode == VNET_PACK_BWD_X3, w, reinterpret_cast<u32x4*>(wp), I, O, NP, u);
         return;
     }
+    if (mode == VNET_PACK_BOTH_X3) {
+        // Both f32x3 images of a 5^3 filter from ONE read (round 6).  The per-unit form above reads w twice, the backward image in
+        // 32-byte pieces (8 consecutive co of one ci per lane, lanes 1 KB apart): 879 MB of traffic at 3.5 TB/s for the network's 44 M
+        // parameters.  Here, like the bf16 twin below: a workgroup stages one tap's [32 ci][32 co] fp32 slice in LDS (rows of 128
+        // contiguous bytes) and emits its 128 forward units (8 consecutive ci of one co) and its 128 backward-data units (8 consecutive
+        // co of one ci, at the flipped tap) -- the same units, the same exact split, the same image positions (bit-identical images:
+        // tests/test_hip_parity_holes.py).  The empty half of the last pair (62) is zero-filled by the thread that holds the pair's only tap.
+        __shared__ float sl[32][33];
+        const uint32_t nci = (uint32_t)I / 32, nco = (uint32_t)O / 32, per_t = nci * nco, ntiles = 125u * per_t;
+        const uint32_t ncobf = (uint32_t)O / 16, ncobb = (uint32_t)I / 16;      // n blocks of the forward / backward image
+        u32x4* outf = reinterpret_cast<u32x4*>(wp);
+        u32x4* outb = reinterpret_cast<u32x4*>(d[6]);
+        const int tid = threadIdx.x;
+        for (uint32_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+            const uint32_t t = tix / per_t, rem = tix - t * per_t, bi = rem / nco, bo = rem - bi * nco;
+            const float* wt = w + ((size_t)t * I + bi * 32) * O + bo * 32;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = (tid >> 5) + 8 * j, c = tid & 31;
+                sl[r][c] = wt[(size_t)r * O + c];
+            }
+            __syncthreads();
+            const uint32_t m = tid & 31, kg = (tid >> 5) & 3;           // unit: 8 k-values kg*8 .. of column / row m
+            const bool fwd = tid < 128;
+            const uint32_t tt = fwd ? t : 124u - t;                     // backward-data: the flipped tap
+            int p, hi;
+            x3_tap_pair((int)(tt / 25), (int)((tt / 5) % 5), (int)(tt % 5), p, hi);
+            float v[8];
+            if (fwd) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = sl[kg * 8 + e][m];   // k = ci = bi*32 + kg*8 .., n = co = bo*32 + m
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = sl[m][kg * 8 + e];   // k = co = bo*32 + kg*8 .., n = ci = bi*32 + m
+            }
+            const uint32_t kb = fwd ? bi : bo, nb = fwd ? bo : bi, ncob = fwd ? ncobf : ncobb;
+            const uint32_t chunk = kb * 2 + (kg >> 1), half = kg & 1, cob = nb * 2 + (m >> 4), nl = m & 15;
+            u32x4* out = fwd ? outf : outb;
+            const size_t q = ((size_t)chunk * X3_NPAIR + p) * ncob + cob;
+            x3_store_unit(out, q, nl + 16 * (half + 2 * hi), v);
+            if (p == 62) {                                              // the pair's second half does not exist: zeros
+                u32x4* dz0 = out + q * 3 * 64 + (nl + 16 * (half + 2));
+                dz0[0] = dz0[64] = dz0[128] = u32x4{0u, 0u, 0u, 0u};
+            }
+            __syncthreads();
+        }
+        return;
+    }
     if (mode == VNET_PACK_BOTH_BF16) {
         // Both bf16 images of a filter from ONE read (round 4): the two separate passes read every fp32 weight twice (352 MB for the
         // C5 network's 44 M parameters, + 176 MB of images).  A workgroup stages one tap's [32 ci][32 co] fp32 slice in LDS (rows of

@@ -25,6 +25,13 @@ __host__ __device__ __forceinline__ bool x3_pair_tap(int p, int hi, int& dz, int
     return !(p == 62 && hi);
 }
 
+// the inverse: pair and half of tap (dz, dy, dx)
+__host__ __device__ __forceinline__ void x3_tap_pair(int dz, int dy, int dx, int& p, int& hi) {
+    if (dz < 4) { p = 25 * (dz >> 1) + 5 * dx + dy; hi = dz & 1; }
+    else if (dy < 4) { p = 50 + 2 * dx + (dy >> 1); hi = dy & 1; }
+    else { p = 60 + (dx >> 1); hi = dx & 1; }
+}
+
 // one 16-byte unit (8 consecutive k of one n) of the three filter images:
 //   image [k chunk 16][pair 63][n block 16][piece 3][64 lanes][8 k];  lane = (n % 16) + 16 * (k half + 2 * pair half)
 //   FWD: k = ci, n = co;  BWD: k = co, n = ci at the flipped tap  (the backward-data convolution)
@@ -57,6 +64,17 @@ __device__ __forceinline__ void x3_pack_unit(bool bwd, const float* __restrict__
     x3_split4(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
     x3_split4(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
     u32x4* dst = out + (size_t)qfull * 3 * 64 + lane;
+    dst[0] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+    dst[64] = u32x4{m0[0], m0[1], m1[0], m1[1]};
+    dst[128] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+}
+
+// store the three pieces of one unit: v = 8 consecutive k of one n; q = (chunk * X3_NPAIR + pair) * ncob + cob; lane as above
+__device__ __forceinline__ void x3_store_unit(u32x4* __restrict__ out, size_t q, uint32_t lane, const float (&v)[8]) {
+    u32x2 h0, m0, l0, h1, m1, l1;
+    x3_split4(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
+    x3_split4(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
+    u32x4* dst = out + q * 3 * 64 + lane;
     dst[0] = u32x4{h0[0], h0[1], h1[0], h1[1]};
     dst[64] = u32x4{m0[0], m0[1], m1[0], m1[1]};
     dst[128] = u32x4{l0[0], l0[1], l1[0], l1[1]};

@@ -21,7 +21,7 @@ BN_MOMENTUM = 0.99   # reference networks.py:259 momentum=0.99
 
 ACT = {None: 0, "none": 0, "relu": 1, "prelu": 2, "lrelu": 3}
 PACK_FWD, PACK_BWD, PACK_UP, PACK_FWD_BF16, PACK_BWD_BF16, PACK_BOTH_BF16, PACK_BOTH = 0, 1, 2, 3, 4, 5, 6
-PACK_FWD_X3, PACK_BWD_X3 = 7, 8
+PACK_FWD_X3, PACK_BWD_X3, PACK_BOTH_X3 = 7, 8, 9
 
 # Arithmetic of the 5x5x5 convolutions (forward, backward-data and filter gradient): "fp32" = exact fp32 MFMA (the reference's
 # arithmetic), "bf16" = operands rounded to bf16, fp32 accumulation (BASELINE config C5).  Everything else
@@ -297,7 +297,10 @@ def repack_registered():
         # a filter with BOTH bf16 images registered (forward + backward-data: every 5^3 filter of a bf16 training step) and whole
         # 32-channel blocks: one descriptor, one read of w for the two images (VNET_PACK_BOTH_BF16; -0.06 ms per C5 step)
         both = {}
-        fams = {PACK_FWD_BF16: 0, PACK_BWD_BF16: 0, PACK_FWD: 1, PACK_BWD: 1}       # (the plain fp32 pair the same way: VNET_PACK_BOTH)
+        fams = {PACK_FWD_BF16: 0, PACK_BWD_BF16: 0, PACK_FWD: 1, PACK_BWD: 1,       # (the plain fp32 pair the same way: VNET_PACK_BOTH;
+                PACK_FWD_X3: 2, PACK_BWD_X3: 2}                                    #  the f32x3 pair: VNET_PACK_BOTH_X3, round 6)
+        if _os.environ.get("VNET_PACK_BOTH_X3", "1") == "0":
+            fams.pop(PACK_FWD_X3); fams.pop(PACK_BWD_X3)
         if _PACK_BOTH["on"]:
             for w, (mode, taps, I, O), wp in ents:
                 if mode in fams and I % 32 == 0 and O % 32 == 0:
@@ -309,7 +312,8 @@ def repack_registered():
             if mode in fams and len(pair) == 2 and I % 32 == 0 and O % 32 == 0:
                 if key not in done:
                     done.add(key)
-                    f, bk, mb = (PACK_FWD_BF16, PACK_BWD_BF16, PACK_BOTH_BF16) if fams[mode] == 0 else (PACK_FWD, PACK_BWD, PACK_BOTH)
+                    f, bk, mb = ((PACK_FWD_BF16, PACK_BWD_BF16, PACK_BOTH_BF16), (PACK_FWD, PACK_BWD, PACK_BOTH),
+                                 (PACK_FWD_X3, PACK_BWD_X3, PACK_BOTH_X3))[fams[mode]]
                     rows.append([w.data_ptr(), pair[f].data_ptr(), mb, taps, I, O, pair[bk].data_ptr(), 0])
                 continue
             cq, npad = ctypes.c_int(), ctypes.c_int()
