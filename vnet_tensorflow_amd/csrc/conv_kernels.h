@@ -848,15 +848,21 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const long long* __re
         u32x4* outf = reinterpret_cast<u32x4*>(wp);
         u32x4* outb = reinterpret_cast<u32x4*>(d[6]);
         const int tid = threadIdx.x;
-        for (uint32_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+        // (the next tile's four loads are issued before this tile's 24 stores: a workgroup keeps 4 KB of reads in flight under them)
+        float nx[4];
+        auto tile_load = [&](uint32_t tix) {
             const uint32_t t = tix / per_t, rem = tix - t * per_t, bi = rem / nco, bo = rem - bi * nco;
             const float* wt = w + ((size_t)t * I + bi * 32) * O + bo * 32;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = (tid >> 5) + 8 * j, c = tid & 31;
-                sl[r][c] = wt[(size_t)r * O + c];
-            }
+            for (int j = 0; j < 4; ++j) nx[j] = wt[(size_t)((tid >> 5) + 8 * j) * O + (tid & 31)];
+        };
+        if (blockIdx.x < ntiles) tile_load(blockIdx.x);
+        for (uint32_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+            const uint32_t t = tix / per_t, rem = tix - t * per_t, bi = rem / nco, bo = rem - bi * nco;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sl[(tid >> 5) + 8 * j][tid & 31] = nx[j];
             __syncthreads();
+            if (tix + gridDim.x < ntiles) tile_load(tix + gridDim.x);
             const uint32_t m = tid & 31, kg = (tid >> 5) & 3;           // unit: 8 k-values kg*8 .. of column / row m
             const bool fwd = tid < 128;
             const uint32_t tt = fwd ? t : 124u - t;                     // backward-data: the flipped tap
@@ -895,15 +901,21 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const long long* __re
         u32x4* outf = reinterpret_cast<u32x4*>(wp);
         u32x4* outb = reinterpret_cast<u32x4*>(d[6]);
         const int tid = threadIdx.x;
-        for (uint32_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+        // (round 6: the next tile's four loads are issued before this tile's stores, as in the f32x3 twin above: 184 -> 126 us there)
+        float nx[4];
+        auto tile_load = [&](uint32_t tix) {
             const uint32_t t = tix / per_t, rem = tix - t * per_t, bi = rem / nco, bo = rem - bi * nco;
             const float* wt = w + ((size_t)t * I + bi * 32) * O + bo * 32;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = (tid >> 5) + 8 * j, c = tid & 31;
-                sl[r][c] = wt[(size_t)r * O + c];
-            }
+            for (int j = 0; j < 4; ++j) nx[j] = wt[(size_t)((tid >> 5) + 8 * j) * O + (tid & 31)];
+        };
+        if (blockIdx.x < ntiles) tile_load(blockIdx.x);
+        for (uint32_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+            const uint32_t t = tix / per_t, rem = tix - t * per_t, bi = rem / nco, bo = rem - bi * nco;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sl[(tid >> 5) + 8 * j][tid & 31] = nx[j];
             __syncthreads();
+            if (tix + gridDim.x < ntiles) tile_load(tix + gridDim.x);
             const uint32_t m = tid & 31, kg = (tid >> 5) & 3;           // unit: 8 k-values kg*8 .. of column / row m
             if (tid < 128) {
                 // forward image [cin chunk][tap][cout block][cin half][32 cout][8 cin]: n = co = bo*32 + m, k = ci = bi*32 + kg*8 ..
@@ -933,15 +945,21 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const long long* __re
         float4* outf = reinterpret_cast<float4*>(wp);
         float4* outb = reinterpret_cast<float4*>(d[6]);
         const int tid = threadIdx.x;
-        for (uint32_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+        // (round 6: the next tile's four loads are issued before this tile's stores, as in the f32x3 twin above: 184 -> 126 us there)
+        float nx[4];
+        auto tile_load = [&](uint32_t tix) {
             const uint32_t t = tix / per_t, rem = tix - t * per_t, bi = rem / nco, bo = rem - bi * nco;
             const float* wt = w + ((size_t)t * I + bi * 32) * O + bo * 32;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = (tid >> 5) + 8 * j, c = tid & 31;
-                sl[r][c] = wt[(size_t)r * O + c];
-            }
+            for (int j = 0; j < 4; ++j) nx[j] = wt[(size_t)((tid >> 5) + 8 * j) * O + (tid & 31)];
+        };
+        if (blockIdx.x < ntiles) tile_load(blockIdx.x);
+        for (uint32_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+            const uint32_t t = tix / per_t, rem = tix - t * per_t, bi = rem / nco, bo = rem - bi * nco;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sl[(tid >> 5) + 8 * j][tid & 31] = nx[j];
             __syncthreads();
+            if (tix + gridDim.x < ntiles) tile_load(tix + gridDim.x);
             const uint32_t m = tid & 31, kg = tid >> 5;                 // 8 groups of 4 k-values x 32 columns / rows
             {
                 const float4 v = make_float4(sl[kg * 4][m], sl[kg * 4 + 1][m], sl[kg * 4 + 2][m], sl[kg * 4 + 3][m]);
