@@ -159,7 +159,7 @@ __device__ __forceinline__ void x3_yrows_single(f32x4 (&acc)[8], const unsigned 
 
 // NB: 16-cout blocks per item (1 or 2).  With two, a step runs the four pieces twice on the SAME tile -- once per block, one block's
 // accumulators and filter fragments at a time -- so the tile commit, its two barriers and the item's reduction are paid once per
-// 2 x 6240 MFMAs instead of once per 6240.
+// 2 x 6048 MFMAs instead of once per 6048 (63 pairs x 8 rows x 6 products x 2 planes).
 template <bool STATS, int NB, bool W8 = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv5_x3_kernel(ConvArgs a) {
     constexpr int NT = 512;
